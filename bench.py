@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py — gradient-steps/sec of the HER-sample + critic/actor update path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+One "step" = one agent.update(step): HER batch draw + gather, critic update, actor update when
+due, Polyak when due (reference src/agent.py:1378-1404 / src/env.py:384-385).  Steps are issued
+as the trainer issues them, `gradient_step` (40) at a time with the buffer untouched in between.
+Inputs (the replay ring) are resident in HBM before the timed region.
+
+N > 1: one process per GPU (torchrun env), each rank owns a local ring and draws its own batch
+of B rows; gradients are all-reduced over RCCL twice per step (critic, then actor).  Per-GPU
+work is fixed -> "scaling": "weak"; value = per-rank gradient steps summed over ranks / time.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      HER gather kernel: algorithmic bytes / HIP-event kernel time vs HBM peak
+  cpu_baseline  the oracle (CPU restatement of the reference) timed on this host, same workload
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TF = 157.3
+
+WORKLOADS = {
+    # north-star headline: PandaPickAndPlace-v3 DDPG+HER, batch 256 (config_ddpg_pickplace.yaml
+    # hyper-parameters, batch overridden to the metric's 256)
+    "ddpg_pickplace_b256": dict(kind="DDPG", S=23, A=4, H=256, L=3, B=256, cap=1_000_000, k=8, gamma=0.98,
+                                tau=0.05, grad_clip=10.0, freq=1, gstep=40, lr=1e-3),
+    # BASELINE.json configs[1]: Reach, B=1024, buffer 1e6, MLP(256,256)
+    "ddpg_reach_b1024": dict(kind="DDPG", S=10, A=3, H=256, L=2, B=1024, cap=1_000_000, k=4, gamma=0.98,
+                             tau=0.05, grad_clip=10.0, freq=1, gstep=40, lr=1e-3),
+    # configs[0]: the reference's CPU-runnable case
+    "ddpg_reach_b256": dict(kind="DDPG", S=10, A=3, H=64, L=3, B=256, cap=100_000, k=4, gamma=0.98,
+                            tau=0.05, grad_clip=10.0, freq=1, gstep=40, lr=1e-3),
+    "td3_pickplace_b2048": dict(kind="TD3", S=23, A=4, H=256, L=3, B=2048, cap=1_000_000, k=8, gamma=0.98,
+                                tau=0.005, grad_clip=2.0, freq=2, gstep=40, lr=1e-3, policy_noise=0.2, noise_clamp=0.5),
+    "tqc_push_b2048": dict(kind="TQC", S=22, A=3, H=512, L=3, B=2048, cap=1_000_000, k=4, gamma=0.95,
+                           tau=0.05, grad_clip=5.0, freq=1, gstep=40, lr=3e-4),
+    "sac_slide_b512": dict(kind="SAC", S=22, A=3, H=256, L=3, B=512, cap=1_000_000, k=4, gamma=0.98,
+                           tau=0.005, grad_clip=2.0, freq=1, gstep=40, lr=5e-4),
+}
+
+
+def make_cfg(w):
+    from oracle.agent_oracle import make_config
+    return make_config(w["kind"], hidden_dim=w["H"], layer_count=w["L"], batch_size=w["B"], max_len=w["cap"],
+                       k_future=w["k"], gamma=w["gamma"], tau=w["tau"], grad_clip=w["grad_clip"],
+                       ac_update_freq=w["freq"], actor_lr=w["lr"], actor_lr_min=w["lr"], critic_lr=w["lr"],
+                       critic_lr_min=w["lr"], policy_noise=w.get("policy_noise", 0.0),
+                       noise_clamp=w.get("noise_clamp", 0.5))
+
+
+def episode_pool(w, n, seed):
+    from oracle.her_oracle import synthetic_episode
+    gen = np.random.default_rng(seed)
+    return [synthetic_episode(gen, 50, w["S"], w["A"]) for _ in range(n)]
+
+
+def episode_arrays(steps):
+    s, a, ns, r, d, dg, ag = zip(*steps)
+    return (np.array(s, np.float32), np.array(a, np.float32), np.array(ns, np.float32),
+            np.array(r, np.float32), np.zeros(len(steps), np.float32), np.array(ag, np.float32))
+
+
+def flops_per_step(w, actor_step=True):
+    """fwd = dX = dW = 2*B*P per network pass."""
+    S, A, H, L, B = w["S"], w["A"], w["H"], w["L"], w["B"]
+    Pa = S * H + (L - 1) * H * H + H * A
+    Pc = (S + A) * H + (L - 1) * H * H + H
+    kind = w["kind"]
+    if kind == "DDPG":
+        return 2 * B * (4 * Pa + 6 * Pc)
+    if kind == "TD3":
+        return 2 * B * ((4 * Pa + 10 * Pc) if actor_step else (Pa + 8 * Pc))
+    if kind == "SAC":
+        return 2 * B * (4 * Pa + 12 * Pc)
+    return 2 * B * (4 * Pa + 7 * 5 * Pc)
+
+
+def cpu_baseline(w, pool, budget_s):
+    """The oracle (CPU port of the reference: deque + random.sample + eager torch) on the same
+    workload, bounded to ~budget_s seconds of CPU work."""
+    from oracle.agent_oracle import OracleAgent
+    cfg = make_cfg(w)
+    threads = torch.get_num_threads()
+    orc = OracleAgent(w["kind"], w["S"], w["A"], cfg, nenvs=8, gradient_step=w["gstep"], rng=random.Random(1898))
+    rows_per_ep = 50 + w["k"] * 49
+    n_eps = -(-w["cap"] // rows_per_ep)
+    t0 = time.perf_counter()
+    for ep in range(n_eps):
+        for st in pool[ep % len(pool)]:
+            orc.push_her(ep % 8, *st)
+    fill_s = time.perf_counter() - t0
+    for step in range(1, 4):
+        orc.update(step)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.update(4 + n)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 1000:
+            break
+    return dict(value=n / el, unit="gradient-steps/s", cores=threads, kind="port",
+                sample=f"{n} oracle update() calls in {el:.1f}s after filling the deque to {len(orc.buffer)} rows "
+                       f"({fill_s:.1f}s); {w['kind']} B={w['B']} H={w['H']} L={w['L']}; torch {threads} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--workload", default="ddpg_pickplace_b256", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torchrun with WORLD_SIZE={args.gpus} (got {world})")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import gcrl_amd
+    from gcrl_amd._ffi import lib, check
+    from gcrl_amd.src.dp import DataParallelUpdater, rank_seed
+
+    w = WORKLOADS[args.workload]
+    cfg = make_cfg(w)
+    cls = dict(DDPG=gcrl_amd.DDPG, TD3=gcrl_amd.TD3Agent, SAC=gcrl_amd.SACAgent, TQC=gcrl_amd.TQCAgent)[w["kind"]]
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        agent = cls(w["S"], w["A"], cfg, None, nenvs=8, gradient_step=w["gstep"], use_graph=not args.no_graph,
+                    rng="engine", seed=rank_seed(1898, rank), device_index=local_rank)
+        pool = episode_pool(w, 64, seed=1898 + rank)
+        arrays = [episode_arrays(ep) for ep in pool]
+        rows_per_ep = 50 + w["k"] * 49
+        n_eps = -(-w["cap"] // rows_per_ep)          # fill to capacity before timing
+        t_fill = time.perf_counter()
+        for ep in range(n_eps):
+            s, a, ns, r, d, ag = arrays[ep % len(arrays)]
+            agent.buffer.push_episode(ep % 8, s, a, ns, r, d, ag)
+        torch.cuda.synchronize()
+        t_fill = time.perf_counter() - t_fill
+        assert len(agent.buffer) == min(w["cap"], n_eps * rows_per_ep)
+
+        dp = DataParallelUpdater(agent) if world > 1 else None
+        gstep = w["gstep"]
+
+        def run(step0, n):
+            if dp is None:
+                done = 0
+                while done < n:
+                    m = min(gstep, n - done)
+                    agent.update_many(step0 + done, m)
+                    done += m
+            else:
+                for i in range(n):
+                    dp.update(step0 + i)
+
+        run(1, args.warmup)
+        torch.cuda.synchronize()
+        her = agent.buffer.handle
+        check(lib.gcrl_her_profile_enable(her, 1))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(1 + args.warmup, args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        launches, ms, rows = C.c_int64(), C.c_double(), C.c_int64()
+        check(lib.gcrl_her_profile_read(her, C.byref(launches), C.byref(ms), C.byref(rows)))
+        check(lib.gcrl_her_profile_enable(her, 0))
+        # a last metrics fetch proves the steps really ran to completion
+        last = [float(x) for x in (agent.update_many(1 + args.warmup + args.steps, 1)[0] if dp is None
+                                   else dp.update(1 + args.warmup + args.steps))]
+        assert all(np.isfinite(last)), last
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        R = (2 * w["S"] + w["A"] + 2) * 4
+        alg_bytes_per_row = 2 * R                      # read the record + write the batch row
+        rows_per_launch = rows.value / max(1, launches.value)
+        avg_us = ms.value * 1e3 / max(1, launches.value)
+        achieved = (alg_bytes_per_row * rows_per_launch) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "gradient-steps/sec (HER sample + critic+actor update)",
+            "value": value, "unit": "gradient-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "agent": w["kind"], "batch_per_gpu": w["B"], "buffer_rows": len(agent.buffer),
+                       "state_dim": w["S"], "action_dim": w["A"], "hidden": w["H"], "layers": w["L"], "k_future": w["k"],
+                       "gradient_step": gstep, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "hip_graph": not args.no_graph, "rng": "cpython-mt19937 (host) indices"},
+            "roofline": {"kernel": "her_gather_update_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": launches.value, "avg_launch_us": avg_us, "rows_per_launch": rows_per_launch,
+                         "algorithmic_bytes_per_row": alg_bytes_per_row},
+            "update_flops": {"gflop_per_step": flops_per_step(w) / 1e9,
+                             "achieved_tflops": flops_per_step(w) * args.steps / elapsed / 1e12,
+                             "peak_tflops": FP32_MFMA_PEAK_TF},
+            "fill_s": t_fill, "last_metrics": last,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            torch.set_num_threads(os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(w, pool, args.cpu_seconds)
+            out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

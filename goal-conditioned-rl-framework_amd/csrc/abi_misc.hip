@@ -1,0 +1,75 @@
+// abi_misc.hip — small C-ABI helpers: stand-alone sort op, hipEvent timing, raw device memory.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "gemm_mfma.h"
+#include "ops.h"
+
+namespace {
+hipStream_t as_stream(void* s) {
+  if (!s || s == GCRL_STREAM_LEGACY) return (hipStream_t) nullptr;
+  return (hipStream_t)s;
+}
+}  // namespace
+
+extern "C" {
+
+int gcrl_sort_truncate_mean(const float* in_dev, int64_t rows, int width, int drop, float* sorted_dev,
+                            float* mean_dev, void* stream) {
+  return gcrl::launch_sort_truncate_mean(as_stream(stream), in_dev, rows, width, drop, sorted_dev, mean_dev);
+}
+
+int gcrl_gemm_f32(const float* a, int64_t a_rs, int64_t a_cs, const float* b, int64_t b_rs, int64_t b_cs,
+                  float* c, int64_t c_rs, const float* bias, int M, int N, int K, int act, int shape,
+                  void* stream) {
+  GCRL_CHECK_ARG(act >= 0 && act <= 3 && shape >= 0 && shape <= 3, "gcrl_gemm_f32: bad act/shape");
+  gcrl::GemmDesc d;
+  std::memset(&d, 0, sizeof(d));
+  d.A = a; d.a_rs = a_rs; d.a_cs = a_cs;
+  d.B = b; d.b_rs = b_rs; d.b_cs = b_cs;
+  d.C = c; d.c_rs = c_rs;
+  d.bias = bias;
+  d.M = M; d.N = N; d.K = K;
+  d.epi = act;
+  return gcrl::launch_gemm_batch(as_stream(stream), &d, 1, shape);
+}
+
+void* gcrl_event_create(void) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreate(&ev) != hipSuccess) { gcrl::fail(GCRL_ERR_HIP, "hipEventCreate failed"); return nullptr; }
+  return (void*)ev;
+}
+void gcrl_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int gcrl_event_record(void* ev, void* stream) {
+  GCRL_CHECK_ARG(ev, "gcrl_event_record: null event");
+  GCRL_HIP(hipEventRecord((hipEvent_t)ev, as_stream(stream)));
+  return GCRL_OK;
+}
+int gcrl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out) {
+  GCRL_CHECK_ARG(ev_start && ev_stop && ms_out, "gcrl_event_elapsed_ms: null argument");
+  GCRL_HIP(hipEventSynchronize((hipEvent_t)ev_stop));
+  GCRL_HIP(hipEventElapsedTime(ms_out, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+  return GCRL_OK;
+}
+int gcrl_stream_synchronize(void* stream) {
+  GCRL_HIP(hipStreamSynchronize(as_stream(stream)));
+  return GCRL_OK;
+}
+void* gcrl_malloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) { gcrl::fail(GCRL_ERR_HIP, "hipMalloc(%zu) failed", bytes); return nullptr; }
+  return p;
+}
+void gcrl_free(void* p) { if (p) (void)hipFree(p); }
+int gcrl_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  GCRL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+  GCRL_HIP(hipStreamSynchronize(as_stream(stream)));
+  return GCRL_OK;
+}
+int gcrl_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  GCRL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  GCRL_HIP(hipStreamSynchronize(as_stream(stream)));
+  return GCRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1106 @@
+// agent.hip — the actor-critic update engine behind gcrl_agent_*.
+//
+// Replaces, for all four reference agents, update() and everything it calls:
+//   DDPG      src/agent.py:1288-1343 (actor_update, critic_update), :1378-1404 (update)
+//   TD3Agent  src/agent.py:149-251, :281-317
+//   SACAgent  src/agent.py:513-639, :659-699
+//   TQCAgent  src/agent.py:912-1042, :1062-1100
+// and the networks of src/model.py (Actor, Critic, SACActorModel).
+//
+// One update step is a fixed sequence of launches (batched MFMA GEMMs + small fused
+// element-wise / reduction kernels) split in three phases at the two points where a
+// data-parallel run exchanges gradients:
+//   phase 0  begin_step, target pass + online critic pass, TD target/loss, critic backward
+//   phase 1  critic clip+Adam(W)(+Polyak), [TQC metric re-evaluation], actor pass through the
+//            stepped critics, actor backward, log-alpha gradient
+//   phase 2  actor clip+Adam(W)(+Polyak), log-alpha step
+// The sequence is captured once per variant into a hipGraph and replayed; everything that
+// changes between steps (learning rates, bias corrections, batch slot, metrics slot, RNG
+// counters) travels through a device-resident StepCtrl table, so no pointer is re-bound.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "gemm_mfma.h"
+#include "her_ring.h"
+#include "ops.h"
+
+using namespace gcrl;
+
+namespace {
+
+constexpr int kMaxStepsPerCall = 128;
+constexpr int kCtrlSlots = 4;
+constexpr int kEventRing = 256;
+constexpr double kBeta1 = 0.9, kBeta2 = 0.999, kAdamEps = 1e-8, kWeightDecay = 0.01;
+
+struct Lin { int in, out; long long w, b; };
+
+struct NetSpec {
+  int in_dim = 0, H = 0, L = 0, out_dim = 0;
+  bool sac = false;
+  std::vector<Lin> lin;               // L hidden layers, then head(s)
+  std::vector<long long> bn_g, bn_b;  // per hidden layer (sac)
+  long long numel = 0;
+};
+
+// parameter order = torch module.parameters(): Linear w,b [, BatchNorm w,b] per block, heads
+NetSpec make_net(int in, int H, int L, int out, bool sac) {
+  NetSpec n;
+  n.in_dim = in; n.H = H; n.L = L; n.out_dim = out; n.sac = sac;
+  long long off = 0;
+  for (int l = 0; l < L; ++l) {
+    const int k = l == 0 ? in : H;
+    n.lin.push_back({k, H, off, off + (long long)k * H});
+    off += (long long)k * H + H;
+    if (sac) { n.bn_g.push_back(off); n.bn_b.push_back(off + H); off += 2 * H; }
+  }
+  const int heads = sac ? 2 : 1;  // mean_head, log_std_head (src/model.py:114-115)
+  for (int h = 0; h < heads; ++h) {
+    n.lin.push_back({H, out, off, off + (long long)H * out});
+    off += (long long)H * out + out;
+  }
+  n.numel = off;
+  return n;
+}
+
+long long align_up(long long x, long long a) { return (x + a - 1) / a * a; }
+
+struct UploadBlock {  // device image of one call's upload: control table, then batch indices
+  CtrlBlock cb;       // cb.table[0] is table entry 0 ...
+  StepCtrl more[kMaxStepsPerCall - 1];
+  // uint32_t idx[...] follows
+};
+
+}  // namespace
+
+struct gcrl_agent {
+  gcrl_agent_config cfg;
+  int S = 0, A = 0, H = 0, L = 0, B = 0, C = 0, ldx = 0, Mmax = 0, Apad = 0;
+  bool has_target_actor = false, sac = false;
+  NetSpec actor, critic;
+  hipStream_t stream = nullptr, cap_stream = nullptr;
+
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  long long n_params = 0, n_grads = 0;
+  long long off_actor = 0, off_tactor = 0, off_critic = 0, off_tcritic = 0, off_logalpha = 0;
+  long long goff_critic = 0, goff_actor = 0, goff_alpha = 0;
+  long long critic_stride = 0;
+  float *bn_rmean = nullptr, *bn_rvar = nullptr;  // [L*H]
+  float* alpha_dev = nullptr;                     // exp(log_alpha) as of the last alpha step
+
+  float* work = nullptr;
+  float *sa = nullptr, *nsa = nullptr, *spa = nullptr, *rbuf = nullptr, *dbuf = nullptr;
+  long long slot_x = 0, slot_rd = 0;
+  float *hTA[2] = {}, *hA = nullptr, *hC = nullptr, *hTC = nullptr, *gC = nullptr, *gA[2] = {};
+  float *q = nullptr, *qt = nullptr, *q2 = nullptr, *dq = nullptr, *dq2 = nullptr, *dact = nullptr;
+  float *zA = nullptr, *xhatA = nullptr, *invstdA = nullptr, *headA = nullptr, *ghead = nullptr, *dh2 = nullptr;
+  float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
+  float *noise_in = nullptr, *eps_next_in = nullptr, *eps_cur_in = nullptr, *norm_partial = nullptr;
+  float *act_in = nullptr, *act_tmp[2] = {};
+
+  char* upload_dev = nullptr;
+  size_t upload_bytes = 0;
+  char* upload_pinned[kCtrlSlots] = {};
+  hipEvent_t upload_ev[kCtrlSlots] = {};
+  int next_upload = 0;
+  float *metrics_host = nullptr, *metrics_dev = nullptr;
+  int64_t next_ticket = 0;
+  std::vector<int> ticket_len;
+  hipEvent_t call_ev[kEventRing] = {};
+  int64_t call_last_ticket[kEventRing];
+  int64_t calls = 0;
+
+  int64_t t_actor = 0, t_critic = 0, t_alpha = 0;
+  double lr_actor = 0, lr_critic = 0;
+  uint64_t rng_ctr = 0;
+  int pending_variant = 0;  // variant of the step whose phases are being issued one by one
+
+  std::map<int, hipGraphExec_t> graphs;
+  std::map<std::string, std::pair<float*, long long>> names;
+
+  hipStream_t pick(void* s) const {
+    if (!s) return stream;
+    if (s == GCRL_STREAM_LEGACY) return (hipStream_t) nullptr;
+    return (hipStream_t)s;
+  }
+  CtrlBlock* ctrl() const { return (CtrlBlock*)upload_dev; }
+  uint32_t* idx_dev() const { return (uint32_t*)(upload_dev + sizeof(UploadBlock)); }
+  const StepCtrl* cur() const { return &ctrl()->cur; }
+  const int* slot_ptr() const { return &ctrl()->cur.batch_slot; }
+  float* P_actor() const { return params + off_actor; }
+  float* P_tactor() const { return params + off_tactor; }
+  float* P_critic(int c) const { return params + off_critic + c * critic_stride; }
+  float* P_tcritic(int c) const { return params + off_tcritic + c * critic_stride; }
+  float* P_logalpha() const { return params + off_logalpha; }
+  float* G_actor() const { return grads + goff_actor; }
+  float* G_critic(int c) const { return grads + goff_critic + c * critic_stride; }
+  float* hC_at(int c, int l) const { return hC + ((long long)c * L + l) * B * H; }
+  float* hTC_at(int c, int i) const { return hTC + ((long long)c * 2 + i) * B * H; }
+  float* gC_at(int c, int i) const { return gC + ((long long)c * 2 + i) * B * H; }
+  float* hA_at(int l) const { return hA + (long long)l * B * H; }
+  int n_actor_critics() const { return (cfg.kind == GCRL_AGENT_DDPG || cfg.kind == GCRL_AGENT_TD3) ? 1 : C; }
+};
+
+namespace {
+
+#define TRY(x) do { if (int rc__ = (x)) return rc__; } while (0)
+
+// ---------------------------------------------------------------- small kernels of this file
+__global__ void pack_batch_kernel(const float* s, int ld_s, const float* a, int ld_a, const float* r,
+                                  const float* ns, int ld_ns, const float* d, int B, int S, int A, int ldx,
+                                  float* sa, float* nsa, float* spa, float* rb, float* db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = 2 * S + A + 2;
+  if (i >= B * W) return;
+  const int b = i / W, c = i - b * W;
+  if (c < S) {
+    const float v = s[(long long)b * ld_s + c];
+    sa[(long long)b * ldx + c] = v;
+    spa[(long long)b * ldx + c] = v;
+  } else if (c < S + A) sa[(long long)b * ldx + c] = a[(long long)b * ld_a + (c - S)];
+  else if (c < W - 2) nsa[(long long)b * ldx + (c - S - A)] = ns[(long long)b * ld_ns + (c - S - A)];
+  else if (c == W - 2) rb[b] = r[b];
+  else db[b] = d[b];
+}
+
+__global__ void copy_rows_kernel(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int r = i / cols, c = i - r * cols;
+  dst[(long long)r * ld_dst + c] = src[(long long)r * ld_src + c];
+}
+
+// ---------------------------------------------------------------- descriptor builders
+GemmDesc blank() {
+  GemmDesc d;
+  std::memset(&d, 0, sizeof(d));
+  return d;
+}
+// Y[B,out] = act(X[B,in] W^T + b)
+GemmDesc fwd(const float* X, long long ldx, const float* P, const Lin& ln, float* Y, long long ldy, int B, int epi) {
+  GemmDesc d = blank();
+  d.A = X; d.a_rs = ldx; d.a_cs = 1;
+  d.B = P + ln.w; d.b_rs = 1; d.b_cs = ln.in;
+  d.C = Y; d.c_rs = ldy;
+  d.bias = P + ln.b;
+  d.M = B; d.N = ln.out; d.K = ln.in;
+  d.epi = epi;
+  return d;
+}
+// dX[B,ncols] = (G[B,out] . W[out, col0:col0+ncols]) * act'(Hprev)
+GemmDesc bwd_dx(const float* G, long long ldg, const float* P, const Lin& ln, int col0, int ncols, float* dX,
+                long long lddx, int B, int mul, const float* Hprev, long long ldh) {
+  GemmDesc d = blank();
+  d.A = G; d.a_rs = ldg; d.a_cs = 1;
+  d.B = P + ln.w + col0; d.b_rs = ln.in; d.b_cs = 1;
+  d.C = dX; d.c_rs = lddx;
+  d.M = B; d.N = ncols; d.K = ln.out;
+  d.mul = mul; d.H = Hprev; d.h_rs = ldh;
+  return d;
+}
+// dW[out,in] = G^T X ; db[out] = colsum(G)      (X = the layer's input [B,in])
+GemmDesc bwd_dw(const float* G, long long ldg, const float* X, long long ldx, float* Gp, const Lin& ln, int B) {
+  GemmDesc d = blank();
+  d.A = G; d.a_rs = 1; d.a_cs = ldg;
+  d.B = X; d.b_rs = ldx; d.b_cs = 1;
+  d.C = Gp + ln.w; d.c_rs = ln.in;
+  d.M = ln.out; d.N = ln.in + 1; d.K = B;
+  d.ones_col = 1; d.col_out = Gp + ln.b;
+  return d;
+}
+
+struct Launches {  // problems grouped by launch index
+  std::vector<std::vector<GemmDesc>> steps;
+  void add(size_t at, const GemmDesc& d) {
+    if (steps.size() <= at) steps.resize(at + 1);
+    steps[at].push_back(d);
+  }
+  int run(hipStream_t st) {
+    for (auto& v : steps)
+      for (size_t o = 0; o < v.size(); o += kMaxProb)
+        TRY(launch_gemm_batch(st, v.data() + o, (int)std::min<size_t>(kMaxProb, v.size() - o)));
+    return GCRL_OK;
+  }
+};
+
+typedef float* (*HidFn)(gcrl_agent*, int, int);
+float* hid_TA(gcrl_agent* a, int, int l) { return a->hTA[l & 1]; }
+float* hid_A(gcrl_agent* a, int, int l) { return a->hA_at(l); }
+float* hid_C(gcrl_agent* a, int c, int l) { return a->hC_at(c, l); }
+float* hid_TC(gcrl_agent* a, int c, int l) { return a->hTC_at(c, l & 1); }
+float* hid_ACT(gcrl_agent* a, int, int l) { return a->act_tmp[l & 1]; }
+
+// plain MLP chain (Actor / Critic of src/model.py): layer l goes to launch at+l.
+// x_slot / out_slot: per-batch-slot strides when input / output live in the batch array.
+void chain_mlp(gcrl_agent* a, Launches& ls, size_t at, const NetSpec& net, const float* P, const float* X0,
+               long long ldx0, long long x_slot, HidFn hid, int key, float* out, long long ld_out,
+               long long out_slot, int out_epi, int rows) {
+  for (int l = 0; l <= net.L; ++l) {
+    const float* X = l == 0 ? X0 : hid(a, key, l - 1);
+    float* Y = l < net.L ? hid(a, key, l) : out;
+    GemmDesc d = fwd(X, l == 0 ? ldx0 : net.H, P, net.lin[l], Y, l < net.L ? net.H : ld_out, rows,
+                     l < net.L ? EPI_LEAKY : out_epi);
+    if (l == 0 && x_slot) { d.slot = a->slot_ptr(); d.a_slot = x_slot; }
+    if (l == net.L && out_slot) { d.slot = a->slot_ptr(); d.c_slot = out_slot; }
+    ls.add(at + l, d);
+  }
+}
+
+// SACActorModel forward (src/model.py:118-141): [Linear -> BatchNorm1d(train) -> ReLU] x L, two
+// heads, tanh-Gaussian sample.  save: keep what the backward needs.  extra: critic-chain
+// launches co-scheduled with the actor's GEMM launches (may be null).
+int sac_actor_forward(gcrl_agent* a, hipStream_t st, const float* X0, long long x_slot, bool save, float* act_dst,
+                      long long act_slot, float* logp_dst, const float* eps_in, int rng_stream, Launches* extra) {
+  const NetSpec& net = a->actor;
+  const float* P = a->P_actor();
+  const int B = a->B, H = a->H;
+  for (int l = 0; l < net.L; ++l) {
+    const float* X = l == 0 ? X0 : a->hA_at(l - 1);
+    GemmDesc d = fwd(X, l == 0 ? a->ldx : H, P, net.lin[l], a->zA, H, B, EPI_NONE);
+    if (l == 0 && x_slot) { d.slot = a->slot_ptr(); d.a_slot = x_slot; }
+    std::vector<GemmDesc> v{d};
+    if (extra && (size_t)l < extra->steps.size()) v.insert(v.end(), extra->steps[l].begin(), extra->steps[l].end());
+    TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
+    TRY(launch_bn_relu_fwd(st, a->zA, B, H, P + net.bn_g[l], P + net.bn_b[l], a->hA_at(l),
+                           save ? a->xhatA + (long long)l * B * H : nullptr,
+                           save ? a->invstdA + (long long)l * H : nullptr, a->bn_rmean + (long long)l * H,
+                           a->bn_rvar + (long long)l * H));
+  }
+  {
+    const int ldh = 2 * a->Apad;
+    std::vector<GemmDesc> v;
+    v.push_back(fwd(a->hA_at(net.L - 1), H, P, net.lin[net.L], a->headA, ldh, B, EPI_NONE));                // mean
+    v.push_back(fwd(a->hA_at(net.L - 1), H, P, net.lin[net.L + 1], a->headA + a->Apad, ldh, B, EPI_NONE));  // log_std
+    if (extra && (size_t)net.L < extra->steps.size())
+      v.insert(v.end(), extra->steps[net.L].begin(), extra->steps[net.L].end());
+    TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
+  }
+  TanhGaussArgs tg;
+  std::memset(&tg, 0, sizeof(tg));
+  tg.cur = a->cur();
+  tg.mu = a->headA; tg.ls_raw = a->headA + a->Apad; tg.ld_head = 2 * a->Apad;
+  tg.eps = eps_in;
+  tg.act = act_dst; tg.act_slot_stride = act_slot; tg.ld_act = a->ldx;
+  tg.logp = logp_dst;
+  tg.save_eps = save ? a->epsbuf : nullptr;
+  tg.save_std = save ? a->stdbuf : nullptr;
+  tg.B = B; tg.A = a->A;
+  tg.seed = a->cfg.seed; tg.rng_stream = rng_stream;
+  TRY(launch_tanh_gauss_fwd(st, tg));
+  return GCRL_OK;
+}
+
+enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32 };
+
+// ---------------------------------------------------------------- phase 0
+int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
+  const int kind = a->cfg.kind, B = a->B, C = a->C, S = a->S, L = a->L, H = a->H;
+  TRY(launch_begin_step(st, a->ctrl()));
+  Launches crit;  // online critics on [s|a], activations kept for the backward
+  for (int c = 0; c < C; ++c)
+    chain_mlp(a, crit, 0, a->critic, a->P_critic(c), a->sa, a->ldx, a->slot_x, hid_C, c, a->q + (long long)c * B, 1, 0, EPI_NONE, B);
+  if (!a->sac) {
+    // target actor on ns, co-scheduled with the online critics; its tanh output lands in the
+    // action columns of the target critics' input rows
+    Launches ls = crit;
+    chain_mlp(a, ls, 0, a->actor, a->P_tactor(), a->nsa, a->ldx, a->slot_x, hid_TA, 0, a->nsa + S, a->ldx, a->slot_x, EPI_TANH, B);
+    TRY(ls.run(st));
+    if (kind == GCRL_AGENT_TD3)
+      TRY(launch_td3_smooth(st, a->cur(), a->nsa + S, a->slot_x, a->ldx, B, a->A,
+                            (variant & V_NOISE) ? a->noise_in : nullptr, (float)a->cfg.policy_noise,
+                            (float)a->cfg.noise_clamp, a->cfg.seed));
+  } else {
+    // actor.sample(next_state) under no_grad, BatchNorm in training mode (src/agent.py:558, :961)
+    TRY(sac_actor_forward(a, st, a->nsa, a->slot_x, false, a->nsa + S, a->slot_x, a->logp_next,
+                          (variant & V_EPSN) ? a->eps_next_in : nullptr, 1, &crit));
+  }
+  Launches tc;
+  for (int c = 0; c < C; ++c)
+    chain_mlp(a, tc, 0, a->critic, a->P_tcritic(c), a->nsa, a->ldx, a->slot_x, hid_TC, c, a->qt + (long long)c * B, 1, 0, EPI_NONE, B);
+  TRY(tc.run(st));
+
+  TdLossArgs td;
+  std::memset(&td, 0, sizeof(td));
+  td.cur = a->cur();
+  td.r = a->rbuf; td.d = a->dbuf; td.slot_stride = a->slot_rd;
+  td.qt = a->qt; td.q = a->q; td.dq = a->dq;
+  td.metrics = a->metrics_dev;
+  td.B = B; td.C = C; td.drop = 0;
+  td.gamma = (float)a->cfg.gamma;
+  td.loss_kind = LOSS_MSE;
+  switch (kind) {
+    case GCRL_AGENT_DDPG: td.target_kind = TGT_DDPG; td.clamp_lo = (float)(-1.0 / (1.0 - a->cfg.gamma)); break;
+    case GCRL_AGENT_TD3: td.target_kind = TGT_MIN; td.loss_kind = LOSS_SMOOTH_L1; break;
+    case GCRL_AGENT_SAC: td.target_kind = TGT_MIN_ENT; td.logp_next = a->logp_next; td.alpha_const = 0.2f; break;
+    default: td.target_kind = TGT_TRUNC_ENT; td.logp_next = a->logp_next; td.alpha_dev = a->alpha_dev; td.drop = a->cfg.top_drop; break;
+  }
+  TRY(launch_td_loss(st, td));
+
+  // critic backward, layer L..0: dW|db and dX of a layer share a launch
+  Launches bw;
+  for (int c = 0; c < C; ++c) {
+    float* Gp = a->G_critic(c);
+    const float* P = a->P_critic(c);
+    for (int l = L; l >= 0; --l) {
+      const size_t at = (size_t)(L - l);
+      const float* G = l == L ? a->dq + (long long)c * B : a->gC_at(c, l & 1);
+      const long long ldg = l == L ? 1 : H;
+      GemmDesc dw = bwd_dw(G, ldg, l == 0 ? a->sa : a->hC_at(c, l - 1), l == 0 ? a->ldx : H, Gp, a->critic.lin[l], B);
+      if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
+      bw.add(at, dw);
+      if (l > 0)
+        bw.add(at, bwd_dx(G, ldg, P, a->critic.lin[l], 0, H, a->gC_at(c, (l - 1) & 1), H, B, MUL_DLEAKY, a->hC_at(c, l - 1), H));
+    }
+  }
+  TRY(bw.run(st));
+  return GCRL_OK;
+}
+
+int adam_common(gcrl_agent* a, AdamArgs& ad) {
+  ad.cur = a->cur();
+  ad.beta2 = (float)kBeta2;
+  ad.w1 = (float)(1.0 - kBeta1);
+  ad.w2 = (float)(1.0 - kBeta2);
+  ad.eps = (float)kAdamEps;
+  ad.tau = (float)a->cfg.tau;
+  ad.one_m_tau = (float)(1.0 - a->cfg.tau);
+  ad.metrics = a->metrics_dev;
+  ad.partial = a->norm_partial;
+  return GCRL_OK;
+}
+
+// ---------------------------------------------------------------- phase 1
+int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
+  const int kind = a->cfg.kind, B = a->B, C = a->C, S = a->S, A = a->A, L = a->L, H = a->H;
+  // critic optimiser: global-norm clip + Adam(W) (+ Polyak into the target critics)
+  TRY(launch_sumsq(st, a->G_critic(0), a->critic.numel, a->critic_stride, C, a->norm_partial));
+  {
+    AdamArgs ad;
+    std::memset(&ad, 0, sizeof(ad));
+    adam_common(a, ad);
+    ad.which = 1;
+    ad.p = a->P_critic(0); ad.g = a->G_critic(0);
+    ad.m = a->adam_m + a->goff_critic; ad.v = a->adam_v + a->goff_critic;
+    ad.target = a->P_tcritic(0);
+    ad.n = a->critic.numel; ad.net_stride = a->critic_stride; ad.nets = C;
+    for (int c = 0; c < kMaxCritics; ++c) ad.clip[c] = (float)a->cfg.grad_clip;
+    if (kind == GCRL_AGENT_TD3) ad.clip[0] = -1.f;  // critic_1 is not clipped (src/agent.py:201)
+    ad.polyak = (variant & V_POLYAK_C) ? 1 : 0;
+    ad.metric_index = MET_CRITIC_GRAD;
+    TRY(launch_adam(st, ad));
+  }
+  if (kind == GCRL_AGENT_TQC) {
+    // q_value metric from the UPDATED critics (src/agent.py:1016-1019)
+    Launches re;
+    for (int c = 0; c < C; ++c)
+      chain_mlp(a, re, 0, a->critic, a->P_critic(c), a->sa, a->ldx, a->slot_x, hid_TC, c, a->qt + (long long)c * B, 1, 0, EPI_NONE, B);
+    TRY(re.run(st));
+    TRY(launch_mean_metric(st, a->cur(), a->qt, C * B, 1.0f, a->metrics_dev, MET_Q));
+  }
+  if (kind == GCRL_AGENT_DDPG && (variant & V_POLYAK_A))  // before the actor step (src/agent.py:1397-1401)
+    TRY(launch_polyak(st, a->P_actor(), a->P_tactor(), a->actor.numel, a->cfg.tau));
+  if (!(variant & V_ACTOR)) return GCRL_OK;
+
+  const int nac = a->n_actor_critics();
+  // actor forward on s; its action lands in the action columns of spa
+  if (!a->sac) {
+    Launches af;
+    chain_mlp(a, af, 0, a->actor, a->P_actor(), a->spa, a->ldx, a->slot_x, hid_A, 0, a->spa + S, a->ldx, a->slot_x, EPI_TANH, B);
+    TRY(af.run(st));
+  } else {
+    TRY(sac_actor_forward(a, st, a->spa, a->slot_x, true, a->spa + S, a->slot_x, a->logp,
+                          (variant & V_EPSC) ? a->eps_cur_in : nullptr, 2, nullptr));
+  }
+  // stepped critic(s) on [s | pi(s)]
+  Launches c2;
+  for (int c = 0; c < nac; ++c)
+    chain_mlp(a, c2, 0, a->critic, a->P_critic(c), a->spa, a->ldx, a->slot_x, hid_C, c, a->q2 + (long long)c * B, 1, 0, EPI_NONE, B);
+  TRY(c2.run(st));
+  if (!a->sac) {
+    // actor_loss = -Q.mean(); dq2 holds the constant -1/B
+    TRY(launch_mean_metric(st, a->cur(), a->q2, B, -1.0f, a->metrics_dev, MET_ACTOR_LOSS));
+  } else {
+    ActorSelArgs as;
+    std::memset(&as, 0, sizeof(as));
+    as.cur = a->cur(); as.q = a->q2; as.logp = a->logp; as.dq = a->dq2; as.metrics = a->metrics_dev;
+    as.B = B; as.C = nac;
+    if (kind == GCRL_AGENT_SAC) { as.alpha_const = 0.2f; as.drop = 0; }
+    else { as.alpha_dev = a->alpha_dev; as.drop = a->cfg.top_drop; }
+    TRY(launch_actor_select(st, as));
+  }
+  // input gradient of the critic(s) down to the action columns
+  Launches cb;
+  for (int c = 0; c < nac; ++c) {
+    const float* P = a->P_critic(c);
+    for (int l = L; l >= 1; --l) {
+      const float* G = l == L ? a->dq2 + (long long)c * B : a->gC_at(c, l & 1);
+      cb.add((size_t)(L - l), bwd_dx(G, l == L ? 1 : H, P, a->critic.lin[l], 0, H, a->gC_at(c, (l - 1) & 1), H, B,
+                                     MUL_DLEAKY, a->hC_at(c, l - 1), H));
+    }
+    GemmDesc d0 = bwd_dx(a->gC_at(c, 0), H, P, a->critic.lin[0], S, A, a->dact + (long long)c * B * a->Apad, a->Apad, B,
+                         a->sac ? MUL_NONE : MUL_DTANH, a->sac ? nullptr : a->spa + S, a->ldx);
+    if (!a->sac) { d0.slot = a->slot_ptr(); d0.h_slot = a->slot_x; }
+    cb.add((size_t)L, d0);
+  }
+  TRY(cb.run(st));
+
+  float* Ga = a->G_actor();
+  const float* Pa = a->P_actor();
+  if (!a->sac) {
+    Launches ab;
+    for (int l = L; l >= 0; --l) {
+      const size_t at = (size_t)(L - l);
+      const float* G = l == L ? a->dact : a->gA[l & 1];
+      const long long ldg = l == L ? a->Apad : H;
+      GemmDesc dw = bwd_dw(G, ldg, l == 0 ? a->spa : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
+      if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
+      ab.add(at, dw);
+      if (l > 0) ab.add(at, bwd_dx(G, ldg, Pa, a->actor.lin[l], 0, H, a->gA[(l - 1) & 1], H, B, MUL_DLEAKY, a->hA_at(l - 1), H));
+    }
+    TRY(ab.run(st));
+  } else {
+    TanhGaussBwdArgs tb;
+    std::memset(&tb, 0, sizeof(tb));
+    tb.dact = a->dact; tb.C = nac; tb.ld_dact = a->Apad; tb.dact_stride = (long long)B * a->Apad;
+    tb.act = a->spa + S; tb.act_slot_stride = a->slot_x; tb.ld_act = a->ldx; tb.cur = a->cur();
+    tb.eps = a->epsbuf; tb.std = a->stdbuf; tb.ls_raw = a->headA + a->Apad; tb.ld_head = 2 * a->Apad;
+    if (kind == GCRL_AGENT_SAC) tb.alpha_const = 0.2f; else tb.alpha_dev = a->alpha_dev;
+    tb.gmu = a->ghead; tb.gls = a->ghead + a->Apad; tb.ld_g = 2 * a->Apad;
+    tb.B = B; tb.A = A;
+    TRY(launch_tanh_gauss_bwd(st, tb));
+    {
+      const int ldg = 2 * a->Apad;
+      std::vector<GemmDesc> v;
+      v.push_back(bwd_dw(a->ghead, ldg, a->hA_at(L - 1), H, Ga, a->actor.lin[L], B));
+      v.push_back(bwd_dw(a->ghead + a->Apad, ldg, a->hA_at(L - 1), H, Ga, a->actor.lin[L + 1], B));
+      v.push_back(bwd_dx(a->ghead, ldg, Pa, a->actor.lin[L], 0, H, a->gA[0], H, B, MUL_NONE, nullptr, 0));
+      v.push_back(bwd_dx(a->ghead + a->Apad, ldg, Pa, a->actor.lin[L + 1], 0, H, a->dh2, H, B, MUL_NONE, nullptr, 0));
+      TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
+    }
+    for (int l = L - 1; l >= 0; --l) {
+      const float* dh = l == L - 1 ? a->gA[0] : a->gA[(l + 1) & 1];
+      // (dh for layer l<L-1 was written by the dX of layer l+1 into gA[(l+1)&1])
+      TRY(launch_bn_relu_bwd(st, dh, l == L - 1 ? a->dh2 : nullptr, a->hA_at(l), a->xhatA + (long long)l * B * H,
+                             a->invstdA + (long long)l * H, Pa + a->actor.bn_g[l], B, H, a->zA, Ga + a->actor.bn_g[l],
+                             Ga + a->actor.bn_b[l]));
+      std::vector<GemmDesc> v;
+      GemmDesc dw = bwd_dw(a->zA, H, l == 0 ? a->spa : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
+      if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
+      v.push_back(dw);
+      if (l > 0) v.push_back(bwd_dx(a->zA, H, Pa, a->actor.lin[l], 0, H, a->gA[l & 1], H, B, MUL_NONE, nullptr, 0));
+      TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
+    }
+    // log-alpha gradient + loss metric (the optimiser step itself is in phase 2)
+    AlphaArgs al;
+    std::memset(&al, 0, sizeof(al));
+    al.cur = a->cur(); al.logp = a->logp; al.B = B;
+    al.target_entropy = kind == GCRL_AGENT_SAC ? -0.5f * (float)A : -(float)A;  // src/agent.py:424, :820
+    al.log_alpha = a->P_logalpha(); al.m = a->adam_m + a->goff_alpha; al.v = a->adam_v + a->goff_alpha;
+    al.alpha = a->alpha_dev; al.grad_out = a->grads + a->goff_alpha;
+    al.metrics = a->metrics_dev; al.phase = 0;
+    TRY(launch_alpha_update(st, al));
+  }
+  return GCRL_OK;
+}
+
+// ---------------------------------------------------------------- phase 2
+int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
+  if (!(variant & V_ACTOR)) return GCRL_OK;
+  const int kind = a->cfg.kind;
+  TRY(launch_sumsq(st, a->G_actor(), a->actor.numel, 0, 1, a->norm_partial));
+  AdamArgs ad;
+  std::memset(&ad, 0, sizeof(ad));
+  adam_common(a, ad);
+  ad.which = 0;
+  ad.p = a->P_actor(); ad.g = a->G_actor();
+  ad.m = a->adam_m + a->goff_actor; ad.v = a->adam_v + a->goff_actor;
+  ad.n = a->actor.numel; ad.net_stride = 0; ad.nets = 1;
+  for (int c = 0; c < kMaxCritics; ++c) ad.clip[c] = (float)a->cfg.grad_clip;
+  if (kind == GCRL_AGENT_TD3 && (variant & V_POLYAK_A)) { ad.target = a->P_tactor(); ad.polyak = 1; }
+  ad.metric_index = MET_ACTOR_GRAD;
+  TRY(launch_adam(st, ad));
+  if (a->sac) {
+    AlphaArgs al;
+    std::memset(&al, 0, sizeof(al));
+    al.cur = a->cur(); al.logp = a->logp; al.B = a->B;
+    al.log_alpha = a->P_logalpha(); al.m = a->adam_m + a->goff_alpha; al.v = a->adam_v + a->goff_alpha;
+    al.alpha = a->alpha_dev; al.grad_out = a->grads + a->goff_alpha;
+    al.beta2 = (float)kBeta2; al.w1 = (float)(1.0 - kBeta1); al.w2 = (float)(1.0 - kBeta2); al.eps = (float)kAdamEps;
+    al.metrics = a->metrics_dev; al.phase = 1;
+    TRY(launch_alpha_update(st, al));
+  }
+  return GCRL_OK;
+}
+
+int enqueue_phases(gcrl_agent* a, hipStream_t st, int variant, int mask) {
+  if (mask & 1) TRY(enqueue_phase0(a, st, variant));
+  if (mask & 2) TRY(enqueue_phase1(a, st, variant));
+  if (mask & 4) TRY(enqueue_phase2(a, st, variant));
+  return GCRL_OK;
+}
+
+int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask) {
+  if (!a->cfg.use_graph) return enqueue_phases(a, st, variant, mask);
+  const int key = variant | (mask << 8);
+  auto it = a->graphs.find(key);
+  if (it == a->graphs.end()) {
+    hipGraph_t g = nullptr;
+    GCRL_HIP(hipStreamBeginCapture(a->cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_phases(a, a->cap_stream, variant, mask);
+    hipError_t e = hipStreamEndCapture(a->cap_stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    GCRL_HIP(e);
+    hipGraphExec_t ex = nullptr;
+    GCRL_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    it = a->graphs.emplace(key, ex).first;
+  }
+  GCRL_HIP(hipGraphLaunch(it->second, st));
+  return GCRL_OK;
+}
+
+// ---------------------------------------------------------------- per-step host bookkeeping
+struct StepPlan { int variant; int tuple_len; };
+
+StepPlan plan_step(gcrl_agent* a, int64_t step, float grad_scale, int batch_slot, int64_t ticket, StepCtrl* sc) {
+  const gcrl_agent_config& c = a->cfg;
+  StepPlan p{0, 0};
+  const bool do_actor = (step % c.ac_update_freq) == 0;
+  if (do_actor) p.variant |= V_ACTOR;
+  switch (c.kind) {
+    case GCRL_AGENT_DDPG:
+      if (step % c.polyak_every == 0) p.variant |= V_POLYAK_C | V_POLYAK_A;
+      p.tuple_len = do_actor ? 6 : 4;
+      break;
+    case GCRL_AGENT_TD3:
+      p.variant |= V_POLYAK_C;
+      if (do_actor) p.variant |= V_POLYAK_A;
+      p.tuple_len = do_actor ? 8 : 6;
+      break;
+    case GCRL_AGENT_SAC:
+      if (step % c.gradient_step == 0) p.variant |= V_POLYAK_C;
+      p.tuple_len = do_actor ? 9 : 6;
+      break;
+    default:
+      p.variant |= V_POLYAK_C;
+      p.tuple_len = do_actor ? 9 : 6;
+      break;
+  }
+  const bool adamw = c.kind != GCRL_AGENT_DDPG;  // DDPG: Adam; others AdamW, weight_decay 0.01
+  std::memset(sc, 0, sizeof(*sc));
+  auto fill = [&](int64_t t, double lr, float* step_size, float* bc2s, float* decay) {
+    *step_size = (float)(lr / (1.0 - std::pow(kBeta1, (double)t)));
+    *bc2s = (float)std::sqrt(1.0 - std::pow(kBeta2, (double)t));
+    *decay = adamw ? (float)(1.0 - lr * kWeightDecay) : 1.0f;
+  };
+  // critics step every update; lr = value after (t-1) scheduler steps
+  a->t_critic++;
+  fill(a->t_critic, a->lr_critic, &sc->step_size_critic, &sc->bc2s_critic, &sc->decay_critic);
+  a->lr_critic = gcrl_cosine_lr_next(a->lr_critic, c.critic_lr, c.critic_lr_min, c.cr_scheduler_steps, a->t_critic);
+  sc->step_size_actor = 0.f; sc->bc2s_actor = 1.f; sc->decay_actor = 1.f;
+  sc->step_size_alpha = 0.f; sc->bc2s_alpha = 1.f; sc->decay_alpha = 1.f;
+  if (do_actor) {
+    a->t_actor++;
+    fill(a->t_actor, a->lr_actor, &sc->step_size_actor, &sc->bc2s_actor, &sc->decay_actor);
+    a->lr_actor = gcrl_cosine_lr_next(a->lr_actor, c.actor_lr, c.actor_lr_min, c.ac_scheduler_steps, a->t_actor);
+    if (a->sac && (double)step > c.alpha_min_steps) {
+      sc->do_alpha = 1;
+      a->t_alpha++;
+      fill(a->t_alpha, c.alpha_lr, &sc->step_size_alpha, &sc->bc2s_alpha, &sc->decay_alpha);
+    }
+  }
+  sc->grad_scale = grad_scale;
+  sc->batch_slot = batch_slot;
+  sc->metrics_slot = (int)(ticket % kMetricSlots);
+  sc->rng_hi = (unsigned int)(a->rng_ctr >> 32);
+  sc->rng_lo = (unsigned int)(a->rng_ctr & 0xffffffffu);
+  a->rng_ctr += (uint64_t)a->B * 16;
+  return p;
+}
+
+int stage_injected(gcrl_agent* a, const gcrl_update_inputs* in, hipStream_t st, int* vbits) {
+  const int B = a->B, S = a->S, A = a->A;
+  if (in->s_dev) {
+    GCRL_CHECK_ARG(in->a_dev && in->r_dev && in->ns_dev && in->d_dev, "update: injected batch needs s, a, r, ns, d");
+    GCRL_CHECK_ARG(in->ld_s >= S && in->ld_ns >= S && in->ld_a >= A, "update: injected batch row stride too small");
+    const int n = B * (2 * S + A + 2);
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in->s_dev, in->ld_s, in->a_dev,
+                       in->ld_a, in->r_dev, in->ns_dev, in->ld_ns, in->d_dev, B, S, A, a->ldx, a->sa, a->nsa, a->spa,
+                       a->rbuf, a->dbuf);
+    GCRL_HIP(hipGetLastError());
+  }
+  const size_t nb = (size_t)B * A * sizeof(float);
+  if (in->noise_dev) { GCRL_HIP(hipMemcpyAsync(a->noise_in, in->noise_dev, nb, hipMemcpyDeviceToDevice, st)); *vbits |= V_NOISE; }
+  if (in->eps_next_dev) { GCRL_HIP(hipMemcpyAsync(a->eps_next_in, in->eps_next_dev, nb, hipMemcpyDeviceToDevice, st)); *vbits |= V_EPSN; }
+  if (in->eps_cur_dev) { GCRL_HIP(hipMemcpyAsync(a->eps_cur_in, in->eps_cur_dev, nb, hipMemcpyDeviceToDevice, st)); *vbits |= V_EPSC; }
+  return GCRL_OK;
+}
+
+// phase-0 entry of `n` steps: control table + indices upload, batch gather / pack
+int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_update_inputs* in, float grad_scale,
+               hipStream_t st, std::vector<StepPlan>& plans, int64_t* tickets, int32_t* lens) {
+  GCRL_CHECK_ARG(n >= 1 && n <= kMaxStepsPerCall && n <= a->Mmax, "update: n=%d steps per call (max %d)", n, std::min(kMaxStepsPerCall, a->Mmax));
+  const bool injected = in && in->s_dev;
+  GCRL_CHECK_ARG(injected || her, "update: neither a replay ring nor an injected batch was given");
+  GCRL_CHECK_ARG(!injected || n == 1, "update: an injected batch drives exactly one step");
+  if (!injected) {
+    GCRL_CHECK_ARG(her->S == a->S && her->A == a->A, "update: ring dims (S=%d,A=%d) differ from the agent's (S=%d,A=%d)", her->S, her->A, a->S, a->A);
+    if (her->len < a->B) return fail(GCRL_ERR_NOT_ENOUGH, "[ERROR] Not enough in buffer to sample");
+  }
+  const int slot = a->next_upload;
+  a->next_upload = (slot + 1) % kCtrlSlots;
+  GCRL_HIP(hipEventSynchronize(a->upload_ev[slot]));
+  UploadBlock* ub = (UploadBlock*)a->upload_pinned[slot];
+  uint32_t* idx = (uint32_t*)(a->upload_pinned[slot] + sizeof(UploadBlock));
+  ub->cb.cursor = 0;
+  plans.resize(n);
+  StepCtrl* table = ub->cb.table;
+  for (int i = 0; i < n; ++i) {
+    const int64_t ticket = a->next_ticket++;
+    plans[i] = plan_step(a, step0 + i, grad_scale, i, ticket, &table[i]);
+    a->ticket_len[ticket % kMetricSlots] = plans[i].tuple_len;
+    if (tickets) tickets[i] = ticket;
+    if (lens) lens[i] = plans[i].tuple_len;
+  }
+  ub->cb.cur = table[0];
+  size_t bytes = sizeof(UploadBlock);
+  if (!injected) {
+    for (int i = 0; i < n; ++i) {
+      if (her->cfg.rng_mode == GCRL_RNG_CPYTHON_MT) {
+        TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)a->B, idx + (size_t)i * a->B));
+      } else {
+        uint32_t* out = idx + (size_t)i * a->B;
+        uint64_t ctr = 0;
+        for (int k = 0; k < a->B;) {
+          uint32_t j = hash_below(her->cfg.seed ^ 0x5bd1e995u, her->draws_done, ctr++, (uint32_t)her->len);
+          bool dup = false;
+          for (int q = 0; q < k; ++q) if (out[q] == j) { dup = true; break; }
+          if (!dup) out[k++] = j;
+        }
+        her->draws_done++;
+      }
+    }
+    bytes += (size_t)n * a->B * sizeof(uint32_t);
+  }
+  GCRL_HIP(hipMemcpyAsync(a->upload_dev, ub, bytes, hipMemcpyHostToDevice, st));
+  GCRL_HIP(hipEventRecord(a->upload_ev[slot], st));
+  if (!injected)
+    TRY(her_gather_update(her, a->idx_dev(), (int64_t)n * a->B, a->sa, a->nsa, a->spa, a->ldx, a->rbuf, a->dbuf, st));
+  return GCRL_OK;
+}
+
+int end_call(gcrl_agent* a, hipStream_t st) {
+  const int e = (int)(a->calls % kEventRing);
+  GCRL_HIP(hipEventRecord(a->call_ev[e], st));
+  a->call_last_ticket[e] = a->next_ticket - 1;
+  a->calls++;
+  return GCRL_OK;
+}
+
+int bytes_alloc(float** p, long long n) {
+  GCRL_HIP(hipMalloc((void**)p, (size_t)n * sizeof(float)));
+  GCRL_HIP(hipMemset(*p, 0, (size_t)n * sizeof(float)));
+  return GCRL_OK;
+}
+
+int build(gcrl_agent* a) {
+  const gcrl_agent_config& c = a->cfg;
+  GCRL_HIP(hipSetDevice(c.device));
+  GCRL_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+  GCRL_HIP(hipStreamCreateWithFlags(&a->cap_stream, hipStreamNonBlocking));
+  const int S = a->S, A = a->A, H = a->H, L = a->L, B = a->B, C = a->C;
+  a->actor = make_net(S, H, L, A, a->sac);
+  a->critic = make_net(S + A, H, L, 1, false);
+  a->critic_stride = align_up(a->critic.numel, 64);
+  const long long na = align_up(a->actor.numel, 64);
+  // params: actor | target_actor | critics | target critics | log_alpha
+  long long off = 0;
+  a->off_actor = off; off += na;
+  a->off_tactor = off; if (a->has_target_actor) off += na;
+  a->off_critic = off; off += C * a->critic_stride;
+  a->off_tcritic = off; off += C * a->critic_stride;
+  a->off_logalpha = off; off += 64;
+  a->n_params = off;
+  // grads / moments: critics | actor | log_alpha   (each DP exchange block is contiguous)
+  off = 0;
+  a->goff_critic = off; off += C * a->critic_stride;
+  a->goff_actor = off; off += na;
+  a->goff_alpha = off; off += 64;
+  a->n_grads = off;
+  TRY(bytes_alloc(&a->params, a->n_params));
+  TRY(bytes_alloc(&a->grads, a->n_grads));
+  TRY(bytes_alloc(&a->adam_m, a->n_grads));
+  TRY(bytes_alloc(&a->adam_v, a->n_grads));
+  TRY(bytes_alloc(&a->bn_rmean, (long long)std::max(1, L * H)));
+  TRY(bytes_alloc(&a->bn_rvar, (long long)std::max(1, L * H)));
+  TRY(bytes_alloc(&a->alpha_dev, 64));
+
+  // work buffers
+  const long long BH = (long long)B * H;
+  std::vector<std::pair<float**, long long>> wants = {
+      {&a->sa, a->Mmax * a->slot_x}, {&a->nsa, a->Mmax * a->slot_x}, {&a->spa, a->Mmax * a->slot_x},
+      {&a->rbuf, (long long)a->Mmax * B}, {&a->dbuf, (long long)a->Mmax * B},
+      {&a->hTA[0], BH}, {&a->hTA[1], BH}, {&a->hA, L * BH}, {&a->hC, (long long)C * L * BH},
+      {&a->hTC, (long long)C * 2 * BH}, {&a->gC, (long long)C * 2 * BH}, {&a->gA[0], BH}, {&a->gA[1], BH},
+      {&a->q, (long long)C * B}, {&a->qt, (long long)C * B}, {&a->q2, (long long)C * B}, {&a->dq, (long long)C * B},
+      {&a->dq2, (long long)C * B}, {&a->dact, (long long)C * B * a->Apad}, {&a->zA, BH}, {&a->xhatA, L * BH},
+      {&a->invstdA, (long long)L * H}, {&a->headA, (long long)B * 2 * a->Apad}, {&a->ghead, (long long)B * 2 * a->Apad},
+      {&a->dh2, BH}, {&a->logp, B}, {&a->logp_next, B}, {&a->epsbuf, (long long)B * A}, {&a->stdbuf, (long long)B * A},
+      {&a->noise_in, (long long)B * A}, {&a->eps_next_in, (long long)B * A}, {&a->eps_cur_in, (long long)B * A},
+      {&a->norm_partial, (long long)kMaxCritics * kNormBlocks}, {&a->act_in, (long long)B * a->ldx},
+      {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH}};
+  long long total = 0;
+  for (auto& w : wants) total += align_up(w.second, 64);
+  TRY(bytes_alloc(&a->work, total));
+  long long used = 0;
+  for (auto& w : wants) { *w.first = a->work + used; used += align_up(w.second, 64); }
+
+  // upload block + pinned mirrors, metrics, events
+  a->upload_bytes = sizeof(UploadBlock) + (size_t)kMaxStepsPerCall * B * sizeof(uint32_t);
+  GCRL_HIP(hipMalloc((void**)&a->upload_dev, a->upload_bytes));
+  GCRL_HIP(hipMemset(a->upload_dev, 0, a->upload_bytes));
+  for (int i = 0; i < kCtrlSlots; ++i) {
+    GCRL_HIP(hipHostMalloc((void**)&a->upload_pinned[i], a->upload_bytes, hipHostMallocDefault));
+    GCRL_HIP(hipEventCreateWithFlags(&a->upload_ev[i], hipEventDisableTiming));
+  }
+  for (int i = 0; i < kEventRing; ++i) {
+    GCRL_HIP(hipEventCreateWithFlags(&a->call_ev[i], hipEventDisableTiming));
+    a->call_last_ticket[i] = -1;
+  }
+  GCRL_HIP(hipHostMalloc((void**)&a->metrics_host, (size_t)kMetricSlots * kMetricFloats * sizeof(float), hipHostMallocMapped));
+  std::memset(a->metrics_host, 0, (size_t)kMetricSlots * kMetricFloats * sizeof(float));
+  GCRL_HIP(hipHostGetDevicePointer((void**)&a->metrics_dev, a->metrics_host, 0));
+  a->ticket_len.assign(kMetricSlots, 0);
+
+  // constant upstream gradient of -Q.mean()
+  TRY(launch_fill(a->stream, a->dq2, (long long)C * B, -1.0f / (float)B));
+  TRY(launch_fill(a->stream, a->alpha_dev, 1, 1.0f));  // exp(log_alpha = 0)
+  GCRL_HIP(hipStreamSynchronize(a->stream));
+
+  // names
+  auto reg = [&](const std::string& k, float* p, long long n) { a->names[k] = {p, n}; };
+  reg("actor", a->P_actor(), a->actor.numel);
+  reg("grad:actor", a->G_actor(), a->actor.numel);
+  reg("adam_m:actor", a->adam_m + a->goff_actor, a->actor.numel);
+  reg("adam_v:actor", a->adam_v + a->goff_actor, a->actor.numel);
+  if (a->has_target_actor) reg("target_actor", a->P_tactor(), a->actor.numel);
+  for (int i = 0; i < C; ++i) {
+    const std::string s = std::to_string(i);
+    reg("critic_" + s, a->P_critic(i), a->critic.numel);
+    reg("target_critic_" + s, a->P_tcritic(i), a->critic.numel);
+    reg("grad:critic_" + s, a->G_critic(i), a->critic.numel);
+    reg("adam_m:critic_" + s, a->adam_m + a->goff_critic + i * a->critic_stride, a->critic.numel);
+    reg("adam_v:critic_" + s, a->adam_v + a->goff_critic + i * a->critic_stride, a->critic.numel);
+  }
+  if (a->sac) {
+    reg("log_alpha", a->P_logalpha(), 1);
+    reg("grad:log_alpha", a->grads + a->goff_alpha, 1);
+    reg("adam_m:log_alpha", a->adam_m + a->goff_alpha, 1);
+    reg("adam_v:log_alpha", a->adam_v + a->goff_alpha, 1);
+    reg("alpha", a->alpha_dev, 1);
+    reg("bn_running_mean", a->bn_rmean, (long long)L * H);
+    reg("bn_running_var", a->bn_rvar, (long long)L * H);
+  }
+  return GCRL_OK;
+}
+
+void xavier_fill(std::vector<float>& p, const NetSpec& net, std::mt19937_64& gen, bool touch_bn) {
+  for (const Lin& ln : net.lin) {
+    const double bound = std::sqrt(6.0 / (double)(ln.in + ln.out));  // nn.init.xavier_uniform_
+    std::uniform_real_distribution<double> u(-bound, bound);
+    for (long long i = 0; i < (long long)ln.in * ln.out; ++i) p[ln.w + i] = (float)u(gen);
+    for (int i = 0; i < ln.out; ++i) p[ln.b + i] = 0.01f;  // bias.data.fill_(0.01)
+  }
+  if (touch_bn)
+    for (size_t l = 0; l < net.bn_g.size(); ++l)
+      for (int i = 0; i < net.H; ++i) { p[net.bn_g[l] + i] = 1.f; p[net.bn_b[l] + i] = 0.f; }
+}
+
+}  // namespace
+
+extern "C" {
+
+gcrl_agent* gcrl_agent_create(const gcrl_agent_config* cfg) {
+  auto bad = [](const char* m) -> gcrl_agent* { fail(GCRL_ERR_ARG, "gcrl_agent_create: %s", m); return nullptr; };
+  if (!cfg) return bad("null config");
+  if (cfg->kind < GCRL_AGENT_DDPG || cfg->kind > GCRL_AGENT_TQC) return bad("unknown agent kind");
+  if (cfg->obs_dim < 1 || cfg->ac_dim < 1 || cfg->ac_dim > 16) return bad("obs_dim >= 1 and 1 <= ac_dim <= 16 required");
+  if (cfg->hidden_dim < 1 || cfg->layer_count < 1 || cfg->layer_count > 8) return bad("hidden_dim >= 1, 1 <= layer_count <= 8 required");
+  if (cfg->batch_size < 1 || cfg->batch_size > 65536) return bad("batch_size must be 1..65536");
+  if (cfg->ac_update_freq < 1 || cfg->gradient_step < 1 || cfg->polyak_every < 1) return bad("ac_update_freq, gradient_step, polyak_every must be >= 1");
+  int C = 1;
+  if (cfg->kind == GCRL_AGENT_TD3 || cfg->kind == GCRL_AGENT_SAC) C = 2;
+  if (cfg->kind == GCRL_AGENT_TQC) {
+    C = cfg->num_critics;
+    if (C < 2 || C > kMaxCritics) return bad("TQC needs 2..8 critics");
+    if (cfg->top_drop < 0 || cfg->top_drop >= C) return bad("top_drop must be in [0, num_critics)");
+  }
+  int ndev = gcrl_device_count();
+  if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    fail(GCRL_ERR_HIP, "gcrl_agent_create: no usable HIP device (count=%d, requested %d); there is no CPU fallback", ndev, cfg->device);
+    return nullptr;
+  }
+  gcrl_agent* a = new gcrl_agent;
+  a->cfg = *cfg;
+  a->S = cfg->obs_dim; a->A = cfg->ac_dim; a->H = cfg->hidden_dim; a->L = cfg->layer_count;
+  a->B = cfg->batch_size; a->C = C;
+  a->ldx = round_up(a->S + a->A, 4);
+  a->Apad = round_up(a->A, 4);
+  a->Mmax = std::min(kMaxStepsPerCall, std::max(1, cfg->gradient_step));
+  a->slot_x = (long long)a->B * a->ldx;
+  a->slot_rd = a->B;
+  a->sac = cfg->kind == GCRL_AGENT_SAC || cfg->kind == GCRL_AGENT_TQC;
+  a->has_target_actor = !a->sac;
+  a->lr_actor = cfg->actor_lr;
+  a->lr_critic = cfg->critic_lr;
+  if (build(a) != GCRL_OK) { gcrl_agent_destroy(a); return nullptr; }
+  if (gcrl_agent_init_weights(a, cfg->seed, 1) != GCRL_OK) { gcrl_agent_destroy(a); return nullptr; }
+  return a;
+}
+
+void gcrl_agent_destroy(gcrl_agent* a) {
+  if (!a) return;
+  if (a->stream) (void)hipStreamSynchronize(a->stream);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
+  float* bufs[] = {a->params, a->grads, a->adam_m, a->adam_v, a->bn_rmean, a->bn_rvar, a->alpha_dev, a->work};
+  for (float* p : bufs) if (p) (void)hipFree(p);
+  if (a->upload_dev) (void)hipFree(a->upload_dev);
+  for (int i = 0; i < kCtrlSlots; ++i) {
+    if (a->upload_pinned[i]) (void)hipHostFree(a->upload_pinned[i]);
+    if (a->upload_ev[i]) (void)hipEventDestroy(a->upload_ev[i]);
+  }
+  for (int i = 0; i < kEventRing; ++i) if (a->call_ev[i]) (void)hipEventDestroy(a->call_ev[i]);
+  if (a->metrics_host) (void)hipHostFree(a->metrics_host);
+  if (a->stream) (void)hipStreamDestroy(a->stream);
+  if (a->cap_stream) (void)hipStreamDestroy(a->cap_stream);
+  delete a;
+}
+
+void* gcrl_agent_stream(const gcrl_agent* a) { return a ? (void*)a->stream : nullptr; }
+
+int64_t gcrl_agent_numel(const gcrl_agent* a, const char* name) {
+  if (!a || !name) return -1;
+  auto it = a->names.find(name);
+  return it == a->names.end() ? -1 : it->second.second;
+}
+
+int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr, int64_t* numel) {
+  GCRL_CHECK_ARG(a && name && ptr, "gcrl_agent_dev_ptr: null argument");
+  auto it = a->names.find(name);
+  GCRL_CHECK_ARG(it != a->names.end(), "unknown vector name '%s'", name);
+  *ptr = it->second.first;
+  if (numel) *numel = it->second.second;
+  return GCRL_OK;
+}
+
+int gcrl_agent_get(gcrl_agent* a, const char* name, float* dst, int64_t n) {
+  float* p = nullptr; int64_t numel = 0;
+  TRY(gcrl_agent_dev_ptr(a, name, &p, &numel));
+  GCRL_CHECK_ARG(dst && n == numel, "gcrl_agent_get('%s'): n=%lld but the vector has %lld elements", name, (long long)n, (long long)numel);
+  GCRL_HIP(hipDeviceSynchronize());
+  GCRL_HIP(hipMemcpy(dst, p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return GCRL_OK;
+}
+
+int gcrl_agent_set(gcrl_agent* a, const char* name, const float* src, int64_t n) {
+  float* p = nullptr; int64_t numel = 0;
+  TRY(gcrl_agent_dev_ptr(a, name, &p, &numel));
+  GCRL_CHECK_ARG(src && n == numel, "gcrl_agent_set('%s'): n=%lld but the vector has %lld elements", name, (long long)n, (long long)numel);
+  GCRL_HIP(hipDeviceSynchronize());
+  GCRL_HIP(hipMemcpy(p, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  if (std::string(name) == "log_alpha") {  // keep alpha = exp(log_alpha) coherent (src/agent.py:106, :878)
+    const float al = std::exp(src[0]);
+    GCRL_HIP(hipMemcpy(a->alpha_dev, &al, sizeof(float), hipMemcpyHostToDevice));
+  }
+  return GCRL_OK;
+}
+
+int gcrl_agent_init_weights(gcrl_agent* a, uint64_t seed, int recreate_alpha) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_init_weights: null handle");
+  GCRL_HIP(hipDeviceSynchronize());
+  std::mt19937_64 gen(seed * 0x9e3779b97f4a7c15ull + 12345);
+  const bool first = a->t_critic == 0 && a->t_actor == 0;
+  std::vector<float> host;
+  auto push = [&](const NetSpec& net, float* dev, bool bn_too) -> int {
+    host.assign((size_t)net.numel, 0.f);
+    if (!bn_too && net.sac) GCRL_HIP(hipMemcpy(host.data(), dev, (size_t)net.numel * sizeof(float), hipMemcpyDeviceToHost));
+    xavier_fill(host, net, gen, bn_too);
+    GCRL_HIP(hipMemcpy(dev, host.data(), (size_t)net.numel * sizeof(float), hipMemcpyHostToDevice));
+    return GCRL_OK;
+  };
+  // reset() re-initialises Linear layers of every network, targets included, independently
+  // (src/agent.py:1461-1465); BatchNorm affine/statistics only at construction
+  TRY(push(a->actor, a->P_actor(), first));
+  if (a->has_target_actor) TRY(push(a->actor, a->P_tactor(), first));
+  for (int c = 0; c < a->C; ++c) TRY(push(a->critic, a->P_critic(c), false));
+  for (int c = 0; c < a->C; ++c) TRY(push(a->critic, a->P_tcritic(c), false));
+  if (first) {
+    TRY(gcrl_agent_hard_update_targets(a));
+    std::vector<float> ones((size_t)std::max(1, a->L * a->H), 1.f);
+    GCRL_HIP(hipMemcpy(a->bn_rvar, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+    GCRL_HIP(hipMemset(a->bn_rmean, 0, ones.size() * sizeof(float)));
+  }
+  if (a->sac && recreate_alpha) {
+    const float zero = 0.f, one = 1.f;
+    GCRL_HIP(hipMemcpy(a->P_logalpha(), &zero, sizeof(float), hipMemcpyHostToDevice));
+    GCRL_HIP(hipMemcpy(a->alpha_dev, &one, sizeof(float), hipMemcpyHostToDevice));
+    GCRL_HIP(hipMemset(a->adam_m + a->goff_alpha, 0, sizeof(float)));
+    GCRL_HIP(hipMemset(a->adam_v + a->goff_alpha, 0, sizeof(float)));
+    a->t_alpha = 0;
+  }
+  return GCRL_OK;
+}
+
+int gcrl_agent_hard_update_targets(gcrl_agent* a) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_hard_update_targets: null handle");
+  GCRL_HIP(hipDeviceSynchronize());
+  if (a->has_target_actor)
+    GCRL_HIP(hipMemcpy(a->P_tactor(), a->P_actor(), (size_t)a->actor.numel * sizeof(float), hipMemcpyDeviceToDevice));
+  GCRL_HIP(hipMemcpy(a->P_tcritic(0), a->P_critic(0), (size_t)a->C * a->critic_stride * sizeof(float), hipMemcpyDeviceToDevice));
+  return GCRL_OK;
+}
+
+int gcrl_agent_update(gcrl_agent* a, gcrl_her* her, int64_t step, const gcrl_update_inputs* in, int64_t* ticket_out, void* stream) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_update: null handle");
+  hipStream_t st = a->pick(stream);
+  std::vector<StepPlan> plans;
+  int32_t len = 0;
+  TRY(begin_call(a, her, step, 1, in, 1.0f, st, plans, ticket_out, &len));
+  int variant = plans[0].variant;
+  if (in) TRY(stage_injected(a, in, st, &variant));
+  TRY(run_step(a, st, variant, 7));
+  TRY(end_call(a, st));
+  return len;
+}
+
+int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int64_t* tickets_out, int32_t* lens_out, void* stream) {
+  GCRL_CHECK_ARG(a && her, "gcrl_agent_update_n: null handle");
+  GCRL_CHECK_ARG(n >= 1, "gcrl_agent_update_n: n must be >= 1");
+  hipStream_t st = a->pick(stream);
+  const int chunk = std::min(kMaxStepsPerCall, a->Mmax);
+  for (int done = 0; done < n; done += chunk) {
+    const int m = std::min(chunk, n - done);
+    std::vector<StepPlan> plans;
+    TRY(begin_call(a, her, step0 + done, m, nullptr, 1.0f, st, plans, tickets_out ? tickets_out + done : nullptr,
+                   lens_out ? lens_out + done : nullptr));
+    for (int i = 0; i < m; ++i) TRY(run_step(a, st, plans[i].variant, 7));
+    TRY(end_call(a, st));
+  }
+  return GCRL_OK;
+}
+
+int gcrl_agent_update_phase(gcrl_agent* a, gcrl_her* her, int64_t step, int phase, const gcrl_update_inputs* in,
+                            float grad_scale, int64_t* ticket_out, void* stream) {
+  GCRL_CHECK_ARG(a && phase >= 0 && phase <= 2, "gcrl_agent_update_phase: bad arguments");
+  hipStream_t st = a->pick(stream);
+  int len = 0;
+  if (phase == 0) {
+    std::vector<StepPlan> plans;
+    int32_t l = 0;
+    TRY(begin_call(a, her, step, 1, in, grad_scale, st, plans, ticket_out, &l));
+    int variant = plans[0].variant;
+    if (in) TRY(stage_injected(a, in, st, &variant));
+    a->pending_variant = variant;
+    len = l;
+  }
+  TRY(run_step(a, st, a->pending_variant, 1 << phase));
+  if (phase == 2) TRY(end_call(a, st));
+  return len;
+}
+
+int gcrl_agent_grad_ptr(gcrl_agent* a, int phase, float** ptr, int64_t* numel) {
+  GCRL_CHECK_ARG(a && ptr && numel && (phase == 0 || phase == 1), "gcrl_agent_grad_ptr: phase must be 0 or 1");
+  if (phase == 0) { *ptr = a->grads + a->goff_critic; *numel = a->C * a->critic_stride; }
+  else { *ptr = a->grads + a->goff_actor; *numel = (a->goff_alpha - a->goff_actor) + (a->sac ? 1 : 0); }
+  return GCRL_OK;
+}
+
+int gcrl_agent_metrics(gcrl_agent* a, int64_t ticket, double* out, int n) {
+  GCRL_CHECK_ARG(a && out, "gcrl_agent_metrics: null argument");
+  GCRL_CHECK_ARG(ticket >= 0 && ticket < a->next_ticket && ticket >= a->next_ticket - kMetricSlots, "gcrl_agent_metrics: ticket %lld is not live", (long long)ticket);
+  const int len = a->ticket_len[ticket % kMetricSlots];
+  GCRL_CHECK_ARG(n == len, "gcrl_agent_metrics: this step's tuple has %d entries, %d requested", len, n);
+  // wait for the call that produced the ticket (the oldest recorded call covering it)
+  int64_t best = -1;
+  const int64_t lo = std::max<int64_t>(0, a->calls - kEventRing);
+  for (int64_t cidx = lo; cidx < a->calls; ++cidx)
+    if (a->call_last_ticket[cidx % kEventRing] >= ticket) { best = cidx; break; }
+  if (best >= 0) GCRL_HIP(hipEventSynchronize(a->call_ev[best % kEventRing]));
+  else GCRL_HIP(hipDeviceSynchronize());
+  const volatile float* m = a->metrics_host + (ticket % kMetricSlots) * kMetricFloats;
+  const int C = a->C;
+  auto meanv = [&](int base) { double s = 0; for (int c = 0; c < C; ++c) s += (double)m[base + c]; return s / C; };
+  const bool act = (a->cfg.kind == GCRL_AGENT_DDPG) ? len == 6 : (a->cfg.kind == GCRL_AGENT_TD3 ? len == 8 : len == 9);
+  int o = 0;
+  switch (a->cfg.kind) {
+    case GCRL_AGENT_DDPG:  // (critic_loss, [ac_loss,] td_error, q_value, critic_grad [, ac_grad])
+      out[o++] = m[MET_CRITIC_LOSS];
+      if (act) out[o++] = m[MET_ACTOR_LOSS];
+      out[o++] = m[MET_TD]; out[o++] = m[MET_Q]; out[o++] = m[MET_CRITIC_GRAD];
+      if (act) out[o++] = m[MET_ACTOR_GRAD];
+      break;
+    case GCRL_AGENT_TD3:
+    case GCRL_AGENT_SAC:
+    default: {
+      const bool tqc = a->cfg.kind == GCRL_AGENT_TQC;
+      const double l1 = tqc ? meanv(MET_CRITIC_LOSS) : m[MET_CRITIC_LOSS];
+      const double l2 = tqc ? l1 : m[MET_CRITIC_LOSS + 1];
+      const double g1 = tqc ? meanv(MET_CRITIC_GRAD) : m[MET_CRITIC_GRAD];
+      const double g2 = tqc ? g1 : m[MET_CRITIC_GRAD + 1];
+      out[o++] = l1; out[o++] = l2;
+      if (act) out[o++] = m[MET_ACTOR_LOSS];
+      out[o++] = m[MET_TD]; out[o++] = m[MET_Q]; out[o++] = g1; out[o++] = g2;
+      if (act) out[o++] = m[MET_ACTOR_GRAD];
+      if (act && a->cfg.kind != GCRL_AGENT_TD3) out[o++] = m[MET_ALPHA_LOSS];
+      break;
+    }
+  }
+  return GCRL_OK;
+}
+
+int gcrl_agent_act(gcrl_agent* a, const float* obs, int n, int ld_obs, float* out, int ld_out, const float* eps, void* stream) {
+  GCRL_CHECK_ARG(a && obs && out && n >= 1 && ld_obs >= a->S && ld_out >= a->A, "gcrl_agent_act: bad arguments");
+  hipStream_t st = a->pick(stream);
+  const int H = a->H, L = a->L;
+  for (int r0 = 0; r0 < n; r0 += a->B) {
+    const int rows = std::min(a->B, n - r0);
+    const float* X = obs + (long long)r0 * ld_obs;
+    float* Y = out + (long long)r0 * ld_out;
+    if (!a->sac) {
+      Launches ls;
+      chain_mlp(a, ls, 0, a->actor, a->P_actor(), X, ld_obs, 0, hid_ACT, 0, Y, ld_out, 0, EPI_TANH, rows);
+      TRY(ls.run(st));
+    } else {
+      const float* P = a->P_actor();
+      for (int l = 0; l < L; ++l) {
+        GemmDesc d = fwd(l == 0 ? X : a->act_tmp[(l - 1) & 1], l == 0 ? ld_obs : H, P, a->actor.lin[l], a->zA, H, rows, EPI_NONE);
+        TRY(launch_gemm_batch(st, &d, 1));
+        TRY(launch_bn_relu_eval(st, a->zA, rows, H, P + a->actor.bn_g[l], P + a->actor.bn_b[l], a->bn_rmean + (long long)l * H,
+                                a->bn_rvar + (long long)l * H, a->act_tmp[l & 1]));
+      }
+      const int ldh = 2 * a->Apad;
+      GemmDesc hd[2] = {fwd(a->act_tmp[(L - 1) & 1], H, P, a->actor.lin[L], a->headA, ldh, rows, EPI_NONE),
+                        fwd(a->act_tmp[(L - 1) & 1], H, P, a->actor.lin[L + 1], a->headA + a->Apad, ldh, rows, EPI_NONE)};
+      TRY(launch_gemm_batch(st, hd, 2));
+      TanhGaussArgs tg;
+      std::memset(&tg, 0, sizeof(tg));
+      tg.cur = a->cur();
+      tg.mu = a->headA; tg.ls_raw = a->headA + a->Apad; tg.ld_head = ldh;
+      tg.eps = eps ? eps + (long long)r0 * a->A : nullptr;
+      tg.act = Y; tg.act_slot_stride = 0; tg.ld_act = ld_out;
+      tg.B = rows; tg.A = a->A;
+      tg.deterministic = eps ? 0 : 1;
+      TRY(launch_tanh_gauss_fwd(st, tg));
+    }
+  }
+  return GCRL_OK;
+}
+
+}  // extern "C"

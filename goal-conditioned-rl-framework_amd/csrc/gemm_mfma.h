@@ -1,0 +1,221 @@
+// gemm_mfma.h — batched small-GEMM kernel on the gfx950 fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact f32 fma chains, 64 FLOP/clk/SIMD).
+//
+// Every Linear layer of the reference's networks (src/model.py:18,57,63,106,114-115) and its
+// backward is one problem of the form  C[M,N] = epilogue(A[M,K] . B[K,N])  with arbitrary
+// element strides, so the same kernel serves
+//   forward   Y  = act(X W^T + b)            A = X  (k contiguous)   B(k,n) = W[n][k]
+//   dX        G' = (G W) * act'(H_prev)      A = G  (k contiguous)   B(k,n) = W[k][n]
+//   dW | db   dW = G^T [X | 1]               A(m,k) = G[k][m]        B(k,n) = X[k][n], col N-1 = 1
+// Up to kMaxProb independent problems (twin / ensemble critics, target and online nets of the
+// same layer depth) share one launch; a wavefront owns a (16*TM)x(16*TN) tile.
+//
+// k-permutation: lane (i = lane&15, g = lane>>4) loads FOUR consecutive k (one 16-byte load
+// when the operand is k-contiguous) at k0+4g..k0+4g+3 and issues four MFMAs, MFMA t consuming
+// element t of both fragments; the instruction's own k index (lane>>4) then stands for
+// k0+4g+t, and A and B agree on it, which is all the contraction needs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace gcrl {
+
+constexpr int kMaxProb = 12;
+
+enum { EPI_NONE = 0, EPI_LEAKY = 1, EPI_RELU = 2, EPI_TANH = 3 };
+enum { MUL_NONE = 0, MUL_DLEAKY = 1, MUL_DRELU = 2, MUL_DTANH = 3 };
+
+struct GemmDesc {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;  // + bias[n] before the activation (may be null)
+  const float* H;     // MUL_*: multiply by act'(H[m*h_rs + n]) (H = saved post-activation)
+  float* col_out;     // ones_col: column N-1 of the result goes to col_out[m] (bias gradient)
+  long long a_rs, a_cs, b_rs, b_cs, c_rs, h_rs;
+  int M, N, K;
+  int epi, mul;
+  int ones_col;  // B(k, N-1) := 1
+  // batch-slot indirection: the step's kernels are replayed from a hipGraph with frozen
+  // pointers, so operands that live in the pre-gathered batch array are addressed as
+  // base + (*slot) * stride, `slot` pointing at the current step's batch_slot on the device
+  const int* slot;
+  long long a_slot, b_slot, c_slot, h_slot;
+  int a_vec, b_vec;  // 16-byte loads legal along k (filled by the launcher)
+  int tile0, tiles_n, ntiles;  // filled by the launcher
+};
+
+struct GemmBatch {
+  int n;
+  GemmDesc d[kMaxProb];
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ inline float act_apply(float v, int epi) {
+  switch (epi) {
+    case EPI_LEAKY: return v > 0.f ? v : 0.01f * v;  // nn.LeakyReLU() default slope
+    case EPI_RELU: return v > 0.f ? v : 0.f;
+    case EPI_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+__device__ inline float act_deriv(float h, int mul) {
+  switch (mul) {
+    case MUL_DLEAKY: return h > 0.f ? 1.f : 0.01f;
+    case MUL_DRELU: return h > 0.f ? 1.f : 0.f;
+    case MUL_DTANH: return 1.f - h * h;
+    default: return 1.f;
+  }
+}
+
+template <int TM, int TN, int KSPLIT>
+__global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
+  static_assert(KSPLIT == 1 || (TM == 1 && TN == 1), "k-split only for single 16x16 tiles");
+  constexpr int NACC = (TM * TN >= 4) ? 1 : (TM * TN == 2 ? 2 : 4);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wtile = (KSPLIT == 4) ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxProb; ++q)
+    if (q < gb.n && wtile >= gb.d[q].tile0) pi = q;
+  const GemmDesc& d = gb.d[pi];
+  const int t = wtile - d.tile0;
+  const bool active = t < d.ntiles;
+  if (KSPLIT == 1 && !active) return;
+
+  const int M = d.M, N = d.N, K = d.K;
+  const int tn = active ? t % d.tiles_n : 0, tm = active ? t / d.tiles_n : 0;
+  const int m0 = tm * 16 * TM, n0 = tn * 16 * TN;
+  const int li = lane & 15, lg = lane >> 4;
+  const long long sl = d.slot ? (long long)*d.slot : 0;
+  const float* __restrict__ A = d.A + sl * d.a_slot;
+  const float* __restrict__ Bm = d.B + sl * d.b_slot;
+  const long long a_rs = d.a_rs, a_cs = d.a_cs, b_rs = d.b_rs, b_cs = d.b_cs;
+  const bool a_vec = d.a_vec, b_vec = d.b_vec;
+  const int ones_col = d.ones_col;
+
+  const int kchunks = (K + 15) >> 4;
+  int kc_beg = 0, kc_end = kchunks;
+  if (KSPLIT == 4) {
+    const int per = (kchunks + 3) >> 2;
+    kc_beg = wave * per;
+    kc_end = min(kchunks, kc_beg + per);
+  }
+
+  v4f acc[TM][TN][NACC];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) acc[i][j][q] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  // row / column bases of this lane's fragments (clamped: out-of-range rows are computed on
+  // valid memory and dropped at the store)
+  const float* ap[TM];
+  const float* bp[TN];
+  bool bone[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ap[i] = A + (long long)min(m0 + 16 * i + li, M - 1) * a_rs;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + 16 * j + li;
+    bone[j] = ones_col && (n == N - 1);
+    const int nmax = ones_col ? N - 2 : N - 1;
+    bp[j] = Bm + (long long)min(n, nmax) * b_cs;
+  }
+
+  if (active) {
+#pragma unroll 2
+    for (int kc = kc_beg; kc < kc_end; ++kc) {
+      const int kb = (kc << 4) + (lg << 2);
+      const bool full = kb + 3 < K;
+      float a[TM][4], b[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float* p = ap[i] + (long long)kb * a_cs;
+        if (a_vec && full) {
+          const float4 v = *reinterpret_cast<const float4*>(p);
+          a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[i][q] = (kb + q < K) ? p[q * a_cs] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float* p = bp[j] + (long long)kb * b_rs;
+        if (b_vec && full) {
+          const float4 v = *reinterpret_cast<const float4*>(p);
+          b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) b[j][q] = (kb + q < K) ? p[q * b_rs] : 0.f;
+        }
+        if (bone[j]) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) b[j][q] = (kb + q < K) ? 1.f : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j][q % NACC] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j][q % NACC], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 1; q < NACC; ++q) acc[i][j][0] += acc[i][j][q];
+
+  const float* __restrict__ bias = d.bias;
+  const float* __restrict__ H = d.H + sl * d.h_slot;
+  float* __restrict__ C = d.C + sl * d.c_slot;
+  const int epi = d.epi, mul = d.mul;
+
+  auto finish = [&](float v, int m, int n) {
+    if (m >= M || n >= N) return;
+    if (bias) v += bias[n];
+    v = act_apply(v, epi);
+    if (mul != MUL_NONE) v *= act_deriv(H[(long long)m * d.h_rs + n], mul);
+    if (ones_col && n == N - 1) d.col_out[m] = v;
+    else C[(long long)m * d.c_rs + n] = v;
+  };
+
+  if (KSPLIT == 4) {
+    // four waves hold k-partials of the same 16x16 tile: exchange through LDS, wave w
+    // finishes accumulator register w (row 4*(lane>>4)+w of the tile)
+    __shared__ float red[4][4][64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[0][0][0][r];
+    __syncthreads();
+    if (!active) return;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[w][wave][lane];
+    finish(v, m0 + 4 * lg + wave, n0 + li);
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          finish(acc[i][j][0][r], m0 + 16 * i + 4 * lg + r, n0 + 16 * j + li);
+  }
+}
+
+// Launch `n` problems in one grid.  shape: 0 = auto.
+int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape = 0);
+
+}  // namespace gcrl

@@ -1,0 +1,96 @@
+// her_ring.h — internal view of the HER replay ring (shared with the update engine).
+//
+// HBM layout.  One transition = one packed record of RS floats, 64-byte aligned:
+//     [ s (S) | a (A) | ns (S) | r | d | zero pad ]            RS = roundup(2S+A+2, 16)
+// Records are contiguous in arrival order: ring[cap][RS].  A uniformly random row gather then
+// touches ceil(4*RS/128) whole 128-B lines per row (PickAndPlace: 2 lines for 208 useful
+// bytes) where five separate field arrays would touch 6-7; and [s|a] is already the critic's
+// input row.  Logical index j (0 = oldest, what random.sample indexes in the reference's
+// deque, src/buffer.py:124) lives at physical row (head + j) mod cap; head/len are host state.
+//
+// Staging: per env, up to flush_len records of RG = roundup(2S+A+2+G, 16) floats:
+//     [ s | a | ns | r | d | ag (G) | pad ]       (the dg column is the goal slot of s itself)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace gcrl {
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// uniform integer in [0, n) from a 64-bit counter hash — the device-RNG ("fast") mode of the
+// future-index pick and of the batch draw.  Restated bit-for-bit in oracle/her_oracle.py.
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline uint32_t hash_below(uint64_t seed, uint64_t stream, uint64_t ctr,
+                                                uint32_t n) {
+  uint64_t h = mix64(mix64(seed ^ (stream * 0xd1342543de82ef95ull)) + ctr);
+  return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);  // multiply-high range reduction
+}
+
+}  // namespace gcrl
+
+struct gcrl_her {
+  gcrl_her_config cfg;
+  int S, A, G, W, RS, RG;
+  gcrl_mt* rng = nullptr;
+  bool own_rng = false;
+  hipStream_t stream = nullptr;
+
+  float* ring = nullptr;   // [cap][RS]
+  float* stage = nullptr;  // [nenvs][flush_len][RG]
+  int64_t head = 0, len = 0;
+  std::vector<int> staged;
+  uint64_t episodes_flushed = 0;  // stream id of the device RNG
+  uint64_t draws_done = 0;        // batch-draw counter of the device RNG
+  uint64_t mutation_epoch = 0;    // bumped by every flush
+
+  // index upload: pinned host slots -> idx_dev
+  static constexpr int kSlots = 8;
+  uint32_t* idx_pinned[kSlots] = {};
+  hipEvent_t slot_ev[kSlots] = {};
+  size_t slot_rows = 0;
+  int next_slot = 0;
+  uint32_t* idx_dev = nullptr;
+  size_t idx_dev_rows = 0;
+  // pinned slots for whole-episode uploads
+  float* epi_pinned[kSlots] = {};
+  hipEvent_t epi_ev[kSlots] = {};
+  int next_epi_slot = 0;
+
+  // gather-launch timing (gcrl_her_profile_*)
+  bool prof = false;
+  std::vector<hipEvent_t> prof_a, prof_b;
+  size_t prof_used = 0;
+  int64_t prof_launches = 0, prof_rows = 0;
+  double prof_ms = 0.0;
+
+  // NULL -> the handle's own stream; GCRL_STREAM_LEGACY -> HIP's legacy default stream
+  hipStream_t pick(void* s) const {
+    if (!s) return stream;
+    if (s == GCRL_STREAM_LEGACY) return (hipStream_t) nullptr;
+    return (hipStream_t)s;
+  }
+};
+
+namespace gcrl {
+
+// Draw M*B logical indices (random.sample semantics per batch) into a pinned slot and upload
+// them to h->idx_dev on `st`.  idx_host != NULL: use those instead of drawing.  Returns the
+// pinned host copy through *host_copy (valid until kSlots more uploads).
+int her_upload_indices(gcrl_her* h, int B, int M, const uint32_t* idx_host, hipStream_t st,
+                       const uint32_t** host_copy);
+
+// Gather for the update engine: rows idx_dev[0..n) -> three GEMM-ready matrices with row
+// stride ldx = roundup(S+A,4): sa = [s|a], nsa = [ns|0..], spa = [s|0..]; r[n], d[n].
+int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa, float* nsa,
+                      float* spa, int ldx, float* r, float* d, hipStream_t st);
+
+}  // namespace gcrl

@@ -1,0 +1,610 @@
+// her_ring.hip — HER replay ring in HBM: staging, relabel+flush kernel, batch gather kernels.
+//
+// Replaces reference class HERBuffer (src/buffer.py:92-179):
+//   push      src/buffer.py:110-119  -> gcrl_her_push / gcrl_her_push_episode (+ stage kernel)
+//   apply_her src/buffer.py:143-179  -> her_flush_kernel (LDS-staged goal swap + reward)
+//   sample    src/buffer.py:121-135  -> gcrl_her_sample (her_gather_kernel)
+// Record layout and ring indexing: her_ring.h.
+#include "her_ring.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int kMaxT = 64;          // flush_len limit (reference literal is 50)
+constexpr int kMaxG = 8;
+constexpr int kMaxInline = 128;    // S limit for host-pointer pushes (values travel as kernargs)
+constexpr int kMaxFut = 2048;      // k_future*(T-1) limit for inline future indices
+constexpr int kMaxEp = 8;          // episodes per flush launch
+constexpr int kStepsPerBlock = 4;
+
+// ---------------------------------------------------------------- stage one transition
+struct StageArgs {
+  float* dst;            // record base: stage[env][t][0]
+  const float* s_dev;    // device source or nullptr -> s_inl
+  const float* ns_dev;
+  int S, A, G;
+  float r, d;
+  float a[16];
+  float ag[kMaxG];
+  float s_inl[kMaxInline];
+  float ns_inl[kMaxInline];
+};
+
+__global__ __launch_bounds__(64) void her_stage_kernel(StageArgs p) {
+  const int W = 2 * p.S + p.A + 2;
+  for (int c = threadIdx.x; c < W + p.G; c += 64) {
+    float v;
+    if (c < p.S) v = p.s_dev ? p.s_dev[c] : p.s_inl[c];
+    else if (c < p.S + p.A) v = p.a[c - p.S];
+    else if (c < 2 * p.S + p.A) {
+      int k = c - p.S - p.A;
+      v = p.ns_dev ? p.ns_dev[k] : p.ns_inl[k];
+    } else if (c == W - 2) v = p.r;
+    else if (c == W - 1) v = p.d;
+    else v = p.ag[c - W];
+    p.dst[c] = v;
+  }
+}
+
+// ---------------------------------------------------------------- relabel + flush
+struct FlushArgs {
+  float* ring;
+  long long cap, tail, skip;  // rows whose running number is < skip fell off a too-small ring
+  int nep, k, S, A, G, W, RS, RG;
+  int reward_kind;
+  float thr;
+  int rng_mode;
+  unsigned long long seed;
+  const float* stage[kMaxEp];
+  int T[kMaxEp];
+  unsigned long long epi_id[kMaxEp];
+  int fut_off[kMaxEp];
+  uint8_t fut[kMaxFut];
+};
+
+// grid.x = ceil(maxT / kStepsPerBlock), grid.y = episode.  Each block:
+//   (1) exclusive scan of per-episode output-row counts (one wavefront, cross-lane shifts)
+//       -> first row number of its episode (segment base of the multi-episode flush);
+//   (2) stages its steps' records and the whole achieved-goal column of the episode in LDS;
+//   (3) writes the original row and the k relabelled rows of each of its steps; relabel =
+//       goal slot of s and ns swapped for ag[f] from LDS, reward recomputed, done = 0
+//       (src/buffer.py:151-179).
+__global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
+  __shared__ float ag_lds[kMaxT * kMaxG];
+  __shared__ float rec_lds[kStepsPerBlock][160];
+  __shared__ long long base_lds;
+
+  const int e = blockIdx.y;
+  const int T = p.T[e];
+  const int i0 = blockIdx.x * kStepsPerBlock;
+  if (i0 >= T) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  if (wave == 0) {
+    long long rows = 0;
+    if (lane < p.nep) rows = (long long)p.T[lane] + (long long)p.k * (p.T[lane] - 1);
+    long long incl = rows;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      long long up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane == e) base_lds = incl - rows;
+  }
+  const float* stg = p.stage[e];
+  for (int t = threadIdx.x; t < T * p.G; t += 256) ag_lds[t] = stg[(t / p.G) * p.RG + p.W + (t % p.G)];
+  const int nsteps = min(kStepsPerBlock, T - i0);
+  for (int t = threadIdx.x; t < nsteps * p.RG; t += 256) {
+    int li = t / p.RG, c = t - li * p.RG;
+    rec_lds[li][c] = stg[(long long)(i0 + li) * p.RG + c];
+  }
+  __syncthreads();
+  const long long base = base_lds;
+
+  const int reps = 1 + p.k;
+  for (int job = wave; job < nsteps * reps; job += 4) {
+    const int li = job / reps, rep = job - li * reps;
+    const int i = i0 + li;
+    if (rep > 0 && i >= T - 1) continue;  // last step: no relabels (src/buffer.py:152)
+    const long long g = base + (long long)i * reps + rep;
+    if (g < p.skip) continue;
+    const long long phys = (p.tail + g) % p.cap;
+    int f = 0;
+    float rew = rec_lds[li][p.W - 2], done = rec_lds[li][p.W - 1];
+    if (rep > 0) {
+      if (p.rng_mode == GCRL_RNG_CPYTHON_MT) f = p.fut[p.fut_off[e] + i * p.k + (rep - 1)];
+      else f = i + 1 + (int)gcrl::hash_below(p.seed, p.epi_id[e], (unsigned long long)(i * p.k + rep - 1), (uint32_t)(T - 1 - i));
+      // compute_reward(ag_i, ag_f): d = ||ag_i - ag_f||_2 in fp32, one rounding per op
+      float acc = 0.f;
+      for (int q = 0; q < p.G; ++q) {
+        float df = __fsub_rn(rec_lds[li][p.W + q], ag_lds[f * p.G + q]);
+        acc = __fadd_rn(acc, __fmul_rn(df, df));
+      }
+      float dist = __fsqrt_rn(acc);
+      rew = (p.reward_kind == GCRL_REWARD_SPARSE) ? ((dist > p.thr) ? -1.0f : -0.0f) : -dist;
+      done = 0.f;
+    }
+    float* out = p.ring + phys * p.RS;
+    const int gs0 = p.S - p.G;            // goal slot of s
+    const int gs1 = 2 * p.S + p.A - p.G;  // goal slot of ns
+    for (int c = lane; c < p.RS; c += 64) {
+      float v = 0.f;
+      if (c < p.W - 2) {
+        v = rec_lds[li][c];
+        if (rep > 0) {
+          if (c >= gs0 && c < p.S) v = ag_lds[f * p.G + (c - gs0)];
+          else if (c >= gs1) v = ag_lds[f * p.G + (c - gs1)];
+        }
+      } else if (c == p.W - 2) v = rew;
+      else if (c == p.W - 1) v = done;
+      out[c] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- gather (public sample)
+struct GatherArgs {
+  const float* ring;
+  const uint32_t* idx;  // logical indices
+  long long n, head, cap;
+  int S, A, RS;
+  float *out_s, *out_a, *out_r, *out_ns, *out_d;
+  int ld_s, ld_a, ld_ns;
+};
+
+// 16 lanes x float4 cover one <=64-float record, so one wave-load instruction fetches four
+// records (whole 128-B lines); each lane then routes its four floats to the dense outputs.
+template <int kUnroll>
+__global__ __launch_bounds__(256) void her_gather_kernel(GatherArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane >> 4, v4 = lane & 15;
+  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  const int W = 2 * p.S + p.A + 2;
+  const int chunks = (p.RS + 63) / 64;  // 64-float pieces per record
+  for (long long r0 = wave_id * (4 * kUnroll); r0 < p.n; r0 += nwaves * (4 * kUnroll)) {
+    for (int ch = 0; ch < chunks; ++ch) {
+      float4 val[kUnroll];
+      long long row[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        row[u] = r0 + u * 4 + sub;
+        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = ch * 64 + v4 * 4;
+        if (row[u] < p.n && c0 < p.RS) {
+          long long phys = (p.head + (long long)p.idx[row[u]]) % p.cap;
+          val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (row[u] >= p.n) continue;
+        const float vv[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = ch * 64 + v4 * 4 + q;
+          if (c >= W) continue;
+          if (c < p.S) p.out_s[row[u] * p.ld_s + c] = vv[q];
+          else if (c < p.S + p.A) p.out_a[row[u] * p.ld_a + (c - p.S)] = vv[q];
+          else if (c < W - 2) p.out_ns[row[u] * p.ld_ns + (c - p.S - p.A)] = vv[q];
+          else if (c == W - 2) p.out_r[row[u]] = vv[q];
+          else p.out_d[row[u]] = vv[q];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- gather (update engine)
+struct GatherUpdArgs {
+  const float* ring;
+  const uint32_t* idx;
+  long long n, head, cap;
+  int S, A, RS, ldx;
+  float *sa, *nsa, *spa, *r, *d;
+};
+
+__global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane >> 4, v4 = lane & 15;
+  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  const int W = 2 * p.S + p.A + 2;
+  const int chunks = (p.RS + 63) / 64;
+  for (long long r0 = wave_id * 4; r0 < p.n; r0 += nwaves * 4) {
+    const long long row = r0 + sub;
+    if (row >= p.n) continue;
+    const long long phys = (p.head + (long long)p.idx[row]) % p.cap;
+    for (int ch = 0; ch < chunks; ++ch) {
+      const int c0 = ch * 64 + v4 * 4;
+      if (c0 >= p.RS) continue;
+      const float4 val = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
+      const float vv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + q;
+        if (c >= W) continue;
+        if (c < p.S + p.A) {
+          p.sa[row * p.ldx + c] = vv[q];
+          if (c < p.S) p.spa[row * p.ldx + c] = vv[q];
+        } else if (c < W - 2) p.nsa[row * p.ldx + (c - p.S - p.A)] = vv[q];
+        else if (c == W - 2) p.r[row] = vv[q];
+        else p.d[row] = vv[q];
+      }
+    }
+  }
+}
+
+// rows [first, first+n) in logical order -> contiguous records (read_rows)
+__global__ void her_copy_rows_kernel(const float* ring, long long head, long long cap, int RS,
+                                     long long first, long long n, float* out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * RS) return;
+  long long row = t / RS;
+  int c = (int)(t - row * RS);
+  out[t] = ring[((head + first + row) % cap) * RS + c];
+}
+
+constexpr size_t kProfPairs = 256;
+
+int prof_drain(gcrl_her* h) {
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    float ms = 0.f;
+    GCRL_HIP(hipEventSynchronize(h->prof_b[i]));
+    GCRL_HIP(hipEventElapsedTime(&ms, h->prof_a[i], h->prof_b[i]));
+    h->prof_ms += ms;
+  }
+  h->prof_used = 0;
+  return GCRL_OK;
+}
+int prof_begin(gcrl_her* h, hipStream_t st) {
+  if (!h->prof) return GCRL_OK;
+  if (h->prof_used == kProfPairs)
+    if (int rc = prof_drain(h)) return rc;
+  GCRL_HIP(hipEventRecord(h->prof_a[h->prof_used], st));
+  return GCRL_OK;
+}
+int prof_end(gcrl_her* h, hipStream_t st, int64_t rows) {
+  if (!h->prof) return GCRL_OK;
+  GCRL_HIP(hipEventRecord(h->prof_b[h->prof_used], st));
+  h->prof_used++;
+  h->prof_launches++;
+  h->prof_rows += rows;
+  return GCRL_OK;
+}
+
+int ensure_index_capacity(gcrl_her* h, size_t rows) {
+  if (rows <= h->slot_rows && rows <= h->idx_dev_rows) return GCRL_OK;
+  GCRL_HIP(hipStreamSynchronize(h->stream));
+  GCRL_HIP(hipDeviceSynchronize());
+  size_t want = std::max<size_t>(rows, 4096);
+  for (int i = 0; i < gcrl_her::kSlots; ++i) {
+    if (h->idx_pinned[i]) GCRL_HIP(hipHostFree(h->idx_pinned[i]));
+    GCRL_HIP(hipHostMalloc((void**)&h->idx_pinned[i], want * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  if (h->idx_dev) GCRL_HIP(hipFree(h->idx_dev));
+  GCRL_HIP(hipMalloc((void**)&h->idx_dev, want * sizeof(uint32_t)));
+  h->slot_rows = h->idx_dev_rows = want;
+  return GCRL_OK;
+}
+
+int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uint8_t* const* futs,
+                 hipStream_t st, int64_t* rows_out) {
+  const gcrl_her_config& c = h->cfg;
+  FlushArgs fa;
+  std::memset(&fa, 0, sizeof(fa));
+  fa.ring = h->ring;
+  fa.cap = c.capacity;
+  fa.tail = (h->head + h->len) % c.capacity;
+  fa.nep = nep;
+  fa.k = c.k_future; fa.S = h->S; fa.A = h->A; fa.G = h->G; fa.W = h->W; fa.RS = h->RS; fa.RG = h->RG;
+  fa.reward_kind = c.reward_kind;
+  fa.thr = c.reward_threshold;
+  fa.rng_mode = c.rng_mode;
+  fa.seed = c.seed;
+  int64_t total = 0;
+  int fut_used = 0, maxT = 0;
+  for (int e = 0; e < nep; ++e) {
+    const int T = Ts[e];
+    fa.stage[e] = h->stage + ((size_t)envs[e] * c.flush_len) * h->RG;
+    fa.T[e] = T;
+    fa.epi_id[e] = h->episodes_flushed + e;
+    fa.fut_off[e] = fut_used;
+    const int nf = c.k_future * (T - 1);
+    if (c.rng_mode == GCRL_RNG_CPYTHON_MT) {
+      if (fut_used + nf > kMaxFut)
+        return gcrl::fail(GCRL_ERR_ARG, "flush: k_future*(T-1) = %d exceeds the inline limit %d", fut_used + nf, kMaxFut);
+      if (futs && futs[e]) std::memcpy(fa.fut + fut_used, futs[e], nf);
+      else if (int rc = gcrl_mt_future_indices(h->rng, T, c.k_future, fa.fut + fut_used)) return rc;
+      fut_used += nf;
+    }
+    total += T + (int64_t)c.k_future * (T - 1);
+    maxT = std::max(maxT, T);
+  }
+  fa.skip = total > c.capacity ? total - c.capacity : 0;
+  dim3 grid((maxT + kStepsPerBlock - 1) / kStepsPerBlock, nep);
+  hipLaunchKernelGGL(her_flush_kernel, grid, dim3(256), 0, st, fa);
+  GCRL_HIP(hipGetLastError());
+  // deque(maxlen) bookkeeping: append `total` rows, the oldest fall off the front
+  int64_t newlen = h->len + total;
+  if (newlen > c.capacity) {
+    h->head = (h->head + (newlen - c.capacity)) % c.capacity;
+    newlen = c.capacity;
+  }
+  h->len = newlen;
+  h->episodes_flushed += nep;
+  h->mutation_epoch++;
+  *rows_out = total;
+  return GCRL_OK;
+}
+
+}  // namespace
+
+namespace gcrl {
+
+int her_upload_indices(gcrl_her* h, int B, int M, const uint32_t* idx_host, hipStream_t st,
+                       const uint32_t** host_copy) {
+  const size_t rows = (size_t)B * M;
+  if (h->len < B) return fail(GCRL_ERR_NOT_ENOUGH, "[ERROR] Not enough in buffer to sample");
+  if (int rc = ensure_index_capacity(h, rows)) return rc;
+  const int slot = h->next_slot;
+  h->next_slot = (slot + 1) % gcrl_her::kSlots;
+  GCRL_HIP(hipEventSynchronize(h->slot_ev[slot]));  // previous upload from this slot is done
+  uint32_t* dst = h->idx_pinned[slot];
+  if (idx_host) {
+    for (size_t i = 0; i < rows; ++i) {
+      if (idx_host[i] >= (uint64_t)h->len) return fail(GCRL_ERR_ARG, "sample: index %u out of range (len %lld)", idx_host[i], (long long)h->len);
+      dst[i] = idx_host[i];
+    }
+  } else if (h->cfg.rng_mode == GCRL_RNG_CPYTHON_MT) {
+    for (int m = 0; m < M; ++m)
+      if (int rc = gcrl_mt_sample_indices(h->rng, (uint32_t)h->len, (uint32_t)B, dst + (size_t)m * B)) return rc;
+  } else {
+    // device-RNG mode: uniform WITH the hash stream; exact without-replacement comes from
+    // rejecting duplicates inside a batch, in draw order (restated in oracle/her_oracle.py)
+    for (int m = 0; m < M; ++m) {
+      uint32_t* out = dst + (size_t)m * B;
+      uint64_t ctr = 0;
+      for (int i = 0; i < B;) {
+        uint32_t j = hash_below(h->cfg.seed ^ 0x5bd1e995u, h->draws_done, ctr++, (uint32_t)h->len);
+        bool dup = false;
+        for (int q = 0; q < i; ++q) if (out[q] == j) { dup = true; break; }
+        if (!dup) out[i++] = j;
+      }
+      h->draws_done++;
+    }
+  }
+  GCRL_HIP(hipMemcpyAsync(h->idx_dev, dst, rows * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  GCRL_HIP(hipEventRecord(h->slot_ev[slot], st));
+  if (host_copy) *host_copy = dst;
+  return GCRL_OK;
+}
+
+int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa, float* nsa,
+                      float* spa, int ldx, float* r, float* d, hipStream_t st) {
+  GatherUpdArgs ga{h->ring, idx_dev, n, h->head, h->cfg.capacity, h->S, h->A, h->RS, ldx, sa, nsa, spa, r, d};
+  int blocks = (int)std::min<int64_t>((n + 15) / 16, 2048);
+  if (int rc = prof_begin(h, st)) return rc;
+  hipLaunchKernelGGL(her_gather_update_kernel, dim3(blocks), dim3(256), 0, st, ga);
+  GCRL_HIP(hipGetLastError());
+  return prof_end(h, st, n);
+}
+
+}  // namespace gcrl
+
+extern "C" {
+
+int gcrl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+gcrl_her* gcrl_her_create(const gcrl_her_config* cfg, gcrl_mt* rng) {
+  auto bad = [](const char* m) -> gcrl_her* { gcrl::fail(GCRL_ERR_ARG, "gcrl_her_create: %s", m); return nullptr; };
+  if (!cfg) return bad("null config");
+  if (cfg->state_dim < 1 || cfg->action_dim < 1 || cfg->action_dim > 16) return bad("state_dim >= 1 and 1 <= action_dim <= 16 required");
+  if (cfg->goal_dim < 1 || cfg->goal_dim > kMaxG || cfg->goal_dim > cfg->state_dim) return bad("goal_dim must be 1..8 and <= state_dim");
+  if (cfg->capacity < 1 || cfg->capacity >= (1ll << 32)) return bad("capacity must be in [1, 2^32)");
+  if (cfg->nenvs < 1 || cfg->k_future < 0) return bad("nenvs >= 1 and k_future >= 0 required");
+  if (cfg->flush_len < 1 || cfg->flush_len > kMaxT) return bad("flush_len must be 1..64");
+  if (2 * cfg->state_dim + cfg->action_dim + 2 + cfg->goal_dim > 160) return bad("record wider than 160 floats");
+  int ndev = gcrl_device_count();
+  if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    gcrl::fail(GCRL_ERR_HIP, "gcrl_her_create: no usable HIP device (count=%d, requested %d); there is no CPU fallback", ndev, cfg->device);
+    return nullptr;
+  }
+  gcrl_her* h = new gcrl_her;
+  h->cfg = *cfg;
+  h->S = cfg->state_dim; h->A = cfg->action_dim; h->G = cfg->goal_dim;
+  h->W = 2 * h->S + h->A + 2;
+  h->RS = gcrl::round_up(h->W, 16);
+  h->RG = gcrl::round_up(h->W + h->G, 16);
+  h->staged.assign(cfg->nenvs, 0);
+  if (rng) { h->rng = rng; h->own_rng = false; }
+  else { h->rng = gcrl_mt_create(); h->own_rng = true; gcrl_mt_seed(h->rng, cfg->seed); }
+  auto ok = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    gcrl::fail(GCRL_ERR_HIP, "gcrl_her_create: %s failed: %s", what, hipGetErrorString(e));
+    return false;
+  };
+  bool good = ok(hipSetDevice(cfg->device), "hipSetDevice") &&
+              ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate") &&
+              ok(hipMalloc((void**)&h->ring, (size_t)cfg->capacity * h->RS * sizeof(float)), "hipMalloc(ring)") &&
+              ok(hipMalloc((void**)&h->stage, (size_t)cfg->nenvs * cfg->flush_len * h->RG * sizeof(float)), "hipMalloc(stage)");
+  for (int i = 0; good && i < gcrl_her::kSlots; ++i) {
+    good = ok(hipEventCreateWithFlags(&h->slot_ev[i], hipEventDisableTiming), "hipEventCreate") &&
+           ok(hipEventCreateWithFlags(&h->epi_ev[i], hipEventDisableTiming), "hipEventCreate") &&
+           ok(hipHostMalloc((void**)&h->epi_pinned[i], (size_t)cfg->flush_len * h->RG * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+  }
+  if (good) good = ok(hipMemsetAsync(h->stage, 0, (size_t)cfg->nenvs * cfg->flush_len * h->RG * sizeof(float), h->stream), "hipMemset");
+  if (!good) { gcrl_her_destroy(h); return nullptr; }
+  return h;
+}
+
+void gcrl_her_destroy(gcrl_her* h) {
+  if (!h) return;
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int i = 0; i < gcrl_her::kSlots; ++i) {
+    if (h->idx_pinned[i]) (void)hipHostFree(h->idx_pinned[i]);
+    if (h->epi_pinned[i]) (void)hipHostFree(h->epi_pinned[i]);
+    if (h->slot_ev[i]) (void)hipEventDestroy(h->slot_ev[i]);
+    if (h->epi_ev[i]) (void)hipEventDestroy(h->epi_ev[i]);
+  }
+  for (hipEvent_t e : h->prof_a) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->prof_b) (void)hipEventDestroy(e);
+  if (h->idx_dev) (void)hipFree(h->idx_dev);
+  if (h->ring) (void)hipFree(h->ring);
+  if (h->stage) (void)hipFree(h->stage);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->own_rng) gcrl_mt_destroy(h->rng);
+  delete h;
+}
+
+int64_t gcrl_her_len(const gcrl_her* h) { return h ? h->len : 0; }
+int64_t gcrl_her_head(const gcrl_her* h) { return h ? h->head : 0; }
+int32_t gcrl_her_staged(const gcrl_her* h, int env) {
+  return (h && env >= 0 && env < h->cfg.nenvs) ? h->staged[env] : -1;
+}
+void* gcrl_her_stream(const gcrl_her* h) { return h ? (void*)h->stream : nullptr; }
+
+int64_t gcrl_her_push(gcrl_her* h, int env, const float* state, int state_on_device,
+                      const float* action_host, const float* next_state, int next_on_device,
+                      float reward, int done, const float* dg_host, const float* ag_host,
+                      void* stream) {
+  GCRL_CHECK_ARG(h && state && action_host && next_state && ag_host, "gcrl_her_push: null argument");
+  GCRL_CHECK_ARG(env >= 0 && env < h->cfg.nenvs, "gcrl_her_push: env %d out of range", env);
+  (void)dg_host;  // the desired goal is the goal slot of `state` itself (src/env.py:177-182)
+  if ((!state_on_device || !next_on_device) && h->S > kMaxInline)
+    return gcrl::fail(GCRL_ERR_ARG, "gcrl_her_push: host-pointer states support state_dim <= %d", kMaxInline);
+  hipStream_t st = h->pick(stream);
+  const int t = h->staged[env];
+  StageArgs sa;
+  sa.dst = h->stage + ((size_t)env * h->cfg.flush_len + t) * h->RG;
+  sa.s_dev = state_on_device ? state : nullptr;
+  sa.ns_dev = next_on_device ? next_state : nullptr;
+  sa.S = h->S; sa.A = h->A; sa.G = h->G;
+  sa.r = reward;
+  sa.d = done ? 1.0f : 0.0f;
+  std::memcpy(sa.a, action_host, sizeof(float) * h->A);
+  std::memcpy(sa.ag, ag_host, sizeof(float) * h->G);
+  if (!state_on_device) std::memcpy(sa.s_inl, state, sizeof(float) * h->S);
+  if (!next_on_device) std::memcpy(sa.ns_inl, next_state, sizeof(float) * h->S);
+  hipLaunchKernelGGL(her_stage_kernel, dim3(1), dim3(64), 0, st, sa);
+  GCRL_HIP(hipGetLastError());
+  h->staged[env] = t + 1;
+  if (done || h->staged[env] >= h->cfg.flush_len) {  // src/buffer.py:117
+    int64_t rows = 0;
+    const int T = h->staged[env];
+    if (int rc = launch_flush(h, 1, &env, &T, nullptr, st, &rows)) return rc;
+    h->staged[env] = 0;
+    return rows;
+  }
+  return 0;
+}
+
+int64_t gcrl_her_push_episode(gcrl_her* h, int env, int T, const float* s, const float* a,
+                              const float* ns, const float* r, const float* d, const float* ag,
+                              const uint8_t* fut, void* stream) {
+  GCRL_CHECK_ARG(h && s && a && ns && r && d && ag, "gcrl_her_push_episode: null argument");
+  GCRL_CHECK_ARG(env >= 0 && env < h->cfg.nenvs, "gcrl_her_push_episode: env %d out of range", env);
+  GCRL_CHECK_ARG(T >= 1 && T <= h->cfg.flush_len, "gcrl_her_push_episode: T=%d not in 1..%d", T, h->cfg.flush_len);
+  if (h->staged[env] != 0) return gcrl::fail(GCRL_ERR_STATE, "gcrl_her_push_episode: env %d has %d staged transitions", env, h->staged[env]);
+  hipStream_t st = h->pick(stream);
+  const int slot = h->next_epi_slot;
+  h->next_epi_slot = (slot + 1) % gcrl_her::kSlots;
+  GCRL_HIP(hipEventSynchronize(h->epi_ev[slot]));
+  float* buf = h->epi_pinned[slot];
+  std::memset(buf, 0, (size_t)T * h->RG * sizeof(float));
+  for (int t = 0; t < T; ++t) {
+    float* rec = buf + (size_t)t * h->RG;
+    std::memcpy(rec, s + (size_t)t * h->S, sizeof(float) * h->S);
+    std::memcpy(rec + h->S, a + (size_t)t * h->A, sizeof(float) * h->A);
+    std::memcpy(rec + h->S + h->A, ns + (size_t)t * h->S, sizeof(float) * h->S);
+    rec[h->W - 2] = r[t];
+    rec[h->W - 1] = d[t];
+    std::memcpy(rec + h->W, ag + (size_t)t * h->G, sizeof(float) * h->G);
+  }
+  float* dst = h->stage + ((size_t)env * h->cfg.flush_len) * h->RG;
+  GCRL_HIP(hipMemcpyAsync(dst, buf, (size_t)T * h->RG * sizeof(float), hipMemcpyHostToDevice, st));
+  GCRL_HIP(hipEventRecord(h->epi_ev[slot], st));
+  int64_t rows = 0;
+  const uint8_t* futs[1] = {fut};
+  if (int rc = launch_flush(h, 1, &env, &T, futs, st, &rows)) return rc;
+  return rows;
+}
+
+int gcrl_her_sample(gcrl_her* h, int B, int M, const uint32_t* idx_host, float* out_s, int ld_s,
+                    float* out_a, int ld_a, float* out_r, float* out_ns, int ld_ns,
+                    float* out_d, uint32_t* drawn_idx_host, void* stream) {
+  GCRL_CHECK_ARG(h && out_s && out_a && out_r && out_ns && out_d, "gcrl_her_sample: null output");
+  GCRL_CHECK_ARG(B >= 1 && M >= 1, "gcrl_her_sample: B and M must be >= 1");
+  GCRL_CHECK_ARG(ld_s >= h->S && ld_ns >= h->S && ld_a >= h->A, "gcrl_her_sample: row stride smaller than the row");
+  hipStream_t st = h->pick(stream);
+  const uint32_t* host_copy = nullptr;
+  if (int rc = gcrl::her_upload_indices(h, B, M, idx_host, st, &host_copy)) return rc;
+  if (drawn_idx_host) std::memcpy(drawn_idx_host, host_copy, (size_t)B * M * sizeof(uint32_t));
+  const long long n = (long long)B * M;
+  GatherArgs ga{h->ring, h->idx_dev, n, h->head, h->cfg.capacity, h->S, h->A, h->RS,
+                out_s, out_a, out_r, out_ns, out_d, ld_s, ld_a, ld_ns};
+  constexpr int kUnroll = 2;
+  int blocks = (int)std::min<long long>((n + 4 * 4 * kUnroll - 1) / (4 * 4 * kUnroll), 4096);
+  if (int rc = prof_begin(h, st)) return rc;
+  hipLaunchKernelGGL(her_gather_kernel<kUnroll>, dim3(blocks), dim3(256), 0, st, ga);
+  GCRL_HIP(hipGetLastError());
+  return prof_end(h, st, n);
+}
+
+int gcrl_her_profile_enable(gcrl_her* h, int on) {
+  GCRL_CHECK_ARG(h, "gcrl_her_profile_enable: null handle");
+  if (on && h->prof_a.empty()) {
+    h->prof_a.resize(kProfPairs);
+    h->prof_b.resize(kProfPairs);
+    for (size_t i = 0; i < kProfPairs; ++i) {
+      GCRL_HIP(hipEventCreate(&h->prof_a[i]));
+      GCRL_HIP(hipEventCreate(&h->prof_b[i]));
+    }
+  }
+  if (int rc = prof_drain(h)) return rc;
+  h->prof = on != 0;
+  h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0;
+  return GCRL_OK;
+}
+
+int gcrl_her_profile_read(gcrl_her* h, int64_t* launches, double* total_ms, int64_t* rows) {
+  GCRL_CHECK_ARG(h, "gcrl_her_profile_read: null handle");
+  if (int rc = prof_drain(h)) return rc;
+  if (launches) *launches = h->prof_launches;
+  if (total_ms) *total_ms = h->prof_ms;
+  if (rows) *rows = h->prof_rows;
+  return GCRL_OK;
+}
+
+int gcrl_her_read_rows(gcrl_her* h, int64_t first, int64_t n, float* s, float* a, float* ns,
+                       float* r, float* d) {
+  GCRL_CHECK_ARG(h, "gcrl_her_read_rows: null handle");
+  GCRL_CHECK_ARG(first >= 0 && n >= 0 && first + n <= h->len, "gcrl_her_read_rows: range [%lld,+%lld) outside len %lld", (long long)first, (long long)n, (long long)h->len);
+  if (n == 0) return GCRL_OK;
+  float* tmp = nullptr;
+  GCRL_HIP(hipMalloc((void**)&tmp, (size_t)n * h->RS * sizeof(float)));
+  long long total = n * h->RS;
+  hipLaunchKernelGGL(her_copy_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                     h->ring, (long long)h->head, (long long)h->cfg.capacity, h->RS, (long long)first, (long long)n, tmp);
+  std::vector<float> host((size_t)total);
+  hipError_t e = hipMemcpyAsync(host.data(), tmp, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(tmp);
+  GCRL_HIP(e);
+  for (int64_t i = 0; i < n; ++i) {
+    const float* rec = host.data() + (size_t)i * h->RS;
+    if (s) std::memcpy(s + (size_t)i * h->S, rec, sizeof(float) * h->S);
+    if (a) std::memcpy(a + (size_t)i * h->A, rec + h->S, sizeof(float) * h->A);
+    if (ns) std::memcpy(ns + (size_t)i * h->S, rec + h->S + h->A, sizeof(float) * h->S);
+    if (r) r[i] = rec[h->W - 2];
+    if (d) d[i] = rec[h->W - 1];
+  }
+  return GCRL_OK;
+}
+
+}  // extern "C"

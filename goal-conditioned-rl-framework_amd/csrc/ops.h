@@ -1,0 +1,178 @@
+// ops.h — non-GEMM kernels of the update step: TD target + critic loss, actor-loss pieces,
+// tanh-Gaussian head, BatchNorm1d, sort/truncate, gradient norm, Adam/AdamW + clip + Polyak.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace gcrl {
+
+constexpr int kMaxCritics = 8;
+constexpr int kMetricFloats = 32;   // one metrics record per update step (host-mapped memory)
+constexpr int kMetricSlots = 4096;
+// record layout
+enum {
+  MET_CRITIC_LOSS = 0,   // [0..7]  per-critic loss
+  MET_CRITIC_GRAD = 8,   // [8..15] per-critic post-clip gradient norm
+  MET_TD = 16,
+  MET_Q = 17,
+  MET_ACTOR_LOSS = 18,
+  MET_ACTOR_GRAD = 19,
+  MET_ALPHA_LOSS = 20,
+  MET_ALPHA = 21
+};
+
+// Per-step scalars.  The host uploads a table of these (one per step of an update_n call); the
+// first kernel of each step copies table[cursor++] to the fixed `cur` slot that all other
+// kernels of the (graph-replayed) step read.
+struct StepCtrl {
+  float step_size_actor, bc2s_actor, decay_actor;    // lr/(1-b1^t), sqrt(1-b2^t), 1-lr*wd
+  float step_size_critic, bc2s_critic, decay_critic;
+  float step_size_alpha, bc2s_alpha, decay_alpha;
+  float grad_scale;
+  int batch_slot;     // which pre-gathered batch this step consumes
+  int metrics_slot;
+  int do_alpha;       // SAC/TQC: step > alpha_min_steps
+  unsigned int rng_hi, rng_lo;  // device-RNG counter base of this step
+  int pad;
+};
+
+struct CtrlBlock {   // device layout: cursor, then cur, then the table
+  int cursor;
+  int pad[3];
+  StepCtrl cur;
+  StepCtrl table[1];
+};
+
+int launch_begin_step(hipStream_t st, CtrlBlock* cb);
+
+enum { LOSS_MSE = 0, LOSS_SMOOTH_L1 = 1 };
+enum { TGT_DDPG = 0, TGT_MIN = 1, TGT_MIN_ENT = 2, TGT_TRUNC_ENT = 3 };
+
+struct TdLossArgs {
+  const StepCtrl* cur;
+  const float* r;  const float* d;   // + cur->batch_slot * slot_stride
+  long long slot_stride;
+  const float* qt;          // [C][B] target-critic outputs
+  const float* q;           // [C][B] online-critic outputs
+  const float* logp_next;   // [B] (entropy targets) or null
+  const float* alpha_dev;   // device scalar alpha (TQC) or null -> alpha_const
+  float alpha_const;        // SAC: literal 0.2 (src/agent.py:569)
+  float* dq;                // [C][B]  dLoss_c/dq_c
+  float* metrics;           // host-mapped records
+  int B, C, drop, target_kind, loss_kind;
+  float gamma, clamp_lo;
+};
+int launch_td_loss(hipStream_t st, const TdLossArgs& a);
+
+// mean over [C][B] (actor loss of DDPG/TD3 = -mean(Q), TQC post-update q_value metric)
+int launch_mean_metric(hipStream_t st, const StepCtrl* cur, const float* x, int n, float scale,
+                       float* metrics, int metric_index);
+int launch_fill(hipStream_t st, float* x, long long n, float v);
+
+// TD3 target-policy smoothing (src/agent.py:174-179): act = clamp(act + clamp(eps*pn, +-nc), -1, 1)
+// act: [B, A] rows with stride ld inside the next-state critic input; eps: injected randn or
+// null (device RNG).
+int launch_td3_smooth(hipStream_t st, const StepCtrl* cur, float* act, long long slot_stride,
+                      int ld, int B, int A, const float* eps, float policy_noise,
+                      float noise_clamp, unsigned long long seed);
+
+// ---- optimiser -------------------------------------------------------------------------
+constexpr int kNormBlocks = 64;
+// partial[net][kNormBlocks] = sum of squares of block-strided chunks of g[net][n]
+int launch_sumsq(hipStream_t st, const float* g, long long n, long long net_stride, int nets,
+                 float* partial);
+
+struct AdamArgs {
+  const StepCtrl* cur;
+  int which;            // 0 actor, 1 critic, 2 alpha : selects the StepCtrl triple
+  float* p; const float* g; float* m; float* v;  // net i at + i*net_stride
+  float* target;        // Polyak destination (null: none), same stride
+  long long n, net_stride;
+  int nets;
+  const float* partial; // [nets][kNormBlocks] from launch_sumsq
+  float clip[kMaxCritics];   // per net max_norm; < 0: no clipping (TD3 critic_1, src/agent.py:201)
+  float beta2, w1, w2, eps;   // w = fp32(1 - beta) formed in double on the host, like torch
+  float tau, one_m_tau;
+  int polyak;           // 1: target = tau*p + (1-tau)*target after the step
+  float* metrics;       // post-clip grad norm -> metrics[slot][metric_index + net]
+  int metric_index;
+};
+int launch_adam(hipStream_t st, const AdamArgs& a);
+int launch_polyak(hipStream_t st, const float* p, float* target, long long n, double tau);
+
+// ---- SAC / TQC pieces (ops_sac.hip) -------------------------------------------------------
+// nn.BatchNorm1d in training mode followed by ReLU (src/model.py:106-108): z [B,H] -> h [B,H];
+// saves xhat [B,H] and invstd [H] when `xhat` is non-null; updates running_mean/var
+// (momentum 0.1, unbiased variance) in place.
+int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
+                       const float* beta, float* h, float* xhat, float* invstd,
+                       float* running_mean, float* running_var);
+// eval mode (running statistics): select_action path
+int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const float* gamma,
+                        const float* beta, const float* running_mean, const float* running_var,
+                        float* h);
+// backward of BN(train)+ReLU: dh -> dz, dgamma, dbeta
+int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* h, const float* xhat,
+                       const float* invstd, const float* gamma, int B, int H, float* dz,
+                       float* dgamma, float* dbeta);
+
+// SACActorModel.sample (src/model.py:125-141): mean/log_std head outputs -> action + log-prob.
+struct TanhGaussArgs {
+  const StepCtrl* cur;
+  const float* mu; const float* ls_raw; int ld_head;  // [B,A] head outputs
+  const float* eps;        // injected N(0,1) [B,A] or null (device RNG, stream id rng_stream)
+  float* act; long long act_slot_stride; int ld_act;  // destination rows (inside a critic input)
+  float* logp;             // [B]
+  float* save_eps; float* save_std;   // [B,A] (null in the no-grad pass)
+  int B, A;
+  int deterministic;       // act = tanh(mu), no log-prob
+  unsigned long long seed; int rng_stream;
+};
+int launch_tanh_gauss_fwd(hipStream_t st, const TanhGaussArgs& a);
+
+// actor loss of SAC/TQC: L = mean(alpha*logp - sel(q_c)) with sel = min (C=2) or mean of the
+// lowest C-drop of the sorted ensemble (src/agent.py:516-521, :916-925).  Writes
+// dq[c][b] = dL/dq_c(b) and the loss metric.
+struct ActorSelArgs {
+  const StepCtrl* cur;
+  const float* q;      // [C][B]
+  const float* logp;   // [B]
+  const float* alpha_dev; float alpha_const;
+  float* dq;           // [C][B]
+  float* metrics;
+  int B, C, drop;
+};
+int launch_actor_select(hipStream_t st, const ActorSelArgs& a);
+
+// backward of the tanh-Gaussian head: action grads of the critics -> grads of the two heads.
+struct TanhGaussBwdArgs {
+  const float* dact;   // [C][B][ld_dact] dL/da from each critic's input gradient
+  int C, ld_dact; long long dact_stride;
+  const float* act; long long act_slot_stride; int ld_act; const StepCtrl* cur;
+  const float* eps; const float* std; const float* ls_raw; int ld_head;
+  const float* alpha_dev; float alpha_const;
+  float* gmu; float* gls; int ld_g;   // [B,A]
+  int B, A;
+};
+int launch_tanh_gauss_bwd(hipStream_t st, const TanhGaussBwdArgs& a);
+
+// alpha_update (src/agent.py:532-546, :936-949): AdamW on the scalar log_alpha
+struct AlphaArgs {
+  const StepCtrl* cur;
+  const float* logp; int B;
+  float target_entropy;
+  float* log_alpha; float* m; float* v; float* alpha;  // device scalars
+  float* grad_out;   // the scalar gradient (for get("grad:log_alpha") and DP)
+  float beta2, w1, w2, eps;
+  float* metrics;
+  int phase;  // 0: gradient + loss metric only, 1: optimiser step only, 2: both
+};
+int launch_alpha_update(hipStream_t st, const AlphaArgs& a);
+
+// one wavefront per row: bitonic sort of width<=64 values by cross-lane exchange, mean of the
+// lowest width-drop
+int launch_sort_truncate_mean(hipStream_t st, const float* in, long long rows, int width, int drop,
+                              float* sorted, float* mean);
+
+}  // namespace gcrl

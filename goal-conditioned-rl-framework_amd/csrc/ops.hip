@@ -1,0 +1,290 @@
+// ops.hip — TD target + critic loss, gradient norm, Adam/AdamW (+ global-norm clip + Polyak),
+// and the small per-step helper kernels.  Reference arithmetic being restated:
+//   TD targets   src/agent.py:1311-1317 (DDPG), :173-186 (TD3), :557-570 (SAC), :960-979 (TQC)
+//   losses       F.mse_loss / F.smooth_l1_loss (mean) and their backward
+//   clip         torch.nn.utils.clip_grad_norm_  (coef = max_norm/(norm+1e-6), clamped to 1)
+//   optimiser    torch.optim.Adam / AdamW single-tensor path (lerp, addcmul, addcdiv order)
+//   Polyak       tau*p + (1-tau)*p_target  (src/agent.py:1260-1271 etc.)
+#include "ops.h"
+
+#include <cmath>
+
+namespace gcrl {
+namespace {
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+// sum over a 256-thread block; result valid in thread 0.  `scratch` holds 4 floats.
+__device__ inline float block_sum_256(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__global__ void begin_step_kernel(CtrlBlock* cb) {
+  if (threadIdx.x == 0) {
+    const int c = cb->cursor;
+    cb->cur = cb->table[c];
+    cb->cursor = c + 1;
+  }
+}
+
+// ------------------------------------------------------------------ TD target + loss
+__global__ __launch_bounds__(256) void td_loss_kernel(TdLossArgs a) {
+  __shared__ float scratch[4];
+  const StepCtrl c = *a.cur;
+  const float* __restrict__ r = a.r + (long long)c.batch_slot * a.slot_stride;
+  const float* __restrict__ d = a.d + (long long)c.batch_slot * a.slot_stride;
+  const float alpha = a.alpha_dev ? *a.alpha_dev : a.alpha_const;
+  const int B = a.B, C = a.C;
+  const int keep = C - a.drop;
+  float loss[kMaxCritics];
+#pragma unroll
+  for (int k = 0; k < kMaxCritics; ++k) loss[k] = 0.f;
+  float td = 0.f, qsum = 0.f;
+  const float mse_norm = 2.0f / (float)B, l1_norm = 1.0f / (float)B;
+
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float qt[kMaxCritics];
+#pragma unroll
+    for (int k = 0; k < kMaxCritics; ++k) qt[k] = (k < C) ? a.qt[(long long)k * B + b] : INFINITY;
+    float tq;
+    if (a.target_kind == TGT_DDPG) {
+      tq = qt[0];
+    } else if (a.target_kind == TGT_MIN || a.target_kind == TGT_MIN_ENT) {
+      tq = fminf(qt[0], qt[1]);
+    } else {
+      // torch.sort over the critic axis, drop the largest `drop`, mean (src/agent.py:972-974)
+#pragma unroll
+      for (int pass = 0; pass < kMaxCritics - 1; ++pass)
+#pragma unroll
+        for (int k = 0; k < kMaxCritics - 1 - pass; ++k) {
+          const float lo = fminf(qt[k], qt[k + 1]), hi = fmaxf(qt[k], qt[k + 1]);
+          qt[k] = lo; qt[k + 1] = hi;
+        }
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxCritics; ++k) if (k < keep) s = __fadd_rn(s, qt[k]);
+      tq = s / (float)keep;
+    }
+    if (a.target_kind == TGT_MIN_ENT || a.target_kind == TGT_TRUNC_ENT)
+      tq = __fsub_rn(tq, __fmul_rn(alpha, a.logp_next[b]));
+    // y = r + gamma * (1 - d) * tq   (left to right, one rounding per op)
+    float y = __fadd_rn(r[b], __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, d[b])), tq));
+    if (a.target_kind == TGT_DDPG) y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
+    float tdmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxCritics; ++k) {
+      if (k < C) {
+        const float qc = a.q[(long long)k * B + b];
+        const float diff = __fsub_rn(qc, y);
+        const float ad = fabsf(diff);
+        float g;
+        if (a.loss_kind == LOSS_MSE) {
+          loss[k] += diff * diff;
+          g = mse_norm * diff;
+        } else {
+          loss[k] += (ad < 1.0f) ? 0.5f * diff * diff : ad - 0.5f;
+          g = (diff < -1.0f) ? -l1_norm : (diff > 1.0f ? l1_norm : l1_norm * diff);
+        }
+        a.dq[(long long)k * B + b] = g;
+        tdmax = fmaxf(tdmax, ad);
+        qsum += qc;
+      }
+    }
+    td += tdmax;
+  }
+  float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
+#pragma unroll
+  for (int k = 0; k < kMaxCritics; ++k) {
+    if (k < C) {
+      const float s = block_sum_256(loss[k], scratch);
+      if (threadIdx.x == 0) met[MET_CRITIC_LOSS + k] = s / (float)B;
+    }
+  }
+  const float tds = block_sum_256(td, scratch);
+  const float qs = block_sum_256(qsum, scratch);
+  if (threadIdx.x == 0) {
+    met[MET_TD] = tds / (float)B;
+    met[MET_Q] = qs / (float)(B * C);
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_metric_kernel(const StepCtrl* cur, const float* x, int n,
+                                                          float scale, float* metrics, int idx) {
+  __shared__ float scratch[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = block_sum_256(s, scratch);
+  if (threadIdx.x == 0) metrics[(long long)cur->metrics_slot * kMetricFloats + idx] = scale * (s / (float)n);
+}
+
+__global__ void fill_kernel(float* x, long long n, float v) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
+__device__ inline unsigned long long mix64d(unsigned long long z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+// standard normal from a 64-bit counter hash (Box-Muller); device-RNG mode only
+__device__ inline float hash_normal(unsigned long long seed, unsigned long long ctr) {
+  const unsigned long long h = mix64d(mix64d(seed) + ctr);
+  const float u1 = ((float)((h >> 40) + 1)) * (1.0f / 16777217.0f);  // (0,1]
+  const float u2 = (float)((h >> 8) & 0xffffff) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
+}
+
+__global__ void td3_smooth_kernel(const StepCtrl* cur, float* act, long long slot_stride, int ld, int B,
+                                  int A, const float* eps, float pn, float nc, unsigned long long seed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * A) return;
+  const StepCtrl c = *cur;
+  const int b = i / A, j = i - b * A;
+  float* p = act + (long long)c.batch_slot * slot_stride + (long long)b * ld + j;
+  const float e = eps ? eps[i] : hash_normal(seed, (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
+  const float noise = fminf(fmaxf(__fmul_rn(e, pn), -nc), nc);
+  *p = fminf(fmaxf(__fadd_rn(*p, noise), -1.0f), 1.0f);
+}
+
+// ------------------------------------------------------------------ gradient norm
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long long n, long long net_stride,
+                                                    float* partial) {
+  __shared__ float scratch[4];
+  const float* gp = g + (long long)blockIdx.y * net_stride;
+  const long long chunk = (n + kNormBlocks - 1) / kNormBlocks;
+  const long long beg = (long long)blockIdx.x * chunk;
+  const long long end = beg + chunk < n ? beg + chunk : n;
+  float s = 0.f;
+  for (long long i = beg + threadIdx.x; i < end; i += 256) s += gp[i] * gp[i];
+  s = block_sum_256(s, scratch);
+  if (threadIdx.x == 0) partial[blockIdx.y * kNormBlocks + blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------ Adam / AdamW
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  __shared__ float s_coef;
+  const StepCtrl c = *a.cur;
+  const int net = blockIdx.y;
+  float step_size, bc2s, decay;
+  if (a.which == 0) { step_size = c.step_size_actor; bc2s = c.bc2s_actor; decay = c.decay_actor; }
+  else if (a.which == 1) { step_size = c.step_size_critic; bc2s = c.bc2s_critic; decay = c.decay_critic; }
+  else { step_size = c.step_size_alpha; bc2s = c.bc2s_alpha; decay = c.decay_alpha; }
+  const float gscale = c.grad_scale;
+
+  if (threadIdx.x < 64) {
+    double s = (double)a.partial[net * kNormBlocks + threadIdx.x];  // kNormBlocks == 64
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) {
+      const float norm = gscale * (float)sqrt(s);
+      const float clip = a.clip[net];
+      float coef = 1.0f;
+      if (clip >= 0.f) coef = fminf(clip / (norm + 1e-6f), 1.0f);
+      s_coef = coef;
+      if (blockIdx.x == 0 && a.metrics)
+        a.metrics[(long long)c.metrics_slot * kMetricFloats + a.metric_index + net] = norm * coef;
+    }
+  }
+  __syncthreads();
+  const float gmul = gscale * s_coef;
+  const long long base = (long long)net * a.net_stride;
+  float* __restrict__ p = a.p + base;
+  const float* __restrict__ g = a.g + base;
+  float* __restrict__ m = a.m + base;
+  float* __restrict__ v = a.v + base;
+  float* __restrict__ tp = a.target ? a.target + base : nullptr;
+  const float w1 = a.w1, w2 = a.w2, one_m_tau = a.one_m_tau;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+    const float gi = __fmul_rn(g[i], gmul);
+    float pi = p[i];
+    if (decay != 1.0f) pi = __fmul_rn(pi, decay);
+    float mi = m[i];
+    mi = __fadd_rn(mi, __fmul_rn(w1, __fsub_rn(gi, mi)));
+    float vi = __fadd_rn(__fmul_rn(v[i], a.beta2), __fmul_rn(__fmul_rn(w2, gi), gi));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2s), a.eps);
+    pi = __fadd_rn(pi, __fdiv_rn(__fmul_rn(-step_size, mi), denom));
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (tp && a.polyak) tp[i] = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, tp[i]));
+  }
+}
+
+__global__ void polyak_kernel(const float* p, float* tp, long long n, float tau, float one_m_tau) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tp[i] = __fadd_rn(__fmul_rn(tau, p[i]), __fmul_rn(one_m_tau, tp[i]));
+}
+
+}  // namespace
+
+int launch_begin_step(hipStream_t st, CtrlBlock* cb) {
+  hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(64), 0, st, cb);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_td_loss(hipStream_t st, const TdLossArgs& a) {
+  GCRL_CHECK_ARG(a.C >= 1 && a.C <= kMaxCritics && a.B >= 1, "td_loss: bad C=%d B=%d", a.C, a.B);
+  hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_mean_metric(hipStream_t st, const StepCtrl* cur, const float* x, int n, float scale,
+                       float* metrics, int idx) {
+  hipLaunchKernelGGL(mean_metric_kernel, dim3(1), dim3(256), 0, st, cur, x, n, scale, metrics, idx);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_fill(hipStream_t st, float* x, long long n, float v) {
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, v);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_td3_smooth(hipStream_t st, const StepCtrl* cur, float* act, long long slot_stride, int ld,
+                      int B, int A, const float* eps, float pn, float nc, unsigned long long seed) {
+  hipLaunchKernelGGL(td3_smooth_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, cur, act,
+                     slot_stride, ld, B, A, eps, pn, nc, seed);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_sumsq(hipStream_t st, const float* g, long long n, long long net_stride, int nets,
+                 float* partial) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks, nets), dim3(256), 0, st, g, n, net_stride, partial);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_adam(hipStream_t st, const AdamArgs& a) {
+  GCRL_CHECK_ARG(a.nets >= 1 && a.nets <= kMaxCritics, "adam: bad net count %d", a.nets);
+  long long blocks = (a.n + 256 * 4 - 1) / (256 * 4);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, a.nets), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_polyak(hipStream_t st, const float* p, float* target, long long n, double tau) {
+  hipLaunchKernelGGL(polyak_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, target, n,
+                     (float)tau, (float)(1.0 - tau));
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+}  // namespace gcrl

@@ -1,0 +1,343 @@
+// ops_sac.hip — kernels only the stochastic-actor agents need:
+//   BatchNorm1d(train)+ReLU fwd/bwd and eval        reference src/model.py:106-108
+//   tanh-squashed Gaussian sample / log-prob        src/model.py:125-141
+//   actor-loss critic selection (min / sort-trunc)  src/agent.py:516-521, :916-925
+//   log-alpha AdamW step                            src/agent.py:532-546, :936-949
+//   wavefront bitonic sort + truncated mean         generalisation of src/agent.py:919-921
+#include "ops.h"
+
+#include <cmath>
+
+namespace gcrl {
+namespace {
+
+constexpr float kBnEps = 1e-5f;       // nn.BatchNorm1d default eps
+constexpr float kBnMomentum = 0.1f;   // default momentum
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ inline float block_sum_256(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+__device__ inline unsigned long long mix64d(unsigned long long z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__device__ inline float hash_normal(unsigned long long seed, unsigned long long ctr) {
+  const unsigned long long h = mix64d(mix64d(seed) + ctr);
+  const float u1 = ((float)((h >> 40) + 1)) * (1.0f / 16777217.0f);
+  const float u2 = (float)((h >> 8) & 0xffffff) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
+}
+
+// A block owns 64 feature columns; its 4 wavefronts stride over the batch rows, so every
+// wave-load is one coalesced 256-B row segment; column sums meet in LDS.
+__device__ inline float col_sum4(float v, float (*red)[64], int cl, int rg) {
+  __syncthreads();
+  red[rg][cl] = v;
+  __syncthreads();
+  return red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const float* __restrict__ z, int B, int H,
+                                                          const float* gamma, const float* beta,
+                                                          float* __restrict__ h, float* xhat,
+                                                          float* invstd_out, float* rmean, float* rvar) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const bool ok = col < H;
+  float s = 0.f;
+  if (ok) for (int b = rg; b < B; b += 4) s += z[(long long)b * H + col];
+  const float mean = col_sum4(s, red, cl, rg) / (float)B;
+  float q = 0.f;
+  if (ok) for (int b = rg; b < B; b += 4) { const float df = z[(long long)b * H + col] - mean; q += df * df; }
+  const float var = col_sum4(q, red, cl, rg) / (float)B;  // biased: what normalises the batch
+  if (!ok) return;
+  const float invstd = 1.0f / sqrtf(var + kBnEps);
+  const float g = gamma[col], bt = beta[col];
+  for (int b = rg; b < B; b += 4) {
+    const long long i = (long long)b * H + col;
+    const float xh = (z[i] - mean) * invstd;
+    const float y = xh * g + bt;
+    h[i] = y > 0.f ? y : 0.f;
+    if (xhat) xhat[i] = xh;
+  }
+  if (rg == 0) {
+    if (invstd_out) invstd_out[col] = invstd;
+    const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+    rmean[col] = (1.0f - kBnMomentum) * rmean[col] + kBnMomentum * mean;
+    rvar[col] = (1.0f - kBnMomentum) * rvar[col] + kBnMomentum * unbiased;
+  }
+}
+
+__global__ void bn_relu_eval_kernel(const float* z, int B, int H, const float* gamma, const float* beta,
+                                    const float* rmean, const float* rvar, float* h) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * H) return;
+  const int col = (int)(i % H);
+  const float y = (z[i] - rmean[col]) * (1.0f / sqrtf(rvar[col] + kBnEps)) * gamma[col] + beta[col];
+  h[i] = y > 0.f ? y : 0.f;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2,
+                                                          const float* __restrict__ h,
+                                                          const float* __restrict__ xhat,
+                                                          const float* invstd, const float* gamma, int B,
+                                                          int H, float* __restrict__ dz, float* dgamma,
+                                                          float* dbeta) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const bool ok = col < H;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok)
+    for (int b = rg; b < B; b += 4) {
+      const long long i = (long long)b * H + col;
+      const float dy = h[i] > 0.f ? (dh2 ? dh[i] + dh2[i] : dh[i]) : 0.f;
+      s1 += dy;
+      s2 += dy * xhat[i];
+    }
+  const float sum_dy = col_sum4(s1, red, cl, rg);
+  const float sum_dyx = col_sum4(s2, red, cl, rg);
+  if (!ok) return;
+  const float k = gamma[col] * invstd[col];
+  const float m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B;
+  for (int b = rg; b < B; b += 4) {
+    const long long i = (long long)b * H + col;
+    const float dy = h[i] > 0.f ? (dh2 ? dh[i] + dh2[i] : dh[i]) : 0.f;
+    dz[i] = (dy - m1 - xhat[i] * m2) * k;
+  }
+  if (rg == 0) { dgamma[col] = sum_dyx; dbeta[col] = sum_dy; }
+}
+
+__global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const StepCtrl c = *a.cur;
+  float* act = a.act + (long long)c.batch_slot * a.act_slot_stride + (long long)b * a.ld_act;
+  float lp = 0.f;
+  for (int j = 0; j < a.A; ++j) {
+    const float mu = a.mu[(long long)b * a.ld_head + j];
+    if (a.deterministic) { act[j] = tanhf(mu); continue; }
+    const float ls = fminf(fmaxf(a.ls_raw[(long long)b * a.ld_head + j], -20.0f), 2.0f);
+    const float sd = expf(ls);
+    const long long i = (long long)b * a.A + j;
+    const float e = a.eps ? a.eps[i]
+                          : hash_normal(a.seed + (unsigned long long)a.rng_stream,
+                                        (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
+    const float x = __fadd_rn(mu, __fmul_rn(e, sd));  // rsample: loc + eps*scale
+    const float t = tanhf(x);
+    act[j] = t;
+    // Normal(mu, sd).log_prob(x) - log(1 - tanh(x)^2 + 1e-8)
+    const float df = __fsub_rn(x, mu);
+    const float var = __fmul_rn(sd, sd);
+    float term = -(df * df) / (2.0f * var) - logf(sd) - 0.91893853320467274f;
+    term -= logf(1.0f - t * t + 1e-8f);
+    lp += term;
+    if (a.save_eps) { a.save_eps[i] = e; a.save_std[i] = sd; }
+  }
+  if (!a.deterministic && a.logp) a.logp[b] = lp;
+}
+
+__global__ __launch_bounds__(256) void actor_select_kernel(ActorSelArgs a) {
+  __shared__ float scratch[4];
+  const StepCtrl c = *a.cur;
+  const float alpha = a.alpha_dev ? *a.alpha_dev : a.alpha_const;
+  const int B = a.B, C = a.C, keep = a.C - a.drop;
+  const float gb = -1.0f / (float)B;
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float q[kMaxCritics];
+#pragma unroll
+    for (int k = 0; k < kMaxCritics; ++k) q[k] = (k < C) ? a.q[(long long)k * B + b] : INFINITY;
+    float sel;
+    if (C == 2 && a.drop == 0) {
+      // torch.min(q1, q2): gradient to the smaller, split on ties
+      sel = fminf(q[0], q[1]);
+      const float w0 = q[0] < q[1] ? 1.f : (q[0] == q[1] ? 0.5f : 0.f);
+      a.dq[b] = gb * w0;
+      a.dq[(long long)B + b] = gb * (1.f - w0);
+    } else {
+      // rank of each critic in the ascending (stable) order; the lowest `keep` carry gradient
+      const float gk = gb / (float)keep;
+#pragma unroll
+      for (int k = 0; k < kMaxCritics; ++k) {
+        if (k < C) {
+          int rank = 0;
+#pragma unroll
+          for (int j = 0; j < kMaxCritics; ++j)
+            if (j < C && (q[j] < q[k] || (q[j] == q[k] && j < k))) ++rank;
+          a.dq[(long long)k * B + b] = rank < keep ? gk : 0.f;
+        }
+      }
+#pragma unroll
+      for (int pass = 0; pass < kMaxCritics - 1; ++pass)
+#pragma unroll
+        for (int k = 0; k < kMaxCritics - 1 - pass; ++k) {
+          const float lo = fminf(q[k], q[k + 1]), hi = fmaxf(q[k], q[k + 1]);
+          q[k] = lo; q[k + 1] = hi;
+        }
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxCritics; ++k) if (k < keep) s = __fadd_rn(s, q[k]);
+      sel = s / (float)keep;
+    }
+    acc += __fsub_rn(__fmul_rn(alpha, a.logp[b]), sel);
+  }
+  acc = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) a.metrics[(long long)c.metrics_slot * kMetricFloats + MET_ACTOR_LOSS] = acc / (float)B;
+}
+
+__global__ void tanh_gauss_bwd_kernel(TanhGaussBwdArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.B * a.A) return;
+  const int b = i / a.A, j = i - b * a.A;
+  const StepCtrl c = *a.cur;
+  const float alpha = a.alpha_dev ? *a.alpha_dev : a.alpha_const;
+  float da = 0.f;
+  for (int k = 0; k < a.C; ++k) da += a.dact[(long long)k * a.dact_stride + (long long)b * a.ld_dact + j];
+  const float t = a.act[(long long)c.batch_slot * a.act_slot_stride + (long long)b * a.ld_act + j];
+  const float om = 1.0f - t * t;
+  const float wlp = alpha / (float)a.B;  // d loss / d logp_b
+  // d/dx [ -log(1 - tanh(x)^2 + 1e-8) ] = 2 t (1-t^2) / (1 - t^2 + 1e-8); the Normal terms of
+  // the log-prob cancel through the reparameterisation (x - mu = eps*sd)
+  const float dx = da * om + wlp * (2.0f * t * om / (om + 1e-8f));
+  const float lsr = a.ls_raw[(long long)b * a.ld_head + j];
+  const bool in_range = lsr >= -20.0f && lsr <= 2.0f;  // clamp backward
+  a.gmu[(long long)b * a.ld_g + j] = dx;
+  a.gls[(long long)b * a.ld_g + j] = in_range ? (dx * a.eps[i] * a.std[i] - wlp) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void alpha_update_kernel(AlphaArgs a) {
+  __shared__ float scratch[4];
+  const StepCtrl c = *a.cur;
+  float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
+  if (!c.do_alpha) {  // `gradient_step <= alpha_min_steps: return 0.0`
+    if (threadIdx.x == 0 && a.phase != 1) { met[MET_ALPHA_LOSS] = 0.f; met[MET_ALPHA] = *a.alpha; }
+    return;
+  }
+  if (a.phase != 1) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < a.B; b += 256) s += a.logp[b] + a.target_entropy;
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) {
+      const float mean_x = s / (float)a.B;
+      met[MET_ALPHA_LOSS] = -(*a.log_alpha * mean_x);
+      *a.grad_out = -mean_x;
+    }
+  }
+  if (a.phase != 0 && threadIdx.x == 0) {
+    const float g = *a.grad_out * c.grad_scale;
+    float p = *a.log_alpha;
+    if (c.decay_alpha != 1.0f) p = __fmul_rn(p, c.decay_alpha);
+    float m = *a.m, v = *a.v;
+    m = __fadd_rn(m, __fmul_rn(a.w1, __fsub_rn(g, m)));
+    v = __fadd_rn(__fmul_rn(v, a.beta2), __fmul_rn(__fmul_rn(a.w2, g), g));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), c.bc2s_alpha), a.eps);
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-c.step_size_alpha, m), denom));
+    *a.log_alpha = p; *a.m = m; *a.v = v;
+    *a.alpha = expf(p);
+    met[MET_ALPHA] = expf(p);
+  }
+}
+
+// lane i holds element i of the row (+inf beyond `width`): 21 compare-exchange rounds with the
+// partner lane i^j, direction from bit k of the lane id -> ascending order across the wave.
+__global__ __launch_bounds__(256) void sort_trunc_kernel(const float* in, long long rows, int width, int drop,
+                                                         float* sorted, float* mean) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v = lane < width ? in[row * width + lane] : INFINITY;
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const float o = __shfl_xor(v, j, 64);
+      const bool up = (lane & k) == 0;          // ascending block?
+      const bool lower = (lane & j) == 0;       // this lane is the lower index of the pair
+      v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+    }
+  }
+  if (sorted && lane < width) sorted[row * width + lane] = v;
+  const int keep = width - drop;
+  float s = wave_sum(lane < keep ? v : 0.f);
+  if (lane == 0 && mean) mean[row] = s / (float)keep;
+}
+
+}  // namespace
+
+int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
+                       const float* beta, float* h, float* xhat, float* invstd, float* rmean,
+                       float* rvar) {
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3((H + 63) / 64), dim3(256), 0, st, z, B, H, gamma, beta, h,
+                     xhat, invstd, rmean, rvar);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const float* gamma,
+                        const float* beta, const float* rmean, const float* rvar, float* h) {
+  const long long n = (long long)B * H;
+  hipLaunchKernelGGL(bn_relu_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, B, H,
+                     gamma, beta, rmean, rvar, h);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* h, const float* xhat,
+                       const float* invstd, const float* gamma, int B, int H, float* dz,
+                       float* dgamma, float* dbeta) {
+  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3((H + 63) / 64), dim3(256), 0, st, dh, dh2, h, xhat, invstd,
+                     gamma, B, H, dz, dgamma, dbeta);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_tanh_gauss_fwd(hipStream_t st, const TanhGaussArgs& a) {
+  hipLaunchKernelGGL(tanh_gauss_fwd_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_actor_select(hipStream_t st, const ActorSelArgs& a) {
+  GCRL_CHECK_ARG(a.C >= 1 && a.C <= kMaxCritics && a.drop >= 0 && a.drop < a.C, "actor_select: bad C=%d drop=%d", a.C, a.drop);
+  hipLaunchKernelGGL(actor_select_kernel, dim3(1), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_tanh_gauss_bwd(hipStream_t st, const TanhGaussBwdArgs& a) {
+  hipLaunchKernelGGL(tanh_gauss_bwd_kernel, dim3((a.B * a.A + 255) / 256), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_alpha_update(hipStream_t st, const AlphaArgs& a) {
+  hipLaunchKernelGGL(alpha_update_kernel, dim3(1), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_sort_truncate_mean(hipStream_t st, const float* in, long long rows, int width, int drop,
+                              float* sorted, float* mean) {
+  GCRL_CHECK_ARG(in && rows >= 1 && width >= 1 && width <= 64 && drop >= 0 && drop < width,
+                 "sort_truncate_mean: need 1 <= width <= 64 and 0 <= drop < width");
+  hipLaunchKernelGGL(sort_trunc_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, in, rows, width,
+                     drop, sorted, mean);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+}  // namespace gcrl

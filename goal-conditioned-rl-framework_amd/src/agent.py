@@ -1,0 +1,445 @@
+"""DDPG / TD3Agent / SACAgent / TQCAgent — drop-ins for the reference's classes of the same
+names (src/agent.py), backed by the update engine of libgcrl_hip.so (csrc/agent.hip).
+
+Constructor signature `(obs_dim, ac_dim, config, weights, nenvs, gradient_step)` and the
+methods the trainer calls (src/env.py: select_action, push_her, update(step), is_buffer_filled,
+update_normalizers, normalize_*, save_weights, reset, set_train/set_eval) are the reference's;
+`update` returns the same tuple shapes (DDPG 6/4, TD3 8/6, SAC & TQC 9/6 entries) because the
+trainer dispatches on the length (src/env.py:448-506).  The entries are lazily materialised
+scalars by default (float(x), np.asarray(x), x.item() all work) so that a run of updates is
+enqueued without a host sync per step; `sync_metrics=True` returns plain floats with `td_error`
+as a 0-d numpy array, exactly like the reference (src/agent.py:1342).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from .. import _ffi
+from .._ffi import lib
+from .buffer import HERBuffer
+from .model import Actor, Critic, SACActorModel
+
+KIND = {"DDPG": 0, "TD3": 1, "SAC": 2, "TQC": 3}
+
+
+class LazyScalar:
+    """One entry of an update()'s return tuple, fetched from the device on first use."""
+    __slots__ = ("_agent", "_ticket", "_n", "_i", "_as_array")
+
+    def __init__(self, agent, ticket, n, i, as_array=False):
+        self._agent, self._ticket, self._n, self._i, self._as_array = agent, ticket, n, i, as_array
+
+    def _value(self) -> float:
+        return self._agent._metrics(self._ticket, self._n)[self._i]
+
+    def __float__(self):
+        return float(self._value())
+
+    def item(self):
+        return float(self._value())
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self._value(), dtype=dtype or np.float32)
+
+    def __repr__(self):
+        return f"LazyScalar({self._value()!r})"
+
+    def _bin(op):
+        def f(self, other):
+            return op(float(self), float(other))
+        return f
+
+    __add__ = _bin(lambda a, b: a + b)
+    __radd__ = _bin(lambda a, b: b + a)
+    __sub__ = _bin(lambda a, b: a - b)
+    __rsub__ = _bin(lambda a, b: b - a)
+    __mul__ = _bin(lambda a, b: a * b)
+    __rmul__ = _bin(lambda a, b: b * a)
+    __truediv__ = _bin(lambda a, b: a / b)
+    __lt__ = _bin(lambda a, b: a < b)
+    __gt__ = _bin(lambda a, b: a > b)
+    del _bin
+
+
+class _AlphaView:
+    """`agent.alpha.item()` (src/env.py:574,604)."""
+
+    def __init__(self, agent):
+        self._agent = agent
+
+    def item(self):
+        a = self._agent
+        if not a._sac:
+            raise AttributeError("alpha")
+        buf = np.empty(1, np.float32)
+        _ffi.check(lib.gcrl_agent_get(a._h, b"alpha", buf.ctypes.data, 1))
+        return float(buf[0])
+
+
+class _EngineAgent:
+    KIND_NAME = "DDPG"
+    TD_INDEX = {6: 2, 4: 1}  # position of td_error in the tuple, by tuple length
+
+    def __init__(self, obs_dim: int, ac_dim: int, config, weights, nenvs: int, gradient_step: int, *,
+                 use_graph: bool = True, sync_metrics: bool = False, rng: str = "python",
+                 seed: int | None = None, device_index: int = 0, num_critics: int = 5,
+                 top_quantiles_to_drop: int = 2):
+        if not torch.cuda.is_available() or lib.gcrl_device_count() <= 0:
+            raise _ffi.GcrlError(f"{type(self).__name__} needs a HIP device; there is no CPU fallback")
+        self.device = "cuda"
+        self.device_index = device_index
+        self.config = config
+        self.gradient_step = int(gradient_step)
+        self.obs_dim, self.ac_dim = int(obs_dim), int(ac_dim)
+        self.sync_metrics = sync_metrics
+        kind = KIND[self.KIND_NAME]
+        self._sac = kind >= 2
+
+        if config.buffer_type != "HER":
+            # the reference also accepts "PER"/"REPLAY" (src/agent.py:1214-1228); no shipped config
+            # selects them and they are outside the hot path
+            raise ValueError(f"[ERROR] Invalid Buffer type. Received {config.buffer_type}.")
+        self.buffer = HERBuffer(config.max_len, config.max_eps_len, nenvs, k_future=config.k_future,
+                                rng=rng, seed=seed, device_index=device_index)
+
+        # the YAML keys num_critics / top_quantiles_to_drop are dropped by pydantic in the
+        # reference, so getattr(config, ..., 5/2) always yields the defaults (src/agent.py:789-790)
+        self.num_critics = int(getattr(config, "num_critics", num_critics)) if kind == 3 else (1 if kind == 0 else 2)
+        self.top_quantiles_to_drop = int(getattr(config, "top_quantiles_to_drop", top_quantiles_to_drop))
+
+        cfg = _ffi.AgentConfig(
+            kind=kind, obs_dim=obs_dim, ac_dim=ac_dim, hidden_dim=config.hidden_dim,
+            layer_count=config.layer_count, batch_size=config.batch_size,
+            num_critics=self.num_critics, top_drop=self.top_quantiles_to_drop if kind == 3 else 0,
+            ac_update_freq=config.ac_update_freq, gradient_step=self.gradient_step, polyak_every=40,
+            gamma=config.gamma, tau=config.tau,
+            grad_clip=-1.0 if config.grad_clip is None else float(config.grad_clip),
+            policy_noise=config.policy_noise, noise_clamp=config.noise_clamp,
+            actor_lr=config.actor_lr, actor_lr_min=config.actor_lr_min,
+            critic_lr=config.critic_lr, critic_lr_min=config.critic_lr_min,
+            alpha_lr=float(getattr(config, "alpha_lr", 0.0003)),
+            ac_scheduler_steps=config.ac_scheduler_steps, cr_scheduler_steps=config.cr_scheduler_steps,
+            alpha_min_steps=float(getattr(config, "alpha_min_steps", 10000)),
+            device=device_index, use_graph=1 if use_graph else 0,
+            seed=0 if seed is None else int(seed))
+        self._h = _ffi.check_ptr(lib.gcrl_agent_create(C.byref(cfg)), "gcrl_agent_create")
+        self._metric_cache: dict[int, list[float]] = {}
+
+        self.noise_std = config.noise_std
+        self.noise_clamp = config.noise_clamp
+        self.policy_noise = config.policy_noise
+        self.gamma = config.gamma
+        self.batch_size = config.batch_size
+        self.ac_update_freq = config.ac_update_freq
+        self.grad_clip = config.grad_clip
+        self.tau = config.tau
+        self.beta = config.beta
+        self.beta_start = config.beta
+        self.beta_max = 1.0
+        self.beta_end = config.beta_end
+        self.alpha_min = getattr(config, "alpha_min", 0.05)
+        self.alpha_min_steps = getattr(config, "alpha_min_steps", 10000)
+        self.alpha = _AlphaView(self)
+
+        get = lambda: self._h
+        H, L = config.hidden_dim, config.layer_count
+        if self._sac:
+            self.actor = SACActorModel(get, "actor", obs_dim, H, ac_dim, L)
+        else:
+            self.actor = Actor(get, "actor", obs_dim, H, ac_dim, L)
+            self.target_actor = Actor(get, "target_actor", obs_dim, H, ac_dim, L)
+        self.critics = [Critic(get, f"critic_{i}", obs_dim + ac_dim, H, 1, L) for i in range(self.num_critics)]
+        self.target_critics = [Critic(get, f"target_critic_{i}", obs_dim + ac_dim, H, 1, L)
+                               for i in range(self.num_critics)]
+        self._bind_names()
+        if weights:
+            self._load_weights(weights)
+        self.update_target_network()
+
+    # reference attribute names (critic / critic_1 / critic_2 ...)
+    def _bind_names(self):
+        pass
+
+    def _load_weights(self, weights: str):
+        raise NotImplementedError
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.gcrl_agent_destroy(h)
+
+    # ------------------------------------------------------------------ update
+    def _metrics(self, ticket: int, n: int):
+        vals = self._metric_cache.get(ticket)
+        if vals is None:
+            buf = (C.c_double * n)()
+            _ffi.check(lib.gcrl_agent_metrics(self._h, ticket, buf, n))
+            vals = list(buf)
+            if len(self._metric_cache) > 2048:
+                self._metric_cache.clear()
+            self._metric_cache[ticket] = vals
+        return vals
+
+    def _tuple(self, ticket: int, n: int):
+        td = self.TD_INDEX[n]
+        if self.sync_metrics:
+            vals = self._metrics(ticket, n)
+            return tuple(np.asarray(v, dtype=np.float32) if i == td else v for i, v in enumerate(vals))
+        return tuple(LazyScalar(self, ticket, n, i, i == td) for i in range(n))
+
+    def beta_scheduler(self, step: int):
+        ratio = step / self.beta_end
+        self.beta = min(self.beta_max, self.beta_start + ratio * (self.beta_max - self.beta_start))
+
+    def update(self, step: int, *, batch=None, noise=None, eps_next=None, eps_cur=None):
+        """agent.update(step).  Keyword arguments inject an explicit batch / noise (parity tests):
+        batch = (states, actions, rewards, next_states, dones) cuda float32 tensors."""
+        self.set_train()
+        inputs = None
+        keep = []
+        if batch is not None or noise is not None or eps_next is not None or eps_cur is not None:
+            inputs = _ffi.UpdateInputs()
+
+            def dev(t):
+                t = t.to(device="cuda", dtype=torch.float32).contiguous()
+                keep.append(t)
+                return t
+
+            if batch is not None:
+                s, a, r, ns, d = (dev(t) for t in batch)
+                inputs.s_dev, inputs.ld_s = s.data_ptr(), s.shape[1]
+                inputs.a_dev, inputs.ld_a = a.data_ptr(), a.shape[1]
+                inputs.r_dev, inputs.d_dev = r.data_ptr(), d.data_ptr()
+                inputs.ns_dev, inputs.ld_ns = ns.data_ptr(), ns.shape[1]
+            if noise is not None:
+                inputs.noise_dev = dev(noise).data_ptr()
+            if eps_next is not None:
+                inputs.eps_next_dev = dev(eps_next).data_ptr()
+            if eps_cur is not None:
+                inputs.eps_cur_dev = dev(eps_cur).data_ptr()
+        her = None
+        if batch is None:
+            her = self.buffer.handle
+            assert her is not None and len(self.buffer) >= self.batch_size, "[ERROR] Not enough in buffer to sample"
+            self.buffer.rng.pull()
+        ticket = C.c_int64(-1)
+        n = _ffi.check(lib.gcrl_agent_update(self._h, her, int(step), C.byref(inputs) if inputs is not None else None,
+                                             C.byref(ticket), _ffi.stream_handle()))
+        if batch is None:
+            self.buffer.rng.push_back()
+        self.beta_scheduler(step)
+        if self._sac:
+            self.actor.num_batches_tracked += 1 + (1 if n == 9 else 0)
+        return self._tuple(ticket.value, n)
+
+    def update_many(self, step0: int, n: int):
+        """The trainer's `for _ in range(gradient_step): update(step)` loop (src/env.py:384-385) as
+        one call: all n batches are drawn (same RNG stream order) and gathered by one launch."""
+        self.set_train()
+        her = self.buffer.handle
+        assert her is not None and len(self.buffer) >= self.batch_size, "[ERROR] Not enough in buffer to sample"
+        tickets = (C.c_int64 * n)()
+        lens = (C.c_int32 * n)()
+        self.buffer.rng.pull()
+        _ffi.check(lib.gcrl_agent_update_n(self._h, her, int(step0), int(n), tickets, lens, _ffi.stream_handle()))
+        self.buffer.rng.push_back()
+        self.beta_scheduler(step0 + n - 1)
+        if self._sac:
+            self.actor.num_batches_tracked += sum(1 + (1 if l == 9 else 0) for l in lens)
+        return [self._tuple(int(t), int(l)) for t, l in zip(tickets, lens)]
+
+    # ------------------------------------------------------------------ acting
+    def _actor_forward(self, obs, eps=None) -> torch.Tensor:
+        obs_t = torch.as_tensor(np.asarray(obs), dtype=torch.float32).to("cuda").contiguous()
+        if obs_t.dim() == 1:
+            obs_t = obs_t.unsqueeze(0)
+        out = torch.empty((obs_t.shape[0], self.ac_dim), dtype=torch.float32, device="cuda")
+        _ffi.check(lib.gcrl_agent_act(self._h, obs_t.data_ptr(), obs_t.shape[0], obs_t.shape[1], out.data_ptr(),
+                                      self.ac_dim, eps.data_ptr() if eps is not None else None,
+                                      _ffi.stream_handle()))
+        return out
+
+    def push(self, state, action, reward, next_state, done):
+        # reference passes 5 args to a HERBuffer.push that takes 8 -> TypeError there too
+        self.buffer.push(state, action, reward, next_state, done)
+
+    def push_her(self, idx, state, action, next_state, reward, done, desired_goal, achieved_goal):
+        self.buffer.push(idx, state, action, next_state, reward, done, desired_goal, achieved_goal)
+
+    def is_buffer_filled(self):
+        return len(self.buffer) >= self.batch_size
+
+    def set_train(self):
+        self.actor.train()
+        for c in self.critics:
+            c.train()
+
+    def set_eval(self):
+        self.actor.eval()
+        for c in self.critics:
+            c.eval()
+
+    # ------------------------------------------------------------------ normalisers (host, src/agent.py:1425-1459)
+    def update_normalizers(self, obs_list, dg_list, obs_normalize, g_normalize):
+        if hasattr(self.buffer, "obs_normalizer") and obs_list and obs_normalize:
+            self.buffer.obs_normalizer.update(np.concatenate(obs_list, axis=0))
+        if hasattr(self.buffer, "dg_normalizer") and dg_list and g_normalize:
+            self.buffer.dg_normalizer.update(np.concatenate(dg_list, axis=0))
+
+    def normalize_obs(self, obs, normalize: bool):
+        if hasattr(self.buffer, "obs_normalizer") and normalize:
+            return self.buffer.obs_normalizer.normalize(obs)
+        return obs
+
+    def normalize_goal(self, goal, normalize: bool):
+        if hasattr(self.buffer, "dg_normalizer") and normalize:
+            return self.buffer.dg_normalizer.normalize(goal)
+        return goal
+
+    def normalize_state_batch(self, obs_batch, dg_batch, obs_normalize, g_normalize):
+        return np.concatenate([self.normalize_obs(obs_batch, obs_normalize),
+                               self.normalize_goal(dg_batch, g_normalize)], axis=-1)
+
+    # ------------------------------------------------------------------ targets / reset
+    def update_target_network(self, hard_update: bool = True, tau: float = 0.005):
+        if not hard_update:
+            raise NotImplementedError("soft target updates happen inside update(), fused into the optimiser kernel")
+        _ffi.check(lib.gcrl_agent_hard_update_targets(self._h))
+
+    def reset(self):
+        """Re-initialise Linear layers (src/agent.py:1461-1465, :760-769)."""
+        seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
+        _ffi.check(lib.gcrl_agent_init_weights(self._h, seed, 1 if self._sac else 0))
+
+    def get_gradient_norm(self, model) -> float:
+        g = model.grad_flat().astype(np.float64)
+        return float(np.sqrt(np.sum(g * g)))
+
+
+class DDPG(_EngineAgent):
+    KIND_NAME = "DDPG"
+    TD_INDEX = {6: 2, 4: 1}
+
+    def _bind_names(self):
+        self.critic, self.target_critic = self.critics[0], self.target_critics[0]
+
+    def _load_weights(self, weights):
+        self.actor.load(os.path.join(weights, "actor.pth"))
+        p = os.path.join(weights, "critic.pth")
+        self.critic.load(p if os.path.exists(p) else os.path.join(weights, "critic_1.pth"))
+
+    def select_action(self, obs_tensor, eval_action: bool = False):
+        self.set_eval()
+        if not eval_action:
+            if self.buffer.rng.random() < 0.2:  # src/agent.py:1348 — shares the HER stream
+                return np.clip(np.random.randn(np.asarray(obs_tensor).shape[0], self.ac_dim), a_min=-1, a_max=1)
+            action = torch.tanh(self._actor_forward(obs_tensor)).cpu().numpy()  # double tanh, as the reference
+            return np.clip(action + np.random.normal(0, self.noise_std, size=action.shape), -1, 1)
+        return np.clip(torch.tanh(self._actor_forward(obs_tensor)).cpu().numpy(), -1, 1)
+
+    def save_weights(self, path: str):
+        self.actor.save(os.path.join(path, "actor.pth"))
+        self.critic.save(os.path.join(path, "critic.pth"))
+
+
+class TD3Agent(_EngineAgent):
+    KIND_NAME = "TD3"
+    TD_INDEX = {8: 3, 6: 2}
+
+    def _bind_names(self):
+        self.critic_1, self.critic_2 = self.critics
+        self.target_critic_1, self.target_critic_2 = self.target_critics
+
+    def _load_weights(self, weights):
+        self.actor.load(os.path.join(weights, "actor.pth"))
+        self.critic_1.load(os.path.join(weights, "critic_1.pth"))
+        self.critic_2.load(os.path.join(weights, "critic_2.pth"))
+
+    def select_action(self, obs_tensor, eval_action: bool = False):
+        self.set_eval()
+        if not eval_action:
+            action = torch.tanh(self._actor_forward(obs_tensor)).cpu().numpy()
+            return np.clip(action + np.random.normal(0, self.noise_std, size=action.shape), -1, 1)
+        return self._actor_forward(obs_tensor).cpu().numpy()
+
+    def save_weights(self, path: str):
+        self.actor.save(os.path.join(path, "actor.pth"))
+        self.critic_1.save(os.path.join(path, "critic_1.pth"))
+        self.critic_2.save(os.path.join(path, "critic_2.pth"))
+
+
+class _StochasticAgent(_EngineAgent):
+    TD_INDEX = {9: 3, 6: 2}
+
+    def select_action(self, obs_tensor, eval_action: bool = False):
+        self.set_eval()
+        eps = None
+        if not eval_action:
+            n = np.asarray(obs_tensor).reshape(-1, self.obs_dim).shape[0]
+            eps = torch.randn((n, self.ac_dim), dtype=torch.float32, device="cuda")
+        return self._actor_forward(obs_tensor, eps).cpu().numpy()
+
+    def _log_alpha_tensor(self):
+        buf = np.empty(1, np.float32)
+        _ffi.check(lib.gcrl_agent_get(self._h, b"log_alpha", buf.ctypes.data, 1))
+        return torch.tensor(buf, requires_grad=True)
+
+    @property
+    def log_alpha(self):
+        return self._log_alpha_tensor()
+
+    def _save_log_alpha(self, path):
+        torch.save(self._log_alpha_tensor(), os.path.join(path, "log_alpha.pth"))
+
+
+class SACAgent(_StochasticAgent):
+    KIND_NAME = "SAC"
+
+    def __init__(self, obs_dim, ac_dim, config, weights, nenvs, gradient_step, **kw):
+        super().__init__(obs_dim, ac_dim, config, weights, nenvs, gradient_step, **kw)
+        self.target_entropy = -ac_dim * 0.5
+        self.train_alpha = False
+
+    def _bind_names(self):
+        self.critic_1, self.critic_2 = self.critics
+        self.target_critic_1, self.target_critic_2 = self.target_critics
+
+    def _load_weights(self, weights):
+        self.actor.load(os.path.join(weights, "actor.pth"))
+        self.critic_1.load(os.path.join(weights, "critic_1.pth"))
+        self.critic_2.load(os.path.join(weights, "critic_2.pth"))
+
+    def save_weights(self, path: str):
+        self.actor.save(os.path.join(path, "actor.pth"))
+        self.critic_1.save(os.path.join(path, "critic_1.pth"))
+        self.critic_2.save(os.path.join(path, "critic_2.pth"))
+        self._save_log_alpha(path)
+
+
+class TQCAgent(_StochasticAgent):
+    KIND_NAME = "TQC"
+
+    def __init__(self, obs_dim, ac_dim, config, weights, nenvs, gradient_step, **kw):
+        super().__init__(obs_dim, ac_dim, config, weights, nenvs, gradient_step, **kw)
+        self.target_entropy = -ac_dim
+
+    def _load_weights(self, weights):
+        self.actor.load(os.path.join(weights, "actor.pth"))
+        for i, c in enumerate(self.critics):
+            p = os.path.join(weights, f"critic_{i}.pth")
+            if os.path.exists(p):
+                c.load(p)
+        p = os.path.join(weights, "log_alpha.pth")
+        if os.path.exists(p):
+            la = torch.load(p, map_location="cpu").detach().float().reshape(-1).numpy()
+            _ffi.check(lib.gcrl_agent_set(self._h, b"log_alpha", la.ctypes.data, 1))
+
+    def save_weights(self, path: str):
+        self.actor.save(os.path.join(path, "actor.pth"))
+        for i, c in enumerate(self.critics):
+            c.save(os.path.join(path, f"critic_{i}.pth"))
+        self._save_log_alpha(path)

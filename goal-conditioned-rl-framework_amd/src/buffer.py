@@ -1,0 +1,238 @@
+"""HERBuffer — drop-in for the reference's class of the same name (src/buffer.py:92-179),
+backed by the HBM replay ring of libgcrl_hip.so (csrc/her_ring.hip).
+
+Same constructor, `push`, `sample`, `__len__` and externally assigned attributes
+(`compute_reward`, `obs_normalizer`, `dg_normalizer`) as the reference, so src/env.py can use
+it unchanged.  What differs is where things happen: transitions are staged in HBM, the HER
+"future" relabelling + reward recomputation is one kernel at episode flush, and `sample` is a
+gather kernel over host-drawn (CPython-exact Mersenne Twister) indices.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random as _pyrandom
+
+import numpy as np
+import torch
+
+from .. import _ffi
+from .._ffi import lib
+
+FLUSH_LEN = 50  # literal in the reference (src/buffer.py:117); max_eps_len is not what triggers it
+
+
+class MTStream:
+    """CPython-exact MT19937 living in the library (csrc/mt19937_cpython.cc).
+
+    mode "python": the generator mirrors Python's global `random` state around every use, so
+    HER picks, batch draws and the reference's own random.random() calls (src/agent.py:1348)
+    interleave exactly as in the reference.  mode "engine": a private stream seeded once —
+    bit-identical to the reference as long as nothing else consumes `random` in between,
+    without the ~30 us state round trip per call.
+    """
+
+    def __init__(self, mode: str = "python", seed: int | None = None):
+        if mode not in ("python", "engine"):
+            raise ValueError(f"rng mode must be 'python' or 'engine', got {mode!r}")
+        self.mode = mode
+        self.handle = _ffi.check_ptr(lib.gcrl_mt_create(), "gcrl_mt_create")
+        self._buf = (C.c_uint32 * 625)()
+        if mode == "engine":
+            self.seed(0 if seed is None else seed)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            lib.gcrl_mt_destroy(h)
+
+    def seed(self, s: int):
+        _ffi.check(lib.gcrl_mt_seed(self.handle, int(s)))
+
+    def pull(self):
+        """python mode: copy random.getstate() into the library's generator."""
+        if self.mode != "python":
+            return
+        _, words, self._gauss = _pyrandom.getstate()
+        self._buf[:] = words
+        _ffi.check(lib.gcrl_mt_set_state(self.handle, self._buf))
+
+    def push_back(self):
+        """python mode: write the advanced state back to the `random` module."""
+        if self.mode != "python":
+            return
+        _ffi.check(lib.gcrl_mt_get_state(self.handle, self._buf))
+        _pyrandom.setstate((3, tuple(self._buf), self._gauss))
+
+    def random(self) -> float:
+        if self.mode == "python":
+            return _pyrandom.random()
+        return float(lib.gcrl_mt_random(self.handle))
+
+
+def _classify_reward(fn, goal_dim: int, default_threshold: float):
+    """Map the injected compute_reward callable (src/env.py:105) to a built-in reward kind by
+    probing it: sparse -(d > thr) with thr found by bisection, or dense -d."""
+    if fn is None:
+        return 0, float(default_threshold)
+    zero = np.zeros(goal_dim, dtype=np.float32)
+
+    def at(dist):
+        g = np.zeros(goal_dim, dtype=np.float32)
+        g[0] = dist
+        return float(np.asarray(fn(zero, g, {})))
+
+    probes = [0.0, 1e-3, 0.3, 5.0]
+    vals = [at(p) for p in probes]
+    if all(v in (0.0, -1.0) for v in vals) and vals[0] == 0.0 and vals[-1] == -1.0:
+        lo, hi = 0.0, 5.0
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            if at(mid) == 0.0:
+                lo = mid
+            else:
+                hi = mid
+        thr = float(np.float32(0.5 * (lo + hi)))
+        # snap to the advertised threshold when the probe agrees with it
+        if abs(thr - default_threshold) < 1e-6:
+            thr = float(default_threshold)
+        return 0, thr
+    if all(abs(v + p) <= 1e-6 * max(1.0, p) for v, p in zip(vals, probes)):
+        return 1, float(default_threshold)
+    raise NotImplementedError(
+        "compute_reward is neither sparse -(||ag-g|| > thr) nor dense -||ag-g||; "
+        "only these two goal-distance rewards have a device implementation")
+
+
+class HERBuffer:
+    def __init__(self, max_mem_len: int, max_eps_len: int, nenvs: int, threshold: float = 0.05,
+                 k_future: int = 4, *, rng: str = "python", seed: int | None = None,
+                 device_index: int = 0):
+        if not torch.cuda.is_available() or lib.gcrl_device_count() <= 0:
+            raise _ffi.GcrlError("HERBuffer needs a HIP device: the replay ring lives in HBM and "
+                                 "there is no CPU fallback")
+        self.max_mem_len = int(max_mem_len)
+        self.max_eps_len = int(max_eps_len)
+        self.nenvs = int(nenvs)
+        self.device = "cuda"
+        self.device_index = device_index
+        self.threshold = threshold
+        self.k_future = int(k_future)
+        self.compute_reward = None
+        self.obs_normalizer = None
+        self.dg_normalizer = None
+        self.rng = MTStream(rng, seed)
+        self._h = None
+        self._dims = None
+
+    # ------------------------------------------------------------------ handle management
+    def _ensure(self, S: int, A: int, G: int):
+        if self._h is not None:
+            if self._dims != (S, A, G):
+                raise ValueError(f"transition dims {(S, A, G)} differ from the ring's {self._dims}")
+            return
+        kind, thr = _classify_reward(self.compute_reward, G, self.threshold)
+        cfg = _ffi.HerConfig(state_dim=S, action_dim=A, goal_dim=G, capacity=self.max_mem_len,
+                             nenvs=self.nenvs, k_future=self.k_future, flush_len=FLUSH_LEN,
+                             reward_kind=kind, reward_threshold=thr, device=self.device_index,
+                             rng_mode=0, seed=0)
+        self._h = _ffi.check_ptr(lib.gcrl_her_create(C.byref(cfg), self.rng.handle), "gcrl_her_create")
+        self._dims = (S, A, G)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.gcrl_her_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __len__(self):
+        return 0 if self._h is None else int(lib.gcrl_her_len(self._h))
+
+    # ------------------------------------------------------------------ reference surface
+    @staticmethod
+    def _state_arg(x):
+        """-> (keepalive, pointer, on_device) for a state given as cuda/cpu tensor or ndarray."""
+        if isinstance(x, torch.Tensor):
+            t = x.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            return t, t.data_ptr(), 1 if t.is_cuda else 0
+        arr = np.ascontiguousarray(x, dtype=np.float32)
+        return arr, arr.ctypes.data, 0
+
+    def push(self, idx, state, action, next_state, reward, done, desired_goal, achieved_goal):
+        act = np.ascontiguousarray(action, dtype=np.float32).reshape(-1)
+        dg = np.ascontiguousarray(desired_goal, dtype=np.float32).reshape(-1)
+        ag = np.ascontiguousarray(achieved_goal, dtype=np.float32).reshape(-1)
+        ks, ps, ds = self._state_arg(state)
+        kn, pn, dn = self._state_arg(next_state)
+        S = int(ks.numel() if isinstance(ks, torch.Tensor) else ks.size)
+        self._ensure(S, act.size, ag.size)
+        flushing = bool(done) or lib.gcrl_her_staged(self._h, int(idx)) + 1 >= FLUSH_LEN
+        if flushing:
+            self.rng.pull()
+        rows = lib.gcrl_her_push(self._h, int(idx), ps, ds, act.ctypes.data, pn, dn,
+                                 float(reward), 1 if done else 0, dg.ctypes.data, ag.ctypes.data,
+                                 _ffi.stream_handle())
+        _ffi.check(int(rows))
+        if flushing:
+            self.rng.push_back()
+
+    def push_episode(self, idx, states, actions, next_states, rewards, dones, achieved_goals):
+        """Whole-episode fast path (one upload + one flush launch); same result as T push calls."""
+        s = np.ascontiguousarray(states, dtype=np.float32)
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        ns = np.ascontiguousarray(next_states, dtype=np.float32)
+        r = np.ascontiguousarray(rewards, dtype=np.float32).reshape(-1)
+        d = np.ascontiguousarray(dones, dtype=np.float32).reshape(-1)
+        ag = np.ascontiguousarray(achieved_goals, dtype=np.float32)
+        T = s.shape[0]
+        self._ensure(s.shape[1], a.shape[1], ag.shape[1])
+        self.rng.pull()
+        rows = lib.gcrl_her_push_episode(self._h, int(idx), T, s.ctypes.data, a.ctypes.data,
+                                         ns.ctypes.data, r.ctypes.data, d.ctypes.data,
+                                         ag.ctypes.data, None, _ffi.stream_handle())
+        _ffi.check(int(rows))
+        self.rng.push_back()
+        return int(rows)
+
+    def sample(self, batch_size: int, num_batches: int = 1, indices=None, return_indices: bool = False):
+        assert len(self) >= batch_size, "[ERROR] Not enough in buffer to sample"
+        S, A, _ = self._dims
+        n = batch_size * num_batches
+        dev = torch.device("cuda", self.device_index)
+        states = torch.empty((n, S), dtype=torch.float32, device=dev)
+        actions = torch.empty((n, A), dtype=torch.float32, device=dev)
+        rewards = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        next_states = torch.empty((n, S), dtype=torch.float32, device=dev)
+        dones = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        idx_in = None
+        if indices is not None:
+            idx_in = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+            assert idx_in.size == n
+        drawn = np.empty(n, dtype=np.uint32) if return_indices else None
+        if idx_in is None:
+            self.rng.pull()
+        _ffi.check(lib.gcrl_her_sample(
+            self._h, batch_size, num_batches, idx_in.ctypes.data if idx_in is not None else None,
+            states.data_ptr(), S, actions.data_ptr(), A, rewards.data_ptr(), next_states.data_ptr(), S,
+            dones.data_ptr(), drawn.ctypes.data if drawn is not None else None, _ffi.stream_handle()))
+        if idx_in is None:
+            self.rng.push_back()
+        out = (states, actions, rewards, next_states, dones)
+        return out + (drawn,) if return_indices else out
+
+    def rows(self, first: int = 0, count: int | None = None):
+        """Test helper: ring rows in logical (oldest-first) order as numpy arrays."""
+        n = len(self) - first if count is None else count
+        S, A, _ = self._dims
+        s = np.empty((n, S), np.float32); a = np.empty((n, A), np.float32)
+        ns = np.empty((n, S), np.float32); r = np.empty(n, np.float32); d = np.empty(n, np.float32)
+        _ffi.check(lib.gcrl_her_read_rows(self._h, first, n, s.ctypes.data, a.ctypes.data,
+                                          ns.ctypes.data, r.ctypes.data, d.ctypes.data))
+        return s, a, ns, r, d
+
+    def compute_termination(self, dg, ag):
+        return np.linalg.norm(dg - ag, axis=-1) < self.threshold

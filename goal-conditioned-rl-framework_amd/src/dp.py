@@ -1,0 +1,112 @@
+"""Data-parallel update over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in CPU tests).  New design — the reference is single-process.
+
+One process per GPU.  Env streams are sharded `nenvs / world` per rank; each rank owns a local
+HER ring and draws its own batch of B rows (seed + rank); parameters, optimiser state and
+targets are replicas kept identical by construction: identical initial parameters (broadcast
+from rank 0) and identical post-exchange gradients.  The step is cut at the two gradient
+exchanges (csrc/agent.hip phases):
+
+    phase 0  sample + critic forward/backward            -> all-reduce(sum) critic gradients
+    phase 1  critic clip/Adam/Polyak + actor fwd/bwd     -> all-reduce(sum) actor (+log_alpha) grads
+    phase 2  actor clip/Adam (+alpha step, actor Polyak)
+
+with `grad_scale = 1/world` applied inside the optimiser kernels, so G ranks x B rows equal one
+rank x G*B rows up to fp32 summation order (DDPG/TD3).  SAC/TQC actors keep LOCAL BatchNorm
+statistics per rank (stated divergence from a single big batch).  Each exchange is ONE flat
+buffer: messages are 37 KB - 11 MB, latency-bound on point-to-point xGMI, so fewer, larger
+collectives beat per-tensor ones.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+
+def shard_env_streams(nenvs: int, rank: int, world: int) -> range:
+    """Contiguous block of env ids owned by `rank` (64 envs / 8 ranks -> 8 each)."""
+    base, extra = divmod(nenvs, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def rank_seed(seed: int, rank: int) -> int:
+    return int(seed) + int(rank)
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over ranks, then divide: what grad_scale does inside the engine."""
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+    return flat
+
+
+def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
+class _DevVec:
+    """Zero-copy torch view of a device vector owned by the engine."""
+
+    def __init__(self, ptr: int, numel: int):
+        self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_view(ptr: int, numel: int) -> torch.Tensor:
+    return torch.as_tensor(_DevVec(ptr, numel), device="cuda")
+
+
+class DataParallelUpdater:
+    """Drives agent.update(step) across ranks.  `agent` is a gcrl_amd agent on this rank's GPU."""
+
+    def __init__(self, agent, group=None):
+        from .. import _ffi
+        self._ffi = _ffi
+        self.agent = agent
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.scale = 1.0 / self.world
+        lib = _ffi.lib
+        self._blocks = []
+        for phase in (0, 1):
+            p, n = C.c_void_p(), C.c_int64()
+            _ffi.check(lib.gcrl_agent_grad_ptr(agent._h, phase, C.byref(p), C.byref(n)))
+            self._blocks.append(device_view(p.value, n.value))
+        self.sync_parameters()
+
+    def sync_parameters(self):
+        """Rank 0's parameters (and BN statistics, log_alpha) become everyone's."""
+        lib, ffi = self._ffi.lib, self._ffi
+        names = ["actor"] + [f"critic_{i}" for i in range(self.agent.num_critics)]
+        if self.agent._sac:
+            names += ["log_alpha", "bn_running_mean", "bn_running_var"]
+        for name in names:
+            p, n = C.c_void_p(), C.c_int64()
+            ffi.check(lib.gcrl_agent_dev_ptr(self.agent._h, name.encode(), C.byref(p), C.byref(n)))
+            broadcast_(device_view(p.value, n.value), 0, self.group)
+        torch.cuda.synchronize()
+        self.agent.update_target_network()
+
+    def update(self, step: int):
+        a, lib, ffi = self.agent, self._ffi.lib, self._ffi
+        her = a.buffer.handle
+        ticket = C.c_int64(-1)
+        a.buffer.rng.pull()
+        n = ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 0, None, self.scale, C.byref(ticket),
+                                                  ffi.stream_handle()))
+        a.buffer.rng.push_back()
+        dist.all_reduce(self._blocks[0], op=dist.ReduceOp.SUM, group=self.group)
+        ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 1, None, self.scale, None, ffi.stream_handle()))
+        if n == {0: 6, 1: 8, 2: 9, 3: 9}[ffi_kind(a)]:   # tuple length of an actor step
+            dist.all_reduce(self._blocks[1], op=dist.ReduceOp.SUM, group=self.group)
+        ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 2, None, self.scale, None, ffi.stream_handle()))
+        return a._tuple(ticket.value, n)
+
+
+def ffi_kind(agent) -> int:
+    from .agent import KIND
+    return KIND[agent.KIND_NAME]

@@ -1,0 +1,152 @@
+"""Host-side configuration and normaliser, field-compatible with the reference's src/utils.py.
+
+Only what the hot path consumes is mirrored: the hyper-parameter models whose FIELD NAMES the
+engine reads (reference src/utils.py:10-65), the YAML loaders (:177-194), the running
+normaliser that sits in front of push() (:68-117) and set_seed (:197-208, minus the gym env).
+The gym wrappers of the reference are env-side and out of scope.
+"""
+from __future__ import annotations
+
+import os
+import random
+from typing import Union
+
+import numpy as np
+import yaml
+from pydantic import BaseModel, Field
+
+
+class BaseAgentConfig(BaseModel):
+    """Same 23 required fields as the reference (src/utils.py:10-33); unknown YAML keys are
+    ignored exactly as pydantic's default does there."""
+    hidden_dim: int = Field(..., ge=1)
+    layer_count: int = Field(..., ge=1)
+    actor_lr: float = Field(..., gt=0)
+    actor_lr_min: float = Field(..., gt=0)
+    ac_scheduler_steps: int = Field(..., ge=1)
+    critic_lr: float = Field(..., gt=0)
+    critic_lr_min: float = Field(..., gt=0)
+    cr_scheduler_steps: int = Field(..., ge=1)
+    buffer_type: str
+    max_len: int = Field(..., ge=1)
+    alpha: float = Field(..., ge=0)
+    batch_size: int = Field(..., ge=1)
+    gamma: float = Field(..., ge=0, le=1)
+    ac_update_freq: int = Field(..., ge=1)
+    noise_std: float = Field(..., ge=0)
+    noise_clamp: float = Field(..., ge=0)
+    policy_noise: float = Field(..., ge=0)
+    grad_clip: float = Field(..., ge=0)
+    beta: float = Field(..., ge=0)
+    beta_end: int = Field(..., ge=1)
+    k_future: int = Field(..., ge=0)
+    max_eps_len: int = Field(..., ge=1)
+    tau: float = Field(..., ge=0)
+
+
+class SACAgentConfig(BaseAgentConfig):
+    alpha_lr: float = Field(default=0.0003, gt=0)
+    alpha_min: float = Field(default=0.05, gt=0)
+    alpha_min_steps: float = Field(..., ge=0)
+
+
+class HERConfig(BaseModel):
+    max_episode: int = Field(..., ge=1)
+    max_cycle: int = Field(..., ge=1)
+    max_epoch: int = Field(..., ge=1)
+    save_freq: int = Field(..., ge=1)
+    video_freq: int = Field(..., ge=1)
+    window_size: int = Field(..., ge=1)
+    gradient_step: int = Field(..., ge=1)
+    reset_freq: int = Field(..., ge=1)
+    g_normalize: bool = Field(default=False)
+    obs_normalize: bool = Field(default=True)
+    agent: Union[BaseAgentConfig, SACAgentConfig]
+
+
+class Config(BaseModel):
+    max_frames: int = Field(..., ge=1)
+    save_freq: int = Field(..., ge=1)
+    video_freq: int = Field(..., ge=1)
+    window_size: int = Field(..., ge=1)
+    gradient_step: int = Field(..., ge=1)
+    reset_freq: int = Field(..., ge=1)
+    g_normalize: bool = Field(default=True)
+    obs_normalize: bool = Field(default=True)
+    agent: Union[BaseAgentConfig, SACAgentConfig]
+
+
+def _agent_model(agent_type: str):
+    return SACAgentConfig if agent_type in ("SAC", "TQC") else BaseAgentConfig
+
+
+def load_config(path: str, agent_type: str) -> Config:
+    with open(path, "r") as fh:
+        raw = yaml.safe_load(fh)
+    raw["agent"] = _agent_model(agent_type)(**raw["agent"])
+    return Config(**raw)
+
+
+def load_her_config(path: str, agent_type: str) -> HERConfig:
+    with open(path, "r") as fh:
+        raw = yaml.safe_load(fh)
+    raw["agent"] = _agent_model(agent_type)(**raw["agent"])
+    return HERConfig(**raw)
+
+
+class RunningNormalizer:
+    """Streaming mean/variance with the parallel-merge (Chan et al.) update, float64, clip to
+    +-clip_range — the arithmetic of reference src/utils.py:68-98.  O(num_envs * dim) per env
+    step on the host; the device version is a 'next' row."""
+
+    def __init__(self, size, clip_range: float = 5.0, eps: float = 1e-8):
+        self.mean = np.zeros(size)
+        self.var = np.ones(size)
+        self.count = eps
+        self.clip_range = clip_range
+
+    def update(self, x):
+        x = np.asarray(x)
+        self._merge(x.mean(axis=0), x.var(axis=0), x.shape[0])
+
+    def _merge(self, b_mean, b_var, b_count):
+        n = self.count + b_count
+        delta = b_mean - self.mean
+        m2 = self.var * self.count + b_var * b_count + np.square(delta) * self.count * b_count / n
+        self.mean = self.mean + delta * b_count / n
+        self.var = m2 / n
+        self.count = n
+
+    # name used by the reference's callers
+    _update_from_moments = _merge
+
+    def normalize(self, x):
+        z = (x - self.mean) / (np.sqrt(self.var) + 1e-8)
+        return np.clip(z, -self.clip_range, self.clip_range)
+
+    def save(self, path: str):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            yaml.dump({"mean": self.mean.tolist(), "var": self.var.tolist(),
+                       "count": float(self.count), "clip_range": float(self.clip_range)}, fh)
+
+    def load(self, path: str):
+        with open(path, "r") as fh:
+            d = yaml.safe_load(fh)
+        self.mean = np.array(d["mean"], dtype=np.float32)
+        self.var = np.array(d["var"], dtype=np.float32)
+        self.count = float(d["count"])
+        self.clip_range = float(d["clip_range"])
+
+
+def set_seed(seed: int, env=None):
+    """Seeds the three host generators the reference seeds (src/utils.py:197-208)."""
+    import torch
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    if env is not None:
+        env.action_space.seed(seed)
+        env.observation_space.seed(seed)

@@ -1,0 +1,308 @@
+/*
+ * gcrl.h — C ABI of libgcrl_hip.so: MI355X-native HER replay + actor-critic update engine.
+ *
+ * The reference (CodeKnight314/Goal-Conditioned-RL-Framework) has NO native/FFI layer: its
+ * boundary is the duck-typed Python surface that src/env.py uses on `agent` and `agent.buffer`
+ * (SURVEY.md §8b).  Each entry point below therefore cites the reference *Python* method it
+ * replaces; the Python classes in goal-conditioned-rl-framework_amd/src/ (same names and
+ * signatures as the reference's) are thin ctypes callers of these functions.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  `*_dev` = device (HBM) pointer,
+ *     `*_host` = host pointer.  `stream` is a hipStream_t passed as void*: NULL = the
+ *     handle's own (non-blocking) stream, GCRL_STREAM_LEGACY = HIP's legacy default stream
+ *     (what torch.cuda.current_stream().cuda_stream == 0 means).
+ *   - every function returning int returns GCRL_OK (0) or a negative gcrl_status; nothing
+ *     throws across the boundary.  gcrl_last_error() gives the message (thread-local).
+ *   - one calling thread per handle (the reference's trainer is single-threaded,
+ *     src/env.py:334-406); all device work of a handle is stream-ordered.
+ *   - there is NO CPU fallback: every device entry point fails with GCRL_ERR_HIP when no
+ *     gfx950 device is usable.  Host-only entry points (gcrl_mt_*, gcrl_cosine_lr_*) work
+ *     without a GPU.
+ */
+#ifndef GCRL_H
+#define GCRL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCRL_ABI_VERSION 1
+#define GCRL_STREAM_LEGACY ((void*)1)
+
+typedef enum gcrl_status {
+  GCRL_OK = 0,
+  GCRL_ERR_ARG = -1,        /* bad argument / unsupported shape */
+  GCRL_ERR_HIP = -2,        /* HIP runtime error (message has hipGetErrorString) */
+  GCRL_ERR_NOT_ENOUGH = -3, /* sample(B) with len < B  (reference: assert, src/buffer.py:122) */
+  GCRL_ERR_STATE = -4       /* call made in the wrong state */
+} gcrl_status;
+
+const char* gcrl_last_error(void);
+int gcrl_abi_version(void);
+/* number of usable HIP devices (0 when none); never fails */
+int gcrl_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * CPython-exact Mersenne Twister.  Replaces the stdlib `random` calls the reference makes on
+ * the hot path: random.randint (src/buffer.py:153) and random.sample (src/buffer.py:124);
+ * random.random (src/agent.py:1348) shares the same stream.  Algorithm: CPython 3.10
+ * Lib/random.py (_randbelow_with_getrandbits, sample, randrange) + Modules/_randommodule.c
+ * (init_by_array, genrand_uint32, genrand_res53).  Host-only.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gcrl_mt gcrl_mt;
+
+gcrl_mt* gcrl_mt_create(void);
+void gcrl_mt_destroy(gcrl_mt* mt);
+/* random.seed(n) for a non-negative int n < 2**64 */
+int gcrl_mt_seed(gcrl_mt* mt, uint64_t seed);
+/* state[0..623] = MT words, state[624] = index; same layout as random.getstate()[1] */
+int gcrl_mt_get_state(const gcrl_mt* mt, uint32_t* state625);
+int gcrl_mt_set_state(gcrl_mt* mt, const uint32_t* state625);
+uint32_t gcrl_mt_getrandbits(gcrl_mt* mt, int k /* 1..32 */);
+uint32_t gcrl_mt_randbelow(gcrl_mt* mt, uint32_t n /* >= 1 */);
+int64_t gcrl_mt_randint(gcrl_mt* mt, int64_t a, int64_t b); /* a + randbelow(b-a+1) */
+double gcrl_mt_random(gcrl_mt* mt);
+/* index stream of random.sample(population_of_len_n, k): out[i] = index chosen i-th.
+ * Both the pool path (n <= setsize(k)) and the set path are reproduced. */
+int gcrl_mt_sample_indices(gcrl_mt* mt, uint32_t n, uint32_t k, uint32_t* out_host);
+/* draw order of HERBuffer.apply_her (src/buffer.py:146-153): for i in 0..T-2, k_future times
+ * randint(i+1, T-1); nothing for the last step.  out has k_future*(T-1) entries. */
+int gcrl_mt_future_indices(gcrl_mt* mt, int T, int k_future, uint8_t* out_host);
+
+/* ------------------------------------------------------------------------------------------
+ * torch.optim.lr_scheduler.CosineAnnealingLR (recursive/"chainable" form) as the reference
+ * configures it (src/agent.py:1203-1212 etc.).  Host-only, double precision like torch.
+ * lr_after_k_steps: lr used by the optimiser step number k+1 (k scheduler.step() calls done).
+ * ---------------------------------------------------------------------------------------- */
+double gcrl_cosine_lr_next(double lr_now, double base_lr, double eta_min, int64_t t_max,
+                           int64_t last_epoch_after_step);
+
+/* ------------------------------------------------------------------------------------------
+ * HER replay ring in HBM.  Replaces class HERBuffer (src/buffer.py:92-179).
+ * Layout (fp32): one 64-byte-aligned packed record per transition, [s(S)|a(A)|ns(S)|r|d|pad],
+ * records contiguous in arrival order (DESIGN.md "HBM layout" explains why not five field
+ * arrays: a random row gather would touch ~3x the 128-B lines).  sample() returns the five
+ * dense field matrices of the reference.  The stored dg/ag columns of the reference's tuples
+ * are never read by sample() (src/buffer.py:125) and are not materialised.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gcrl_her gcrl_her;
+
+enum { GCRL_REWARD_SPARSE = 0, GCRL_REWARD_DENSE = 1 };
+enum { GCRL_RNG_CPYTHON_MT = 0, GCRL_RNG_DEVICE = 1 };
+
+typedef struct gcrl_her_config {
+  int32_t state_dim;   /* S: obs + time feature + goal (goal = LAST goal_dim entries) */
+  int32_t action_dim;  /* A */
+  int32_t goal_dim;    /* G */
+  int64_t capacity;    /* max_mem_len (deque maxlen, src/buffer.py:101) */
+  int32_t nenvs;       /* per-env staging areas (src/buffer.py:102) */
+  int32_t k_future;    /* relabels per step (src/buffer.py:151) */
+  int32_t flush_len;   /* 50: literal in src/buffer.py:117 (max_eps_len is ignored there) */
+  int32_t reward_kind; /* GCRL_REWARD_*: stands in for the injected compute_reward
+                          (src/env.py:105, src/buffer.py:166): sparse = -(||ag-g||2 > thr) */
+  float reward_threshold; /* 0.05 for all Panda tasks */
+  int32_t device;
+  int32_t rng_mode;    /* GCRL_RNG_* */
+  uint64_t seed;       /* used when the handle owns its RNG */
+} gcrl_her_config;
+
+/* rng: shared CPython-exact generator (may be NULL: the handle creates one seeded with
+ * cfg->seed).  The ring never frees a shared rng. */
+gcrl_her* gcrl_her_create(const gcrl_her_config* cfg, gcrl_mt* rng);
+void gcrl_her_destroy(gcrl_her* h);
+int64_t gcrl_her_len(const gcrl_her* h);       /* HERBuffer.__len__  src/buffer.py:137 */
+int64_t gcrl_her_head(const gcrl_her* h);      /* physical row of logical index 0 */
+int32_t gcrl_her_staged(const gcrl_her* h, int env);
+void* gcrl_her_stream(const gcrl_her* h);
+
+/* HERBuffer.push (src/buffer.py:110-119).  state/next_state: S floats, either device
+ * pointers (the reference passes device tensors, src/env.py:217-219) or host pointers
+ * (flag *_on_device).  action (A), desired_goal/achieved_goal (G): host floats.
+ * Stages the transition; when `done` or the env has flush_len staged transitions, runs the
+ * HER relabel+flush kernel (apply_her) and clears the staging area.
+ * Returns the number of ring rows appended (0 = staged only) or a negative status. */
+int64_t gcrl_her_push(gcrl_her* h, int env, const float* state, int state_on_device,
+                      const float* action_host, const float* next_state,
+                      int next_state_on_device, float reward, int done,
+                      const float* desired_goal_host, const float* achieved_goal_host,
+                      void* stream);
+
+/* Whole-episode variant (one H2D copy + one flush launch): T transitions of env `env` given as
+ * host arrays s[T][S], a[T][A], ns[T][S], r[T], d[T] (0/1), ag[T][G].  Equivalent to T calls
+ * of gcrl_her_push whose last one triggers the flush; any partially staged episode of that env
+ * must be empty.  future_idx (k_future*(T-1) entries, draw order of src/buffer.py:146-153) may
+ * be NULL: then drawn from the handle's RNG. */
+int64_t gcrl_her_push_episode(gcrl_her* h, int env, int T, const float* s_host,
+                              const float* a_host, const float* ns_host, const float* r_host,
+                              const float* d_host, const float* ag_host,
+                              const uint8_t* future_idx_host, void* stream);
+
+/* HERBuffer.sample (src/buffer.py:121-135), M batches per launch.  Logical indices
+ * (0 = oldest row) are drawn by random.sample semantics from the handle's RNG, or taken from
+ * idx_host (M*B entries) when non-NULL.  Outputs are device pointers; row strides ld_* in
+ * floats (ld_s >= S etc.; rewards/dones are [M*B] contiguous = the reference's [B,1]).
+ * drawn_idx_host (optional, M*B) receives the indices used. */
+int gcrl_her_sample(gcrl_her* h, int B, int M, const uint32_t* idx_host,
+                    float* out_s_dev, int ld_s, float* out_a_dev, int ld_a, float* out_r_dev,
+                    float* out_ns_dev, int ld_ns, float* out_d_dev,
+                    uint32_t* drawn_idx_host, void* stream);
+
+/* Measurement: when enabled, every gather launch of this ring (gcrl_her_sample and the update
+ * engine's batch gather) is bracketed by two hipEvents on the stream it is launched on.
+ * gcrl_her_profile_read waits for the pending events and returns, since enabling, the number
+ * of gather launches, their summed device time (ms) and the rows they gathered. */
+int gcrl_her_profile_enable(gcrl_her* h, int on);
+int gcrl_her_profile_read(gcrl_her* h, int64_t* launches_out, double* total_ms_out,
+                          int64_t* rows_out);
+
+/* Test/debug: copy `n` ring rows starting at logical index `first` to host arrays
+ * (any may be NULL).  Synchronises the handle's stream. */
+int gcrl_her_read_rows(gcrl_her* h, int64_t first, int64_t n, float* s_host, float* a_host,
+                       float* ns_host, float* r_host, float* d_host);
+
+/* ------------------------------------------------------------------------------------------
+ * Update engine.  Replaces DDPG / TD3Agent / SACAgent / TQCAgent .update() and what it calls
+ * (src/agent.py:1378-1404, :281-317, :659-699, :1062-1100) plus the networks of src/model.py.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gcrl_agent gcrl_agent;
+
+enum { GCRL_AGENT_DDPG = 0, GCRL_AGENT_TD3 = 1, GCRL_AGENT_SAC = 2, GCRL_AGENT_TQC = 3 };
+
+typedef struct gcrl_agent_config {
+  int32_t kind;           /* GCRL_AGENT_* */
+  int32_t obs_dim;        /* S = obs + goal, the `obs_dim` ctor argument (src/env.py:120-127) */
+  int32_t ac_dim;         /* A */
+  int32_t hidden_dim;     /* BaseAgentConfig.hidden_dim (src/utils.py:11) */
+  int32_t layer_count;    /* BaseAgentConfig.layer_count */
+  int32_t batch_size;
+  int32_t num_critics;    /* TQC: 5 (src/agent.py:789); DDPG 1; TD3/SAC 2 */
+  int32_t top_drop;       /* TQC: 2 (src/agent.py:790) */
+  int32_t ac_update_freq;
+  int32_t gradient_step;  /* ctor argument; SAC Polyak cadence (src/agent.py:681) */
+  int32_t polyak_every;   /* DDPG: literal 40 (src/agent.py:1397) */
+  /* hyper-parameters are Python floats (doubles) in the reference's pydantic config */
+  double gamma, tau;
+  double grad_clip;       /* < 0: no clipping (grad_clip None) */
+  double policy_noise, noise_clamp; /* TD3 target smoothing (src/agent.py:174-179) */
+  double actor_lr, actor_lr_min, critic_lr, critic_lr_min, alpha_lr;
+  int64_t ac_scheduler_steps, cr_scheduler_steps;
+  double alpha_min_steps; /* SACAgentConfig.alpha_min_steps is a float (src/utils.py:39) */
+  int32_t device;
+  int32_t use_graph;      /* 1: replay the step as a hipGraph */
+  uint64_t seed;          /* device RNG for TD3 noise / SAC eps when not injected */
+} gcrl_agent_config;
+
+gcrl_agent* gcrl_agent_create(const gcrl_agent_config* cfg);
+void gcrl_agent_destroy(gcrl_agent* a);
+void* gcrl_agent_stream(const gcrl_agent* a);
+
+/* Networks are addressed by name: "actor", "target_actor", "critic_<i>", "target_critic_<i>"
+ * (i from 0), "log_alpha".  A network's parameters are ONE flat fp32 vector in
+ * torch `module.parameters()` order (weight [out,in] row-major, then bias, per layer; SAC
+ * actor: Linear w,b, BatchNorm w,b per block, then mean_head, log_std_head — src/model.py),
+ * so state_dict tensors are contiguous slices of it.  Buffers "bn_running_mean"/
+ * "bn_running_var" are separate named vectors [L*H]. */
+int64_t gcrl_agent_numel(const gcrl_agent* a, const char* name); /* <0: unknown name */
+int gcrl_agent_get(gcrl_agent* a, const char* name, float* dst_host, int64_t n);
+int gcrl_agent_set(gcrl_agent* a, const char* name, const float* src_host, int64_t n);
+/* gradient of the last update() for "actor" / "critic_<i>" (pre-clip), optimiser moments
+ * "adam_m:<net>" / "adam_v:<net>" — through the same get call. */
+
+/* Xavier-uniform weights, bias 0.01 (src/model.py:39-42), targets hard-copied
+ * (src/agent.py:1257-1258); device RNG seeded from cfg->seed.  Statistically, not bitwise,
+ * equal to torch's initialisation: parity tests load explicit parameters with gcrl_agent_set.
+ * Also what reset() does (src/agent.py:1461-1465): Linear layers only; optimiser moments,
+ * schedulers and BN statistics are kept. `recreate_alpha` = SAC/TQC reset (src/agent.py:767). */
+int gcrl_agent_init_weights(gcrl_agent* a, uint64_t seed, int recreate_alpha);
+/* update_target_network(hard_update=True) */
+int gcrl_agent_hard_update_targets(gcrl_agent* a);
+
+/* Optional injected inputs for one update (parity tests; all device pointers, may be NULL). */
+typedef struct gcrl_update_inputs {
+  const float* s_dev;   int32_t ld_s;    /* [B, S]  explicit batch instead of sampling */
+  const float* a_dev;   int32_t ld_a;
+  const float* r_dev;
+  const float* ns_dev;  int32_t ld_ns;
+  const float* d_dev;
+  const float* noise_dev;      /* TD3: randn_like(action) [B, A]   (src/agent.py:175) */
+  const float* eps_next_dev;   /* SAC/TQC: rsample eps for actor.sample(next_state) [B, A] */
+  const float* eps_cur_dev;    /* SAC/TQC: rsample eps for actor.sample(states)     [B, A] */
+} gcrl_update_inputs;
+
+/* One agent.update(step).  Batch: sampled from `her` (HERBuffer.sample semantics) unless
+ * inputs->s_dev is given.  Asynchronous: returns after enqueueing.  Returns the length of the
+ * reference's return tuple for this step (DDPG 6/4, TD3 8/6, SAC & TQC 9/6 — the caller
+ * dispatches on it, src/env.py:448-506) or a negative status.  `ticket_out` identifies the
+ * metrics slot of this step. */
+int gcrl_agent_update(gcrl_agent* a, gcrl_her* her, int64_t step,
+                      const gcrl_update_inputs* inputs, int64_t* ticket_out, void* stream);
+/* `n` consecutive updates step0..step0+n-1 (the loop of src/env.py:384-385; the buffer is not
+ * mutated inside it, so all n batches are drawn and gathered by ONE gather launch).
+ * tickets_out[n], tuple_len_out[n] optional. */
+int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n,
+                        int64_t* tickets_out, int32_t* tuple_len_out, void* stream);
+/* Metrics of a ticket, in the reference's tuple order, as fp32 (waits for that step only).
+ * n = tuple length returned by the update. */
+int gcrl_agent_metrics(gcrl_agent* a, int64_t ticket, double* out_host, int n);
+
+/* Data-parallel hooks: the step is split at the two gradient exchanges.
+ * phase 0: sample + critic fwd/bwd  -> caller all-reduces grads of "critic_*"
+ * phase 1: critic clip/optimiser/Polyak + actor fwd/bwd -> caller all-reduces "actor" grads
+ * phase 2: actor clip/optimiser (+alpha, + actor Polyak)
+ * gcrl_agent_grad_ptr returns the device pointer + numel of the flat gradient block of the
+ * phase (all critics contiguous / actor (+log_alpha grad)). `grad_scale` multiplies the
+ * gradients before clipping (1/world after an all-reduce sum). */
+int gcrl_agent_update_phase(gcrl_agent* a, gcrl_her* her, int64_t step, int phase,
+                            const gcrl_update_inputs* inputs, float grad_scale,
+                            int64_t* ticket_out, void* stream);
+int gcrl_agent_grad_ptr(gcrl_agent* a, int phase, float** ptr_dev_out, int64_t* numel_out);
+/* device pointer of a named vector (parameters / grads), for zero-copy interop */
+int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr_dev_out, int64_t* numel_out);
+
+/* Batched actor inference for select_action (src/agent.py:1345-1366, :641-647): obs_dev
+ * [n, S] -> out_dev [n, A]: DDPG/TD3 the network output (already tanh, src/model.py:24);
+ * SAC/TQC tanh(mean) in eval mode (BatchNorm running statistics) when eps_dev is NULL,
+ * else tanh(mean + std*eps). */
+int gcrl_agent_act(gcrl_agent* a, const float* obs_dev, int n, int ld_obs, float* out_dev,
+                   int ld_out, const float* eps_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stand-alone ops exposed for tests / reuse.
+ * ---------------------------------------------------------------------------------------- */
+/* Row-wise sort of `width` (<= 64) fp32 values per row in one wavefront (bitonic network via
+ * cross-lane swaps), drop the `drop` largest, mean of the rest: the truncation of
+ * src/agent.py:919-921 / :972-974 generalised to BASELINE.json's 25x2-atom shape.
+ * in_dev [rows, width] -> sorted_dev [rows, width] (optional) , mean_dev [rows]. */
+int gcrl_sort_truncate_mean(const float* in_dev, int64_t rows, int width, int drop,
+                            float* sorted_dev, float* mean_dev, void* stream);
+
+/* The batched fp32-MFMA GEMM every Linear forward/backward of the engine runs on, as a single
+ * problem: C[M,N] = act(A.B + bias) with element strides (A(m,k) = A[m*a_rs + k*a_cs],
+ * B(k,n) = B[k*b_rs + n*b_cs], C row stride c_rs); act: 0 none, 1 LeakyReLU(0.01), 2 ReLU,
+ * 3 tanh.  shape: 0 auto, 1 = 16x16 tile per workgroup with K split over its 4 waves,
+ * 2 = 16x16 per wave, 3 = 32x32 per wave (tests sweep all three). */
+int gcrl_gemm_f32(const float* a_dev, int64_t a_rs, int64_t a_cs, const float* b_dev, int64_t b_rs,
+                  int64_t b_cs, float* c_dev, int64_t c_rs, const float* bias_dev, int M, int N,
+                  int K, int act, int shape, void* stream);
+
+/* hipEvent helpers so a Python caller can time the engine's own stream (torch.cuda.Event only
+ * sees torch's current stream). */
+void* gcrl_event_create(void);
+void gcrl_event_destroy(void* ev);
+int gcrl_event_record(void* ev, void* stream);
+int gcrl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* syncs on stop */
+int gcrl_stream_synchronize(void* stream);
+/* plain device memory for callers without torch */
+void* gcrl_malloc(size_t bytes);
+void gcrl_free(void* p);
+int gcrl_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int gcrl_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCRL_H */

@@ -1,0 +1,144 @@
+"""CPU tests of the host-only part of libgcrl_hip.so and of the boundary itself: the library
+loads without a GPU, exports every symbol include/gcrl.h declares, its Mersenne Twister is
+CPython-exact (golden index streams of the reference + live `random`), its cosine schedule is
+torch's.  No device entry point is called here."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_header_symbols_are_all_exported(gcrl):
+    hdr = open(os.path.join(ROOT, "include", "gcrl.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gcrl_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) > 40
+    lib = C.CDLL(gcrl._ffi.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    # and the ctypes table binds exactly the declared set
+    assert set(gcrl._ffi.PROTOTYPES) == declared
+
+
+def test_abi_version_and_error_channel(lib):
+    assert lib.gcrl_abi_version() == 1
+    mt = lib.gcrl_mt_create()
+    bad = (C.c_uint32 * 625)()
+    bad[624] = 999
+    assert lib.gcrl_mt_set_state(mt, bad) == -1
+    assert b"index" in lib.gcrl_last_error()
+    lib.gcrl_mt_destroy(mt)
+
+
+def _state(lib, mt):
+    buf = (C.c_uint32 * 625)()
+    assert lib.gcrl_mt_get_state(mt, buf) == 0
+    return np.frombuffer(buf, dtype=np.uint32).copy()
+
+
+def test_mt_future_indices_match_reference_goldens(lib):
+    g = load_golden("her_index_streams.npz")
+    mt = lib.gcrl_mt_create()
+    for key in [k for k in g.files if k.startswith("future_") and not k.endswith("_state")]:
+        _, s, T, k = key.split("_")
+        seed, T, k = int(s[1:]), int(T[1:]), int(k[1:])
+        lib.gcrl_mt_seed(mt, seed)
+        out = (C.c_uint8 * max(1, k * (T - 1)))()
+        assert lib.gcrl_mt_future_indices(mt, T, k, out) == 0
+        assert list(out)[: k * (T - 1)] == g[key].tolist(), key
+        assert np.array_equal(_state(lib, mt)[:624], g[key + "_state"][:624]), key
+    lib.gcrl_mt_destroy(mt)
+
+
+def test_mt_sample_indices_match_reference_goldens(lib):
+    g = load_golden("her_index_streams.npz")
+    mt = lib.gcrl_mt_create()
+    for key in [k for k in g.files if k.startswith("sample_") and not k.endswith("_state")]:
+        _, s, n, b = key.split("_")
+        seed, n, b = int(s[1:]), int(n[1:]), int(b[1:])
+        lib.gcrl_mt_seed(mt, seed)
+        out = np.empty(b, dtype=np.uint32)
+        assert lib.gcrl_mt_sample_indices(mt, n, b, out.ctypes.data) == 0
+        assert np.array_equal(out.astype(np.int64), g[key]), key   # pool path and set path
+        st = _state(lib, mt)
+        assert np.array_equal(st[:624], g[key + "_state"][:624]) and st[624] == g[key + "_state"][624], key
+    lib.gcrl_mt_destroy(mt)
+
+
+def test_mt_mixed_stream_and_state_round_trip(lib):
+    g = load_golden("her_index_streams.npz")
+    mt = lib.gcrl_mt_create()
+    lib.gcrl_mt_seed(mt, 1898)
+    a = np.empty(64, np.uint32); b = np.empty(64, np.uint32)
+    lib.gcrl_mt_sample_indices(mt, 5000, 64, a.ctypes.data)
+    lib.gcrl_mt_sample_indices(mt, 5000, 64, b.ctypes.data)
+    c = lib.gcrl_mt_randint(mt, 3, 40)
+    d = lib.gcrl_mt_random(mt)
+    assert np.array_equal(np.concatenate([a, b, [c]]).astype(np.int64), g["mixed_stream"])
+    assert d == g["mixed_stream_random"][0]
+    # hand the state to Python's random and back: both continue identically
+    random.setstate((3, tuple(int(x) for x in _state(lib, mt)), None))
+    for _ in range(1000):
+        assert random.getrandbits(32) == lib.gcrl_mt_getrandbits(mt, 32)
+    words = (C.c_uint32 * 625)(*random.getstate()[1])
+    assert lib.gcrl_mt_set_state(mt, words) == 0
+    assert random.sample(range(12345), 77) == [int(x) for x in _sample(lib, mt, 12345, 77)]
+    lib.gcrl_mt_destroy(mt)
+
+
+def _sample(lib, mt, n, k):
+    out = np.empty(k, np.uint32)
+    assert lib.gcrl_mt_sample_indices(mt, n, k, out.ctypes.data) == 0
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 1898, 2**32 - 1, 2**32, 2**63 + 12345])
+def test_mt_seed_matches_python(lib, seed):
+    mt = lib.gcrl_mt_create()
+    lib.gcrl_mt_seed(mt, seed)
+    rng = random.Random(seed)
+    for n in [1, 2, 3, 50, 1000, 2**20 + 1, 2**31, 2**32 - 1]:
+        assert lib.gcrl_mt_randbelow(mt, n) == rng._randbelow(n)
+    assert lib.gcrl_mt_random(mt) == rng.random()
+    lib.gcrl_mt_destroy(mt)
+
+
+def test_mt_sample_edge_cases(lib):
+    mt = lib.gcrl_mt_create()
+    lib.gcrl_mt_seed(mt, 3)
+    rng = random.Random(3)
+    for n, k in [(1, 1), (5, 5), (21, 6), (22, 6), (85, 6), (86, 6), (4117, 1024), (4118, 1024)]:
+        assert rng.sample(range(n), k) == [int(x) for x in _sample(lib, mt, n, k)], (n, k)
+    out = np.empty(8, np.uint32)
+    assert lib.gcrl_mt_sample_indices(mt, 4, 8, out.ctypes.data) == -3   # k > n: NOT_ENOUGH
+    lib.gcrl_mt_destroy(mt)
+
+
+@pytest.mark.parametrize("base,eta_min,tmax", [(1e-3, 1e-3, 1), (1e-3, 1e-4, 3), (5e-4, 1e-5, 50000), (1e-3, 1e-4, 1)])
+def test_cosine_schedule_matches_torch(lib, base, eta_min, tmax):
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=base)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=tmax, eta_min=eta_min)
+    lr = base
+    for e in range(1, 30):
+        opt.step()
+        sched.step()
+        lr = lib.gcrl_cosine_lr_next(lr, base, eta_min, tmax, e)
+        assert lr == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12, abs=1e-18), e
+
+
+def test_device_entry_points_fail_loudly_without_gpu(gcrl, lib):
+    if lib.gcrl_device_count() > 0:
+        pytest.skip("GPU present")
+    cfg = gcrl._ffi.HerConfig(state_dim=10, action_dim=3, goal_dim=3, capacity=100, nenvs=1, k_future=4,
+                              flush_len=50, reward_kind=0, reward_threshold=0.05, device=0, rng_mode=0, seed=0)
+    assert not lib.gcrl_her_create(C.byref(cfg), None)
+    assert b"no CPU fallback" in lib.gcrl_last_error()
+    with pytest.raises(gcrl._ffi.GcrlError):
+        gcrl.HERBuffer(100, 50, 1)

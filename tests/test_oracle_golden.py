@@ -1,0 +1,169 @@
+"""CPU tests: the oracle (oracle/*.py) reproduces the golden vectors captured from the REAL
+reference (tests/golden/make_golden.py).  Index streams and stored rows bit-exact; update-step
+losses / gradients within 1e-5 relative (abs floor 1e-6), the north-star tolerance."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import hparams_from_golden, load_golden
+from oracle import her_oracle
+from oracle.agent_oracle import OracleAgent
+
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def close(a, b, rtol=RTOL, atol=ATOL, scale=None):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    floor = atol + rtol * (np.max(np.abs(b)) if scale is None else scale)
+    return np.max(np.abs(a - b)) <= floor if a.size else True
+
+
+# ---------------------------------------------------------------- G1/G2: index streams
+def test_future_index_streams_match_reference():
+    g = load_golden("her_index_streams.npz")
+    for key in [k for k in g.files if k.startswith("future_") and not k.endswith("_state")]:
+        _, s, T, k = key.split("_")
+        rng = random.Random(int(s[1:]))
+        got = her_oracle.future_indices(rng, int(T[1:]), int(k[1:]))
+        assert got == g[key].tolist(), key
+
+
+def test_sample_index_streams_match_reference():
+    g = load_golden("her_index_streams.npz")
+    for key in [k for k in g.files if k.startswith("sample_") and not k.endswith("_state")]:
+        _, s, n, b = key.split("_")
+        rng = random.Random(int(s[1:]))
+        got = her_oracle.sample_indices(rng, int(n[1:]), int(b[1:]))
+        assert got == g[key].tolist(), key
+        assert np.array_equal(np.array(rng.getstate()[1], dtype=np.uint32), g[key + "_state"])
+
+
+# ---------------------------------------------------------------- G3/G4: stored rows, batch
+CASES = ["full50", "done12", "single", "wrap300", "k8_two_envs", "tiny_cap100"]
+
+
+def replay_case(g, name, buf):
+    e = 0
+    while f"{name}_ep{e}_s" in g.files:
+        env = int(g[f"{name}_ep{e}_env"][0])
+        done_last = bool(g[f"{name}_ep{e}_done_last"][0])
+        s, a, ns = g[f"{name}_ep{e}_s"], g[f"{name}_ep{e}_a"], g[f"{name}_ep{e}_ns"]
+        r, dg, ag = g[f"{name}_ep{e}_r"], g[f"{name}_ep{e}_dg"], g[f"{name}_ep{e}_ag"]
+        T = s.shape[0]
+        for t in range(T):
+            buf.push(env, s[t], a[t], ns[t], r[t], bool(done_last and t == T - 1), dg[t], ag[t])
+        e += 1
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_her_rows_match_reference(name):
+    g = load_golden("her_rows.npz")
+    cap, k = (int(x) for x in g[f"{name}_cap_k"])
+    rng = random.Random(1898)
+    buf = her_oracle.HERBufferOracle(cap, 50, 2, k_future=k, rng=rng)
+    replay_case(g, name, buf)
+    s, a, ns, r, d = buf.as_arrays()
+    for key, got in zip("s a ns r d".split(), (s, a, ns, r, d)):
+        want = g[f"{name}_rows_{key}"]
+        assert got.shape == want.shape, (name, key)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, key)  # bitwise (-0.0 too)
+    assert np.array_equal(np.array(rng.getstate()[1], dtype=np.uint32), g[f"{name}_state_after_push"])
+    if f"{name}_batch_s" in g.files:
+        batch = buf.sample(32)
+        for key, got in zip("s a r ns d".split(), batch):
+            assert np.array_equal(got.view(np.uint32), g[f"{name}_batch_{key}"].view(np.uint32)), (name, key)
+        assert np.array_equal(np.array(rng.getstate()[1], dtype=np.uint32), g[f"{name}_state_after_sample"])
+
+
+def test_row_count_and_order_properties():
+    """T + k(T-1) rows per episode, originals at stride 1+k, relabels keep s[:-G] and done=0."""
+    rng = random.Random(5)
+    gen = np.random.default_rng(0)
+    buf = her_oracle.HERBufferOracle(10000, 50, 1, k_future=4, rng=rng)
+    steps = her_oracle.synthetic_episode(gen, 50, 10, 3)
+    for st in steps:
+        buf.push(0, *st)
+    assert len(buf) == 50 + 4 * 49
+    s, a, ns, r, d = buf.as_arrays()
+    for i in range(49):
+        base = i * 5
+        assert np.array_equal(s[base], steps[i][0])
+        for j in range(1, 5):
+            assert np.array_equal(s[base + j][:-3], steps[i][0][:-3])
+            assert np.array_equal(a[base + j], steps[i][1])
+            assert d[base + j] == 0.0
+            assert r[base + j] in (-1.0, 0.0)
+            f = buf.future_log[i * 4 + j - 1]
+            assert i < f <= 49
+            assert np.array_equal(s[base + j][-3:], steps[f][6])
+
+
+# ---------------------------------------------------------------- G5-G8: update steps
+def run_update_fixture(tag):
+    g = load_golden(f"update_{tag}.npz")
+    kind = str(g["kind"][0])
+    S, A, B, gstep = (int(x) for x in g["dims"])
+    cfg = hparams_from_golden(g)
+    torch.set_num_threads(1)
+    ag = OracleAgent(kind, S, A, cfg, nenvs=1, gradient_step=gstep)
+    nets = {"actor": ag.actor}
+    if ag.target_actor is not None:
+        nets["target_actor"] = ag.target_actor
+    for i, (c, t) in enumerate(zip(ag.critics, ag.target_critics)):
+        nets[f"critic_{i}"] = c
+        nets[f"target_critic_{i}"] = t
+    for name, net in nets.items():
+        key = f"init_{name}"
+        src = g[key] if key in g.files else g[f"init_{name.replace('target_', '')}"]
+        ag.set_flat_params(net, src)
+    checks = []
+    for i, step in enumerate(g["steps"]):
+        batch = tuple(torch.from_numpy(g[f"step{i}_{k}"]) for k in ("s", "a", "r", "ns", "d"))
+        kw = {}
+        if f"step{i}_noise" in g.files:
+            kw["noise"] = torch.from_numpy(g[f"step{i}_noise"])
+        if f"step{i}_eps_next" in g.files:
+            kw["eps_next"] = torch.from_numpy(g[f"step{i}_eps_next"])
+            kw["eps_cur"] = torch.from_numpy(g[f"step{i}_eps_cur"])
+        info = ag.update(int(step), batch=batch, **kw)
+        want = g[f"step{i}_tuple"]
+        assert len(info) == len(want), (tag, i)
+        got = np.array([float(np.asarray(x)) for x in info])
+        checks.append((f"tuple step{i}", got, want, None))
+        for c in range(len(ag.critics)):
+            k = f"step{i}_gradpre_critic_{c}"
+            if k in g.files:
+                checks.append((k, ag.last["critic_grads_pre"][c], g[k], None))
+            k = f"step{i}_gradpost_critic_{c}"
+            if k in g.files:
+                checks.append((k, ag.last["critic_grads_post"][c], g[k], None))
+        k = f"step{i}_gradpre_actor"
+        if k in g.files:
+            checks.append((k, ag.last["actor_grads_pre"], g[k], None))
+            if f"step{i}_gradpost_actor" in g.files:
+                checks.append((f"step{i}_gradpost_actor", ag.last["actor_grads_post"], g[f"step{i}_gradpost_actor"], None))
+        for name, net in nets.items():
+            k = f"step{i}_param_{name}"
+            if k in g.files:
+                checks.append((k, ag.flat_params(net), g[k], None))
+        if f"step{i}_log_alpha" in g.files:
+            checks.append((f"step{i}_log_alpha", ag.log_alpha.detach().numpy().copy(), g[f"step{i}_log_alpha"], 1.0))
+            bns = [m for m in ag.actor.base_net if isinstance(m, torch.nn.BatchNorm1d)]
+            checks.append((f"step{i}_bn_mean", np.concatenate([m.running_mean.numpy() for m in bns]), g[f"step{i}_bn_mean"], None))
+            checks.append((f"step{i}_bn_var", np.concatenate([m.running_var.numpy() for m in bns]), g[f"step{i}_bn_var"], None))
+    return checks
+
+
+@pytest.mark.parametrize("tag", ["ddpg_reach", "ddpg_cosine", "ddpg_pickplace_h256", "td3", "sac", "tqc"])
+def test_oracle_update_matches_reference(tag):
+    bad = []
+    for name, got, want, scale in run_update_fixture(tag):
+        if name.startswith("tuple"):
+            ok = all(abs(a - b) <= ATOL + RTOL * abs(b) for a, b in zip(got, want))
+        else:
+            ok = close(got, want, scale=scale)
+        if not ok:
+            bad.append((name, float(np.max(np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))))))
+    assert not bad, bad
