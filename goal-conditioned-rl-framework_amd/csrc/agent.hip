@@ -111,6 +111,7 @@ struct gcrl_agent {
   int next_upload = 0;
   float *metrics_host = nullptr, *metrics_dev = nullptr;
   int64_t next_ticket = 0;
+  int64_t fetched_upto = -1;   // newest ticket whose record is in the host mirror
   std::vector<int> ticket_len;
   hipEvent_t call_ev[kEventRing] = {};
   int64_t call_last_ticket[kEventRing];
@@ -422,10 +423,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
   for (int c = 0; c < nac; ++c)
     chain_mlp(a, c2, 0, a->critic, a->P_critic(c), a->spa, a->ldx, a->slot_x, hid_C, c, a->q2 + (long long)c * B, 1, 0, EPI_NONE, B);
   TRY(c2.run(st));
-  if (!a->sac) {
-    // actor_loss = -Q.mean(); dq2 holds the constant -1/B
-    TRY(launch_mean_metric(st, a->cur(), a->q2, B, -1.0f, a->metrics_dev, MET_ACTOR_LOSS));
-  } else {
+  if (a->sac) {
     ActorSelArgs as;
     std::memset(&as, 0, sizeof(as));
     as.cur = a->cur(); as.q = a->q2; as.logp = a->logp; as.dq = a->dq2; as.metrics = a->metrics_dev;
@@ -524,6 +522,9 @@ int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   for (int c = 0; c < kMaxCritics; ++c) ad.clip[c] = (float)a->cfg.grad_clip;
   if (kind == GCRL_AGENT_TD3 && (variant & V_POLYAK_A)) { ad.target = a->P_tactor(); ad.polyak = 1; }
   ad.metric_index = MET_ACTOR_GRAD;
+  if (!a->sac) {  // actor_loss = -Q.mean() (dq2 holds the constant -1/B), folded into this launch
+    ad.mean_x = a->q2; ad.mean_n = a->B; ad.mean_scale = -1.0f; ad.mean_index = MET_ACTOR_LOSS;
+  }
   TRY(launch_adam(st, ad));
   if (a->sac) {
     AlphaArgs al;
@@ -773,9 +774,12 @@ int build(gcrl_agent* a) {
     GCRL_HIP(hipEventCreateWithFlags(&a->call_ev[i], hipEventDisableTiming));
     a->call_last_ticket[i] = -1;
   }
-  GCRL_HIP(hipHostMalloc((void**)&a->metrics_host, (size_t)kMetricSlots * kMetricFloats * sizeof(float), hipHostMallocMapped));
+  // metrics live in device memory (a kernel that writes host-mapped memory costs +0.9 us at
+  // its boundary, measured); the host mirror is refreshed in bulk when a ticket is asked for
+  GCRL_HIP(hipHostMalloc((void**)&a->metrics_host, (size_t)kMetricSlots * kMetricFloats * sizeof(float), hipHostMallocDefault));
   std::memset(a->metrics_host, 0, (size_t)kMetricSlots * kMetricFloats * sizeof(float));
-  GCRL_HIP(hipHostGetDevicePointer((void**)&a->metrics_dev, a->metrics_host, 0));
+  GCRL_HIP(hipMalloc((void**)&a->metrics_dev, (size_t)kMetricSlots * kMetricFloats * sizeof(float)));
+  GCRL_HIP(hipMemset(a->metrics_dev, 0, (size_t)kMetricSlots * kMetricFloats * sizeof(float)));
   a->ticket_len.assign(kMetricSlots, 0);
 
   // constant upstream gradient of -Q.mean()
@@ -878,6 +882,7 @@ void gcrl_agent_destroy(gcrl_agent* a) {
   }
   for (int i = 0; i < kEventRing; ++i) if (a->call_ev[i]) (void)hipEventDestroy(a->call_ev[i]);
   if (a->metrics_host) (void)hipHostFree(a->metrics_host);
+  if (a->metrics_dev) (void)hipFree(a->metrics_dev);
   if (a->stream) (void)hipStreamDestroy(a->stream);
   if (a->cap_stream) (void)hipStreamDestroy(a->cap_stream);
   delete a;
@@ -1032,9 +1037,27 @@ int gcrl_agent_metrics(gcrl_agent* a, int64_t ticket, double* out, int n) {
   const int64_t lo = std::max<int64_t>(0, a->calls - kEventRing);
   for (int64_t cidx = lo; cidx < a->calls; ++cidx)
     if (a->call_last_ticket[cidx % kEventRing] >= ticket) { best = cidx; break; }
-  if (best >= 0) GCRL_HIP(hipEventSynchronize(a->call_ev[best % kEventRing]));
-  else GCRL_HIP(hipDeviceSynchronize());
-  const volatile float* m = a->metrics_host + (ticket % kMetricSlots) * kMetricFloats;
+  if (ticket > a->fetched_upto) {
+    int64_t upto = ticket;
+    if (best >= 0) {
+      GCRL_HIP(hipEventSynchronize(a->call_ev[best % kEventRing]));
+      upto = a->call_last_ticket[best % kEventRing];
+    } else {
+      GCRL_HIP(hipDeviceSynchronize());
+      upto = a->next_ticket - 1;
+    }
+    // copy every finished, not yet mirrored record in (at most two) contiguous pieces
+    int64_t from = std::max<int64_t>(a->fetched_upto + 1, upto - kMetricSlots + 1);
+    while (from <= upto) {
+      const int64_t s0 = from % kMetricSlots;
+      const int64_t cnt = std::min<int64_t>(upto - from + 1, kMetricSlots - s0);
+      GCRL_HIP(hipMemcpy(a->metrics_host + s0 * kMetricFloats, a->metrics_dev + s0 * kMetricFloats,
+                         (size_t)cnt * kMetricFloats * sizeof(float), hipMemcpyDeviceToHost));
+      from += cnt;
+    }
+    a->fetched_upto = upto;
+  }
+  const float* m = a->metrics_host + (ticket % kMetricSlots) * kMetricFloats;
   const int C = a->C;
   auto meanv = [&](int base) { double s = 0; for (int c = 0; c < C; ++c) s += (double)m[base + c]; return s / C; };
   const bool act = (a->cfg.kind == GCRL_AGENT_DDPG) ? len == 6 : (a->cfg.kind == GCRL_AGENT_TD3 ? len == 8 : len == 9);

@@ -17,6 +17,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace gcrl {
@@ -52,12 +54,24 @@ struct GemmBatch {
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+// 16-byte fragment loads go through a buffer descriptor (raw_buffer_load_b128): a plain
+// `*(float4*)p` next to the strided scalar path was if-converted by hipcc into four dword
+// loads with a selected stride (0 global_load_dwordx4 in the ISA, 2-4x slower).
+__device__ inline __amdgpu_buffer_rsrc_t wave_uniform_rsrc(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  void* q = (void*)(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0x7fffffff, 0x00020000);
+}
 
 __device__ inline float act_apply(float v, int epi) {
   switch (epi) {
     case EPI_LEAKY: return v > 0.f ? v : 0.01f * v;  // nn.LeakyReLU() default slope
     case EPI_RELU: return v > 0.f ? v : 0.f;
-    case EPI_TANH: return tanhf(v);
+    case EPI_TANH: return (float)tanh((double)v);  // rounded once: only B x ac_dim outputs take this path
     default: return v;
   }
 }
@@ -128,46 +142,100 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
     bp[j] = Bm + (long long)min(n, nmax) * b_cs;
   }
 
+  auto mfma_chunk = [&](const float (&a)[TM][4], const float (&b)[TN][4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j][q % NACC] =
+              __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j][q % NACC], 0, 0, 0);
+  };
+
+  // byte offsets of the fragment rows for the 16-byte path (operands are < 2 GiB)
+  const __amdgpu_buffer_rsrc_t rs_a = wave_uniform_rsrc(A);
+  const __amdgpu_buffer_rsrc_t rs_b = wave_uniform_rsrc(Bm);
+  int aoff[TM], boff[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) aoff[i] = (int)((ap[i] - A) * 4);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) boff[j] = (int)((bp[j] - Bm) * 4);
+
   if (active) {
-#pragma unroll 2
-    for (int kc = kc_beg; kc < kc_end; ++kc) {
-      const int kb = (kc << 4) + (lg << 2);
-      const bool full = kb + 3 < K;
+    // Interior chunks (all 16 k inside K) go in groups of U: the group's 2*U fragment loads are
+    // unconditional (addresses clamped, surplus results unused), free of control flow and
+    // independent of any MFMA, so they are all in flight before the first MFMA waits: one
+    // memory round trip per 64 k.  The 16-byte / strided choice is made ONCE per wave (four
+    // straight-line instances of the loop): a branch per chunk made hipcc drain vmcnt(0) at
+    // every join and the loop ran at one L2 latency (0.37 us) per chunk.
+    const int kfull = K >> 4;
+    const int kint_end = min(kc_end, kfull);
+    auto interior = [&](auto va_tag, auto vb_tag) {
+      constexpr bool VA = decltype(va_tag)::value, VB = decltype(vb_tag)::value;
+      constexpr int U = 4;
+      for (int kc = kc_beg; kc < kint_end; kc += U) {
+        float a[U][TM][4], b[U][TN][4];
+        const int nvalid = min(U, kint_end - kc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int kb = (min(kc + u, kint_end - 1) << 4) + (lg << 2);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            if constexpr (VA) {
+              const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff[i] + kb * 4, 0, 0);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) a[u][i][q] = __uint_as_float(v[q]);
+            } else {
+              const float* p = ap[i] + (long long)kb * a_cs;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) a[u][i][q] = p[q * a_cs];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (VB) {
+              const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, boff[j] + kb * 4, 0, 0);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) b[u][j][q] = __uint_as_float(v[q]);
+            } else {
+              const float* p = bp[j] + (long long)kb * b_rs;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) b[u][j][q] = p[q * b_rs];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[u][j][q] = bone[j] ? 1.f : b[u][j][q];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (u < nvalid) mfma_chunk(a[u], b[u]);
+      }
+    };
+    using T1 = std::integral_constant<bool, true>;
+    using T0 = std::integral_constant<bool, false>;
+    if (a_vec) { if (b_vec) interior(T1{}, T1{}); else interior(T1{}, T0{}); }
+    else       { if (b_vec) interior(T0{}, T1{}); else interior(T0{}, T0{}); }
+    if (kc_beg <= kfull && kfull < kc_end) {
+      // the one partial chunk at the end of K: guarded scalar loads
+      const int kb = (kfull << 4) + (lg << 2);
       float a[TM][4], b[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const float* p = ap[i] + (long long)kb * a_cs;
-        if (a_vec && full) {
-          const float4 v = *reinterpret_cast<const float4*>(p);
-          a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
-        } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) a[i][q] = (kb + q < K) ? p[q * a_cs] : 0.f;
-        }
+        for (int q = 0; q < 4; ++q) a[i][q] = (kb + q < K) ? p[q * a_cs] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const float* p = bp[j] + (long long)kb * b_rs;
-        if (b_vec && full) {
-          const float4 v = *reinterpret_cast<const float4*>(p);
-          b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
-        } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) b[j][q] = (kb + q < K) ? p[q * b_rs] : 0.f;
-        }
-        if (bone[j]) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) b[j][q] = (kb + q < K) ? 1.f : 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const float v = (kb + q < K) ? p[q * b_rs] : 0.f;
+          b[j][q] = bone[j] ? ((kb + q < K) ? 1.f : 0.f) : v;
         }
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j][q % NACC] =
-                __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j][q % NACC], 0, 0, 0);
+      mfma_chunk(a, b);
     }
   }
 

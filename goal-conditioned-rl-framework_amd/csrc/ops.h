@@ -97,6 +97,9 @@ struct AdamArgs {
   int polyak;           // 1: target = tau*p + (1-tau)*target after the step
   float* metrics;       // post-clip grad norm -> metrics[slot][metric_index + net]
   int metric_index;
+  // optional fused scalar metric: metrics[slot][mean_index] = mean_scale * mean(mean_x[0..mean_n))
+  // (actor loss -Q.mean() of DDPG/TD3, saving a launch); computed by block (0,0)
+  const float* mean_x; int mean_n; float mean_scale; int mean_index;
 };
 int launch_adam(hipStream_t st, const AdamArgs& a);
 int launch_polyak(hipStream_t st, const float* p, float* target, long long n, double tau);

@@ -200,6 +200,14 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
   }
   __syncthreads();
+  if (a.mean_x && blockIdx.x == 0 && blockIdx.y == 0) {
+    __shared__ float scratch[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.mean_n; i += 256) s += a.mean_x[i];
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0)
+      a.metrics[(long long)c.metrics_slot * kMetricFloats + a.mean_index] = a.mean_scale * (s / (float)a.mean_n);
+  }
   const float gmul = gscale * s_coef;
   const long long base = (long long)net * a.net_stride;
   float* __restrict__ p = a.p + base;

@@ -129,22 +129,26 @@ __global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) {
   float lp = 0.f;
   for (int j = 0; j < a.A; ++j) {
     const float mu = a.mu[(long long)b * a.ld_head + j];
-    if (a.deterministic) { act[j] = tanhf(mu); continue; }
+    if (a.deterministic) { act[j] = (float)tanh((double)mu); continue; }
     const float ls = fminf(fmaxf(a.ls_raw[(long long)b * a.ld_head + j], -20.0f), 2.0f);
-    const float sd = expf(ls);
+    // exp / tanh / log go through fp64 and round once: log(1 - tanh^2 + 1e-8) amplifies a 1-ulp
+    // tanh difference by 2|t|/(1-t^2), so the closer to correctly rounded, the closer to torch
+    const float sd = (float)exp((double)ls);
     const long long i = (long long)b * a.A + j;
     const float e = a.eps ? a.eps[i]
                           : hash_normal(a.seed + (unsigned long long)a.rng_stream,
                                         (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
     const float x = __fadd_rn(mu, __fmul_rn(e, sd));  // rsample: loc + eps*scale
-    const float t = tanhf(x);
+    const float t = (float)tanh((double)x);
     act[j] = t;
-    // Normal(mu, sd).log_prob(x) - log(1 - tanh(x)^2 + 1e-8)
+    // Normal(mu, sd).log_prob(x) - log(1 - tanh(x)^2 + 1e-8), every op rounded to fp32 as torch does
     const float df = __fsub_rn(x, mu);
     const float var = __fmul_rn(sd, sd);
-    float term = -(df * df) / (2.0f * var) - logf(sd) - 0.91893853320467274f;
-    term -= logf(1.0f - t * t + 1e-8f);
-    lp += term;
+    float term = __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(df, df), __fmul_rn(2.0f, var)), (float)log((double)sd)),
+                           0.91893853320467274f);
+    const float om = __fadd_rn(__fsub_rn(1.0f, __fmul_rn(t, t)), 1e-8f);
+    term = __fsub_rn(term, (float)log((double)om));
+    lp = __fadd_rn(lp, term);
     if (a.save_eps) { a.save_eps[i] = e; a.save_std[i] = sd; }
   }
   if (!a.deterministic && a.logp) a.logp[b] = lp;
