@@ -103,6 +103,9 @@ struct gcrl_agent {
   float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
   float *noise_in = nullptr, *eps_next_in = nullptr, *eps_cur_in = nullptr, *norm_partial = nullptr;
   float *act_in = nullptr, *act_tmp[2] = {};
+  float *parts_c = nullptr, *parts_a = nullptr;   // fused-norm partials: [C][nparts_c], [nparts_a]
+  int nparts_c = 0, nparts_a = 0;
+  std::vector<int> part_off_c, part_off_a;        // per-layer offsets inside a net's partials
 
   char* upload_dev = nullptr;
   size_t upload_bytes = 0;
@@ -297,7 +300,9 @@ int sac_actor_forward(gcrl_agent* a, hipStream_t st, const float* X0, long long 
   return GCRL_OK;
 }
 
-enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32 };
+// V_FUSED_NORM: gradient sum-of-squares partials come out of the dW GEMM epilogues (whole step in
+// one graph); off in data-parallel runs, where the norm is of the all-reduced gradients
+enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32, V_FUSED_NORM = 64 };
 
 // ---------------------------------------------------------------- phase 0
 int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
@@ -354,6 +359,7 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
       const long long ldg = l == L ? 1 : H;
       GemmDesc dw = bwd_dw(G, ldg, l == 0 ? a->sa : a->hC_at(c, l - 1), l == 0 ? a->ldx : H, Gp, a->critic.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
+      if (variant & V_FUSED_NORM) dw.sumsq_out = a->parts_c + (long long)c * a->nparts_c + a->part_off_c[l];
       bw.add(at, dw);
       if (l > 0)
         bw.add(at, bwd_dx(G, ldg, P, a->critic.lin[l], 0, H, a->gC_at(c, (l - 1) & 1), H, B, MUL_DLEAKY, a->hC_at(c, l - 1), H));
@@ -373,6 +379,8 @@ int adam_common(gcrl_agent* a, AdamArgs& ad) {
   ad.one_m_tau = (float)(1.0 - a->cfg.tau);
   ad.metrics = a->metrics_dev;
   ad.partial = a->norm_partial;
+  ad.nparts = kNormBlocks;
+  ad.part_stride = kNormBlocks;
   return GCRL_OK;
 }
 
@@ -380,11 +388,13 @@ int adam_common(gcrl_agent* a, AdamArgs& ad) {
 int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
   const int kind = a->cfg.kind, B = a->B, C = a->C, S = a->S, A = a->A, L = a->L, H = a->H;
   // critic optimiser: global-norm clip + Adam(W) (+ Polyak into the target critics)
-  TRY(launch_sumsq(st, a->G_critic(0), a->critic.numel, a->critic_stride, C, a->norm_partial));
+  const bool fused = (variant & V_FUSED_NORM) != 0;
+  if (!fused) TRY(launch_sumsq(st, a->G_critic(0), a->critic.numel, a->critic_stride, C, a->norm_partial));
   {
     AdamArgs ad;
     std::memset(&ad, 0, sizeof(ad));
     adam_common(a, ad);
+    if (fused) { ad.partial = a->parts_c; ad.nparts = a->nparts_c; ad.part_stride = a->nparts_c; }
     ad.which = 1;
     ad.p = a->P_critic(0); ad.g = a->G_critic(0);
     ad.m = a->adam_m + a->goff_critic; ad.v = a->adam_v + a->goff_critic;
@@ -458,6 +468,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
       const long long ldg = l == L ? a->Apad : H;
       GemmDesc dw = bwd_dw(G, ldg, l == 0 ? a->spa : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
+      if (variant & V_FUSED_NORM) dw.sumsq_out = a->parts_a + a->part_off_a[l];
       ab.add(at, dw);
       if (l > 0) ab.add(at, bwd_dx(G, ldg, Pa, a->actor.lin[l], 0, H, a->gA[(l - 1) & 1], H, B, MUL_DLEAKY, a->hA_at(l - 1), H));
     }
@@ -511,10 +522,12 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
 int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   if (!(variant & V_ACTOR)) return GCRL_OK;
   const int kind = a->cfg.kind;
-  TRY(launch_sumsq(st, a->G_actor(), a->actor.numel, 0, 1, a->norm_partial));
+  const bool fused = (variant & V_FUSED_NORM) && !a->sac;   // BN gradients do not come from a GEMM
+  if (!fused) TRY(launch_sumsq(st, a->G_actor(), a->actor.numel, 0, 1, a->norm_partial));
   AdamArgs ad;
   std::memset(&ad, 0, sizeof(ad));
   adam_common(a, ad);
+  if (fused) { ad.partial = a->parts_a; ad.nparts = a->nparts_a; ad.part_stride = a->nparts_a; }
   ad.which = 0;
   ad.p = a->P_actor(); ad.g = a->G_actor();
   ad.m = a->adam_m + a->goff_actor; ad.v = a->adam_v + a->goff_actor;
@@ -742,6 +755,19 @@ int build(gcrl_agent* a) {
   TRY(bytes_alloc(&a->bn_rvar, (long long)std::max(1, L * H)));
   TRY(bytes_alloc(&a->alpha_dev, 64));
 
+  // fused-norm partial slots: a dW problem [out, in+1] has at most ceil(out/16)*ceil((in+1)/16)
+  // tiles of 16x16 and 4 finishing waves per tile
+  auto part_layout = [](const NetSpec& net, std::vector<int>& off) {
+    int total = 0;
+    off.clear();
+    for (const Lin& ln : net.lin) {
+      off.push_back(total);
+      total += ((ln.out + 15) / 16) * ((ln.in + 1 + 15) / 16) * 4;
+    }
+    return total;
+  };
+  a->nparts_c = part_layout(a->critic, a->part_off_c);
+  a->nparts_a = part_layout(a->actor, a->part_off_a);
   // work buffers
   const long long BH = (long long)B * H;
   std::vector<std::pair<float**, long long>> wants = {
@@ -755,7 +781,8 @@ int build(gcrl_agent* a) {
       {&a->dh2, BH}, {&a->logp, B}, {&a->logp_next, B}, {&a->epsbuf, (long long)B * A}, {&a->stdbuf, (long long)B * A},
       {&a->noise_in, (long long)B * A}, {&a->eps_next_in, (long long)B * A}, {&a->eps_cur_in, (long long)B * A},
       {&a->norm_partial, (long long)kMaxCritics * kNormBlocks}, {&a->act_in, (long long)B * a->ldx},
-      {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH}};
+      {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH},
+      {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a}};
   long long total = 0;
   for (auto& w : wants) total += align_up(w.second, 64);
   TRY(bytes_alloc(&a->work, total));
@@ -978,7 +1005,7 @@ int gcrl_agent_update(gcrl_agent* a, gcrl_her* her, int64_t step, const gcrl_upd
   std::vector<StepPlan> plans;
   int32_t len = 0;
   TRY(begin_call(a, her, step, 1, in, 1.0f, st, plans, ticket_out, &len));
-  int variant = plans[0].variant;
+  int variant = plans[0].variant | V_FUSED_NORM;
   if (in) TRY(stage_injected(a, in, st, &variant));
   TRY(run_step(a, st, variant, 7));
   TRY(end_call(a, st));
@@ -995,7 +1022,7 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
     std::vector<StepPlan> plans;
     TRY(begin_call(a, her, step0 + done, m, nullptr, 1.0f, st, plans, tickets_out ? tickets_out + done : nullptr,
                    lens_out ? lens_out + done : nullptr));
-    for (int i = 0; i < m; ++i) TRY(run_step(a, st, plans[i].variant, 7));
+    for (int i = 0; i < m; ++i) TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM, 7));
     TRY(end_call(a, st));
   }
   return GCRL_OK;

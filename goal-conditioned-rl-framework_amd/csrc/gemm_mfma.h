@@ -44,6 +44,10 @@ struct GemmDesc {
   // base + (*slot) * stride, `slot` pointing at the current step's batch_slot on the device
   const int* slot;
   long long a_slot, b_slot, c_slot, h_slot;
+  // dW problems: sum of squares of this problem's outputs, one partial per finishing wave, at
+  // sumsq_out[(tile * KSPLIT) + wave]: the global-norm clip needs ||g||, and producing the
+  // partials here (fixed slots, fixed order -> deterministic) removes a reduction launch
+  float* sumsq_out;
   int a_vec, b_vec;  // 16-byte loads legal along k (filled by the launcher)
   int tile0, tiles_n, ntiles;  // filled by the launcher
 };
@@ -162,6 +166,26 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) boff[j] = (int)((bp[j] - Bm) * 4);
 
+  // epilogue operands (bias, saved activations) are fetched BEFORE the k-loop so their latency
+  // overlaps the fragment loads instead of adding a memory round trip after the last MFMA
+  const float* __restrict__ bias = d.bias;
+  const float* __restrict__ H = d.H + sl * d.h_slot;
+  const int mul = d.mul;
+  constexpr int NE = (KSPLIT == 4) ? 1 : 4;
+  float pre_b[TN], pre_h[TM][TN][NE];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + 16 * j + li;
+    pre_b[j] = (bias && active && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < NE; ++r) {
+        const int m = (KSPLIT == 4) ? m0 + 4 * lg + wave : m0 + 16 * i + 4 * lg + r;
+        pre_h[i][j][r] = (mul != MUL_NONE && active && m < M && n < N) ? H[(long long)m * d.h_rs + n] : 0.f;
+      }
+  }
+
   if (active) {
     // Interior chunks (all 16 k inside K) go in groups of U: the group's 2*U fragment loads are
     // unconditional (addresses clamped, surplus results unused), free of control flow and
@@ -246,16 +270,16 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
 #pragma unroll
       for (int q = 1; q < NACC; ++q) acc[i][j][0] += acc[i][j][q];
 
-  const float* __restrict__ bias = d.bias;
-  const float* __restrict__ H = d.H + sl * d.h_slot;
   float* __restrict__ C = d.C + sl * d.c_slot;
-  const int epi = d.epi, mul = d.mul;
+  const int epi = d.epi;
+  float ss = 0.f;
 
-  auto finish = [&](float v, int m, int n) {
+  auto finish = [&](float v, int m, int n, float b, float h) {
     if (m >= M || n >= N) return;
-    if (bias) v += bias[n];
+    v += b;
     v = act_apply(v, epi);
-    if (mul != MUL_NONE) v *= act_deriv(H[(long long)m * d.h_rs + n], mul);
+    if (mul != MUL_NONE) v *= act_deriv(h, mul);
+    ss += v * v;
     if (ones_col && n == N - 1) d.col_out[m] = v;
     else C[(long long)m * d.c_rs + n] = v;
   };
@@ -271,7 +295,7 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += red[w][wave][lane];
-    finish(v, m0 + 4 * lg + wave, n0 + li);
+    finish(v, m0 + 4 * lg + wave, n0 + li, pre_b[0], pre_h[0][0][0]);
   } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -279,7 +303,12 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          finish(acc[i][j][0][r], m0 + 16 * i + 4 * lg + r, n0 + 16 * j + li);
+          finish(acc[i][j][0][r], m0 + 16 * i + 4 * lg + r, n0 + 16 * j + li, pre_b[j], pre_h[i][j][r % NE]);
+  }
+  if (d.sumsq_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    if (lane == 0) d.sumsq_out[(long long)t * KSPLIT + (KSPLIT == 4 ? wave : 0)] = ss;
   }
 }
 

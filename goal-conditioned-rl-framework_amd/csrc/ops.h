@@ -90,7 +90,8 @@ struct AdamArgs {
   float* target;        // Polyak destination (null: none), same stride
   long long n, net_stride;
   int nets;
-  const float* partial; // [nets][kNormBlocks] from launch_sumsq
+  const float* partial; // sum-of-squares partials of net i at partial + i*part_stride, nparts each
+  int nparts; long long part_stride;  // (launch_sumsq: kNormBlocks; fused into the dW epilogues: per-tile)
   float clip[kMaxCritics];   // per net max_norm; < 0: no clipping (TD3 critic_1, src/agent.py:201)
   float beta2, w1, w2, eps;   // w = fp32(1 - beta) formed in double on the host, like torch
   float tau, one_m_tau;

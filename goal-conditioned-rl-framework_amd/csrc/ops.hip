@@ -186,10 +186,17 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   else { step_size = c.step_size_alpha; bc2s = c.bc2s_alpha; decay = c.decay_alpha; }
   const float gscale = c.grad_scale;
 
-  if (threadIdx.x < 64) {
-    double s = (double)a.partial[net * kNormBlocks + threadIdx.x];  // kNormBlocks == 64
+  {
+    // ||g||: every block sums the same partials in the same order (deterministic), in fp64
+    __shared__ double dred[4];
+    const float* part = a.partial + (long long)net * a.part_stride;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.nparts; i += 256) s += (double)part[i];
     s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = s;
+    __syncthreads();
     if (threadIdx.x == 0) {
+      s = dred[0] + dred[1] + dred[2] + dred[3];
       const float norm = gscale * (float)sqrt(s);
       const float clip = a.clip[net];
       float coef = 1.0f;

@@ -59,6 +59,29 @@ int main() {
     printf("eager: 2000 tiny kernels: %.2f us/kernel\n", ms * 1e3f / 2000);
   }
 
+  {  // do two independent branches of one graph overlap?  (fork/join with events during capture)
+    float *A2, *B2, *C2a, *C2b, *bias2;
+    CK(hipMalloc(&A2, 256 * 256 * 4)); CK(hipMalloc(&B2, 256 * 256 * 4)); CK(hipMalloc(&C2a, 256 * 256 * 4)); CK(hipMalloc(&C2b, 256 * 256 * 4)); CK(hipMalloc(&bias2, 1024));
+    CK(hipMemset(A2, 0, 256 * 256 * 4)); CK(hipMemset(B2, 0, 256 * 256 * 4)); CK(hipMemset(bias2, 0, 1024));
+    hipStream_t side; CK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    hipEvent_t fork, join; hipEventCreateWithFlags(&fork, hipEventDisableTiming); hipEventCreateWithFlags(&join, hipEventDisableTiming);
+    auto chain = [&](hipStream_t s, float* Cout, int n) {
+      for (int i = 0; i < n; ++i) {
+        gcrl::GemmDesc c; memset(&c, 0, sizeof(c));
+        c.A = A2; c.a_rs = 256; c.a_cs = 1; c.B = B2; c.b_rs = 1; c.b_cs = 256; c.C = Cout; c.c_rs = 256; c.bias = bias2; c.M = 256; c.N = 256; c.K = 256; c.epi = 1;
+        gcrl::launch_gemm_batch(s, &c, 1, 1);
+      }
+    };
+    float one = time_graph(st, cap, 100, [&](hipStream_t s) { chain(s, C2a, 16); });
+    float seq = time_graph(st, cap, 100, [&](hipStream_t s) { chain(s, C2a, 16); chain(s, C2b, 16); });
+    float par = time_graph(st, cap, 100, [&](hipStream_t s) {
+      hipEventRecord(fork, s); hipStreamWaitEvent(side, fork, 0);
+      chain(s, C2a, 16); chain(side, C2b, 16);
+      hipEventRecord(join, side); hipStreamWaitEvent(s, join, 0);
+    });
+    printf("graph branches: one chain of 16 gemms %.1f us; 32 sequential %.1f us; two parallel chains of 16 %.1f us\n", one, seq, par);
+  }
+
   // GEMM bodies at the hot shapes
   struct Shape { int M, N, K; const char* what; };
   std::vector<Shape> shapes = {{256, 256, 256, "fwd hidden B=256 H=256"}, {256, 256, 27, "fwd first layer K=27"},
