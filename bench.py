@@ -208,8 +208,8 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        launches, ms, rows = C.c_int64(), C.c_double(), C.c_int64()
-        check(lib.gcrl_her_profile_read(her, C.byref(launches), C.byref(ms), C.byref(rows)))
+        launches, ms, rows, dev_ms = C.c_int64(), C.c_double(), C.c_int64(), C.c_double()
+        check(lib.gcrl_her_profile_read(her, C.byref(launches), C.byref(ms), C.byref(rows), C.byref(dev_ms)))
         check(lib.gcrl_her_profile_enable(her, 0))
         # a last metrics fetch proves the steps really ran to completion
         last = [float(x) for x in (agent.update_many(1 + args.warmup + args.steps, 1)[0] if dp is None
@@ -240,7 +240,10 @@ def main():
             "roofline": {"kernel": "her_gather_update_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launches": launches.value, "avg_launch_us": avg_us, "rows_per_launch": rows_per_launch,
-                         "algorithmic_bytes_per_row": alg_bytes_per_row},
+                         "algorithmic_bytes_per_row": alg_bytes_per_row,
+                         "timing": "hipEvent pair around each launch on its stream (includes event/dispatch overhead)",
+                         "kernel_us_device_clock": dev_ms.value * 1e3 / max(1, launches.value),
+                         "achieved_device_clock": (alg_bytes_per_row * rows_per_launch) / max(1e-9, dev_ms.value * 1e-3 / max(1, launches.value)) / 1e9},
             "update_flops": {"gflop_per_step": flops_per_step(w) / 1e9,
                              "achieved_tflops": flops_per_step(w) * args.steps / elapsed / 1e12,
                              "peak_tflops": FP32_MFMA_PEAK_TF},

@@ -91,7 +91,7 @@ PROTOTYPES = {
     "gcrl_her_sample": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "gcrl_her_read_rows": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_her_profile_enable": (C.c_int, [_vp, C.c_int]),
-    "gcrl_her_profile_read": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_i64)]),
+    "gcrl_her_profile_read": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_f64)]),
     "gcrl_agent_create": (_vp, [C.POINTER(AgentConfig)]),
     "gcrl_agent_destroy": (None, [_vp]),
     "gcrl_agent_stream": (_vp, [_vp]),

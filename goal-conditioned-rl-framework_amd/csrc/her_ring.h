@@ -1,15 +1,17 @@
 // her_ring.h — internal view of the HER replay ring (shared with the update engine).
 //
 // HBM layout.  One transition = one packed record of RS floats, 64-byte aligned:
-//     [ s (S) | a (A) | ns (S) | r | d | zero pad ]            RS = roundup(2S+A+2, 16)
+//     [ s (S) | a (A) | pad ]  [ ns (S) | pad ]  [ r | d ]  zero pad
+//       <-- SA4 = roundup(S+A,4) -->  <-- S4 = roundup(S,4) -->      RS = roundup(SA4+S4+2, 16)
 // Records are contiguous in arrival order: ring[cap][RS].  A uniformly random row gather then
 // touches ceil(4*RS/128) whole 128-B lines per row (PickAndPlace: 2 lines for 208 useful
-// bytes) where five separate field arrays would touch 6-7; and [s|a] is already the critic's
-// input row.  Logical index j (0 = oldest, what random.sample indexes in the reference's
+// bytes) where five separate field arrays would touch 6-7.  Every field group starts on a
+// 16-byte boundary, so the update engine's batch matrices ([s|a], [ns|..], [s|..], row stride
+// SA4) are plain float4 copies of record slices, and [s|a] is already the critic's input row.  Logical index j (0 = oldest, what random.sample indexes in the reference's
 // deque, src/buffer.py:124) lives at physical row (head + j) mod cap; head/len are host state.
 //
-// Staging: per env, up to flush_len records of RG = roundup(2S+A+2+G, 16) floats:
-//     [ s | a | ns | r | d | ag (G) | pad ]       (the dg column is the goal slot of s itself)
+// Staging: per env, up to flush_len records of RG = roundup(RW+G, 16) floats: the ring record's
+// RW = SA4+S4+2 leading floats, then ag (G)          (the dg column is the goal slot of s itself)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -39,7 +41,7 @@ __host__ __device__ inline uint32_t hash_below(uint64_t seed, uint64_t stream, u
 
 struct gcrl_her {
   gcrl_her_config cfg;
-  int S, A, G, W, RS, RG;
+  int S, A, G, SA4, S4, RW, RS, RG;   // o_ns = SA4, o_r = SA4+S4, o_d = o_r+1, o_ag = RW
   gcrl_mt* rng = nullptr;
   bool own_rng = false;
   hipStream_t stream = nullptr;
@@ -70,7 +72,9 @@ struct gcrl_her {
   std::vector<hipEvent_t> prof_a, prof_b;
   size_t prof_used = 0;
   int64_t prof_launches = 0, prof_rows = 0;
-  double prof_ms = 0.0;
+  double prof_ms = 0.0, prof_clk_ticks = 0.0;
+  unsigned long long* prof_clk = nullptr;   // [pairs][2] device words
+  int prof_clk_khz = 100000;
 
   // NULL -> the handle's own stream; GCRL_STREAM_LEGACY -> HIP's legacy default stream
   hipStream_t pick(void* s) const {

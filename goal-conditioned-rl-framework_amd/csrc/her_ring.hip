@@ -23,7 +23,7 @@ struct StageArgs {
   float* dst;            // record base: stage[env][t][0]
   const float* s_dev;    // device source or nullptr -> s_inl
   const float* ns_dev;
-  int S, A, G;
+  int S, A, G, SA4, S4;
   float r, d;
   float a[16];
   float ag[kMaxG];
@@ -32,17 +32,15 @@ struct StageArgs {
 };
 
 __global__ __launch_bounds__(64) void her_stage_kernel(StageArgs p) {
-  const int W = 2 * p.S + p.A + 2;
-  for (int c = threadIdx.x; c < W + p.G; c += 64) {
-    float v;
+  const int o_ns = p.SA4, o_r = p.SA4 + p.S4, RW = o_r + 2;
+  for (int c = threadIdx.x; c < RW + p.G; c += 64) {
+    float v = 0.f;
     if (c < p.S) v = p.s_dev ? p.s_dev[c] : p.s_inl[c];
     else if (c < p.S + p.A) v = p.a[c - p.S];
-    else if (c < 2 * p.S + p.A) {
-      int k = c - p.S - p.A;
-      v = p.ns_dev ? p.ns_dev[k] : p.ns_inl[k];
-    } else if (c == W - 2) v = p.r;
-    else if (c == W - 1) v = p.d;
-    else v = p.ag[c - W];
+    else if (c >= o_ns && c < o_ns + p.S) v = p.ns_dev ? p.ns_dev[c - o_ns] : p.ns_inl[c - o_ns];
+    else if (c == o_r) v = p.r;
+    else if (c == o_r + 1) v = p.d;
+    else if (c >= RW) v = p.ag[c - RW];
     p.dst[c] = v;
   }
 }
@@ -51,7 +49,7 @@ __global__ __launch_bounds__(64) void her_stage_kernel(StageArgs p) {
 struct FlushArgs {
   float* ring;
   long long cap, tail, skip;  // rows whose running number is < skip fell off a too-small ring
-  int nep, k, S, A, G, W, RS, RG;
+  int nep, k, S, A, G, SA4, S4, RW, RS, RG;
   int reward_kind;
   float thr;
   int rng_mode;
@@ -93,7 +91,7 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
     if (lane == e) base_lds = incl - rows;
   }
   const float* stg = p.stage[e];
-  for (int t = threadIdx.x; t < T * p.G; t += 256) ag_lds[t] = stg[(t / p.G) * p.RG + p.W + (t % p.G)];
+  for (int t = threadIdx.x; t < T * p.G; t += 256) ag_lds[t] = stg[(t / p.G) * p.RG + p.RW + (t % p.G)];
   const int nsteps = min(kStepsPerBlock, T - i0);
   for (int t = threadIdx.x; t < nsteps * p.RG; t += 256) {
     int li = t / p.RG, c = t - li * p.RG;
@@ -111,14 +109,15 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
     if (g < p.skip) continue;
     const long long phys = (p.tail + g) % p.cap;
     int f = 0;
-    float rew = rec_lds[li][p.W - 2], done = rec_lds[li][p.W - 1];
+    const int o_ns = p.SA4, o_r = p.SA4 + p.S4;
+    float rew = rec_lds[li][o_r], done = rec_lds[li][o_r + 1];
     if (rep > 0) {
       if (p.rng_mode == GCRL_RNG_CPYTHON_MT) f = p.fut[p.fut_off[e] + i * p.k + (rep - 1)];
       else f = i + 1 + (int)gcrl::hash_below(p.seed, p.epi_id[e], (unsigned long long)(i * p.k + rep - 1), (uint32_t)(T - 1 - i));
       // compute_reward(ag_i, ag_f): d = ||ag_i - ag_f||_2 in fp32, one rounding per op
       float acc = 0.f;
       for (int q = 0; q < p.G; ++q) {
-        float df = __fsub_rn(rec_lds[li][p.W + q], ag_lds[f * p.G + q]);
+        float df = __fsub_rn(rec_lds[li][p.RW + q], ag_lds[f * p.G + q]);
         acc = __fadd_rn(acc, __fmul_rn(df, df));
       }
       float dist = __fsqrt_rn(acc);
@@ -126,21 +125,33 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
       done = 0.f;
     }
     float* out = p.ring + phys * p.RS;
-    const int gs0 = p.S - p.G;            // goal slot of s
-    const int gs1 = 2 * p.S + p.A - p.G;  // goal slot of ns
+    const int gs0 = p.S - p.G;           // goal slot of s
+    const int gs1 = o_ns + p.S - p.G;    // goal slot of ns
     for (int c = lane; c < p.RS; c += 64) {
       float v = 0.f;
-      if (c < p.W - 2) {
+      if (c < o_r) {
         v = rec_lds[li][c];
         if (rep > 0) {
           if (c >= gs0 && c < p.S) v = ag_lds[f * p.G + (c - gs0)];
-          else if (c >= gs1) v = ag_lds[f * p.G + (c - gs1)];
+          else if (c >= gs1 && c < o_ns + p.S) v = ag_lds[f * p.G + (c - gs1)];
         }
-      } else if (c == p.W - 2) v = rew;
-      else if (c == p.W - 1) v = done;
+      } else if (c == o_r) v = rew;
+      else if (c == o_r + 1) v = done;
       out[c] = v;
     }
   }
+}
+
+// Only the first 8 and the last <=64 blocks of the grid stamp (blocks are dispatched in order, so
+// the earliest start and the latest end are among them): one word hammered by every block costs
+// ~11 ns per atomic and doubled the kernel's time at 8K blocks.
+__device__ inline void clk_begin(unsigned long long* clk) {
+  if (clk && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(&clk[0], (unsigned long long)wall_clock64());
+}
+__device__ inline void clk_end(unsigned long long* clk) {
+  if (!clk || blockIdx.x + 64 < gridDim.x) return;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(&clk[1], (unsigned long long)wall_clock64());
 }
 
 // ---------------------------------------------------------------- gather (public sample)
@@ -148,20 +159,67 @@ struct GatherArgs {
   const float* ring;
   const uint32_t* idx;  // logical indices
   long long n, head, cap;
-  int S, A, RS;
+  int S, A, SA4, S4, RS;
   float *out_s, *out_a, *out_r, *out_ns, *out_d;
   int ld_s, ld_a, ld_ns;
+  unsigned long long* clk;  // profiling: {min block start, max block end} in wall_clock64 ticks
 };
 
-// 16 lanes x float4 cover one <=64-float record, so one wave-load instruction fetches four
-// records (whole 128-B lines); each lane then routes its four floats to the dense outputs.
-template <int kUnroll>
+// Records of <= 64 floats: a block owns 64 consecutive batch rows.  Load: 16 lanes x float4
+// cover a record, so one wave-load instruction fetches four records as whole 128-B lines, 16
+// records per wave in flight.  The records go through LDS; then every output field is written
+// as ONE contiguous span (rows r0..r0+63 of a dense [n, S] matrix are adjacent in memory):
+// lane e -> element e of the span, fully coalesced dword stores.
 __global__ __launch_bounds__(256) void her_gather_kernel(GatherArgs p) {
+  __shared__ float tile[64][65];  // +1: column-ish LDS reads of the store phase stay conflict-free
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 4, v4 = lane & 15;
+  const int o_ns = p.SA4, o_r = p.SA4 + p.S4;
+  const int c0 = v4 * 4;
+  clk_begin(p.clk);
+  for (long long r0 = (long long)blockIdx.x * 64; r0 < p.n; r0 += (long long)gridDim.x * 64) {
+    float4 val[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long row = r0 + wave * 16 + u * 4 + sub;
+      val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < p.n && c0 < p.RS) {
+        const long long phys = (p.head + (long long)p.idx[row]) % p.cap;
+        val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
+      }
+    }
+    __syncthreads();  // previous iteration's store phase is done with the tile
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float* dst = &tile[wave * 16 + u * 4 + sub][c0];
+      dst[0] = val[u].x; dst[1] = val[u].y; dst[2] = val[u].z; dst[3] = val[u].w;
+    }
+    __syncthreads();
+    const int rows = (int)min((long long)64, p.n - r0);
+    auto span = [&](float* out, int ld, int width, int col0) {
+      // elements (row, c) of a [rows, width] slab; contiguous in memory when ld == width
+      for (int e = threadIdx.x; e < rows * width; e += 256) {
+        const int row = e / width, c = e - row * width;
+        out[(r0 + row) * ld + c] = tile[row][col0 + c];
+      }
+    };
+    span(p.out_s, p.ld_s, p.S, 0);
+    span(p.out_a, p.ld_a, p.A, p.S);
+    span(p.out_ns, p.ld_ns, p.S, o_ns);
+    span(p.out_r, 1, 1, o_r);
+    span(p.out_d, 1, 1, o_r + 1);
+  }
+  clk_end(p.clk);
+}
+
+// records wider than 64 floats: per-lane routing, no LDS staging
+template <int kUnroll>
+__global__ __launch_bounds__(256) void her_gather_wide_kernel(GatherArgs p) {
   const int lane = threadIdx.x & 63;
   const int sub = lane >> 4, v4 = lane & 15;
   const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nwaves = (long long)gridDim.x * 4;
-  const int W = 2 * p.S + p.A + 2;
+  const int o_ns = p.SA4, o_r = p.SA4 + p.S4;
   const int chunks = (p.RS + 63) / 64;  // 64-float pieces per record
   for (long long r0 = wave_id * (4 * kUnroll); r0 < p.n; r0 += nwaves * (4 * kUnroll)) {
     for (int ch = 0; ch < chunks; ++ch) {
@@ -184,12 +242,11 @@ __global__ __launch_bounds__(256) void her_gather_kernel(GatherArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int c = ch * 64 + v4 * 4 + q;
-          if (c >= W) continue;
           if (c < p.S) p.out_s[row[u] * p.ld_s + c] = vv[q];
           else if (c < p.S + p.A) p.out_a[row[u] * p.ld_a + (c - p.S)] = vv[q];
-          else if (c < W - 2) p.out_ns[row[u] * p.ld_ns + (c - p.S - p.A)] = vv[q];
-          else if (c == W - 2) p.out_r[row[u]] = vv[q];
-          else p.out_d[row[u]] = vv[q];
+          else if (c >= o_ns && c < o_ns + p.S) p.out_ns[row[u] * p.ld_ns + (c - o_ns)] = vv[q];
+          else if (c == o_r) p.out_r[row[u]] = vv[q];
+          else if (c == o_r + 1) p.out_d[row[u]] = vv[q];
         }
       }
     }
@@ -201,39 +258,51 @@ struct GatherUpdArgs {
   const float* ring;
   const uint32_t* idx;
   long long n, head, cap;
-  int S, A, RS, ldx;
+  int SA4, S4, RS, ldx;   // ldx == SA4
   float *sa, *nsa, *spa, *r, *d;
+  unsigned long long* clk;
 };
 
+// 16 lanes x 16 B cover one record; every batch matrix is a 16-byte-aligned slice of it, so each
+// lane's float4 goes out as float4: sa <- [0,SA4), spa <- [0,S4), nsa <- [SA4,SA4+S4), (r,d).
+// kRows records per wave are fetched before any store (independent loads in flight).
+template <int kUnroll>
 __global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p) {
   const int lane = threadIdx.x & 63;
   const int sub = lane >> 4, v4 = lane & 15;
   const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nwaves = (long long)gridDim.x * 4;
-  const int W = 2 * p.S + p.A + 2;
-  const int chunks = (p.RS + 63) / 64;
-  for (long long r0 = wave_id * 4; r0 < p.n; r0 += nwaves * 4) {
-    const long long row = r0 + sub;
-    if (row >= p.n) continue;
-    const long long phys = (p.head + (long long)p.idx[row]) % p.cap;
-    for (int ch = 0; ch < chunks; ++ch) {
-      const int c0 = ch * 64 + v4 * 4;
-      if (c0 >= p.RS) continue;
-      const float4 val = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
-      const float vv[4] = {val.x, val.y, val.z, val.w};
+  const int c0 = v4 * 4;
+  const int o_r = p.SA4 + p.S4;
+  clk_begin(p.clk);
+  for (long long r0 = wave_id * (4 * kUnroll); r0 < p.n; r0 += nwaves * (4 * kUnroll)) {
+    float4 val[kUnroll];
+    long long row[kUnroll];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = c0 + q;
-        if (c >= W) continue;
-        if (c < p.S + p.A) {
-          p.sa[row * p.ldx + c] = vv[q];
-          if (c < p.S) p.spa[row * p.ldx + c] = vv[q];
-        } else if (c < W - 2) p.nsa[row * p.ldx + (c - p.S - p.A)] = vv[q];
-        else if (c == W - 2) p.r[row] = vv[q];
-        else p.d[row] = vv[q];
+    for (int u = 0; u < kUnroll; ++u) {
+      row[u] = r0 + u * 4 + sub;
+      val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row[u] < p.n && c0 < p.RS) {
+        const long long phys = (p.head + (long long)p.idx[row[u]]) % p.cap;
+        val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      if (row[u] >= p.n) continue;
+      const long long ro = row[u] * p.ldx;
+      if (c0 < p.SA4) {
+        *reinterpret_cast<float4*>(p.sa + ro + c0) = val[u];
+        if (c0 < p.S4) *reinterpret_cast<float4*>(p.spa + ro + c0) = val[u];
+      } else if (c0 < o_r) {
+        *reinterpret_cast<float4*>(p.nsa + ro + (c0 - p.SA4)) = val[u];
+      } else if (c0 == o_r) {
+        p.r[row[u]] = val[u].x;
+        p.d[row[u]] = val[u].y;
       }
     }
   }
+  clk_end(p.clk);
 }
 
 // rows [first, first+n) in logical order -> contiguous records (read_rows)
@@ -249,12 +318,18 @@ __global__ void her_copy_rows_kernel(const float* ring, long long head, long lon
 constexpr size_t kProfPairs = 256;
 
 int prof_drain(gcrl_her* h) {
+  if (h->prof_used == 0) return GCRL_OK;
   for (size_t i = 0; i < h->prof_used; ++i) {
     float ms = 0.f;
     GCRL_HIP(hipEventSynchronize(h->prof_b[i]));
     GCRL_HIP(hipEventElapsedTime(&ms, h->prof_a[i], h->prof_b[i]));
     h->prof_ms += ms;
   }
+  // device-clock view of the same launches: max block end - min block start
+  std::vector<unsigned long long> clk(2 * h->prof_used);
+  GCRL_HIP(hipMemcpy(clk.data(), h->prof_clk, clk.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < h->prof_used; ++i)
+    if (clk[2 * i + 1] > clk[2 * i]) h->prof_clk_ticks += (double)(clk[2 * i + 1] - clk[2 * i]);
   h->prof_used = 0;
   return GCRL_OK;
 }
@@ -262,9 +337,12 @@ int prof_begin(gcrl_her* h, hipStream_t st) {
   if (!h->prof) return GCRL_OK;
   if (h->prof_used == kProfPairs)
     if (int rc = prof_drain(h)) return rc;
+  const unsigned long long init[2] = {~0ull, 0ull};
+  GCRL_HIP(hipMemcpyAsync(h->prof_clk + 2 * h->prof_used, init, sizeof(init), hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(h->prof_a[h->prof_used], st));
   return GCRL_OK;
 }
+unsigned long long* prof_slot(gcrl_her* h) { return h->prof ? h->prof_clk + 2 * h->prof_used : nullptr; }
 int prof_end(gcrl_her* h, hipStream_t st, int64_t rows) {
   if (!h->prof) return GCRL_OK;
   GCRL_HIP(hipEventRecord(h->prof_b[h->prof_used], st));
@@ -298,7 +376,7 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
   fa.cap = c.capacity;
   fa.tail = (h->head + h->len) % c.capacity;
   fa.nep = nep;
-  fa.k = c.k_future; fa.S = h->S; fa.A = h->A; fa.G = h->G; fa.W = h->W; fa.RS = h->RS; fa.RG = h->RG;
+  fa.k = c.k_future; fa.S = h->S; fa.A = h->A; fa.G = h->G; fa.SA4 = h->SA4; fa.S4 = h->S4; fa.RW = h->RW; fa.RS = h->RS; fa.RG = h->RG;
   fa.reward_kind = c.reward_kind;
   fa.thr = c.reward_threshold;
   fa.rng_mode = c.rng_mode;
@@ -383,10 +461,13 @@ int her_upload_indices(gcrl_her* h, int B, int M, const uint32_t* idx_host, hipS
 
 int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa, float* nsa,
                       float* spa, int ldx, float* r, float* d, hipStream_t st) {
-  GatherUpdArgs ga{h->ring, idx_dev, n, h->head, h->cfg.capacity, h->S, h->A, h->RS, ldx, sa, nsa, spa, r, d};
-  int blocks = (int)std::min<int64_t>((n + 15) / 16, 2048);
+  if (ldx != h->SA4) return fail(GCRL_ERR_ARG, "her_gather_update: batch row stride %d != roundup(S+A,4) = %d", ldx, h->SA4);
+  if (h->RS > 64) return fail(GCRL_ERR_ARG, "her_gather_update: records wider than 64 floats are not supported by the engine gather");
   if (int rc = prof_begin(h, st)) return rc;
-  hipLaunchKernelGGL(her_gather_update_kernel, dim3(blocks), dim3(256), 0, st, ga);
+  GatherUpdArgs ga{h->ring, idx_dev, n, h->head, h->cfg.capacity, h->SA4, h->S4, h->RS, ldx, sa, nsa, spa, r, d, prof_slot(h)};
+  constexpr int kUnroll = 4;
+  int blocks = (int)std::min<int64_t>((n + 16 * kUnroll - 1) / (16 * kUnroll), 8192);
+  hipLaunchKernelGGL(her_gather_update_kernel<kUnroll>, dim3(blocks), dim3(256), 0, st, ga);
   GCRL_HIP(hipGetLastError());
   return prof_end(h, st, n);
 }
@@ -409,7 +490,7 @@ gcrl_her* gcrl_her_create(const gcrl_her_config* cfg, gcrl_mt* rng) {
   if (cfg->capacity < 1 || cfg->capacity >= (1ll << 32)) return bad("capacity must be in [1, 2^32)");
   if (cfg->nenvs < 1 || cfg->k_future < 0) return bad("nenvs >= 1 and k_future >= 0 required");
   if (cfg->flush_len < 1 || cfg->flush_len > kMaxT) return bad("flush_len must be 1..64");
-  if (2 * cfg->state_dim + cfg->action_dim + 2 + cfg->goal_dim > 160) return bad("record wider than 160 floats");
+  if (2 * cfg->state_dim + cfg->action_dim + 8 + cfg->goal_dim > 160) return bad("record wider than 160 floats");
   int ndev = gcrl_device_count();
   if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
     gcrl::fail(GCRL_ERR_HIP, "gcrl_her_create: no usable HIP device (count=%d, requested %d); there is no CPU fallback", ndev, cfg->device);
@@ -418,9 +499,11 @@ gcrl_her* gcrl_her_create(const gcrl_her_config* cfg, gcrl_mt* rng) {
   gcrl_her* h = new gcrl_her;
   h->cfg = *cfg;
   h->S = cfg->state_dim; h->A = cfg->action_dim; h->G = cfg->goal_dim;
-  h->W = 2 * h->S + h->A + 2;
-  h->RS = gcrl::round_up(h->W, 16);
-  h->RG = gcrl::round_up(h->W + h->G, 16);
+  h->SA4 = gcrl::round_up(h->S + h->A, 4);
+  h->S4 = gcrl::round_up(h->S, 4);
+  h->RW = h->SA4 + h->S4 + 2;
+  h->RS = gcrl::round_up(h->RW, 16);
+  h->RG = gcrl::round_up(h->RW + h->G, 16);
   h->staged.assign(cfg->nenvs, 0);
   if (rng) { h->rng = rng; h->own_rng = false; }
   else { h->rng = gcrl_mt_create(); h->own_rng = true; gcrl_mt_seed(h->rng, cfg->seed); }
@@ -454,6 +537,7 @@ void gcrl_her_destroy(gcrl_her* h) {
   }
   for (hipEvent_t e : h->prof_a) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_b) (void)hipEventDestroy(e);
+  if (h->prof_clk) (void)hipFree(h->prof_clk);
   if (h->idx_dev) (void)hipFree(h->idx_dev);
   if (h->ring) (void)hipFree(h->ring);
   if (h->stage) (void)hipFree(h->stage);
@@ -484,7 +568,7 @@ int64_t gcrl_her_push(gcrl_her* h, int env, const float* state, int state_on_dev
   sa.dst = h->stage + ((size_t)env * h->cfg.flush_len + t) * h->RG;
   sa.s_dev = state_on_device ? state : nullptr;
   sa.ns_dev = next_on_device ? next_state : nullptr;
-  sa.S = h->S; sa.A = h->A; sa.G = h->G;
+  sa.S = h->S; sa.A = h->A; sa.G = h->G; sa.SA4 = h->SA4; sa.S4 = h->S4;
   sa.r = reward;
   sa.d = done ? 1.0f : 0.0f;
   std::memcpy(sa.a, action_host, sizeof(float) * h->A);
@@ -521,10 +605,10 @@ int64_t gcrl_her_push_episode(gcrl_her* h, int env, int T, const float* s, const
     float* rec = buf + (size_t)t * h->RG;
     std::memcpy(rec, s + (size_t)t * h->S, sizeof(float) * h->S);
     std::memcpy(rec + h->S, a + (size_t)t * h->A, sizeof(float) * h->A);
-    std::memcpy(rec + h->S + h->A, ns + (size_t)t * h->S, sizeof(float) * h->S);
-    rec[h->W - 2] = r[t];
-    rec[h->W - 1] = d[t];
-    std::memcpy(rec + h->W, ag + (size_t)t * h->G, sizeof(float) * h->G);
+    std::memcpy(rec + h->SA4, ns + (size_t)t * h->S, sizeof(float) * h->S);
+    rec[h->SA4 + h->S4] = r[t];
+    rec[h->SA4 + h->S4 + 1] = d[t];
+    std::memcpy(rec + h->RW, ag + (size_t)t * h->G, sizeof(float) * h->G);
   }
   float* dst = h->stage + ((size_t)env * h->cfg.flush_len) * h->RG;
   GCRL_HIP(hipMemcpyAsync(dst, buf, (size_t)T * h->RG * sizeof(float), hipMemcpyHostToDevice, st));
@@ -546,12 +630,18 @@ int gcrl_her_sample(gcrl_her* h, int B, int M, const uint32_t* idx_host, float* 
   if (int rc = gcrl::her_upload_indices(h, B, M, idx_host, st, &host_copy)) return rc;
   if (drawn_idx_host) std::memcpy(drawn_idx_host, host_copy, (size_t)B * M * sizeof(uint32_t));
   const long long n = (long long)B * M;
-  GatherArgs ga{h->ring, h->idx_dev, n, h->head, h->cfg.capacity, h->S, h->A, h->RS,
-                out_s, out_a, out_r, out_ns, out_d, ld_s, ld_a, ld_ns};
-  constexpr int kUnroll = 2;
-  int blocks = (int)std::min<long long>((n + 4 * 4 * kUnroll - 1) / (4 * 4 * kUnroll), 4096);
+  GatherArgs ga{h->ring, h->idx_dev, n, h->head, h->cfg.capacity, h->S, h->A, h->SA4, h->S4, h->RS,
+                out_s, out_a, out_r, out_ns, out_d, ld_s, ld_a, ld_ns, nullptr};
   if (int rc = prof_begin(h, st)) return rc;
-  hipLaunchKernelGGL(her_gather_kernel<kUnroll>, dim3(blocks), dim3(256), 0, st, ga);
+  ga.clk = prof_slot(h);
+  if (h->RS <= 64) {
+    int blocks = (int)std::min<long long>((n + 63) / 64, 8192);
+    hipLaunchKernelGGL(her_gather_kernel, dim3(blocks), dim3(256), 0, st, ga);
+  } else {
+    constexpr int kUnroll = 2;
+    int blocks = (int)std::min<long long>((n + 4 * 4 * kUnroll - 1) / (4 * 4 * kUnroll), 4096);
+    hipLaunchKernelGGL(her_gather_wide_kernel<kUnroll>, dim3(blocks), dim3(256), 0, st, ga);
+  }
   GCRL_HIP(hipGetLastError());
   return prof_end(h, st, n);
 }
@@ -565,19 +655,24 @@ int gcrl_her_profile_enable(gcrl_her* h, int on) {
       GCRL_HIP(hipEventCreate(&h->prof_a[i]));
       GCRL_HIP(hipEventCreate(&h->prof_b[i]));
     }
+    GCRL_HIP(hipMalloc((void**)&h->prof_clk, 2 * kProfPairs * sizeof(unsigned long long)));
+    int khz = 0;
+    GCRL_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device));
+    h->prof_clk_khz = khz > 0 ? khz : 100000;
   }
   if (int rc = prof_drain(h)) return rc;
   h->prof = on != 0;
-  h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0;
+  h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0; h->prof_clk_ticks = 0.0;
   return GCRL_OK;
 }
 
-int gcrl_her_profile_read(gcrl_her* h, int64_t* launches, double* total_ms, int64_t* rows) {
+int gcrl_her_profile_read(gcrl_her* h, int64_t* launches, double* total_ms, int64_t* rows, double* device_clock_ms) {
   GCRL_CHECK_ARG(h, "gcrl_her_profile_read: null handle");
   if (int rc = prof_drain(h)) return rc;
   if (launches) *launches = h->prof_launches;
   if (total_ms) *total_ms = h->prof_ms;
   if (rows) *rows = h->prof_rows;
+  if (device_clock_ms) *device_clock_ms = h->prof_clk_ticks / (double)h->prof_clk_khz;
   return GCRL_OK;
 }
 
@@ -600,9 +695,9 @@ int gcrl_her_read_rows(gcrl_her* h, int64_t first, int64_t n, float* s, float* a
     const float* rec = host.data() + (size_t)i * h->RS;
     if (s) std::memcpy(s + (size_t)i * h->S, rec, sizeof(float) * h->S);
     if (a) std::memcpy(a + (size_t)i * h->A, rec + h->S, sizeof(float) * h->A);
-    if (ns) std::memcpy(ns + (size_t)i * h->S, rec + h->S + h->A, sizeof(float) * h->S);
-    if (r) r[i] = rec[h->W - 2];
-    if (d) d[i] = rec[h->W - 1];
+    if (ns) std::memcpy(ns + (size_t)i * h->S, rec + h->SA4, sizeof(float) * h->S);
+    if (r) r[i] = rec[h->SA4 + h->S4];
+    if (d) d[i] = rec[h->SA4 + h->S4 + 1];
   }
   return GCRL_OK;
 }

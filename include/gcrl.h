@@ -154,10 +154,12 @@ int gcrl_her_sample(gcrl_her* h, int B, int M, const uint32_t* idx_host,
 /* Measurement: when enabled, every gather launch of this ring (gcrl_her_sample and the update
  * engine's batch gather) is bracketed by two hipEvents on the stream it is launched on.
  * gcrl_her_profile_read waits for the pending events and returns, since enabling, the number
- * of gather launches, their summed device time (ms) and the rows they gathered. */
+ * of gather launches, their summed hipEvent time (ms, includes the event/dispatch overhead of a
+ * bracketed launch), the rows they gathered, and the summed in-kernel time by the device
+ * wall clock (last block end - first block start; what rocprofv3's kernel duration measures). */
 int gcrl_her_profile_enable(gcrl_her* h, int on);
 int gcrl_her_profile_read(gcrl_her* h, int64_t* launches_out, double* total_ms_out,
-                          int64_t* rows_out);
+                          int64_t* rows_out, double* device_clock_ms_out);
 
 /* Test/debug: copy `n` ring rows starting at logical index `first` to host arrays
  * (any may be NULL).  Synchronises the handle's stream. */
