@@ -98,6 +98,7 @@ struct gcrl_agent {
   float *sa = nullptr, *nsa = nullptr, *spa = nullptr, *rbuf = nullptr, *dbuf = nullptr;
   long long slot_x = 0, slot_rd = 0;
   float *hTA[2] = {}, *hA = nullptr, *hC = nullptr, *hTC = nullptr, *gC = nullptr, *gA[2] = {};
+  float *hC2 = nullptr, *gC2 = nullptr;
   float *q = nullptr, *qt = nullptr, *q2 = nullptr, *dq = nullptr, *dq2 = nullptr, *dact = nullptr;
   float *zA = nullptr, *xhatA = nullptr, *invstdA = nullptr, *headA = nullptr, *ghead = nullptr, *dh2 = nullptr;
   float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
@@ -136,6 +137,7 @@ struct gcrl_agent {
   CtrlBlock* ctrl() const { return (CtrlBlock*)upload_dev; }
   uint32_t* idx_dev() const { return (uint32_t*)(upload_dev + sizeof(UploadBlock)); }
   const StepCtrl* cur() const { return &ctrl()->cur; }
+  const StepCtrl* prev() const { return &ctrl()->prev; }
   const int* slot_ptr() const { return &ctrl()->cur.batch_slot; }
   float* P_actor() const { return params + off_actor; }
   float* P_tactor() const { return params + off_tactor; }
@@ -147,6 +149,10 @@ struct gcrl_agent {
   float* hC_at(int c, int l) const { return hC + ((long long)c * L + l) * B * H; }
   float* hTC_at(int c, int i) const { return hTC + ((long long)c * 2 + i) * B * H; }
   float* gC_at(int c, int i) const { return gC + ((long long)c * 2 + i) * B * H; }
+  // second activation / gradient set of critic 0: the actor phase of step i runs in the same
+  // launches as the critic phase of step i+1 (software-pipelined DDPG)
+  float* hC2_at(int l) const { return hC2 + (long long)l * B * H; }
+  float* gC2_at(int i) const { return gC2 + (long long)i * B * H; }
   float* hA_at(int l) const { return hA + (long long)l * B * H; }
   int n_actor_critics() const { return (cfg.kind == GCRL_AGENT_DDPG || cfg.kind == GCRL_AGENT_TD3) ? 1 : C; }
 };
@@ -239,19 +245,21 @@ float* hid_A(gcrl_agent* a, int, int l) { return a->hA_at(l); }
 float* hid_C(gcrl_agent* a, int c, int l) { return a->hC_at(c, l); }
 float* hid_TC(gcrl_agent* a, int c, int l) { return a->hTC_at(c, l & 1); }
 float* hid_ACT(gcrl_agent* a, int, int l) { return a->act_tmp[l & 1]; }
+float* hid_C2(gcrl_agent* a, int, int l) { return a->hC2_at(l); }
 
 // plain MLP chain (Actor / Critic of src/model.py): layer l goes to launch at+l.
 // x_slot / out_slot: per-batch-slot strides when input / output live in the batch array.
 void chain_mlp(gcrl_agent* a, Launches& ls, size_t at, const NetSpec& net, const float* P, const float* X0,
                long long ldx0, long long x_slot, HidFn hid, int key, float* out, long long ld_out,
-               long long out_slot, int out_epi, int rows) {
+               long long out_slot, int out_epi, int rows, const int* slot = nullptr) {
+  if (!slot) slot = a->slot_ptr();
   for (int l = 0; l <= net.L; ++l) {
     const float* X = l == 0 ? X0 : hid(a, key, l - 1);
     float* Y = l < net.L ? hid(a, key, l) : out;
     GemmDesc d = fwd(X, l == 0 ? ldx0 : net.H, P, net.lin[l], Y, l < net.L ? net.H : ld_out, rows,
                      l < net.L ? EPI_LEAKY : out_epi);
-    if (l == 0 && x_slot) { d.slot = a->slot_ptr(); d.a_slot = x_slot; }
-    if (l == net.L && out_slot) { d.slot = a->slot_ptr(); d.c_slot = out_slot; }
+    if (l == 0 && x_slot) { d.slot = slot; d.a_slot = x_slot; }
+    if (l == net.L && out_slot) { d.slot = slot; d.c_slot = out_slot; }
     ls.add(at + l, d);
   }
 }
@@ -579,6 +587,8 @@ int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask) {
   return GCRL_OK;
 }
 
+#include "agent_pipeline.inc"
+
 // ---------------------------------------------------------------- per-step host bookkeeping
 struct StepPlan { int variant; int tuple_len; };
 
@@ -782,7 +792,8 @@ int build(gcrl_agent* a) {
       {&a->noise_in, (long long)B * A}, {&a->eps_next_in, (long long)B * A}, {&a->eps_cur_in, (long long)B * A},
       {&a->norm_partial, (long long)kMaxCritics * kNormBlocks}, {&a->act_in, (long long)B * a->ldx},
       {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH},
-      {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a}};
+      {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
+      {&a->hC2, L * BH}, {&a->gC2, 2 * BH}};
   long long total = 0;
   for (auto& w : wants) total += align_up(w.second, 64);
   TRY(bytes_alloc(&a->work, total));
@@ -1022,7 +1033,14 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
     std::vector<StepPlan> plans;
     TRY(begin_call(a, her, step0 + done, m, nullptr, 1.0f, st, plans, tickets_out ? tickets_out + done : nullptr,
                    lens_out ? lens_out + done : nullptr));
-    for (int i = 0; i < m; ++i) TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM, 7));
+    if (a->cfg.kind == GCRL_AGENT_DDPG && a->cfg.pipeline_steps != 0) {
+      // plain actor steps overlap pairwise: P(i) shares its launches with K(i+1)
+      std::vector<int> variants(m);
+      for (int i = 0; i < m; ++i) variants[i] = plans[i].variant;
+      TRY(run_steps_ddpg(a, st, variants.data(), m));
+    } else {
+      for (int i = 0; i < m; ++i) TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM, 7));
+    }
     TRY(end_call(a, st));
   }
   return GCRL_OK;

@@ -21,32 +21,44 @@ int launch_shape(hipStream_t st, GemmBatch& gb) {
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
+
+// The tile shape is a function of the PROBLEM alone, never of what else shares the launch: the
+// k-partition (and with it the fp32 summation order) of a problem must not change when the
+// engine co-schedules it with other problems (software-pipelined steps stay bitwise equal to
+// sequential ones).
+//   <= 1024 tiles of 16x16 : one tile per workgroup, K split over its 4 waves (latency-bound
+//                            sizes; small K just leaves waves idle in the exchange)
+//   <= 8192                : one tile per wave
+//   larger                 : 32x32 per wave
+int shape_of(const GemmDesc& d) {
+  const long long tiles16 = (long long)((d.M + 15) / 16) * ((d.N + 15) / 16);
+  if (tiles16 <= 1024) return 1;
+  if (tiles16 <= 8192) return 2;
+  return 3;
+}
 }  // namespace
 
 int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape) {
   GCRL_CHECK_ARG(n >= 1 && n <= kMaxProb, "launch_gemm_batch: %d problems (max %d)", n, kMaxProb);
-  GemmBatch gb;
-  gb.n = n;
-  long long tiles16 = 0;
-  int kmax = 0;
+  int shapes[kMaxProb];
   for (int i = 0; i < n; ++i) {
     GemmDesc& d = descs[i];
     GCRL_CHECK_ARG(d.M >= 1 && d.N >= 1 && d.K >= 1 && d.A && d.B && d.C, "launch_gemm_batch: bad problem %d (M=%d N=%d K=%d)", i, d.M, d.N, d.K);
     GCRL_CHECK_ARG(!d.ones_col || (d.N >= 2 && d.col_out), "launch_gemm_batch: ones_col needs N >= 2 and col_out");
     d.a_vec = (d.a_cs == 1 && d.a_rs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
     d.b_vec = (d.b_rs == 1 && d.b_cs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
-    tiles16 += (long long)((d.M + 15) / 16) * ((d.N + 15) / 16);
-    kmax = d.K > kmax ? d.K : kmax;
-    gb.d[i] = d;
+    shapes[i] = shape ? shape : shape_of(d);
   }
-  // latency-bound sizes: one 16x16 tile per workgroup, K split over its 4 waves (fills the
-  // chip with <= 1024 tiles); otherwise one tile per wave; large problems: 32x32 per wave.
-  if (shape == 1) return launch_shape<1, 1, 4>(st, gb);
-  if (shape == 2) return launch_shape<1, 1, 1>(st, gb);
-  if (shape == 3) return launch_shape<2, 2, 1>(st, gb);
-  if (tiles16 <= 1024 && kmax >= 64) return launch_shape<1, 1, 4>(st, gb);
-  if (tiles16 <= 8192) return launch_shape<1, 1, 1>(st, gb);
-  return launch_shape<2, 2, 1>(st, gb);
+  for (int s = 1; s <= 3; ++s) {  // one launch per shape present (almost always exactly one)
+    GemmBatch gb;
+    gb.n = 0;
+    for (int i = 0; i < n; ++i)
+      if (shapes[i] == s) gb.d[gb.n++] = descs[i];
+    if (gb.n == 0) continue;
+    int rc = s == 1 ? launch_shape<1, 1, 4>(st, gb) : (s == 2 ? launch_shape<1, 1, 1>(st, gb) : launch_shape<2, 2, 1>(st, gb));
+    if (rc) return rc;
+  }
+  return GCRL_OK;
 }
 
 }  // namespace gcrl

@@ -37,14 +37,16 @@ struct StepCtrl {
   int pad;
 };
 
-struct CtrlBlock {   // device layout: cursor, then cur, then the table
+struct CtrlBlock {   // device layout: cursor, then cur / prev, then the table
   int cursor;
   int pad[3];
-  StepCtrl cur;
+  StepCtrl cur;    // the step whose critic phase is running
+  StepCtrl prev;   // software-pipelined DDPG: the step whose actor phase shares the launches
   StepCtrl table[1];
 };
 
-int launch_begin_step(hipStream_t st, CtrlBlock* cb);
+// cur <- table[cursor++]; with shift: prev <- cur first
+int launch_begin_step(hipStream_t st, CtrlBlock* cb, int shift = 0);
 
 enum { LOSS_MSE = 0, LOSS_SMOOTH_L1 = 1 };
 enum { TGT_DDPG = 0, TGT_MIN = 1, TGT_MIN_ENT = 2, TGT_TRUNC_ENT = 3 };

@@ -32,9 +32,10 @@ __device__ inline float block_sum_256(float v, float* scratch) {
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
-__global__ void begin_step_kernel(CtrlBlock* cb) {
+__global__ void begin_step_kernel(CtrlBlock* cb, int shift) {
   if (threadIdx.x == 0) {
     const int c = cb->cursor;
+    if (shift) cb->prev = cb->cur;
     cb->cur = cb->table[c];
     cb->cursor = c + 1;
   }
@@ -244,8 +245,8 @@ __global__ void polyak_kernel(const float* p, float* tp, long long n, float tau,
 
 }  // namespace
 
-int launch_begin_step(hipStream_t st, CtrlBlock* cb) {
-  hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(64), 0, st, cb);
+int launch_begin_step(hipStream_t st, CtrlBlock* cb, int shift) {
+  hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(64), 0, st, cb, shift);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

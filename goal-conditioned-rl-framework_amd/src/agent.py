@@ -85,7 +85,7 @@ class _EngineAgent:
     TD_INDEX = {6: 2, 4: 1}  # position of td_error in the tuple, by tuple length
 
     def __init__(self, obs_dim: int, ac_dim: int, config, weights, nenvs: int, gradient_step: int, *,
-                 use_graph: bool = True, sync_metrics: bool = False, rng: str = "python",
+                 use_graph: bool = True, pipeline: bool = True, sync_metrics: bool = False, rng: str = "python",
                  seed: int | None = None, device_index: int = 0, num_critics: int = 5,
                  top_quantiles_to_drop: int = 2):
         if not torch.cuda.is_available() or lib.gcrl_device_count() <= 0:
@@ -124,7 +124,7 @@ class _EngineAgent:
             alpha_lr=float(getattr(config, "alpha_lr", 0.0003)),
             ac_scheduler_steps=config.ac_scheduler_steps, cr_scheduler_steps=config.cr_scheduler_steps,
             alpha_min_steps=float(getattr(config, "alpha_min_steps", 10000)),
-            device=device_index, use_graph=1 if use_graph else 0,
+            device=device_index, use_graph=1 if use_graph else 0, pipeline_steps=1 if pipeline else 0,
             seed=0 if seed is None else int(seed))
         self._h = _ffi.check_ptr(lib.gcrl_agent_create(C.byref(cfg)), "gcrl_agent_create")
         self._metric_cache: dict[int, list[float]] = {}

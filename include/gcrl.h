@@ -196,6 +196,10 @@ typedef struct gcrl_agent_config {
   int32_t device;
   int32_t use_graph;      /* 1: replay the step as a hipGraph */
   uint64_t seed;          /* device RNG for TD3 noise / SAC eps when not injected */
+  int32_t pipeline_steps; /* DDPG, gcrl_agent_update_n only: 1 = co-schedule the actor phase of
+                             step i with the critic phase of step i+1 (they are independent: the
+                             critic phase reads the TARGET actor); same arithmetic, fewer launches */
+  int32_t reserved;
 } gcrl_agent_config;
 
 gcrl_agent* gcrl_agent_create(const gcrl_agent_config* cfg);

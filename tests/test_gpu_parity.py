@@ -321,6 +321,40 @@ def test_update_many_equals_repeated_update(gcrl):
     assert np.array_equal(a1.actor.flat(), a2.actor.flat())
 
 
+@pytest.mark.parametrize("H,L", [(32, 2), (64, 3)])
+def test_pipelined_ddpg_is_bitwise_the_sequential_path(gcrl, H, L):
+    """Software-pipelined update_many (actor phase of step i co-scheduled with the critic phase of
+    step i+1) vs one update() per step, across two Polyak boundaries (steps 40 and 80) and an
+    update_many call that starts mid-stream: every returned tuple and every parameter bitwise equal."""
+    S, A, B = 10, 3, 32
+    cfg = make_config("DDPG", hidden_dim=H, layer_count=L, batch_size=B, max_len=3000, grad_clip=0.5)
+    gen = np.random.default_rng(4)
+    eps = [her_oracle.synthetic_episode(gen, 50, S, A) for _ in range(3)]
+
+    def build(pipeline):
+        ag = gcrl.DDPG(S, A, cfg, None, nenvs=1, gradient_step=40, rng="engine", seed=11, pipeline=pipeline)
+        for ep in eps:
+            for st in ep:
+                ag.push_her(0, *st)
+        gen2 = np.random.default_rng(5)
+        ag.actor.set_flat((0.1 * gen2.standard_normal(ag.actor.numel())).astype(np.float32))
+        ag.critic.set_flat((0.1 * gen2.standard_normal(ag.critic.numel())).astype(np.float32))
+        ag.update_target_network()
+        return ag
+
+    a_seq, a_pipe = build(False), build(True)
+    seq = [tuple(float(x) for x in a_seq.update(s)) for s in range(1, 91)]
+    pipe = []
+    for s0, n in [(1, 40), (41, 7), (48, 33), (81, 10)]:
+        pipe += [tuple(float(x) for x in t) for t in a_pipe.update_many(s0, n)]
+    assert len(seq) == len(pipe) == 90
+    for i, (x, y) in enumerate(zip(seq, pipe)):
+        assert x == y, (i + 1, x, y)
+    for v1, v2 in [(a_seq.actor, a_pipe.actor), (a_seq.critic, a_pipe.critic), (a_seq.target_actor, a_pipe.target_actor),
+                   (a_seq.target_critic, a_pipe.target_critic)]:
+        assert np.array_equal(v1.flat(), v2.flat())
+
+
 def test_tuple_contract_and_td_error_array(gcrl):
     cfg = make_config("TD3", hidden_dim=32, layer_count=2, batch_size=16, ac_update_freq=2)
     ag = gcrl.TD3Agent(10, 3, cfg, None, nenvs=1, gradient_step=4, sync_metrics=True, rng="engine", seed=1)
