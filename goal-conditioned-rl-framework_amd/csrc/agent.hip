@@ -98,7 +98,7 @@ struct gcrl_agent {
   float *sa = nullptr, *nsa = nullptr, *spa = nullptr, *rbuf = nullptr, *dbuf = nullptr;
   long long slot_x = 0, slot_rd = 0;
   float *hTA[2] = {}, *hA = nullptr, *hC = nullptr, *hTC = nullptr, *gC = nullptr, *gA[2] = {};
-  float *hC2 = nullptr, *gC2 = nullptr;
+  float *hC2 = nullptr, *gC2 = nullptr, *bn_part = nullptr;
   float *q = nullptr, *qt = nullptr, *q2 = nullptr, *dq = nullptr, *dq2 = nullptr, *dact = nullptr;
   float *zA = nullptr, *xhatA = nullptr, *invstdA = nullptr, *headA = nullptr, *ghead = nullptr, *dh2 = nullptr;
   float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
@@ -282,7 +282,7 @@ int sac_actor_forward(gcrl_agent* a, hipStream_t st, const float* X0, long long 
     TRY(launch_bn_relu_fwd(st, a->zA, B, H, P + net.bn_g[l], P + net.bn_b[l], a->hA_at(l),
                            save ? a->xhatA + (long long)l * B * H : nullptr,
                            save ? a->invstdA + (long long)l * H : nullptr, a->bn_rmean + (long long)l * H,
-                           a->bn_rvar + (long long)l * H));
+                           a->bn_rvar + (long long)l * H, a->bn_part));
   }
   {
     const int ldh = 2 * a->Apad;
@@ -505,7 +505,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
       // (dh for layer l<L-1 was written by the dX of layer l+1 into gA[(l+1)&1])
       TRY(launch_bn_relu_bwd(st, dh, l == L - 1 ? a->dh2 : nullptr, a->hA_at(l), a->xhatA + (long long)l * B * H,
                              a->invstdA + (long long)l * H, Pa + a->actor.bn_g[l], B, H, a->zA, Ga + a->actor.bn_g[l],
-                             Ga + a->actor.bn_b[l]));
+                             Ga + a->actor.bn_b[l], a->bn_part));
       std::vector<GemmDesc> v;
       GemmDesc dw = bwd_dw(a->zA, H, l == 0 ? a->spa : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
@@ -793,7 +793,7 @@ int build(gcrl_agent* a) {
       {&a->norm_partial, (long long)kMaxCritics * kNormBlocks}, {&a->act_in, (long long)B * a->ldx},
       {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH},
       {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
-      {&a->hC2, L * BH}, {&a->gC2, 2 * BH}};
+      {&a->hC2, L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H}};
   long long total = 0;
   for (auto& w : wants) total += align_up(w.second, 64);
   TRY(bytes_alloc(&a->work, total));

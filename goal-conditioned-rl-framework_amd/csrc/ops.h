@@ -111,9 +111,10 @@ int launch_polyak(hipStream_t st, const float* p, float* target, long long n, do
 // nn.BatchNorm1d in training mode followed by ReLU (src/model.py:106-108): z [B,H] -> h [B,H];
 // saves xhat [B,H] and invstd [H] when `xhat` is non-null; updates running_mean/var
 // (momentum 0.1, unbiased variance) in place.
+// scratch: 2 * ceil(B/64) * H floats (per-row-block partial statistics)
 int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
                        const float* beta, float* h, float* xhat, float* invstd,
-                       float* running_mean, float* running_var);
+                       float* running_mean, float* running_var, float* scratch);
 // eval mode (running statistics): select_action path
 int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const float* gamma,
                         const float* beta, const float* running_mean, const float* running_var,
@@ -121,7 +122,7 @@ int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const floa
 // backward of BN(train)+ReLU: dh -> dz, dgamma, dbeta
 int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* h, const float* xhat,
                        const float* invstd, const float* gamma, int B, int H, float* dz,
-                       float* dgamma, float* dbeta);
+                       float* dgamma, float* dbeta, float* scratch);
 
 // SACActorModel.sample (src/model.py:125-141): mean/log_std head outputs -> action + log-prob.
 struct TanhGaussArgs {

@@ -40,8 +40,15 @@ __device__ inline float hash_normal(unsigned long long seed, unsigned long long 
   return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
 }
 
-// A block owns 64 feature columns; its 4 wavefronts stride over the batch rows, so every
-// wave-load is one coalesced 256-B row segment; column sums meet in LDS.
+// BatchNorm statistics in two fully parallel, deterministic stages (a single column-owning block
+// per 64 features left 252 of 256 CUs idle and serialised over the batch):
+//   stage 1  grid (H/64, B/64): block (cb, rb) reduces its 64 rows x 64 columns to a per-column
+//            partial — forward: (mean_b, M2_b) by a local two-pass; backward: (sum dy, sum dy*xhat)
+//   stage 2  grid (H/64, B/64): every block merges the <= B/64 partials of its columns in the same
+//            fixed order (Chan's parallel-variance merge / plain sums), then transforms its rows.
+// A block = 64 columns x 4 row groups of 16 rows; every wave-load is one coalesced 256-B row segment.
+constexpr int kBnRows = 64;
+
 __device__ inline float col_sum4(float v, float (*red)[64], int cl, int rg) {
   __syncthreads();
   red[rg][cl] = v;
@@ -49,31 +56,57 @@ __device__ inline float col_sum4(float v, float (*red)[64], int cl, int rg) {
   return red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
-__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const float* __restrict__ z, int B, int H,
-                                                          const float* gamma, const float* beta,
-                                                          float* __restrict__ h, float* xhat,
-                                                          float* invstd_out, float* rmean, float* rvar) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int B, int H,
+                                                       float* __restrict__ part_mean, float* __restrict__ part_m2) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
   const bool ok = col < H;
   float s = 0.f;
-  if (ok) for (int b = rg; b < B; b += 4) s += z[(long long)b * H + col];
-  const float mean = col_sum4(s, red, cl, rg) / (float)B;
+  if (ok) for (int b = r0 + rg; b < r1; b += 4) s += z[(long long)b * H + col];
+  const float mean = col_sum4(s, red, cl, rg) / (float)(r1 - r0);
   float q = 0.f;
-  if (ok) for (int b = rg; b < B; b += 4) { const float df = z[(long long)b * H + col] - mean; q += df * df; }
-  const float var = col_sum4(q, red, cl, rg) / (float)B;  // biased: what normalises the batch
-  if (!ok) return;
+  if (ok) for (int b = r0 + rg; b < r1; b += 4) { const float df = z[(long long)b * H + col] - mean; q += df * df; }
+  const float m2 = col_sum4(q, red, cl, rg);
+  if (ok && rg == 0) {
+    part_mean[(long long)blockIdx.y * H + col] = mean;
+    part_m2[(long long)blockIdx.y * H + col] = m2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, int B, int H,
+                                                            const float* gamma, const float* beta,
+                                                            const float* __restrict__ part_mean,
+                                                            const float* __restrict__ part_m2,
+                                                            float* __restrict__ h, float* xhat, float* invstd_out,
+                                                            float* rmean, float* rvar) {
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  if (col >= H) return;
+  // merge the row-block partials (Chan et al.), same order in every block
+  const int nrb = (B + kBnRows - 1) / kBnRows;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int rb = 0; rb < nrb; ++rb) {
+    const float nb = (float)(min(B, (rb + 1) * kBnRows) - rb * kBnRows);
+    const float mb = part_mean[(long long)rb * H + col], qb = part_m2[(long long)rb * H + col];
+    const float delta = mb - mean, tot = n + nb;
+    mean += delta * (nb / tot);
+    m2 += qb + delta * delta * (n * nb / tot);
+    n = tot;
+  }
+  const float var = m2 / (float)B;  // biased: what normalises the batch
   const float invstd = 1.0f / sqrtf(var + kBnEps);
   const float g = gamma[col], bt = beta[col];
-  for (int b = rg; b < B; b += 4) {
+  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
+  for (int b = r0 + rg; b < r1; b += 4) {
     const long long i = (long long)b * H + col;
     const float xh = (z[i] - mean) * invstd;
     const float y = xh * g + bt;
     h[i] = y > 0.f ? y : 0.f;
     if (xhat) xhat[i] = xh;
   }
-  if (rg == 0) {
+  if (blockIdx.y == 0 && rg == 0) {
     if (invstd_out) invstd_out[col] = invstd;
     const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
     rmean[col] = (1.0f - kBnMomentum) * rmean[col] + kBnMomentum * mean;
@@ -90,19 +123,18 @@ __global__ void bn_relu_eval_kernel(const float* z, int B, int H, const float* g
   h[i] = y > 0.f ? y : 0.f;
 }
 
-__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2,
-                                                          const float* __restrict__ h,
-                                                          const float* __restrict__ xhat,
-                                                          const float* invstd, const float* gamma, int B,
-                                                          int H, float* __restrict__ dz, float* dgamma,
-                                                          float* dbeta) {
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dh, const float* __restrict__ dh2,
+                                                           const float* __restrict__ h, const float* __restrict__ xhat,
+                                                           int B, int H, float* __restrict__ part_dy,
+                                                           float* __restrict__ part_dyx) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
   const bool ok = col < H;
   float s1 = 0.f, s2 = 0.f;
   if (ok)
-    for (int b = rg; b < B; b += 4) {
+    for (int b = r0 + rg; b < r1; b += 4) {
       const long long i = (long long)b * H + col;
       const float dy = h[i] > 0.f ? (dh2 ? dh[i] + dh2[i] : dh[i]) : 0.f;
       s1 += dy;
@@ -110,15 +142,36 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restric
     }
   const float sum_dy = col_sum4(s1, red, cl, rg);
   const float sum_dyx = col_sum4(s2, red, cl, rg);
-  if (!ok) return;
+  if (ok && rg == 0) {
+    part_dy[(long long)blockIdx.y * H + col] = sum_dy;
+    part_dyx[(long long)blockIdx.y * H + col] = sum_dyx;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __restrict__ dh, const float* __restrict__ dh2,
+                                                                const float* __restrict__ h, const float* __restrict__ xhat,
+                                                                const float* invstd, const float* gamma,
+                                                                const float* __restrict__ part_dy,
+                                                                const float* __restrict__ part_dyx, int B, int H,
+                                                                float* __restrict__ dz, float* dgamma, float* dbeta) {
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  if (col >= H) return;
+  const int nrb = (B + kBnRows - 1) / kBnRows;
+  float sum_dy = 0.f, sum_dyx = 0.f;
+  for (int rb = 0; rb < nrb; ++rb) {
+    sum_dy += part_dy[(long long)rb * H + col];
+    sum_dyx += part_dyx[(long long)rb * H + col];
+  }
   const float k = gamma[col] * invstd[col];
   const float m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B;
-  for (int b = rg; b < B; b += 4) {
+  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
+  for (int b = r0 + rg; b < r1; b += 4) {
     const long long i = (long long)b * H + col;
     const float dy = h[i] > 0.f ? (dh2 ? dh[i] + dh2[i] : dh[i]) : 0.f;
     dz[i] = (dy - m1 - xhat[i] * m2) * k;
   }
-  if (rg == 0) { dgamma[col] = sum_dyx; dbeta[col] = sum_dy; }
+  if (blockIdx.y == 0 && rg == 0) { dgamma[col] = sum_dyx; dbeta[col] = sum_dy; }
 }
 
 __global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) {
@@ -284,8 +337,14 @@ __global__ __launch_bounds__(256) void sort_trunc_kernel(const float* in, long l
 
 int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
                        const float* beta, float* h, float* xhat, float* invstd, float* rmean,
-                       float* rvar) {
-  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3((H + 63) / 64), dim3(256), 0, st, z, B, H, gamma, beta, h,
+                       float* rvar, float* scratch) {
+  const int nrb = (B + kBnRows - 1) / kBnRows;
+  const dim3 grid((H + 63) / 64, nrb);
+  float* part_mean = scratch;
+  float* part_m2 = scratch + (long long)nrb * H;
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, st, z, B, H, part_mean, part_m2);
+  GCRL_HIP(hipGetLastError());
+  hipLaunchKernelGGL(bn_relu_apply_kernel, grid, dim3(256), 0, st, z, B, H, gamma, beta, part_mean, part_m2, h,
                      xhat, invstd, rmean, rvar);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
@@ -302,9 +361,15 @@ int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const floa
 
 int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* h, const float* xhat,
                        const float* invstd, const float* gamma, int B, int H, float* dz,
-                       float* dgamma, float* dbeta) {
-  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3((H + 63) / 64), dim3(256), 0, st, dh, dh2, h, xhat, invstd,
-                     gamma, B, H, dz, dgamma, dbeta);
+                       float* dgamma, float* dbeta, float* scratch) {
+  const int nrb = (B + kBnRows - 1) / kBnRows;
+  const dim3 grid((H + 63) / 64, nrb);
+  float* part_dy = scratch;
+  float* part_dyx = scratch + (long long)nrb * H;
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, grid, dim3(256), 0, st, dh, dh2, h, xhat, B, H, part_dy, part_dyx);
+  GCRL_HIP(hipGetLastError());
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, grid, dim3(256), 0, st, dh, dh2, h, xhat, invstd, gamma, part_dy,
+                     part_dyx, B, H, dz, dgamma, dbeta);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
