@@ -49,6 +49,7 @@ struct GemmDesc {
   // partials here (fixed slots, fixed order -> deterministic) removes a reduction launch
   float* sumsq_out;
   int a_vec, b_vec;  // 16-byte loads legal along k (filled by the launcher)
+  int a_rvec, b_rvec;  // 16-byte loads legal along the row index (operand stored k-major)
   int tile0, tiles_n, ntiles;  // filled by the launcher
 };
 

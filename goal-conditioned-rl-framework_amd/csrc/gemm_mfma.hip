@@ -1,5 +1,6 @@
 // gemm_mfma.hip — launcher of the batched fp32-MFMA GEMM (kernel: gemm_mfma.h).
 #include "gemm_mfma.h"
+#include "gemm_tiled.h"
 
 namespace gcrl {
 
@@ -33,8 +34,28 @@ int launch_shape(hipStream_t st, GemmBatch& gb) {
 int shape_of(const GemmDesc& d) {
   const long long tiles16 = (long long)((d.M + 15) / 16) * ((d.N + 15) / 16);
   if (tiles16 <= 1024) return 1;
-  if (tiles16 <= 8192) return 2;
-  return 3;
+  // LDS-tiled 64x64 workgroup tiles (gemm_tiled.h) once a problem alone fills most CUs with
+  // them (>= 192 tiles of 64x64); in between, one 16x16 tile per wave keeps more CUs busy
+  // (TD3 at B=2048, H=256: 128 tiles of 64x64 was 16% slower than 2048 wave tiles)
+  // ... or when the reduction is long (dW at batch 2048: a wave walking 128 k-chunks alone took
+  // 89 us; 64x64 tiles with LDS reuse are MFMA-bound there too)
+  const long long tiles64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+  return (tiles64 >= 192 || d.K >= 1024) ? 4 : 2;
+}
+
+int launch_tiled(hipStream_t st, GemmBatch& gb) {
+  int tiles = 0;
+  for (int i = 0; i < gb.n; ++i) {
+    GemmDesc& d = gb.d[i];
+    const int tm = (d.M + kTB - 1) / kTB;
+    d.tiles_n = (d.N + kTB - 1) / kTB;
+    d.ntiles = tm * d.tiles_n;
+    d.tile0 = tiles;
+    tiles += d.ntiles;
+  }
+  hipLaunchKernelGGL(gemm_tiled_kernel, dim3(tiles), dim3(256), 0, st, gb);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
 }
 }  // namespace
 
@@ -47,15 +68,18 @@ int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape) {
     GCRL_CHECK_ARG(!d.ones_col || (d.N >= 2 && d.col_out), "launch_gemm_batch: ones_col needs N >= 2 and col_out");
     d.a_vec = (d.a_cs == 1 && d.a_rs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
     d.b_vec = (d.b_rs == 1 && d.b_cs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
+    d.a_rvec = (d.a_rs == 1 && d.a_cs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
+    d.b_rvec = (d.b_cs == 1 && d.b_rs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
     shapes[i] = shape ? shape : shape_of(d);
   }
-  for (int s = 1; s <= 3; ++s) {  // one launch per shape present (almost always exactly one)
+  for (int s = 1; s <= 4; ++s) {  // one launch per shape present (almost always exactly one)
     GemmBatch gb;
     gb.n = 0;
     for (int i = 0; i < n; ++i)
       if (shapes[i] == s) gb.d[gb.n++] = descs[i];
     if (gb.n == 0) continue;
-    int rc = s == 1 ? launch_shape<1, 1, 4>(st, gb) : (s == 2 ? launch_shape<1, 1, 1>(st, gb) : launch_shape<2, 2, 1>(st, gb));
+    int rc = s == 1 ? launch_shape<1, 1, 4>(st, gb)
+             : (s == 2 ? launch_shape<1, 1, 1>(st, gb) : (s == 3 ? launch_shape<2, 2, 1>(st, gb) : launch_tiled(st, gb)));
     if (rc) return rc;
   }
   return GCRL_OK;

@@ -28,7 +28,7 @@ def vec_close(got, want, rtol=RTOL, atol=ATOL):
 
 
 # ------------------------------------------------------------------ GEMM kernel (all tile shapes)
-@pytest.mark.parametrize("shape", [1, 2, 3])
+@pytest.mark.parametrize("shape", [1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (64, 64, 27), (33, 7, 13), (256, 1, 256), (17, 300, 70), (2048, 512, 512)])
 def test_gemm_forms_against_fp64(lib, M, N, K, shape):
     gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -61,7 +61,7 @@ def test_gemm_asymmetric_identity(lib):
     A = torch.eye(n).cuda()
     B = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) * 0.5 + 1).cuda()  # B[k][j]
     Cc = torch.empty(n, n, device="cuda")
-    for shape in (1, 2, 3):
+    for shape in (1, 2, 3, 4):
         assert lib.gcrl_gemm_f32(A.data_ptr(), n, 1, B.data_ptr(), n, 1, Cc.data_ptr(), n, None, n, n, n, 0, shape, 1) == 0
         assert torch.equal(Cc, B)
 

@@ -14,6 +14,19 @@
 __global__ void tiny_kernel(int* p) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1; }
 __global__ void tiny_kernel_host(float* hostmapped) { if (threadIdx.x == 0 && blockIdx.x == 0) hostmapped[0] += 1.f; }
 
+// register-only MFMA loop: the fp32 matrix-core ceiling of this box at the clock it actually holds
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f acc[4];
+  for (int q = 0; q < 4; ++q) acc[q] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f + 1.f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+}
+
 template <typename F>
 float time_graph(hipStream_t st, hipStream_t cap, int reps, F enqueue) {
   hipGraph_t g; hipGraphExec_t ex;
@@ -82,6 +95,21 @@ int main() {
     printf("graph branches: one chain of 16 gemms %.1f us; 32 sequential %.1f us; two parallel chains of 16 %.1f us\n", one, seq, par);
   }
 
+  {
+    float* o; CK(hipMalloc(&o, 1024 * 256 * 4));
+    for (int blocks : {256, 512, 1024}) {
+      const int iters = 4096;
+      hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+      hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, o, iters);
+      hipEventRecord(a, st);
+      hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, o, iters);
+      hipEventRecord(b, st); hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b);
+      const double flop = (double)blocks * 4 /*waves*/ * iters * 4 * (2.0 * 16 * 16 * 4);
+      printf("mfma f32 16x16x4 register loop, %4d blocks x 4 waves: %.1f TFLOP/s (%.1f us)\n", blocks, flop / (ms * 1e-3) * 1e-12, ms * 1e3);
+    }
+  }
+
   // GEMM bodies at the hot shapes
   struct Shape { int M, N, K; const char* what; };
   std::vector<Shape> shapes = {{256, 256, 256, "fwd hidden B=256 H=256"}, {256, 256, 27, "fwd first layer K=27"},
@@ -91,7 +119,7 @@ int main() {
   CK(hipMalloc(&A, 2048 * 544 * 4)); CK(hipMalloc(&B, 2048 * 544 * 4)); CK(hipMalloc(&C, 2048 * 512 * 4)); CK(hipMalloc(&bias, 4096));
   CK(hipMemset(A, 0, 2048 * 512 * 4)); CK(hipMemset(B, 0, 2048 * 512 * 4)); CK(hipMemset(bias, 0, 4096));
   for (auto& sh : shapes) {
-    for (int shape = 1; shape <= 3; ++shape) {
+    for (int shape = 1; shape <= 4; ++shape) {
       for (int form = 0; form < 3; ++form) {
         gcrl::GemmDesc dsc;
         memset(&dsc, 0, sizeof(dsc));
