@@ -227,6 +227,15 @@ def main():
         rows_per_launch = rows.value / max(1, launches.value)
         avg_us = ms.value * 1e3 / max(1, launches.value)
         achieved = (alg_bytes_per_row * rows_per_launch) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section); bench.py cannot run the
+        # counter tool on itself, so the per-row figure measured there is scaled to this run's rows
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", f"r01_e_bench_pmc_traffic_{args.workload}.json")
+        if os.path.exists(pmc_file):
+            g = json.load(open(pmc_file)).get("her_gather_update_kernel", {})
+            if g.get("rows_per_launch"):
+                traffic = g["hbm_bytes_corrected"] / g["rows_per_launch"] * rows_per_launch
         value = world * args.steps / elapsed
         out = {
             "metric": "gradient-steps/sec (HER sample + critic+actor update)",
@@ -238,7 +247,7 @@ def main():
                        "gradient_step": gstep, "parallelism": f"dp{world}" if world > 1 else "single",
                        "hip_graph": not args.no_graph, "rng": "cpython-mt19937 (host) indices"},
             "roofline": {"kernel": "her_gather_update_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": launches.value, "avg_launch_us": avg_us, "rows_per_launch": rows_per_launch,
                          "algorithmic_bytes_per_row": alg_bytes_per_row,
                          "timing": "hipEvent pair around each launch on its stream (includes event/dispatch overhead)",

@@ -83,7 +83,8 @@ double gcrl_cosine_lr_next(double lr_now, double base_lr, double eta_min, int64_
 
 /* ------------------------------------------------------------------------------------------
  * HER replay ring in HBM.  Replaces class HERBuffer (src/buffer.py:92-179).
- * Layout (fp32): one 64-byte-aligned packed record per transition, [s(S)|a(A)|ns(S)|r|d|pad],
+ * Layout (fp32): one 64-byte-aligned packed record per transition,
+ * [s(S)|a(A)|pad4][ns(S)|pad4][r|d|pad] (every field group 16-byte aligned),
  * records contiguous in arrival order (DESIGN.md "HBM layout" explains why not five field
  * arrays: a random row gather would touch ~3x the 128-B lines).  sample() returns the five
  * dense field matrices of the reference.  The stored dg/ag columns of the reference's tuples
