@@ -185,15 +185,11 @@ def main():
         gstep = w["gstep"]
 
         def run(step0, n):
-            if dp is None:
-                done = 0
-                while done < n:
-                    m = min(gstep, n - done)
-                    agent.update_many(step0 + done, m)
-                    done += m
-            else:
-                for i in range(n):
-                    dp.update(step0 + i)
+            done = 0
+            while done < n:
+                m = min(gstep, n - done)
+                (agent if dp is None else dp).update_many(step0 + done, m)
+                done += m
 
         run(1, args.warmup)
         torch.cuda.synchronize()

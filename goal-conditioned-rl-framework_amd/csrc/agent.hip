@@ -79,6 +79,8 @@ struct UploadBlock {  // device image of one call's upload: control table, then 
 
 }  // namespace
 
+struct StepPlan { int variant; int tuple_len; };
+
 struct gcrl_agent {
   gcrl_agent_config cfg;
   int S = 0, A = 0, H = 0, L = 0, B = 0, C = 0, ldx = 0, Mmax = 0, Apad = 0;
@@ -125,6 +127,7 @@ struct gcrl_agent {
   double lr_actor = 0, lr_critic = 0;
   uint64_t rng_ctr = 0;
   int pending_variant = 0;  // variant of the step whose phases are being issued one by one
+  std::vector<StepPlan> dp_plans;  // steps of the data-parallel cycle begun by gcrl_agent_dp_begin
 
   std::map<int, hipGraphExec_t> graphs;
   std::map<std::string, std::pair<float*, long long>> names;
@@ -590,7 +593,6 @@ int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask) {
 #include "agent_pipeline.inc"
 
 // ---------------------------------------------------------------- per-step host bookkeeping
-struct StepPlan { int variant; int tuple_len; };
 
 StepPlan plan_step(gcrl_agent* a, int64_t step, float grad_scale, int batch_slot, int64_t ticket, StepCtrl* sc) {
   const gcrl_agent_config& c = a->cfg;
@@ -1063,6 +1065,27 @@ int gcrl_agent_update_phase(gcrl_agent* a, gcrl_her* her, int64_t step, int phas
   TRY(run_step(a, st, a->pending_variant, 1 << phase));
   if (phase == 2) TRY(end_call(a, st));
   return len;
+}
+
+int gcrl_agent_dp_begin(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, float grad_scale, int64_t* tickets_out,
+                        int32_t* lens_out, void* stream) {
+  GCRL_CHECK_ARG(a && her, "gcrl_agent_dp_begin: null handle");
+  hipStream_t st = a->pick(stream);
+  a->dp_plans.clear();
+  TRY(begin_call(a, her, step0, n, nullptr, grad_scale, st, a->dp_plans, tickets_out, lens_out));
+  return GCRL_OK;
+}
+
+int gcrl_agent_dp_phase(gcrl_agent* a, int i, int phase, void* stream) {
+  GCRL_CHECK_ARG(a && phase >= 0 && phase <= 2, "gcrl_agent_dp_phase: bad arguments");
+  GCRL_CHECK_ARG(i >= 0 && i < (int)a->dp_plans.size(), "gcrl_agent_dp_phase: step %d outside the begun cycle of %d", i, (int)a->dp_plans.size());
+  return run_step(a, a->pick(stream), a->dp_plans[i].variant, 1 << phase);
+}
+
+int gcrl_agent_dp_end(gcrl_agent* a, void* stream) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_dp_end: null handle");
+  a->dp_plans.clear();
+  return end_call(a, a->pick(stream));
 }
 
 int gcrl_agent_grad_ptr(gcrl_agent* a, int phase, float** ptr, int64_t* numel) {

@@ -91,14 +91,48 @@ class DataParallelUpdater:
         torch.cuda.synchronize()
         self.agent.update_target_network()
 
-    def update(self, step: int):
+    def update_many(self, step0: int, n: int):
+        """One trainer cycle (src/env.py:384-385) across ranks: the n batches of this rank are drawn
+        and gathered by ONE launch; each step then runs as three graph segments around the two
+        gradient all-reduces."""
         a, lib, ffi = self.agent, self._ffi.lib, self._ffi
         her = a.buffer.handle
-        ticket = C.c_int64(-1)
+        st = ffi.stream_handle()
+        tickets, lens = (C.c_int64 * n)(), (C.c_int32 * n)()
         a.buffer.rng.pull()
-        n = ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 0, None, self.scale, C.byref(ticket),
-                                                  ffi.stream_handle()))
+        ffi.check(lib.gcrl_agent_dp_begin(a._h, her, int(step0), int(n), self.scale, tickets, lens, st))
         a.buffer.rng.push_back()
+        actor_len = {0: 6, 1: 8, 2: 9, 3: 9}[ffi_kind(a)]
+        for i in range(n):
+            ffi.check(lib.gcrl_agent_dp_phase(a._h, i, 0, st))
+            dist.all_reduce(self._blocks[0], op=dist.ReduceOp.SUM, group=self.group)
+            ffi.check(lib.gcrl_agent_dp_phase(a._h, i, 1, st))
+            if lens[i] == actor_len:
+                dist.all_reduce(self._blocks[1], op=dist.ReduceOp.SUM, group=self.group)
+            ffi.check(lib.gcrl_agent_dp_phase(a._h, i, 2, st))
+        ffi.check(lib.gcrl_agent_dp_end(a._h, st))
+        return [a._tuple(int(t), int(l)) for t, l in zip(tickets, lens)]
+
+    def update(self, step: int, batch=None):
+        """One step.  `batch` = (s, a, r, ns, d) cuda tensors injects this rank's rows (tests)."""
+        a, lib, ffi = self.agent, self._ffi.lib, self._ffi
+        ticket = C.c_int64(-1)
+        inputs, keep, her = None, [], a.buffer.handle
+        if batch is not None:
+            inputs = ffi.UpdateInputs()
+            s, ac, r, ns, d = (t.to(device="cuda", dtype=torch.float32).contiguous() for t in batch)
+            keep = [s, ac, r, ns, d]
+            inputs.s_dev, inputs.ld_s = s.data_ptr(), s.shape[1]
+            inputs.a_dev, inputs.ld_a = ac.data_ptr(), ac.shape[1]
+            inputs.r_dev, inputs.d_dev = r.data_ptr(), d.data_ptr()
+            inputs.ns_dev, inputs.ld_ns = ns.data_ptr(), ns.shape[1]
+            her = None
+        else:
+            a.buffer.rng.pull()
+        n = ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 0, C.byref(inputs) if inputs is not None else None,
+                                                  self.scale, C.byref(ticket), ffi.stream_handle()))
+        if batch is None:
+            a.buffer.rng.push_back()
         dist.all_reduce(self._blocks[0], op=dist.ReduceOp.SUM, group=self.group)
         ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 1, None, self.scale, None, ffi.stream_handle()))
         if n == {0: 6, 1: 8, 2: 9, 3: 9}[ffi_kind(a)]:   # tuple length of an actor step

@@ -267,6 +267,13 @@ int gcrl_agent_update_phase(gcrl_agent* a, gcrl_her* her, int64_t step, int phas
                             const gcrl_update_inputs* inputs, float grad_scale,
                             int64_t* ticket_out, void* stream);
 int gcrl_agent_grad_ptr(gcrl_agent* a, int phase, float** ptr_dev_out, int64_t* numel_out);
+/* Data-parallel trainer cycle: plan n steps at once — one index upload and ONE gather launch for
+ * all n batches, as gcrl_agent_update_n does — then run step i's phases 0,1,2 in order with the
+ * caller's two gradient all-reduces in between; gcrl_agent_dp_end closes the cycle. */
+int gcrl_agent_dp_begin(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, float grad_scale,
+                        int64_t* tickets_out, int32_t* tuple_len_out, void* stream);
+int gcrl_agent_dp_phase(gcrl_agent* a, int i, int phase, void* stream);
+int gcrl_agent_dp_end(gcrl_agent* a, void* stream);
 /* device pointer of a named vector (parameters / grads), for zero-copy interop */
 int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr_dev_out, int64_t* numel_out);
 

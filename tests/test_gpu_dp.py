@@ -1,0 +1,88 @@
+"""GPU (-m gpu): the data-parallel engine path end to end — two ranks sharing ONE GPU over gloo
+(RCCL needs one GPU per rank; the exchange code is backend-agnostic) vs a single agent fed the
+concatenated batch.  SURVEY.md §8e invariant: G ranks x B rows with summed gradients scaled by 1/G
+== 1 rank x G*B rows (DDPG / TD3, up to fp32 summation order)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+S, A, B, H, L = 10, 3, 32, 32, 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cfg(kind, batch):
+    from oracle.agent_oracle import make_config
+    return make_config(kind, hidden_dim=H, layer_count=L, batch_size=batch, max_len=4000, grad_clip=0.5,
+                       ac_update_freq=1, policy_noise=0.0)
+
+
+def _global_batches(world, steps):
+    gen = np.random.default_rng(21)
+    out = []
+    for _ in range(steps):
+        n = world * B
+        out.append((gen.standard_normal((n, S)).astype(np.float32), gen.uniform(-1, 1, (n, A)).astype(np.float32),
+                    -(gen.uniform(size=(n, 1)) > 0.3).astype(np.float32), gen.standard_normal((n, S)).astype(np.float32),
+                    (gen.uniform(size=(n, 1)) > 0.9).astype(np.float32)))
+    return out
+
+
+def _init_params(agent):
+    gen = np.random.default_rng(5)
+    agent.actor.set_flat((0.2 * gen.standard_normal(agent.actor.numel())).astype(np.float32))
+    for c in agent.critics:
+        c.set_flat((0.2 * gen.standard_normal(c.numel())).astype(np.float32))
+    agent.update_target_network()
+
+
+def _worker(rank, world, port, kind, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import gcrl_amd
+    from gcrl_amd.src.dp import DataParallelUpdater
+    cls = dict(DDPG=gcrl_amd.DDPG, TD3=gcrl_amd.TD3Agent)[kind]
+    ag = cls(S, A, _cfg(kind, B), None, nenvs=1, gradient_step=4, rng="engine", seed=100 + rank)
+    if rank == 0:
+        _init_params(ag)            # rank 1 keeps its own random init until the broadcast
+    dp = DataParallelUpdater(ag)    # broadcasts rank 0's parameters
+    tuples = []
+    for step, full in enumerate(_global_batches(world, 3), start=1):
+        mine = tuple(torch.from_numpy(x[rank * B:(rank + 1) * B]).cuda() for x in full)
+        tuples.append([float(x) for x in dp.update(step, batch=mine)])
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), actor=ag.actor.flat(), critic=ag.critics[0].flat(),
+             target=ag.target_critics[0].flat(), tuples=np.array(tuples))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["DDPG", "TD3"])
+def test_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in ("actor", "critic", "target"):
+        assert np.array_equal(r0[k], r1[k]), k                 # replicas stay bitwise identical
+    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent)[kind]
+    big = cls(S, A, _cfg(kind, world * B), None, nenvs=1, gradient_step=4, rng="engine", seed=1)
+    _init_params(big)
+    for step, full in enumerate(_global_batches(world, 3), start=1):
+        big.update(step, batch=tuple(torch.from_numpy(x).cuda() for x in full))
+    # same math up to fp32 summation order; Adam can amplify ~0 gradients to +-lr
+    for k, v in (("actor", big.actor), ("critic", big.critics[0]), ("target", big.target_critics[0])):
+        err = np.abs(r0[k].astype(np.float64) - v.flat())
+        assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
