@@ -1,0 +1,143 @@
+"""GPU (-m gpu): the rest of the drop-in surface the trainer touches:
+checkpoint interop with torch modules that have the reference's state_dict keys, select_action,
+reset, the compute_reward classification, error behaviour, the device-RNG mode."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import her_oracle
+from oracle.agent_oracle import DetActor, GaussActor, OracleAgent, QNet, make_config
+
+pytestmark = pytest.mark.gpu
+S, A, H, L = 10, 3, 32, 2
+
+
+def fill(agent, n_eps=2, seed=0):
+    gen = np.random.default_rng(seed)
+    for ep in range(n_eps):
+        for st in her_oracle.synthetic_episode(gen, 50, S, A):
+            agent.push_her(0, *st)
+
+
+@pytest.mark.parametrize("kind", ["DDPG", "TD3", "SAC", "TQC"])
+def test_checkpoints_round_trip_through_torch_modules(gcrl, tmp_path, kind):
+    """save_weights() files load with strict=True into torch modules laid out like the reference's
+    (src/model.py key names / shapes), and weights saved by those modules load back."""
+    cfg = make_config(kind, hidden_dim=H, layer_count=L, batch_size=16)
+    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent, SAC=gcrl.SACAgent, TQC=gcrl.TQCAgent)[kind]
+    ag = cls(S, A, cfg, None, nenvs=1, gradient_step=2, rng="engine", seed=3)
+    fill(ag)
+    for step in (1, 2):
+        ag.update(step)          # moves weights, BN statistics, log_alpha away from their init
+    ag.save_weights(str(tmp_path))
+    actor_mod = (GaussActor if kind in ("SAC", "TQC") else DetActor)(S, H, A, L)
+    actor_mod.load_state_dict(torch.load(tmp_path / "actor.pth"), strict=True)
+    names = {"DDPG": ["critic.pth"], "TD3": ["critic_1.pth", "critic_2.pth"], "SAC": ["critic_1.pth", "critic_2.pth"],
+             "TQC": [f"critic_{i}.pth" for i in range(5)]}[kind]
+    for i, fn in enumerate(names):
+        q = QNet(S + A, H, L)
+        q.load_state_dict(torch.load(tmp_path / fn), strict=True)
+        flat = np.concatenate([p.detach().numpy().reshape(-1) for p in q.parameters()])
+        assert np.array_equal(flat, ag.critics[i].flat())
+    flat = np.concatenate([p.detach().numpy().reshape(-1) for p in actor_mod.parameters()])
+    assert np.array_equal(flat, ag.actor.flat())
+    if kind in ("SAC", "TQC"):
+        assert os.path.exists(tmp_path / "log_alpha.pth")
+        bn = [m for m in actor_mod.base_net if isinstance(m, torch.nn.BatchNorm1d)]
+        assert not torch.equal(bn[0].running_mean, torch.zeros(H))     # statistics travelled
+    # and back: a fresh engine agent constructed with weights=dir reproduces the actor's outputs
+    ag2 = cls(S, A, cfg, str(tmp_path), nenvs=1, gradient_step=2, rng="engine", seed=99)
+    obs = np.random.default_rng(1).standard_normal((7, S)).astype(np.float32)
+    assert np.array_equal(ag.select_action(obs, eval_action=True), ag2.select_action(obs, eval_action=True))
+    with torch.no_grad():
+        actor_mod.eval()
+        x = torch.from_numpy(obs)
+        if kind in ("SAC", "TQC"):
+            want = actor_mod.sample(x, deterministic=True)[0].numpy()
+        elif kind == "DDPG":
+            want = np.clip(torch.tanh(actor_mod(x)).numpy(), -1, 1)    # double tanh, src/agent.py:1366
+        else:
+            want = actor_mod(x).numpy()                                 # src/agent.py:269
+    assert np.allclose(ag.select_action(obs, eval_action=True), want, rtol=1e-5, atol=1e-6)
+
+
+def test_select_action_exploration_branches(gcrl):
+    cfg = make_config("DDPG", hidden_dim=H, layer_count=L, batch_size=16, noise_std=0.2)
+    random.seed(7); np.random.seed(7)
+    ag = gcrl.DDPG(S, A, cfg, None, nenvs=4, gradient_step=2, rng="python")
+    obs = np.zeros((4, S), np.float32)
+    # replay the reference's branch decisions with the same global streams (src/agent.py:1345-1360)
+    st_py, st_np = random.getstate(), np.random.get_state()
+    outs = [ag.select_action(obs) for _ in range(20)]
+    random.setstate(st_py); np.random.set_state(st_np)
+    eval_a = ag.select_action(obs, eval_action=True)
+    n_random = 0
+    for out in outs:
+        if random.random() < 0.2:
+            want = np.clip(np.random.randn(4, A), -1, 1)
+            n_random += 1
+        else:
+            # the eval path is clip(tanh(actor(obs))) = tanh(actor(obs)): the same base action
+            want = np.clip(eval_a + np.random.normal(0, 0.2, size=(4, A)), -1, 1)
+        assert out.shape == (4, A) and np.all(np.abs(out) <= 1)
+        assert np.allclose(out, want, atol=1e-5)
+    assert 0 < n_random < 20
+
+
+def test_reset_and_alpha_view(gcrl):
+    cfg = make_config("SAC", hidden_dim=H, layer_count=L, batch_size=16, alpha_min_steps=0.0, alpha_lr=1e-2)
+    ag = gcrl.SACAgent(S, A, cfg, None, nenvs=1, gradient_step=2, rng="engine", seed=1)
+    fill(ag)
+    assert ag.alpha.item() == 1.0
+    for step in (1, 2, 3):
+        info = ag.update(step)
+    assert len(info) == 9 and float(info[-1]) != 0.0            # alpha_loss is live past alpha_min_steps
+    assert ag.alpha.item() != 1.0
+    before = ag.actor.flat().copy()
+    bn_before = ag.actor._get("bn_running_mean").copy()
+    ag.reset()
+    assert not np.array_equal(before, ag.actor.flat())
+    assert ag.alpha.item() == 1.0                                # log_alpha re-created (src/agent.py:767-769)
+    assert np.array_equal(bn_before, ag.actor._get("bn_running_mean"))   # BN statistics are NOT reset
+
+
+def test_compute_reward_classification(gcrl):
+    buf = gcrl.HERBuffer(1000, 50, 1, rng="engine", seed=1)
+    buf.compute_reward = lambda ag, g, info: her_oracle.sparse_reward(ag, g, info, threshold=0.08)
+    gen = np.random.default_rng(0)
+    steps = her_oracle.synthetic_episode(gen, 50, S, A)
+    for st in steps:
+        buf.push(0, *st)
+    orc = her_oracle.HERBufferOracle(1000, 50, 1, rng=random.Random(1))
+    orc.compute_reward = buf.compute_reward
+    for st in steps:
+        orc.push(0, *st)
+    assert np.array_equal(buf.rows()[3].view(np.uint32), orc.as_arrays()[3].view(np.uint32))   # thr 0.08 was detected
+    dense = gcrl.HERBuffer(1000, 50, 1, rng="engine", seed=1)
+    dense.compute_reward = her_oracle.dense_reward
+    for st in steps:
+        dense.push(0, *st)
+    r = dense.rows()[3]
+    assert np.all(r[1:5] <= 0) and len(np.unique(r)) > 10
+    weird = gcrl.HERBuffer(1000, 50, 1, rng="engine", seed=1)
+    weird.compute_reward = lambda ag, g, info: np.float32(3.0)
+    with pytest.raises(NotImplementedError):
+        weird.push(0, *steps[0])
+
+
+def test_error_behaviour_matches_reference(gcrl):
+    cfg = make_config("DDPG", hidden_dim=H, layer_count=L, batch_size=64)
+    ag = gcrl.DDPG(S, A, cfg, None, nenvs=1, gradient_step=2, rng="engine", seed=1)
+    assert not ag.is_buffer_filled()
+    with pytest.raises(AssertionError):
+        ag.update(1)                                             # nothing pushed yet
+    bad = make_config("DDPG", hidden_dim=H, layer_count=L, buffer_type="NOPE")
+    with pytest.raises(ValueError, match="Invalid Buffer type"):
+        gcrl.DDPG(S, A, bad, None, nenvs=1, gradient_step=2)
+    fill(ag, 1)
+    assert ag.is_buffer_filled()
+    with pytest.raises(TypeError):
+        ag.push(np.zeros(S), np.zeros(A), 0.0, np.zeros(S), False)   # 5-arg push on a HER buffer, as in the reference
