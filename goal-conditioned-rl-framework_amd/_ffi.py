@@ -88,6 +88,7 @@ PROTOTYPES = {
     "gcrl_her_staged": (_i32, [_vp, C.c_int]),
     "gcrl_her_stream": (_vp, [_vp]),
     "gcrl_her_push": (_i64, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _f32, C.c_int, _vp, _vp, _vp]),
+    "gcrl_her_push_batch": (_i64, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "gcrl_her_push_episode": (_i64, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_her_sample": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "gcrl_her_read_rows": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -66,6 +66,9 @@ struct gcrl_her {
   float* epi_pinned[kSlots] = {};
   hipEvent_t epi_ev[kSlots] = {};
   int next_epi_slot = 0;
+  // per-env payload of a vector-env step (gcrl_her_push_batch)
+  float* pay_dev = nullptr;
+  float* pay_pinned[kSlots] = {};
 
   // gather-launch timing (gcrl_her_profile_*)
   bool prof = false;

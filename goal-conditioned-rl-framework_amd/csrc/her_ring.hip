@@ -45,6 +45,29 @@ __global__ __launch_bounds__(64) void her_stage_kernel(StageArgs p) {
   }
 }
 
+// one transition per block for a whole vector-env step; the small per-env payload
+// [t | r | d | a(A) | ag(G)] was uploaded in one copy
+constexpr int kPayW = 32;
+__global__ __launch_bounds__(64) void her_stage_batch_kernel(float* stage, const float* pay, const float* s_dev, int ld_s,
+                                                             const float* ns_dev, int ld_ns, int env0, int flush_len, int S,
+                                                             int A, int G, int SA4, int S4, int RG) {
+  const int i = blockIdx.x;
+  const float* pw = pay + (long long)i * kPayW;
+  const int t = __float_as_int(pw[0]);
+  float* dst = stage + ((long long)(env0 + i) * flush_len + t) * RG;
+  const int o_ns = SA4, o_r = SA4 + S4, RW = o_r + 2;
+  for (int c = threadIdx.x; c < RW + G; c += 64) {
+    float v = 0.f;
+    if (c < S) v = s_dev[(long long)i * ld_s + c];
+    else if (c < S + A) v = pw[3 + (c - S)];
+    else if (c >= o_ns && c < o_ns + S) v = ns_dev[(long long)i * ld_ns + (c - o_ns)];
+    else if (c == o_r) v = pw[1];
+    else if (c == o_r + 1) v = pw[2];
+    else if (c >= RW) v = pw[3 + A + (c - RW)];
+    dst[c] = v;
+  }
+}
+
 // ---------------------------------------------------------------- relabel + flush
 struct FlushArgs {
   float* ring;
@@ -538,6 +561,8 @@ void gcrl_her_destroy(gcrl_her* h) {
   for (hipEvent_t e : h->prof_a) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_b) (void)hipEventDestroy(e);
   if (h->prof_clk) (void)hipFree(h->prof_clk);
+  if (h->pay_dev) (void)hipFree(h->pay_dev);
+  for (int i = 0; i < gcrl_her::kSlots; ++i) if (h->pay_pinned[i]) (void)hipHostFree(h->pay_pinned[i]);
   if (h->idx_dev) (void)hipFree(h->idx_dev);
   if (h->ring) (void)hipFree(h->ring);
   if (h->stage) (void)hipFree(h->stage);
@@ -586,6 +611,67 @@ int64_t gcrl_her_push(gcrl_her* h, int env, const float* state, int state_on_dev
     return rows;
   }
   return 0;
+}
+
+int64_t gcrl_her_push_batch(gcrl_her* h, int env0, int n, const float* states_dev, int ld_s,
+                            const float* actions_host, const float* next_states_dev, int ld_ns,
+                            const float* rewards_host, const uint8_t* dones_host,
+                            const float* achieved_goals_host, void* stream) {
+  GCRL_CHECK_ARG(h && states_dev && actions_host && next_states_dev && rewards_host && dones_host && achieved_goals_host,
+                 "gcrl_her_push_batch: null argument");
+  GCRL_CHECK_ARG(n >= 1 && env0 >= 0 && env0 + n <= h->cfg.nenvs, "gcrl_her_push_batch: envs [%d, %d) outside [0, %d)", env0, env0 + n, h->cfg.nenvs);
+  GCRL_CHECK_ARG(ld_s >= h->S && ld_ns >= h->S, "gcrl_her_push_batch: row stride smaller than state_dim");
+  GCRL_CHECK_ARG(3 + h->A + h->G <= kPayW, "gcrl_her_push_batch: action_dim + goal_dim too large for the payload");
+  hipStream_t st = h->pick(stream);
+  if (!h->pay_dev) {
+    GCRL_HIP(hipMalloc((void**)&h->pay_dev, (size_t)h->cfg.nenvs * kPayW * sizeof(float)));
+    for (int i = 0; i < gcrl_her::kSlots; ++i)
+      GCRL_HIP(hipHostMalloc((void**)&h->pay_pinned[i], (size_t)h->cfg.nenvs * kPayW * sizeof(float), hipHostMallocDefault));
+  }
+  const int slot = h->next_epi_slot;
+  h->next_epi_slot = (slot + 1) % gcrl_her::kSlots;
+  GCRL_HIP(hipEventSynchronize(h->epi_ev[slot]));
+  float* pay = h->pay_pinned[slot];
+  for (int i = 0; i < n; ++i) {
+    float* pw = pay + (size_t)i * kPayW;
+    const int t = h->staged[env0 + i];
+    std::memcpy(&pw[0], &t, sizeof(int));
+    pw[1] = rewards_host[i];
+    pw[2] = dones_host[i] ? 1.0f : 0.0f;
+    std::memcpy(pw + 3, actions_host + (size_t)i * h->A, sizeof(float) * h->A);
+    std::memcpy(pw + 3 + h->A, achieved_goals_host + (size_t)i * h->G, sizeof(float) * h->G);
+  }
+  GCRL_HIP(hipMemcpyAsync(h->pay_dev, pay, (size_t)n * kPayW * sizeof(float), hipMemcpyHostToDevice, st));
+  GCRL_HIP(hipEventRecord(h->epi_ev[slot], st));
+  hipLaunchKernelGGL(her_stage_batch_kernel, dim3(n), dim3(64), 0, st, h->stage, h->pay_dev, states_dev, ld_s, next_states_dev,
+                     ld_ns, env0, h->cfg.flush_len, h->S, h->A, h->G, h->SA4, h->S4, h->RG);
+  GCRL_HIP(hipGetLastError());
+  // envs that finish this step flush together, in env order (the reference's loop order,
+  // src/env.py:192-201), up to kMaxEp episodes per launch
+  int envs[kMaxEp], Ts[kMaxEp], cnt = 0, fut_acc = 0;
+  int64_t total = 0;
+  auto flush_pending = [&]() -> int {
+    if (cnt == 0) return GCRL_OK;
+    int64_t rows = 0;
+    if (int rc = launch_flush(h, cnt, envs, Ts, nullptr, st, &rows)) return rc;
+    for (int q = 0; q < cnt; ++q) h->staged[envs[q]] = 0;
+    total += rows;
+    cnt = 0;
+    fut_acc = 0;
+    return GCRL_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const int env = env0 + i;
+    h->staged[env] += 1;
+    if (dones_host[i] || h->staged[env] >= h->cfg.flush_len) {
+      const int need = h->cfg.k_future * (h->staged[env] - 1);  // inline future indices of this episode
+      if (cnt == kMaxEp || fut_acc + need > kMaxFut) if (int rc = flush_pending()) return rc;
+      envs[cnt] = env; Ts[cnt] = h->staged[env]; ++cnt;
+      fut_acc += need;
+    }
+  }
+  if (int rc = flush_pending()) return rc;
+  return total;
 }
 
 int64_t gcrl_her_push_episode(gcrl_her* h, int env, int T, const float* s, const float* a,

@@ -180,6 +180,27 @@ class HERBuffer:
         if flushing:
             self.rng.push_back()
 
+    def push_batch(self, states, actions, next_states, rewards, dones, achieved_goals, env0: int = 0):
+        """One vector-env step: the `for i in range(num_envs): push_her(i, ...)` loop of the reference's
+        trainer (src/env.py:192-201) as ONE call.  states / next_states: [n, S] cuda tensors (the
+        obs_batch / next_obs_batch that _process_step builds); the rest host arrays.  Same rows, same
+        order and same RNG draws as n push() calls; envs finishing together are flushed together."""
+        s = states.detach().to(device="cuda", dtype=torch.float32).contiguous()
+        ns = next_states.detach().to(device="cuda", dtype=torch.float32).contiguous()
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        r = np.ascontiguousarray(rewards, dtype=np.float32).reshape(-1)
+        d = np.ascontiguousarray(np.asarray(dones).astype(np.uint8)).reshape(-1)
+        ag = np.ascontiguousarray(achieved_goals, dtype=np.float32)
+        n = s.shape[0]
+        assert a.shape[0] == n and ns.shape[0] == n and r.size == n and d.size == n and ag.shape[0] == n
+        self._ensure(s.shape[1], a.shape[1], ag.shape[1])
+        self.rng.pull()
+        rows = lib.gcrl_her_push_batch(self._h, int(env0), n, s.data_ptr(), s.shape[1], a.ctypes.data, ns.data_ptr(),
+                                       ns.shape[1], r.ctypes.data, d.ctypes.data, ag.ctypes.data, _ffi.stream_handle())
+        _ffi.check(int(rows))
+        self.rng.push_back()
+        return int(rows)
+
     def push_episode(self, idx, states, actions, next_states, rewards, dones, achieved_goals):
         """Whole-episode fast path (one upload + one flush launch); same result as T push calls."""
         s = np.ascontiguousarray(states, dtype=np.float32)

@@ -132,6 +132,18 @@ int64_t gcrl_her_push(gcrl_her* h, int env, const float* state, int state_on_dev
                       const float* desired_goal_host, const float* achieved_goal_host,
                       void* stream);
 
+/* One step of a vector env (the loop of src/env.py:192-201 as ONE call): transition i belongs to
+ * env env0+i.  states / next_states: device matrices [n][ld] (what _process_step builds,
+ * src/env.py:189-190); actions [n][A], rewards [n], dones [n] (0/1 bytes), achieved goals [n][G]:
+ * host.  One payload upload + one staging launch; all envs that finish on this step are relabelled
+ * and flushed together (a segment scan over their row counts places each episode), in env order
+ * with the RNG draws in env order — identical rows and RNG state to n gcrl_her_push calls.
+ * Returns the ring rows appended. */
+int64_t gcrl_her_push_batch(gcrl_her* h, int env0, int n, const float* states_dev, int ld_s,
+                            const float* actions_host, const float* next_states_dev, int ld_ns,
+                            const float* rewards_host, const uint8_t* dones_host,
+                            const float* achieved_goals_host, void* stream);
+
 /* Whole-episode variant (one H2D copy + one flush launch): T transitions of env `env` given as
  * host arrays s[T][S], a[T][A], ns[T][S], r[T], d[T] (0/1), ag[T][G].  Equivalent to T calls
  * of gcrl_her_push whose last one triggers the flush; any partially staged episode of that env

@@ -141,3 +141,39 @@ def test_error_behaviour_matches_reference(gcrl):
     assert ag.is_buffer_filled()
     with pytest.raises(TypeError):
         ag.push(np.zeros(S), np.zeros(A), 0.0, np.zeros(S), False)   # 5-arg push on a HER buffer, as in the reference
+
+
+@pytest.mark.parametrize("k,nenvs", [(4, 8), (8, 11)])
+def test_push_batch_equals_per_env_pushes_and_oracle(gcrl, k, nenvs):
+    """Vector-env step API (§8f-1): nenvs transitions per call; envs reach the 50-step flush together
+    (multi-episode flush launches with the in-kernel segment scan, chunked when the inline future
+    indices would overflow), some terminate early.  Rows, order and RNG state must equal the
+    reference's per-env loop (oracle) bit for bit."""
+    Sx, Ax = 23, 4
+    gen = np.random.default_rng(9)
+    eps = [[her_oracle.synthetic_episode(gen, 50, Sx, Ax) for _ in range(3)] for _ in range(nenvs)]
+    buf = gcrl.HERBuffer(20000, 50, nenvs, k_future=k, rng="engine", seed=5)
+    orc = her_oracle.HERBufferOracle(20000, 50, nenvs, k_future=k, rng=random.Random(5))
+    cursor = [(0, 0)] * nenvs            # (episode, step) per env
+    early = {(1, 0): 17, (3, 1): 1, (6, 0): 30}   # (env, episode) -> terminate at this step
+    for _ in range(120):
+        rows = []
+        for e in range(nenvs):
+            ep, t = cursor[e]
+            st = eps[e][ep % 3][t]
+            done = early.get((e, ep)) == t + 1
+            rows.append((st, done))
+            cursor[e] = (ep + 1, 0) if (done or t + 1 >= 50) else (ep, t + 1)
+        s = torch.from_numpy(np.stack([r[0][0] for r in rows])).cuda()
+        ns = torch.from_numpy(np.stack([r[0][2] for r in rows])).cuda()
+        buf.push_batch(s, np.stack([r[0][1] for r in rows]), ns, [r[0][3] for r in rows], [r[1] for r in rows],
+                       np.stack([r[0][6] for r in rows]))
+        for e, (st, done) in enumerate(rows):
+            orc.push(e, st[0], st[1], st[2], st[3], done, st[5], st[6])
+    assert len(buf) == len(orc) > 0
+    for got, want in zip(buf.rows(), orc.as_arrays()):
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    got = buf.sample(64)
+    want = orc.sample(64)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32))
