@@ -105,6 +105,7 @@ struct AdamArgs {
   const float* mean_x; int mean_n; float mean_scale; int mean_index;
 };
 int launch_adam(hipStream_t st, const AdamArgs& a);
+int launch_adam_pair(hipStream_t st, const AdamArgs& a0, const AdamArgs& a1);  // two single-net steps, one launch
 int launch_polyak(hipStream_t st, const float* p, float* target, long long n, double tau);
 
 // ---- SAC / TQC pieces (ops_sac.hip) -------------------------------------------------------

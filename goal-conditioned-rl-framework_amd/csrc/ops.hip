@@ -7,6 +7,7 @@
 //   Polyak       tau*p + (1-tau)*p_target  (src/agent.py:1260-1271 etc.)
 #include "ops.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace gcrl {
@@ -177,10 +178,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long long n,
 }
 
 // ------------------------------------------------------------------ Adam / AdamW
-__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+__device__ inline void adam_body(const AdamArgs& a, const int net) {
   __shared__ float s_coef;
   const StepCtrl c = *a.cur;
-  const int net = blockIdx.y;
   float step_size, bc2s, decay;
   if (a.which == 0) { step_size = c.step_size_actor; bc2s = c.bc2s_actor; decay = c.decay_actor; }
   else if (a.which == 1) { step_size = c.step_size_critic; bc2s = c.bc2s_critic; decay = c.decay_critic; }
@@ -192,7 +192,14 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     __shared__ double dred[4];
     const float* part = a.partial + (long long)net * a.part_stride;
     double s = 0.0;
-    for (int i = threadIdx.x; i < a.nparts; i += 256) s += (double)part[i];
+    // independent 16-byte loads (a dependent scalar loop here cost ~4 us of L2 latency per launch)
+    const int n4 = ((reinterpret_cast<uintptr_t>(part) & 15) == 0) ? a.nparts >> 2 : 0;
+    const float4* part4 = reinterpret_cast<const float4*>(part);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const float4 v = part4[i];
+      s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < a.nparts; i += 256) s += (double)part[i];
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
   }
   __syncthreads();
-  if (a.mean_x && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (a.mean_x && blockIdx.x == 0 && net == 0) {
     __shared__ float scratch[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < a.mean_n; i += 256) s += a.mean_x[i];
@@ -236,6 +243,15 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (tp && a.polyak) tp[i] = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, tp[i]));
   }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) { adam_body(a, blockIdx.y); }
+
+// two independent single-net optimiser steps in one launch (software-pipelined DDPG: the critic of
+// step i+1 and the actor of step i), blockIdx.y picks the argument set
+__global__ __launch_bounds__(256) void adam_pair_kernel(AdamArgs a0, AdamArgs a1) {
+  if (blockIdx.y == 0) adam_body(a0, 0);
+  else adam_body(a1, 0);
 }
 
 __global__ void polyak_kernel(const float* p, float* tp, long long n, float tau, float one_m_tau) {
@@ -292,6 +308,16 @@ int launch_adam(hipStream_t st, const AdamArgs& a) {
   if (blocks < 1) blocks = 1;
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, a.nets), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_adam_pair(hipStream_t st, const AdamArgs& a0, const AdamArgs& a1) {
+  GCRL_CHECK_ARG(a0.nets == 1 && a1.nets == 1, "adam_pair: single-net argument sets only");
+  long long blocks = (std::max(a0.n, a1.n) + 256 * 4 - 1) / (256 * 4);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(adam_pair_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, st, a0, a1);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
