@@ -80,6 +80,9 @@ struct UploadBlock {  // device image of one call's upload: control table, then 
 }  // namespace
 
 struct StepPlan { int variant; int tuple_len; };
+// kind 0: phase `b` of planned step `a`; kind 1: pipelined DDPG segment (a = what, b = seg).
+// reduce/reduce_n: gradient block to all-reduce after the segment (none when reduce_n == 0)
+struct DpSeg { int kind, a, b; float* reduce; long long reduce_n; };
 
 struct gcrl_agent {
   gcrl_agent_config cfg;
@@ -128,6 +131,8 @@ struct gcrl_agent {
   uint64_t rng_ctr = 0;
   int pending_variant = 0;  // variant of the step whose phases are being issued one by one
   std::vector<StepPlan> dp_plans;  // steps of the data-parallel cycle begun by gcrl_agent_dp_begin
+  std::vector<DpSeg> dp_segs;      // ... as segments separated by gradient exchanges
+  size_t dp_pos = 0;
 
   std::map<int, hipGraphExec_t> graphs;
   std::map<std::string, std::pair<float*, long long>> names;
@@ -1073,7 +1078,25 @@ int gcrl_agent_dp_begin(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, floa
   hipStream_t st = a->pick(stream);
   a->dp_plans.clear();
   TRY(begin_call(a, her, step0, n, nullptr, grad_scale, st, a->dp_plans, tickets_out, lens_out));
+  dp_build_schedule(a);
   return GCRL_OK;
+}
+
+int gcrl_agent_dp_run(gcrl_agent* a, float** reduce_ptr_out, int64_t* reduce_numel_out, void* stream) {
+  GCRL_CHECK_ARG(a && reduce_ptr_out && reduce_numel_out, "gcrl_agent_dp_run: null argument");
+  GCRL_CHECK_ARG(a->dp_pos < a->dp_segs.size(), "gcrl_agent_dp_run: no data-parallel cycle in progress");
+  hipStream_t st = a->pick(stream);
+  const DpSeg sg = a->dp_segs[a->dp_pos++];
+  if (sg.kind == 0) TRY(run_step(a, st, a->dp_plans[sg.a].variant, 1 << sg.b));
+  else TRY(run_ddpg_pipe(a, st, sg.a, sg.b));
+  *reduce_ptr_out = sg.reduce;
+  *reduce_numel_out = sg.reduce_n;
+  if (a->dp_pos < a->dp_segs.size()) return 1;
+  a->dp_plans.clear();
+  a->dp_segs.clear();
+  a->dp_pos = 0;
+  TRY(end_call(a, st));
+  return 0;
 }
 
 int gcrl_agent_dp_phase(gcrl_agent* a, int i, int phase, void* stream) {

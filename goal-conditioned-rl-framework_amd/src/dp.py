@@ -16,6 +16,12 @@ rank x G*B rows up to fp32 summation order (DDPG/TD3).  SAC/TQC actors keep LOCA
 statistics per rank (stated divergence from a single big batch).  Each exchange is ONE flat
 buffer: messages are 37 KB - 11 MB, latency-bound on point-to-point xGMI, so fewer, larger
 collectives beat per-tensor ones.
+
+For runs of plain DDPG steps the engine schedules the software-pipelined form instead (actor phase
+of step i in the same launches as the critic phase of step i+1): both gradient blocks are ready at
+the same point and adjacent in memory, so a step costs ONE all-reduce.  The schedule lives in the
+engine (`gcrl_agent_dp_run` names the block to exchange after each segment); this module only
+moves the bytes, with whatever torch.distributed backend the process group has.
 """
 from __future__ import annotations
 
@@ -71,6 +77,7 @@ class DataParallelUpdater:
         self.world = dist.get_world_size(group)
         self.scale = 1.0 / self.world
         lib = _ffi.lib
+        self._views = {}
         self._blocks = []
         for phase in (0, 1):
             p, n = C.c_void_p(), C.c_int64()
@@ -93,8 +100,8 @@ class DataParallelUpdater:
 
     def update_many(self, step0: int, n: int):
         """One trainer cycle (src/env.py:384-385) across ranks: the n batches of this rank are drawn
-        and gathered by ONE launch; each step then runs as three graph segments around the two
-        gradient all-reduces."""
+        and gathered by ONE launch; the engine then hands back graph segments and the gradient
+        block to all-reduce after each (two per ordinary step, one per pipelined DDPG step)."""
         a, lib, ffi = self.agent, self._ffi.lib, self._ffi
         her = a.buffer.handle
         st = ffi.stream_handle()
@@ -102,15 +109,17 @@ class DataParallelUpdater:
         a.buffer.rng.pull()
         ffi.check(lib.gcrl_agent_dp_begin(a._h, her, int(step0), int(n), self.scale, tickets, lens, st))
         a.buffer.rng.push_back()
-        actor_len = {0: 6, 1: 8, 2: 9, 3: 9}[ffi_kind(a)]
-        for i in range(n):
-            ffi.check(lib.gcrl_agent_dp_phase(a._h, i, 0, st))
-            dist.all_reduce(self._blocks[0], op=dist.ReduceOp.SUM, group=self.group)
-            ffi.check(lib.gcrl_agent_dp_phase(a._h, i, 1, st))
-            if lens[i] == actor_len:
-                dist.all_reduce(self._blocks[1], op=dist.ReduceOp.SUM, group=self.group)
-            ffi.check(lib.gcrl_agent_dp_phase(a._h, i, 2, st))
-        ffi.check(lib.gcrl_agent_dp_end(a._h, st))
+        # the engine owns the schedule: run a segment, all-reduce the gradient block it names, repeat
+        ptr, numel = C.c_void_p(), C.c_int64()
+        more = 1
+        while more:
+            more = ffi.check(lib.gcrl_agent_dp_run(a._h, C.byref(ptr), C.byref(numel), st))
+            if numel.value:
+                key = (ptr.value, numel.value)
+                view = self._views.get(key)
+                if view is None:
+                    view = self._views[key] = device_view(ptr.value, numel.value)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         return [a._tuple(int(t), int(l)) for t, l in zip(tickets, lens)]
 
     def update(self, step: int, batch=None):

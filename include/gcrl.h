@@ -286,6 +286,14 @@ int gcrl_agent_dp_begin(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, floa
                         int64_t* tickets_out, int32_t* tuple_len_out, void* stream);
 int gcrl_agent_dp_phase(gcrl_agent* a, int i, int phase, void* stream);
 int gcrl_agent_dp_end(gcrl_agent* a, void* stream);
+/* Engine-scheduled form of the same cycle: after gcrl_agent_dp_begin, call gcrl_agent_dp_run
+ * repeatedly.  Each call enqueues the next segment of the cycle and names the gradient block the
+ * caller must all-reduce (sum over ranks) before the next call (*reduce_numel_out == 0: nothing to
+ * exchange).  Returns 1 while segments remain, 0 when the cycle is complete (it is then closed),
+ * negative on error.  The engine picks the schedule: three phases per step in general; for runs
+ * of plain DDPG steps the software-pipelined form, where the critic gradients of step i+1 and the
+ * actor gradients of step i are adjacent in memory and travel in ONE all-reduce per step. */
+int gcrl_agent_dp_run(gcrl_agent* a, float** reduce_ptr_out, int64_t* reduce_numel_out, void* stream);
 /* device pointer of a named vector (parameters / grads), for zero-copy interop */
 int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr_dev_out, int64_t* numel_out);
 
