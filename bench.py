@@ -151,8 +151,12 @@ def main():
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # GCRL_FORCE_DP=1: take the data-parallel path (process group + exchanges) even at world size 1,
+    # to rehearse the RCCL plumbing on a one-GPU box; never set by the driver
+    force_dp = bool(int(os.environ.get("GCRL_FORCE_DP", "0")))
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -181,7 +185,7 @@ def main():
         t_fill = time.perf_counter() - t_fill
         assert len(agent.buffer) == min(w["cap"], n_eps * rows_per_ep)
 
-        dp = DataParallelUpdater(agent) if world > 1 else None
+        dp = DataParallelUpdater(agent) if (world > 1 or force_dp) else None
         gstep = w["gstep"]
 
         def run(step0, n):
@@ -195,13 +199,13 @@ def main():
         torch.cuda.synchronize()
         her = agent.buffer.handle
         check(lib.gcrl_her_profile_enable(her, 1))
-        if world > 1:
+        if dp is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(1 + args.warmup, args.steps)
         torch.cuda.synchronize()
-        if world > 1:
+        if dp is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         launches, ms, rows, dev_ms = C.c_int64(), C.c_double(), C.c_int64(), C.c_double()

@@ -133,6 +133,9 @@ def _load():
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C csrc). "
             "There is no CPU fallback.")
+    # torch first: its bundled HIP runtime must be the one in the process (streams and device
+    # pointers are shared with torch); loading ours first left torch.cuda unavailable
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

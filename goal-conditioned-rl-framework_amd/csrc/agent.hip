@@ -29,6 +29,7 @@
 #include "gemm_mfma.h"
 #include "her_ring.h"
 #include "ops.h"
+#include "rowchain.h"
 
 using namespace gcrl;
 
@@ -109,6 +110,12 @@ struct gcrl_agent {
   float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
   float *noise_in = nullptr, *eps_next_in = nullptr, *eps_cur_in = nullptr, *norm_partial = nullptr;
   float *act_in = nullptr, *act_tmp[2] = {};
+  // row-block DDPG path (rowchain.h): [in][out] weight copies of actor | target actor | critic 0 |
+  // target critic 0, per-layer gradient buffers, TD targets
+  bool rowchain = false, wt_dirty = true;
+  int row_rg = 1, row_ldl = 0;
+  float *wt = nullptr, *rc_gC = nullptr, *rc_gA = nullptr, *ybuf = nullptr;
+  long long wt_net[4] = {};   // offsets of the four nets inside wt
   float *parts_c = nullptr, *parts_a = nullptr;   // fused-norm partials: [C][nparts_c], [nparts_a]
   int nparts_c = 0, nparts_a = 0;
   std::vector<int> part_off_c, part_off_a;        // per-layer offsets inside a net's partials
@@ -576,6 +583,7 @@ int enqueue_phases(gcrl_agent* a, hipStream_t st, int variant, int mask) {
 }
 
 int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask) {
+  a->wt_dirty = true;   // this path steps / Polyak-averages parameters without their [in][out] copies
   if (!a->cfg.use_graph) return enqueue_phases(a, st, variant, mask);
   const int key = variant | (mask << 8);
   auto it = a->graphs.find(key);
@@ -800,7 +808,22 @@ int build(gcrl_agent* a) {
       {&a->norm_partial, (long long)kMaxCritics * kNormBlocks}, {&a->act_in, (long long)B * a->ldx},
       {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH},
       {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
-      {&a->hC2, L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H}};
+      {&a->hC2, L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H},
+      {&a->rc_gC, L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}};
+  // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
+  {
+    const long long per_a = (long long)round_up(S, 4) * H + (long long)(L - 1) * H * H;
+    const long long per_c = (long long)a->ldx * H + (long long)(L - 1) * H * H;
+    a->wt_net[0] = 0; a->wt_net[1] = align_up(per_a, 64);
+    a->wt_net[2] = 2 * align_up(per_a, 64); a->wt_net[3] = a->wt_net[2] + align_up(per_c, 64);
+    wants.push_back({&a->wt, a->wt_net[3] + align_up(per_c, 64)});
+    a->row_ldl = round_up(std::max(H, a->ldx), 4) + 4;
+    // fewest rows per block that keep both phases of a pipelined step within one wave of blocks
+    a->row_rg = 1;
+    while (a->row_rg < 4 && 2 * ((B + 4 * a->row_rg - 1) / (4 * a->row_rg)) > 256) a->row_rg *= 2;
+    a->rowchain = c.kind == GCRL_AGENT_DDPG && H % 4 == 0 && c.pipeline_steps >= 2 &&
+                  rowchain_lds_bytes(a->row_rg, a->row_ldl) <= 160 * 1024;
+  }
   long long total = 0;
   for (auto& w : wants) total += align_up(w.second, 64);
   TRY(bytes_alloc(&a->work, total));
@@ -941,7 +964,7 @@ int64_t gcrl_agent_numel(const gcrl_agent* a, const char* name) {
   return it == a->names.end() ? -1 : it->second.second;
 }
 
-int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr, int64_t* numel) {
+static int find_vec(gcrl_agent* a, const char* name, float** ptr, int64_t* numel) {
   GCRL_CHECK_ARG(a && name && ptr, "gcrl_agent_dev_ptr: null argument");
   auto it = a->names.find(name);
   GCRL_CHECK_ARG(it != a->names.end(), "unknown vector name '%s'", name);
@@ -950,9 +973,15 @@ int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr, int64_t* nu
   return GCRL_OK;
 }
 
+int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr, int64_t* numel) {
+  TRY(find_vec(a, name, ptr, numel));
+  a->wt_dirty = true;   // the caller may write through the pointer (data-parallel parameter broadcast)
+  return GCRL_OK;
+}
+
 int gcrl_agent_get(gcrl_agent* a, const char* name, float* dst, int64_t n) {
   float* p = nullptr; int64_t numel = 0;
-  TRY(gcrl_agent_dev_ptr(a, name, &p, &numel));
+  TRY(find_vec(a, name, &p, &numel));
   GCRL_CHECK_ARG(dst && n == numel, "gcrl_agent_get('%s'): n=%lld but the vector has %lld elements", name, (long long)n, (long long)numel);
   GCRL_HIP(hipDeviceSynchronize());
   GCRL_HIP(hipMemcpy(dst, p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
@@ -961,10 +990,11 @@ int gcrl_agent_get(gcrl_agent* a, const char* name, float* dst, int64_t n) {
 
 int gcrl_agent_set(gcrl_agent* a, const char* name, const float* src, int64_t n) {
   float* p = nullptr; int64_t numel = 0;
-  TRY(gcrl_agent_dev_ptr(a, name, &p, &numel));
+  TRY(find_vec(a, name, &p, &numel));
   GCRL_CHECK_ARG(src && n == numel, "gcrl_agent_set('%s'): n=%lld but the vector has %lld elements", name, (long long)n, (long long)numel);
   GCRL_HIP(hipDeviceSynchronize());
   GCRL_HIP(hipMemcpy(p, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  a->wt_dirty = true;
   if (std::string(name) == "log_alpha") {  // keep alpha = exp(log_alpha) coherent (src/agent.py:106, :878)
     const float al = std::exp(src[0]);
     GCRL_HIP(hipMemcpy(a->alpha_dev, &al, sizeof(float), hipMemcpyHostToDevice));
@@ -975,6 +1005,7 @@ int gcrl_agent_set(gcrl_agent* a, const char* name, const float* src, int64_t n)
 int gcrl_agent_init_weights(gcrl_agent* a, uint64_t seed, int recreate_alpha) {
   GCRL_CHECK_ARG(a, "gcrl_agent_init_weights: null handle");
   GCRL_HIP(hipDeviceSynchronize());
+  a->wt_dirty = true;
   std::mt19937_64 gen(seed * 0x9e3779b97f4a7c15ull + 12345);
   const bool first = a->t_critic == 0 && a->t_actor == 0;
   std::vector<float> host;
@@ -1011,6 +1042,7 @@ int gcrl_agent_init_weights(gcrl_agent* a, uint64_t seed, int recreate_alpha) {
 int gcrl_agent_hard_update_targets(gcrl_agent* a) {
   GCRL_CHECK_ARG(a, "gcrl_agent_hard_update_targets: null handle");
   GCRL_HIP(hipDeviceSynchronize());
+  a->wt_dirty = true;
   if (a->has_target_actor)
     GCRL_HIP(hipMemcpy(a->P_tactor(), a->P_actor(), (size_t)a->actor.numel * sizeof(float), hipMemcpyDeviceToDevice));
   GCRL_HIP(hipMemcpy(a->P_tcritic(0), a->P_critic(0), (size_t)a->C * a->critic_stride * sizeof(float), hipMemcpyDeviceToDevice));
@@ -1025,7 +1057,12 @@ int gcrl_agent_update(gcrl_agent* a, gcrl_her* her, int64_t step, const gcrl_upd
   TRY(begin_call(a, her, step, 1, in, 1.0f, st, plans, ticket_out, &len));
   int variant = plans[0].variant | V_FUSED_NORM;
   if (in) TRY(stage_injected(a, in, st, &variant));
-  TRY(run_step(a, st, variant, 7));
+  if (a->rowchain && variant == (V_ACTOR | V_FUSED_NORM)) {
+    TRY(run_ddpg_pipe(a, st, 1));   // the phases of a plain DDPG step, row-block kernels
+    TRY(run_ddpg_pipe(a, st, 2));
+  } else {
+    TRY(run_step(a, st, variant, 7));
+  }
   TRY(end_call(a, st));
   return len;
 }

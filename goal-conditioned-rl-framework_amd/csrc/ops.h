@@ -81,6 +81,7 @@ int launch_td3_smooth(hipStream_t st, const StepCtrl* cur, float* act, long long
 
 // ---- optimiser -------------------------------------------------------------------------
 constexpr int kNormBlocks = 64;
+constexpr int kMaxTransposed = 8;
 // partial[net][kNormBlocks] = sum of squares of block-strided chunks of g[net][n]
 int launch_sumsq(hipStream_t st, const float* g, long long n, long long net_stride, int nets,
                  float* partial);
@@ -103,6 +104,14 @@ struct AdamArgs {
   // optional fused scalar metric: metrics[slot][mean_index] = mean_scale * mean(mean_x[0..mean_n))
   // (actor loss -Q.mean() of DDPG/TD3, saving a launch); computed by block (0,0)
   const float* mean_x; int mean_n; float mean_scale; int mean_index;
+  // optional TD metrics of a DDPG critic step whose loss was formed inside the row-block kernel:
+  // critic loss mean((q-y)^2), mean |q-y|, mean q from the per-row q / y it left behind (block (0,0))
+  const float* td_q; const float* td_y; int td_n;
+  // optional [in][out] copies of weight matrices (rowchain.h streams them in the forward pass):
+  // element i of tensor t = [tr_beg, tr_beg + out*in) also lands at wt[tr_dst + k*out + o]
+  float* wt; int n_tr;
+  long long tr_beg[kMaxTransposed], tr_dst[kMaxTransposed];
+  int tr_out[kMaxTransposed], tr_in[kMaxTransposed];
 };
 int launch_adam(hipStream_t st, const AdamArgs& a);
 int launch_adam_pair(hipStream_t st, const AdamArgs& a0, const AdamArgs& a1);  // two single-net steps, one launch

@@ -223,6 +223,27 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
     if (threadIdx.x == 0)
       a.metrics[(long long)c.metrics_slot * kMetricFloats + a.mean_index] = a.mean_scale * (s / (float)a.mean_n);
   }
+  if (a.td_q && blockIdx.x == 0 && net == 0) {
+    // same sums, in the same order, as td_loss_kernel forms for one critic
+    __shared__ float scratch[4];
+    float loss = 0.f, td = 0.f, qs = 0.f;
+    for (int i = threadIdx.x; i < a.td_n; i += 256) {
+      const float q = a.td_q[i];
+      const float diff = __fsub_rn(q, a.td_y[i]);
+      loss += diff * diff;
+      td += fabsf(diff);
+      qs += q;
+    }
+    loss = block_sum_256(loss, scratch);
+    td = block_sum_256(td, scratch);
+    qs = block_sum_256(qs, scratch);
+    if (threadIdx.x == 0) {
+      float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
+      met[MET_CRITIC_LOSS] = loss / (float)a.td_n;
+      met[MET_TD] = td / (float)a.td_n;
+      met[MET_Q] = qs / (float)a.td_n;
+    }
+  }
   const float gmul = gscale * s_coef;
   const long long base = (long long)net * a.net_stride;
   float* __restrict__ p = a.p + base;
@@ -241,6 +262,18 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2s), a.eps);
     pi = __fadd_rn(pi, __fdiv_rn(__fmul_rn(-step_size, mi), denom));
     p[i] = pi; m[i] = mi; v[i] = vi;
+    if (a.wt) {
+#pragma unroll
+      for (int t = 0; t < kMaxTransposed; ++t) {
+        if (t < a.n_tr) {
+          const long long rel = i - a.tr_beg[t];
+          if (rel >= 0 && rel < (long long)a.tr_out[t] * a.tr_in[t]) {
+            const int o = (int)(rel / a.tr_in[t]), k = (int)(rel - (long long)o * a.tr_in[t]);
+            a.wt[a.tr_dst[t] + (long long)k * a.tr_out[t] + o] = pi;
+          }
+        }
+      }
+    }
     if (tp && a.polyak) tp[i] = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, tp[i]));
   }
 }

@@ -1,0 +1,196 @@
+// rowchain.h — row-block MLP primitives: a workgroup keeps kRows batch rows resident in LDS and
+// walks them through consecutive Linear layers, so a whole forward+backward chain of the small
+// actor / critic networks (src/model.py:18,57,63) is ONE launch instead of one launch per layer.
+//
+// The step is latency-bound (256-row batches, 256-wide layers: 33 MFLOP per layer), so what
+// matters is the number of dependent launches, not MFMA occupancy.  Rows of a batch are
+// independent through every forward and dX pass; only dW = G^T X contracts over the batch and
+// stays a separate (full-chip) GEMM launch.
+//
+//   out[r][c] = sum_j x[r][j] * M[j][c]      r < kRows,  M row-major [J][ldm] in global memory
+//
+// serves both directions: forward uses M = W^T (the [in][out] copy kept next to every H x H
+// weight), dX uses M = W (torch's [out][in] layout read as [j = out][c = in]).  Either way lane l
+// owns columns 4l..4l+3 of a 256-column chunk and streams ROWS of M with 16-byte loads (a wave
+// reads one contiguous 1 KB row per k: perfectly coalesced, every WG reads the same rows -> L2
+// hits), the four waves split j four ways and the partial sums meet in LDS.
+//
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products per instruction.  Block b = lane>>2
+// takes A_b[i] from lane 4b+i and B_b[j] from lane 4b+j and accumulates D_b[i][j] in VGPR i of
+// lane 4b+j.  Feeding every block the same four activations x[4g+i][k] (lane l supplies row l&3)
+// and B = component q of the lane's float4 of M gives, in VGPR i of lane l,
+// out[4g+i][4l+q] — 64 FLOP/clk/SIMD, the fp32 MFMA peak, with only FOUR rows per row group
+// (the 16x16x4 form needs sixteen rows per tile, i.e. 4x fewer workgroups at B = 256).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_mfma.h"
+#include "ops.h"
+
+namespace gcrl {
+
+constexpr int kRowThreads = 256;   // 4 waves: j is split four ways
+constexpr int kRowChunk = 256;     // columns per pass (64 lanes x 4)
+
+__device__ inline __amdgpu_buffer_rsrc_t bounded_rsrc(const float* p, long long nfloats) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  void* q = (void*)(((unsigned long long)hi << 32) | lo);
+  const int bytes = __builtin_amdgcn_readfirstlane((int)(nfloats * 4));
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, bytes, 0x00020000);
+}
+
+// One wave's k-share of one 256-column chunk.  RG row groups of 4 rows.
+//   xs   LDS activations [4*RG][ldx] (16-byte aligned rows)
+//   rs   buffer resource over M (reads past the end return 0)
+//   jb, je   this wave's j range (multiples of 4)
+template <int RG>
+__device__ inline void rows_matmul_wave(const float* xs, int ldx, __amdgpu_buffer_rsrc_t rs, int ldm, int c0,
+                                        int jb, int je, v4f (&acc)[RG][4]) {
+  const int lane = threadIdx.x & 63;
+  constexpr int U = 8;  // k per stage; two stages in flight
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[g][q] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const int col_b = (c0 + 4 * lane) * 4;
+  auto load = [&](v4u (&w)[U], int j) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, col_b + (j + u) * ldm * 4, 0, 0);
+  };
+  auto compute = [&](const v4u (&w)[U], int j) {
+#pragma unroll
+    for (int u4 = 0; u4 < U; u4 += 4) {
+      if (j + u4 < je) {
+        v4f xa[RG];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) xa[g] = *(const v4f*)(xs + (4 * g + (lane & 3)) * ldx + j + u4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < RG; ++g)
+              acc[g][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[g][u], __uint_as_float(w[u4 + u][q]), acc[g][q], 0, 0, 0);
+      }
+    }
+  };
+  v4u wa[U], wb[U];
+  load(wa, jb);
+  for (int j = jb; j < je; j += 2 * U) {
+    load(wb, j + U);
+    compute(wa, j);
+    load(wa, j + 2 * U);
+    compute(wb, j + U);
+  }
+}
+
+// y = act(x . M + bias) [* act'(hprev)] for the block's rows; all kRowThreads threads call it.
+//   part   LDS scratch [4 waves][4*RG][kRowChunk]
+//   ys     LDS output [4*RG][ldy]   (must not alias xs)
+//   save   optional global copy of y: row r of the block at save[r*ld_save + c]
+//   mulH   dX form: y *= act'(mulH[r*ld_mul + c]) (saved post-activation of the layer below, global)
+template <int RG>
+__device__ inline void rows_linear(const float* xs, int ldx, int J, const float* M, int ldm, int N, const float* bias,
+                                   int epi, float* part, float* ys, int ldy, float* save, long long ld_save,
+                                   int rows_valid, const float* mulH = nullptr, long long ld_mul = 0, int mul = MUL_NONE) {
+  constexpr int R = 4 * RG;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const __amdgpu_buffer_rsrc_t rs = bounded_rsrc(M, (long long)J * ldm);
+  const int per = ((J + 3) / 4 + 3) & ~3;
+  const int jb = wave * per, je = min(J, jb + per);
+  for (int c0 = 0; c0 < N; c0 += kRowChunk) {
+    const int c = c0 + 4 * lane;
+    // epilogue operands first: their latency hides behind the weight stream
+    v4f b = (v4f){0.f, 0.f, 0.f, 0.f}, hm[RG];
+    if (bias && c < N) b = *(const v4f*)(bias + c);
+#pragma unroll
+    for (int rr = 0; rr < RG; ++rr) {
+      const int r = wave + 4 * rr;
+      hm[rr] = (mulH && c < N && r < rows_valid) ? *(const v4f*)(mulH + (long long)r * ld_mul + c) : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    v4f acc[RG][4];
+    rows_matmul_wave<RG>(xs, ldx, rs, ldm, c0, jb, je, acc);
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *(v4f*)(part + ((wave * R + 4 * g + i) * kRowChunk) + 4 * lane) =
+            (v4f){acc[g][0][i], acc[g][1][i], acc[g][2][i], acc[g][3][i]};
+    __syncthreads();
+    if (c < N) {
+#pragma unroll
+      for (int rr = 0; rr < RG; ++rr) {
+        const int r = wave + 4 * rr;
+        v4f v = *(const v4f*)(part + (0 * R + r) * kRowChunk + 4 * lane);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *(const v4f*)(part + (w * R + r) * kRowChunk + 4 * lane);
+        v += b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = act_apply(v[q], epi);
+          if (mul != MUL_NONE) v[q] *= act_deriv(hm[rr][q], mul);
+        }
+        *(v4f*)(ys + r * ldy + c) = v;
+        if (save && r < rows_valid) *(v4f*)(save + (long long)r * ld_save + c) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// small heads: out[r][o] = epi(sum_k x[r][k] * W[o*ldw + k] + bias[o]) for o < n_out <= 16, into
+// LDS sm[r*16 + o].  One wave per (r, o) pair, lane-strided partial sums + cross-lane reduce.
+template <int RG>
+__device__ inline void rows_head(const float* xs, int ldx, int K, const float* W, long long ldw, const float* bias,
+                                 int n_out, int epi, float* sm) {
+  constexpr int R = 4 * RG;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int p = wave; p < R * n_out; p += 4) {
+    const int r = p / n_out, o = p - r * n_out;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += xs[r * ldx + k] * W[(long long)o * ldw + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) sm[r * 16 + o] = act_apply(s + (bias ? bias[o] : 0.f), epi);
+  }
+}
+
+// ---------------------------------------------------------------- DDPG step as row-block chains
+constexpr int kRowMaxLayers = 8;
+
+struct RowNet {
+  const float* P;    // parameters, torch layout (Linear weight [out][in])
+  const float* Wt;   // [in][out] copies of the hidden-layer weights (layer 0: zero rows up to jpad0)
+  long long w[kRowMaxLayers + 1], b[kRowMaxLayers + 1];  // offsets into P; entry L = the head
+  long long wt[kRowMaxLayers];                           // offsets into Wt
+  int in, jpad0, H, L, out;
+};
+
+// Blocks [0, nblk_k) run the critic phase K of the step described by *cur_k, blocks
+// [nblk_k, nblk_k + nblk_p) the actor phase P of the step described by *cur_p (the previous step in
+// the software-pipelined schedule, the same one otherwise).  Everything a dW GEMM or the optimiser
+// needs afterwards is written to global memory.
+struct RowChainArgs {
+  const StepCtrl* cur_k; const StepCtrl* cur_p;
+  RowNet actor, tactor, critic, tcritic;
+  const float* sa; const float* nsa; const float* rbuf; const float* dbuf;   // + batch_slot * slot_*
+  long long slot_x, slot_rd;
+  int ldx, ldl, B, S, A, Apad;
+  int nblk_k, nblk_p;
+  float *hC, *gC, *q, *y, *dq;      // K: activations / pre-activation gradients [L][B][H], per-row scalars [B]
+  float *hA, *gA, *hC2, *q2, *dz;   // P: ..., critic activations (scratch), Q(s, pi(s)), d(pre-tanh) [B][Apad]
+  float gamma, clamp_lo;
+};
+
+// rows per workgroup = 4*rg, rg in {1, 2, 4}
+int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg);
+size_t rowchain_lds_bytes(int rg, int ldl);
+
+// (re)build the [in][out] copies of one net's hidden-layer weights from its parameter block
+int launch_wt_rebuild(hipStream_t st, const RowNet& net, float* Wt);
+
+}  // namespace gcrl

@@ -1,0 +1,224 @@
+// rowchain.hip — the DDPG critic phase (K) and actor phase (P) as row-block chains: one launch
+// walks each block of 4/8/16 batch rows through every forward and input-gradient pass of the
+// phase (rowchain.h), leaving only the batch-contracting dW GEMMs and the optimiser to follow.
+//
+//   K (src/agent.py:1311-1317, critic_update):  target actor -> target critic -> TD target y;
+//       online critic on [s|a] (activations saved) -> q; dq = 2(q-y)/B; critic input-gradient
+//       chain, every layer's pre-activation gradient saved for dW.
+//   P (src/agent.py:1288-1300, actor_update):  actor on s (saved) -> a = tanh(.); critic on
+//       [s|a] -> q2 (= -loss*B); critic input-gradient chain down to the action columns;
+//       d(pre-tanh) = da*(1-a^2); actor gradient chain, saved for dW.
+#include "rowchain.h"
+
+namespace gcrl {
+namespace {
+
+template <int RG>
+__device__ inline void load_rows(float* X, int ldl, const float* src, long long ld_src, int ncols, int jpad, int rv) {
+  constexpr int R = 4 * RG;
+  for (int i = threadIdx.x; i < R * jpad; i += kRowThreads) {
+    const int r = i / jpad, c = i - r * jpad;
+    X[r * ldl + c] = (r < rv && c < ncols) ? src[(long long)r * ld_src + c] : 0.f;
+  }
+}
+
+// hidden layers 0..L-1 of `net` on the rows in X0 (jpad0 columns, zero padded); returns the LDS
+// buffer holding the last hidden activation.  save: [L][B][H] global, row r0 of the block.
+template <int RG>
+__device__ inline float* mlp_hidden(const RowNet& net, const float* X0, float* X1, float* X2, int ldl, float* part,
+                                    float* save, long long BH, long long row0, int rv) {
+  const float* in = X0;
+  float* out = X1;
+  for (int l = 0; l < net.L; ++l) {
+    rows_linear<RG>(in, ldl, l == 0 ? net.jpad0 : net.H, net.Wt + net.wt[l], net.H, net.H, net.P + net.b[l], EPI_LEAKY,
+                    part, out, ldl, save ? save + l * BH + row0 * net.H : nullptr, net.H, rv);
+    in = out;
+    out = (out == X1) ? X2 : X1;
+  }
+  return (float*)in;
+}
+
+// G <- (upstream[r][o] . Whead[o][k]) * act'(h[r][k]) in place over h (LDS), n_up <= 16 head outputs
+template <int RG>
+__device__ inline void head_backward(float* h, int ldl, int H, const float* Wh, int n_up, const float* up /* LDS [R][16] */,
+                                     float* save, int rv) {
+  constexpr int R = 4 * RG;
+  for (int i = threadIdx.x; i < R * H; i += kRowThreads) {
+    const int r = i / H, k = i - r * H;
+    float s = 0.f;
+    for (int o = 0; o < n_up; ++o) s += up[r * 16 + o] * Wh[(long long)o * H + k];
+    const float g = s * act_deriv(h[r * ldl + k], MUL_DLEAKY);
+    h[r * ldl + k] = g;
+    if (save && r < rv) save[(long long)r * H + k] = g;
+  }
+}
+
+// pre-activation gradients of hidden layers L-2..0 from the one of layer L-1 (in G, LDS)
+template <int RG>
+__device__ inline float* grad_chain(const RowNet& net, float* G, float* X1, float* X2, int ldl, float* part,
+                                    const float* hsaved, float* gsave, long long BH, long long row0, int rv) {
+  float* in = G;
+  for (int l = net.L - 1; l >= 1; --l) {
+    float* out = (in == X1) ? X2 : X1;
+    rows_linear<RG>(in, ldl, net.H, net.P + net.w[l], net.H, net.H, nullptr, EPI_NONE, part, out, ldl,
+                    gsave ? gsave + (l - 1) * BH + row0 * net.H : nullptr, net.H, rv,
+                    hsaved + (l - 1) * BH + row0 * net.H, net.H, MUL_DLEAKY);
+    in = out;
+  }
+  return in;
+}
+
+template <int RG>
+__global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int R = 4 * RG;
+  const int ldl = a.ldl, H = a.critic.H, S = a.S, A = a.A, B = a.B;
+  float* X0 = lds;
+  float* X1 = X0 + R * ldl;
+  float* X2 = X1 + R * ldl;
+  float* part = X2 + R * ldl;
+  float* sm = part + 4 * R * kRowChunk;   // [R][16] head outputs
+  float* sm2 = sm + R * 16;               // [R][16] second small array
+  const bool role_k = (int)blockIdx.x < a.nblk_k;
+  const int blk = role_k ? (int)blockIdx.x : (int)blockIdx.x - a.nblk_k;
+  const long long row0 = (long long)blk * R;
+  const int rv = min(R, B - (int)row0);
+  const long long BH = (long long)B * H;
+  const int tid = threadIdx.x;
+
+  if (role_k) {
+    const StepCtrl c = *a.cur_k;
+    const float* ns_rows = a.nsa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
+    const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
+    const float* rr = a.rbuf + (long long)c.batch_slot * a.slot_rd + row0;
+    const float* dd = a.dbuf + (long long)c.batch_slot * a.slot_rd + row0;
+    // target actor on ns
+    load_rows<RG>(X0, ldl, ns_rows, a.ldx, S, max(a.tactor.jpad0, a.tcritic.jpad0), rv);
+    __syncthreads();
+    float* h = mlp_hidden<RG>(a.tactor, X0, X1, X2, ldl, part, nullptr, BH, row0, rv);
+    rows_head<RG>(h, ldl, H, a.tactor.P + a.tactor.w[a.tactor.L], H, a.tactor.P + a.tactor.b[a.tactor.L], A, EPI_TANH, sm);
+    __syncthreads();
+    if (tid < R * A) { const int r = tid / A, o = tid - r * A; X0[r * ldl + S + o] = sm[r * 16 + o]; }
+    __syncthreads();
+    // target critic on [ns | a']
+    h = mlp_hidden<RG>(a.tcritic, X0, X1, X2, ldl, part, nullptr, BH, row0, rv);
+    rows_head<RG>(h, ldl, H, a.tcritic.P + a.tcritic.w[a.tcritic.L], H, a.tcritic.P + a.tcritic.b[a.tcritic.L], 1, EPI_NONE, sm);
+    __syncthreads();
+    if (tid < R) {
+      // y = clamp(r + gamma*(1-d)*Q'(ns, pi'(ns)), -1/(1-gamma), 0): same roundings as td_loss_kernel
+      const int r = tid;
+      const float rw = r < rv ? rr[r] : 0.f, dn = r < rv ? dd[r] : 0.f;
+      float y = __fadd_rn(rw, __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, dn)), sm[r * 16]));
+      y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
+      sm2[r * 16 + 1] = y;
+    }
+    // online critic on [s | a]
+    load_rows<RG>(X0, ldl, sa_rows, a.ldx, S + A, a.critic.jpad0, rv);
+    __syncthreads();
+    h = mlp_hidden<RG>(a.critic, X0, X1, X2, ldl, part, a.hC, BH, row0, rv);
+    rows_head<RG>(h, ldl, H, a.critic.P + a.critic.w[a.critic.L], H, a.critic.P + a.critic.b[a.critic.L], 1, EPI_NONE, sm);
+    __syncthreads();
+    if (tid < R) {
+      const int r = tid;
+      const float q = sm[r * 16], y = sm2[r * 16 + 1];
+      const float g = (r < rv) ? (2.0f / (float)B) * __fsub_rn(q, y) : 0.f;   // d mse_loss / dq
+      sm2[r * 16] = g;
+      if (r < rv) { a.q[row0 + r] = q; a.y[row0 + r] = y; a.dq[row0 + r] = g; }
+    }
+    __syncthreads();
+    head_backward<RG>(h, ldl, H, a.critic.P + a.critic.w[a.critic.L], 1, sm2, a.gC + (a.critic.L - 1) * BH + row0 * H, rv);
+    __syncthreads();
+    grad_chain<RG>(a.critic, h, X1, X2, ldl, part, a.hC, a.gC, BH, row0, rv);
+  } else {
+    const StepCtrl c = *a.cur_p;
+    const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
+    load_rows<RG>(X0, ldl, sa_rows, a.ldx, S, max(a.actor.jpad0, a.critic.jpad0), rv);
+    __syncthreads();
+    float* h = mlp_hidden<RG>(a.actor, X0, X1, X2, ldl, part, a.hA, BH, row0, rv);
+    rows_head<RG>(h, ldl, H, a.actor.P + a.actor.w[a.actor.L], H, a.actor.P + a.actor.b[a.actor.L], A, EPI_TANH, sm);
+    __syncthreads();
+    if (tid < R * A) { const int r = tid / A, o = tid - r * A; X0[r * ldl + S + o] = sm[r * 16 + o]; }
+    __syncthreads();
+    // critic on [s | pi(s)]
+    h = mlp_hidden<RG>(a.critic, X0, X1, X2, ldl, part, a.hC2, BH, row0, rv);
+    rows_head<RG>(h, ldl, H, a.critic.P + a.critic.w[a.critic.L], H, a.critic.P + a.critic.b[a.critic.L], 1, EPI_NONE, sm2);
+    __syncthreads();
+    if (tid < R) {
+      if (tid < rv) a.q2[row0 + tid] = sm2[tid * 16];
+      sm2[tid * 16] = (tid < rv) ? -1.0f / (float)B : 0.f;   // d(-mean Q)/dq
+    }
+    __syncthreads();
+    head_backward<RG>(h, ldl, H, a.critic.P + a.critic.w[a.critic.L], 1, sm2, nullptr, rv);
+    __syncthreads();
+    float* g0 = grad_chain<RG>(a.critic, h, X1, X2, ldl, part, a.hC2, nullptr, BH, row0, rv);
+    // da[r][j] = g0[r][:] . W0[:, S+j]  (row S+j of the [in][out] copy), then through the tanh
+    rows_head<RG>(g0, ldl, H, a.critic.Wt + a.critic.wt[0] + (long long)S * H, H, nullptr, A, EPI_NONE, sm2);
+    __syncthreads();
+    if (tid < R * A) {
+      const int r = tid / A, o = tid - r * A;
+      const float act = sm[r * 16 + o];
+      const float g = sm2[r * 16 + o] * act_deriv(act, MUL_DTANH);
+      sm2[r * 16 + o] = g;
+      if (r < rv) a.dz[(row0 + r) * a.Apad + o] = g;
+    }
+    // last hidden activation of the actor back into LDS (the buffers were reused by the critic)
+    float* hl = (g0 == X1) ? X2 : X1;
+    const float* hsrc = a.hA + (a.actor.L - 1) * BH + row0 * H;
+    for (int i = tid; i < R * H; i += kRowThreads) {
+      const int r = i / H, k = i - r * H;
+      hl[r * ldl + k] = r < rv ? hsrc[(long long)r * H + k] : 0.f;
+    }
+    __syncthreads();
+    head_backward<RG>(hl, ldl, H, a.actor.P + a.actor.w[a.actor.L], A, sm2, a.gA + (a.actor.L - 1) * BH + row0 * H, rv);
+    __syncthreads();
+    grad_chain<RG>(a.actor, hl, X1, X2, ldl, part, a.hA, a.gA, BH, row0, rv);
+  }
+}
+
+// Wt[wt[l] + k*H + o] = P[w[l] + o*in_l + k]; layer 0 rows in..jpad0-1 are zero
+__global__ void wt_rebuild_kernel(RowNet net, float* Wt) {
+  const int l = blockIdx.y;
+  const int in = l == 0 ? net.in : net.H, J = l == 0 ? net.jpad0 : net.H, H = net.H;
+  const long long n = (long long)J * H;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / H), o = (int)(i - (long long)k * H);
+    Wt[net.wt[l] + i] = k < in ? net.P[net.w[l] + (long long)o * in + k] : 0.f;
+  }
+}
+
+}  // namespace
+
+size_t rowchain_lds_bytes(int rg, int ldl) {
+  const int R = 4 * rg;
+  return (size_t)(3 * R * ldl + 4 * R * kRowChunk + 2 * R * 16) * sizeof(float);
+}
+
+int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
+  GCRL_CHECK_ARG(rg == 1 || rg == 2 || rg == 4, "rowchain: rows per block must be 4, 8 or 16");
+  GCRL_CHECK_ARG(a.critic.H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16, "rowchain: unsupported shape (H=%d, A=%d)", a.critic.H, a.A);
+  const size_t lds = rowchain_lds_bytes(rg, a.ldl);
+  GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain: %zu bytes of LDS needed", lds);
+  const int grid = a.nblk_k + a.nblk_p;
+  if (grid < 1) return GCRL_OK;
+  auto go = [&](auto kern) -> int {
+    static thread_local size_t raised = 0;
+    if (lds > 64 * 1024 && lds > raised) {
+      GCRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      raised = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, st, a);
+    GCRL_HIP(hipGetLastError());
+    return GCRL_OK;
+  };
+  if (rg == 1) return go(rowchain_ddpg_kernel<1>);
+  if (rg == 2) return go(rowchain_ddpg_kernel<2>);
+  return go(rowchain_ddpg_kernel<4>);
+}
+
+int launch_wt_rebuild(hipStream_t st, const RowNet& net, float* Wt) {
+  hipLaunchKernelGGL(wt_rebuild_kernel, dim3(64, net.L), dim3(256), 0, st, net, Wt);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+}  // namespace gcrl
