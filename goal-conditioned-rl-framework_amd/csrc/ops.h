@@ -42,6 +42,10 @@ struct CtrlBlock {   // device layout: cursor, then cur / prev, then the table
   int pad[3];
   StepCtrl cur;    // the step whose critic phase is running
   StepCtrl prev;   // software-pipelined DDPG: the step whose actor phase shares the launches
+  // second copy, read by the optimiser launch of the row-block path: one thread of that launch
+  // can then advance cur/prev for the next step (nobody in that launch reads them), and one thread
+  // of the next step's first launch refreshes the copy — no begin_step launch, no atomics
+  StepCtrl cur_b, prev_b;
   StepCtrl table[1];
 };
 
@@ -109,6 +113,10 @@ struct AdamArgs {
   const float* td_q; const float* td_y; int td_n;
   // optional [in][out] copies of weight matrices (rowchain.h streams them in the forward pass):
   // element i of tensor t = [tr_beg, tr_beg + out*in) also lands at wt[tr_dst + k*out + o]
+  // optional end-of-step control advance: thread 0 of block (0,0) does what begin_step(shift)
+  // would do for the next step (prev <- cur, cur <- table[cursor++]), saving that launch.  Legal
+  // only when this launch reads the copies cur_b / prev_b (CtrlBlock)
+  CtrlBlock* advance;
   float* wt; int n_tr;
   long long tr_beg[kMaxTransposed], tr_dst[kMaxTransposed];
   int tr_out[kMaxTransposed], tr_in[kMaxTransposed];

@@ -186,7 +186,12 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
   else if (a.which == 1) { step_size = c.step_size_critic; bc2s = c.bc2s_critic; decay = c.decay_critic; }
   else { step_size = c.step_size_alpha; bc2s = c.bc2s_alpha; decay = c.decay_alpha; }
   const float gscale = c.grad_scale;
-
+  const long long base = (long long)net * a.net_stride;
+  float* __restrict__ p = a.p + base;
+  const float* __restrict__ g = a.g + base;
+  float* __restrict__ m = a.m + base;
+  float* __restrict__ v = a.v + base;
+  float* __restrict__ tp = a.target ? a.target + base : nullptr;
   {
     // ||g||: every block sums the same partials in the same order (deterministic), in fp64
     __shared__ double dred[4];
@@ -245,12 +250,6 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
     }
   }
   const float gmul = gscale * s_coef;
-  const long long base = (long long)net * a.net_stride;
-  float* __restrict__ p = a.p + base;
-  const float* __restrict__ g = a.g + base;
-  float* __restrict__ m = a.m + base;
-  float* __restrict__ v = a.v + base;
-  float* __restrict__ tp = a.target ? a.target + base : nullptr;
   const float w1 = a.w1, w2 = a.w2, one_m_tau = a.one_m_tau;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
     const float gi = __fmul_rn(g[i], gmul);
@@ -258,19 +257,18 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
     if (decay != 1.0f) pi = __fmul_rn(pi, decay);
     float mi = m[i];
     mi = __fadd_rn(mi, __fmul_rn(w1, __fsub_rn(gi, mi)));
-    float vi = __fadd_rn(__fmul_rn(v[i], a.beta2), __fmul_rn(__fmul_rn(w2, gi), gi));
+    const float vi = __fadd_rn(__fmul_rn(v[i], a.beta2), __fmul_rn(__fmul_rn(w2, gi), gi));
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2s), a.eps);
     pi = __fadd_rn(pi, __fdiv_rn(__fmul_rn(-step_size, mi), denom));
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (a.wt) {
-#pragma unroll
-      for (int t = 0; t < kMaxTransposed; ++t) {
-        if (t < a.n_tr) {
-          const long long rel = i - a.tr_beg[t];
-          if (rel >= 0 && rel < (long long)a.tr_out[t] * a.tr_in[t]) {
-            const int o = (int)(rel / a.tr_in[t]), k = (int)(rel - (long long)o * a.tr_in[t]);
-            a.wt[a.tr_dst[t] + (long long)k * a.tr_out[t] + o] = pi;
-          }
+      // small code on purpose (the kernel's instructions are cold every step): a real loop
+#pragma unroll 1
+      for (int t = 0; t < a.n_tr; ++t) {
+        const long long rel = i - a.tr_beg[t];
+        if (rel >= 0 && rel < (long long)a.tr_out[t] * a.tr_in[t]) {
+          const int o = (int)(rel / a.tr_in[t]), k = (int)(rel - (long long)o * a.tr_in[t]);
+          a.wt[a.tr_dst[t] + (long long)k * a.tr_out[t] + o] = pi;
         }
       }
     }
@@ -278,13 +276,27 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
   }
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) { adam_body(a, blockIdx.y); }
+__device__ inline void advance_ctrl(const AdamArgs& a) {
+  if (a.advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    CtrlBlock* cb = a.advance;
+    const int c = cb->cursor;
+    cb->prev = cb->cur;
+    cb->cur = cb->table[c];
+    cb->cursor = c + 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  adam_body(a, blockIdx.y);
+  advance_ctrl(a);
+}
 
 // two independent single-net optimiser steps in one launch (software-pipelined DDPG: the critic of
 // step i+1 and the actor of step i), blockIdx.y picks the argument set
 __global__ __launch_bounds__(256) void adam_pair_kernel(AdamArgs a0, AdamArgs a1) {
   if (blockIdx.y == 0) adam_body(a0, 0);
   else adam_body(a1, 0);
+  advance_ctrl(a0);
 }
 
 __global__ void polyak_kernel(const float* p, float* tp, long long n, float tau, float one_m_tau) {

@@ -176,6 +176,7 @@ struct RowNet {
 // needs afterwards is written to global memory.
 struct RowChainArgs {
   const StepCtrl* cur_k; const StepCtrl* cur_p;
+  CtrlBlock* cb;   // block 0 refreshes cb->cur_b / prev_b (the optimiser launch reads those)
   RowNet actor, tactor, critic, tcritic;
   const float* sa; const float* nsa; const float* rbuf; const float* dbuf;   // + batch_slot * slot_*
   long long slot_x, slot_rd;

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   const int rv = min(R, B - (int)row0);
   const long long BH = (long long)B * H;
   const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
 
   if (role_k) {
     const StepCtrl c = *a.cur_k;
