@@ -822,7 +822,7 @@ int build(gcrl_agent* a) {
     a->row_rg = 1;
     while (a->row_rg < 4 && 2 * ((B + 4 * a->row_rg - 1) / (4 * a->row_rg)) > 256) a->row_rg *= 2;
     a->rowchain = c.kind == GCRL_AGENT_DDPG && H % 4 == 0 && c.pipeline_steps >= 2 &&
-                  rowchain_lds_bytes(a->row_rg, a->row_ldl) <= 160 * 1024;
+                  rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H) <= 160 * 1024;
   }
   long long total = 0;
   for (auto& w : wants) total += align_up(w.second, 64);

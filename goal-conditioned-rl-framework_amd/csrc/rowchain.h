@@ -189,7 +189,7 @@ struct RowChainArgs {
 
 // rows per workgroup = 4*rg, rg in {1, 2, 4}
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg);
-size_t rowchain_lds_bytes(int rg, int ldl);
+size_t rowchain_lds_bytes(int rg, int ldl, int A, int H);
 
 // (re)build the [in][out] copies of one net's hidden-layer weights from its parameter block
 int launch_wt_rebuild(hipStream_t st, const RowNet& net, float* Wt);

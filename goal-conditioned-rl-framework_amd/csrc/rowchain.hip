@@ -68,6 +68,11 @@ __device__ inline float* grad_chain(const RowNet& net, float* G, float* X1, floa
   return in;
 }
 
+// stage `n` floats of global memory into LDS (all threads)
+__device__ inline void stage(float* dst, const float* src, int n) {
+  for (int i = threadIdx.x; i < n; i += kRowThreads) dst[i] = src[i];
+}
+
 template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -76,9 +81,13 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   float* X0 = lds;
   float* X1 = X0 + R * ldl;
   float* X2 = X1 + R * ldl;
-  float* part = X2 + R * ldl;
+  float* XS = X2 + R * ldl;               // second input rows (K) / last actor activation (P)
+  float* part = XS + R * ldl;
   float* sm = part + 4 * R * kRowChunk;   // [R][16] head outputs
   float* sm2 = sm + R * 16;               // [R][16] second small array
+  float* sm3 = sm2 + R * 16;              // [R][16] reward / done
+  float* hw = sm3 + R * 16;               // head weights of the role: [A*H | H | max(A*H, H)], then head biases [16 | 16]
+  float* hb = hw + (2 * A + 1) * H;
   const bool role_k = (int)blockIdx.x < a.nblk_k;
   const int blk = role_k ? (int)blockIdx.x : (int)blockIdx.x - a.nblk_k;
   const long long row0 = (long long)blk * R;
@@ -87,37 +96,46 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
 
+  // Everything that does not depend on computed data is requested NOW (inputs, rewards, head
+  // weights and biases): each of these was a separate exposed memory round trip (~1 us) in the
+  // middle of the chain.
   if (role_k) {
     const StepCtrl c = *a.cur_k;
     const float* ns_rows = a.nsa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
     const float* rr = a.rbuf + (long long)c.batch_slot * a.slot_rd + row0;
     const float* dd = a.dbuf + (long long)c.batch_slot * a.slot_rd + row0;
-    // target actor on ns
     load_rows<RG>(X0, ldl, ns_rows, a.ldx, S, max(a.tactor.jpad0, a.tcritic.jpad0), rv);
+    load_rows<RG>(XS, ldl, sa_rows, a.ldx, S + A, a.critic.jpad0, rv);
+    if (tid < R) { sm3[tid * 16] = tid < rv ? rr[tid] : 0.f; sm3[tid * 16 + 1] = tid < rv ? dd[tid] : 0.f; }
+    float* hw_ta = hw; float* hw_tc = hw + A * H; float* hw_c = hw_tc + H;
+    stage(hw_ta, a.tactor.P + a.tactor.w[a.tactor.L], A * H);
+    stage(hw_tc, a.tcritic.P + a.tcritic.w[a.tcritic.L], H);
+    stage(hw_c, a.critic.P + a.critic.w[a.critic.L], H);
+    if (tid < A) hb[tid] = a.tactor.P[a.tactor.b[a.tactor.L] + tid];
+    if (tid == 32) hb[16] = a.tcritic.P[a.tcritic.b[a.tcritic.L]];
+    if (tid == 33) hb[17] = a.critic.P[a.critic.b[a.critic.L]];
     __syncthreads();
+    // target actor on ns
     float* h = mlp_hidden<RG>(a.tactor, X0, X1, X2, ldl, part, nullptr, BH, row0, rv);
-    rows_head<RG>(h, ldl, H, a.tactor.P + a.tactor.w[a.tactor.L], H, a.tactor.P + a.tactor.b[a.tactor.L], A, EPI_TANH, sm);
+    rows_head<RG>(h, ldl, H, hw_ta, H, hb, A, EPI_TANH, sm);
     __syncthreads();
     if (tid < R * A) { const int r = tid / A, o = tid - r * A; X0[r * ldl + S + o] = sm[r * 16 + o]; }
     __syncthreads();
     // target critic on [ns | a']
     h = mlp_hidden<RG>(a.tcritic, X0, X1, X2, ldl, part, nullptr, BH, row0, rv);
-    rows_head<RG>(h, ldl, H, a.tcritic.P + a.tcritic.w[a.tcritic.L], H, a.tcritic.P + a.tcritic.b[a.tcritic.L], 1, EPI_NONE, sm);
+    rows_head<RG>(h, ldl, H, hw_tc, H, hb + 16, 1, EPI_NONE, sm);
     __syncthreads();
     if (tid < R) {
       // y = clamp(r + gamma*(1-d)*Q'(ns, pi'(ns)), -1/(1-gamma), 0): same roundings as td_loss_kernel
       const int r = tid;
-      const float rw = r < rv ? rr[r] : 0.f, dn = r < rv ? dd[r] : 0.f;
-      float y = __fadd_rn(rw, __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, dn)), sm[r * 16]));
+      float y = __fadd_rn(sm3[r * 16], __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, sm3[r * 16 + 1])), sm[r * 16]));
       y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
       sm2[r * 16 + 1] = y;
     }
     // online critic on [s | a]
-    load_rows<RG>(X0, ldl, sa_rows, a.ldx, S + A, a.critic.jpad0, rv);
-    __syncthreads();
-    h = mlp_hidden<RG>(a.critic, X0, X1, X2, ldl, part, a.hC, BH, row0, rv);
-    rows_head<RG>(h, ldl, H, a.critic.P + a.critic.w[a.critic.L], H, a.critic.P + a.critic.b[a.critic.L], 1, EPI_NONE, sm);
+    h = mlp_hidden<RG>(a.critic, XS, X1, X2, ldl, part, a.hC, BH, row0, rv);
+    rows_head<RG>(h, ldl, H, hw_c, H, hb + 17, 1, EPI_NONE, sm);
     __syncthreads();
     if (tid < R) {
       const int r = tid;
@@ -127,33 +145,41 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
       if (r < rv) { a.q[row0 + r] = q; a.y[row0 + r] = y; a.dq[row0 + r] = g; }
     }
     __syncthreads();
-    head_backward<RG>(h, ldl, H, a.critic.P + a.critic.w[a.critic.L], 1, sm2, a.gC + (a.critic.L - 1) * BH + row0 * H, rv);
+    head_backward<RG>(h, ldl, H, hw_c, 1, sm2, a.gC + (a.critic.L - 1) * BH + row0 * H, rv);
     __syncthreads();
     grad_chain<RG>(a.critic, h, X1, X2, ldl, part, a.hC, a.gC, BH, row0, rv);
   } else {
     const StepCtrl c = *a.cur_p;
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
     load_rows<RG>(X0, ldl, sa_rows, a.ldx, S, max(a.actor.jpad0, a.critic.jpad0), rv);
+    float* hw_a = hw; float* hw_c = hw + A * H; float* hw_da = hw_c + H;
+    stage(hw_a, a.actor.P + a.actor.w[a.actor.L], A * H);
+    stage(hw_c, a.critic.P + a.critic.w[a.critic.L], H);
+    stage(hw_da, a.critic.Wt + a.critic.wt[0] + (long long)S * H, A * H);   // rows S..S+A-1 of W0^T
+    if (tid < A) hb[tid] = a.actor.P[a.actor.b[a.actor.L] + tid];
+    if (tid == 32) hb[16] = a.critic.P[a.critic.b[a.critic.L]];
     __syncthreads();
     float* h = mlp_hidden<RG>(a.actor, X0, X1, X2, ldl, part, a.hA, BH, row0, rv);
-    rows_head<RG>(h, ldl, H, a.actor.P + a.actor.w[a.actor.L], H, a.actor.P + a.actor.b[a.actor.L], A, EPI_TANH, sm);
+    rows_head<RG>(h, ldl, H, hw_a, H, hb, A, EPI_TANH, sm);
+    // keep the last actor activation: the critic chain reuses X1 / X2
+    for (int i = tid; i < R * H; i += kRowThreads) { const int r = i / H, k = i - r * H; XS[r * ldl + k] = h[r * ldl + k]; }
     __syncthreads();
     if (tid < R * A) { const int r = tid / A, o = tid - r * A; X0[r * ldl + S + o] = sm[r * 16 + o]; }
     __syncthreads();
     // critic on [s | pi(s)]
     h = mlp_hidden<RG>(a.critic, X0, X1, X2, ldl, part, a.hC2, BH, row0, rv);
-    rows_head<RG>(h, ldl, H, a.critic.P + a.critic.w[a.critic.L], H, a.critic.P + a.critic.b[a.critic.L], 1, EPI_NONE, sm2);
+    rows_head<RG>(h, ldl, H, hw_c, H, hb + 16, 1, EPI_NONE, sm2);
     __syncthreads();
     if (tid < R) {
       if (tid < rv) a.q2[row0 + tid] = sm2[tid * 16];
       sm2[tid * 16] = (tid < rv) ? -1.0f / (float)B : 0.f;   // d(-mean Q)/dq
     }
     __syncthreads();
-    head_backward<RG>(h, ldl, H, a.critic.P + a.critic.w[a.critic.L], 1, sm2, nullptr, rv);
+    head_backward<RG>(h, ldl, H, hw_c, 1, sm2, nullptr, rv);
     __syncthreads();
     float* g0 = grad_chain<RG>(a.critic, h, X1, X2, ldl, part, a.hC2, nullptr, BH, row0, rv);
     // da[r][j] = g0[r][:] . W0[:, S+j]  (row S+j of the [in][out] copy), then through the tanh
-    rows_head<RG>(g0, ldl, H, a.critic.Wt + a.critic.wt[0] + (long long)S * H, H, nullptr, A, EPI_NONE, sm2);
+    rows_head<RG>(g0, ldl, H, hw_da, H, nullptr, A, EPI_NONE, sm2);
     __syncthreads();
     if (tid < R * A) {
       const int r = tid / A, o = tid - r * A;
@@ -162,17 +188,10 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
       sm2[r * 16 + o] = g;
       if (r < rv) a.dz[(row0 + r) * a.Apad + o] = g;
     }
-    // last hidden activation of the actor back into LDS (the buffers were reused by the critic)
-    float* hl = (g0 == X1) ? X2 : X1;
-    const float* hsrc = a.hA + (a.actor.L - 1) * BH + row0 * H;
-    for (int i = tid; i < R * H; i += kRowThreads) {
-      const int r = i / H, k = i - r * H;
-      hl[r * ldl + k] = r < rv ? hsrc[(long long)r * H + k] : 0.f;
-    }
     __syncthreads();
-    head_backward<RG>(hl, ldl, H, a.actor.P + a.actor.w[a.actor.L], A, sm2, a.gA + (a.actor.L - 1) * BH + row0 * H, rv);
+    head_backward<RG>(XS, ldl, H, hw_a, A, sm2, a.gA + (a.actor.L - 1) * BH + row0 * H, rv);
     __syncthreads();
-    grad_chain<RG>(a.actor, hl, X1, X2, ldl, part, a.hA, a.gA, BH, row0, rv);
+    grad_chain<RG>(a.actor, XS, X1, X2, ldl, part, a.hA, a.gA, BH, row0, rv);
   }
 }
 
@@ -189,15 +208,15 @@ __global__ void wt_rebuild_kernel(RowNet net, float* Wt) {
 
 }  // namespace
 
-size_t rowchain_lds_bytes(int rg, int ldl) {
+size_t rowchain_lds_bytes(int rg, int ldl, int A, int H) {
   const int R = 4 * rg;
-  return (size_t)(3 * R * ldl + 4 * R * kRowChunk + 2 * R * 16) * sizeof(float);
+  return (size_t)(4 * R * ldl + 4 * R * kRowChunk + 3 * R * 16 + (2 * A + 1) * H + 32) * sizeof(float);
 }
 
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
   GCRL_CHECK_ARG(rg == 1 || rg == 2 || rg == 4, "rowchain: rows per block must be 4, 8 or 16");
   GCRL_CHECK_ARG(a.critic.H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16, "rowchain: unsupported shape (H=%d, A=%d)", a.critic.H, a.A);
-  const size_t lds = rowchain_lds_bytes(rg, a.ldl);
+  const size_t lds = rowchain_lds_bytes(rg, a.ldl, a.A, a.critic.H);
   GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain: %zu bytes of LDS needed", lds);
   const int grid = a.nblk_k + a.nblk_p;
   if (grid < 1) return GCRL_OK;
