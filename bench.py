@@ -9,12 +9,16 @@ as the trainer issues them, `gradient_step` (40) at a time with the buffer untou
 Inputs (the replay ring) are resident in HBM before the timed region.
 
 N > 1: one process per GPU (torchrun env), each rank owns a local ring and draws its own batch
-of B rows; gradients are all-reduced over RCCL twice per step (critic, then actor).  Per-GPU
-work is fixed -> "scaling": "weak"; value = per-rank gradient steps summed over ranks / time.
+of B rows; gradients are all-reduced over RCCL — once per overlapped DDPG step (critic and actor
+blocks are adjacent), twice per step otherwise (critic, then actor).  Per-GPU work is fixed -> "scaling": "weak"; value = per-rank gradient steps summed over ranks / time.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      HER gather kernel: algorithmic bytes / HIP-event kernel time vs HBM peak
-  cpu_baseline  the oracle (CPU restatement of the reference) timed on this host, same workload
+  roofline         the dominant kernel.  DDPG (row-block path): rowchain_ddpg_kernel, the forward and
+                   input-gradient chains of a step's two phases in one launch — algorithmic flops /
+                   HIP-event kernel time vs the fp32 MFMA peak.  Other agents: the HER gather kernel
+                   (algorithmic bytes / HIP-event kernel time vs HBM peak).
+  roofline_gather  the HER gather kernel, always
+  cpu_baseline     the oracle (CPU restatement of the reference) timed on this host, same workload
 """
 import argparse
 import ctypes as C
@@ -87,6 +91,20 @@ def flops_per_step(w, actor_step=True):
     if kind == "SAC":
         return 2 * B * (4 * Pa + 12 * Pc)
     return 2 * B * (4 * Pa + 7 * 5 * Pc)
+
+
+def chain_flops_per_launch(w):
+    """Algorithmic flops of one overlapped row-block launch: critic phase K = target
+    actor fwd + target critic fwd + critic fwd + critic dX (hidden layers); actor phase P = actor fwd
+    + critic fwd + critic dX down to the action columns + actor dX (hidden layers).  2 flop per MAC."""
+    S, A, H, L, B = w["S"], w["A"], w["H"], w["L"], w["B"]
+    fa = S * H + (L - 1) * H * H + H * A          # actor forward MACs per row
+    fc = (S + A) * H + (L - 1) * H * H + H        # critic forward
+    dxc = (L - 1) * H * H + H                     # critic dX, head and hidden layers
+    dxa = (L - 1) * H * H + H * A                 # actor dX
+    k = fa + fc + fc + dxc
+    p = fa + fc + dxc + H * A + dxa
+    return 2 * B * (k + p)
 
 
 def cpu_baseline(w, pool, budget_s):
@@ -211,8 +229,20 @@ def main():
         launches, ms, rows, dev_ms = C.c_int64(), C.c_double(), C.c_int64(), C.c_double()
         check(lib.gcrl_her_profile_read(her, C.byref(launches), C.byref(ms), C.byref(rows), C.byref(dev_ms)))
         check(lib.gcrl_her_profile_enable(her, 0))
+        # roofline leg for the row-block kernel: a short untimed run with the engine's measurement
+        # hooks on (plain launches, each overlapped row-block launch bracketed by hipEvents on its
+        # stream + device clock stamps)
+        rc = None
+        if w["kind"] == "DDPG" and dp is None and w["H"] % 4 == 0:
+            check(lib.gcrl_agent_profile_enable(agent._h, 1))
+            run(1 + args.warmup + args.steps, 10 * gstep)
+            n_l, ev_ms, clk_ms = C.c_int64(), C.c_double(), C.c_double()
+            check(lib.gcrl_agent_profile_read(agent._h, C.byref(n_l), C.byref(ev_ms), C.byref(clk_ms)))
+            check(lib.gcrl_agent_profile_enable(agent._h, 0))
+            if n_l.value:
+                rc = (n_l.value, ev_ms.value * 1e3 / n_l.value, clk_ms.value * 1e3 / n_l.value)
         # a last metrics fetch proves the steps really ran to completion
-        last = [float(x) for x in (agent.update_many(1 + args.warmup + args.steps, 1)[0] if dp is None
+        last = [float(x) for x in (agent.update_many(1 + args.warmup + args.steps + 10 * gstep, 1)[0] if dp is None
                                    else dp.update(1 + args.warmup + args.steps))]
         assert all(np.isfinite(last)), last
 
@@ -246,7 +276,7 @@ def main():
                        "state_dim": w["S"], "action_dim": w["A"], "hidden": w["H"], "layers": w["L"], "k_future": w["k"],
                        "gradient_step": gstep, "parallelism": f"dp{world}" if world > 1 else "single",
                        "hip_graph": not args.no_graph, "rng": "cpython-mt19937 (host) indices"},
-            "roofline": {"kernel": "her_gather_update_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline_gather": {"kernel": "her_gather_update_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": launches.value, "avg_launch_us": avg_us, "rows_per_launch": rows_per_launch,
                          "algorithmic_bytes_per_row": alg_bytes_per_row,
@@ -258,6 +288,19 @@ def main():
                              "peak_tflops": FP32_MFMA_PEAK_TF},
             "fill_s": t_fill, "last_metrics": last,
         }
+        if rc is not None:
+            fl = chain_flops_per_launch(w)
+            out["roofline"] = {
+                "kernel": "rowchain_ddpg_kernel", "bound": "mfma", "achieved": fl / (rc[1] * 1e-6) / 1e12,
+                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / (rc[1] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF,
+                "traffic": None, "launches": rc[0], "avg_launch_us": rc[1], "algorithmic_flops_per_launch": fl,
+                "timing": "hipEvent pair around each launch on its stream, separate untimed leg of 10 trainer cycles "
+                          "(includes event/dispatch overhead)",
+                "kernel_us_device_clock": rc[2], "achieved_device_clock": fl / (rc[2] * 1e-6) / 1e12,
+                "share_of_step_time": rc[2] / (1e6 * elapsed / args.steps),
+                "note": "latency-bound chain (8 dependent 256-wide layer passes per phase, 128 of 256 CUs at B=256), see DESIGN.md §4"}
+        else:
+            out["roofline"] = dict(out["roofline_gather"])
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, pool, args.cpu_seconds)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]

@@ -96,6 +96,8 @@ PROTOTYPES = {
     "gcrl_her_profile_read": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_f64)]),
     "gcrl_agent_create": (_vp, [C.POINTER(AgentConfig)]),
     "gcrl_agent_destroy": (None, [_vp]),
+    "gcrl_agent_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "gcrl_agent_profile_read": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_f64)]),
     "gcrl_agent_stream": (_vp, [_vp]),
     "gcrl_agent_numel": (_i64, [_vp, _cp]),
     "gcrl_agent_get": (C.c_int, [_vp, _cp, _vp, _i64]),

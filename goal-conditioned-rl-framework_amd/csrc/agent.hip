@@ -116,6 +116,14 @@ struct gcrl_agent {
   int row_rg = 1, row_ldl = 0;
   float *wt = nullptr, *rc_gC = nullptr, *rc_gA = nullptr, *ybuf = nullptr;
   long long wt_net[4] = {};   // offsets of the four nets inside wt
+  // measurement hooks (gcrl_agent_profile_*): event pair + device clock around each row-block launch
+  bool prof = false;
+  static constexpr int kProfPairs = 64;
+  hipEvent_t prof_a[kProfPairs] = {}, prof_b[kProfPairs] = {};
+  unsigned long long* prof_clk = nullptr;
+  int prof_used = 0;
+  int64_t prof_launches = 0;
+  double prof_ms = 0, prof_ticks = 0;
   float *parts_c = nullptr, *parts_a = nullptr;   // fused-norm partials: [C][nparts_c], [nparts_a]
   int nparts_c = 0, nparts_a = 0;
   std::vector<int> part_off_c, part_off_a;        // per-layer offsets inside a net's partials
@@ -1046,6 +1054,30 @@ int gcrl_agent_hard_update_targets(gcrl_agent* a) {
   if (a->has_target_actor)
     GCRL_HIP(hipMemcpy(a->P_tactor(), a->P_actor(), (size_t)a->actor.numel * sizeof(float), hipMemcpyDeviceToDevice));
   GCRL_HIP(hipMemcpy(a->P_tcritic(0), a->P_critic(0), (size_t)a->C * a->critic_stride * sizeof(float), hipMemcpyDeviceToDevice));
+  return GCRL_OK;
+}
+
+int gcrl_agent_profile_enable(gcrl_agent* a, int on) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_profile_enable: null handle");
+  if (on && !a->prof_clk) {
+    GCRL_HIP(hipMalloc((void**)&a->prof_clk, 2 * gcrl_agent::kProfPairs * sizeof(unsigned long long)));
+    for (int i = 0; i < gcrl_agent::kProfPairs; ++i) {
+      GCRL_HIP(hipEventCreate(&a->prof_a[i]));
+      GCRL_HIP(hipEventCreate(&a->prof_b[i]));
+    }
+  }
+  if (!on) TRY(prof_drain(a));
+  else { a->prof_launches = 0; a->prof_ms = 0; a->prof_ticks = 0; a->prof_used = 0; }
+  a->prof = on != 0;
+  return GCRL_OK;
+}
+
+int gcrl_agent_profile_read(gcrl_agent* a, int64_t* launches_out, double* total_ms_out, double* device_clock_ms_out) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_profile_read: null handle");
+  TRY(prof_drain(a));
+  if (launches_out) *launches_out = a->prof_launches;
+  if (total_ms_out) *total_ms_out = a->prof_ms;
+  if (device_clock_ms_out) *device_clock_ms_out = a->prof_ticks / 1e5;   // wall_clock64: 100 MHz
   return GCRL_OK;
 }
 

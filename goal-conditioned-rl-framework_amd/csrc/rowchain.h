@@ -185,6 +185,7 @@ struct RowChainArgs {
   float *hC, *gC, *q, *y, *dq;      // K: activations / pre-activation gradients [L][B][H], per-row scalars [B]
   float *hA, *gA, *hC2, *q2, *dz;   // P: ..., critic activations (scratch), Q(s, pi(s)), d(pre-tanh) [B][Apad]
   float gamma, clamp_lo;
+  unsigned long long* clk;   // profiling: {first block start, last block end} in wall_clock64 ticks, or null
 };
 
 // rows per workgroup = 4*rg, rg in {1, 2, 4}

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   const long long BH = (long long)B * H;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
+  if (a.clk && tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nblk_k)) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());
 
   // Everything that does not depend on computed data is requested NOW (inputs, rewards, head
   // weights and biases): each of these was a separate exposed memory round trip (~1 us) in the
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     __syncthreads();
     grad_chain<RG>(a.actor, XS, X1, X2, ldl, part, a.hA, a.gA, BH, row0, rv);
   }
+  if (a.clk && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
 
 // Wt[wt[l] + k*H + o] = P[w[l] + o*in_l + k]; layer 0 rows in..jpad0-1 are zero

@@ -209,13 +209,27 @@ typedef struct gcrl_agent_config {
   int32_t device;
   int32_t use_graph;      /* 1: replay the step as a hipGraph */
   uint64_t seed;          /* device RNG for TD3 noise / SAC eps when not injected */
-  int32_t pipeline_steps; /* DDPG, gcrl_agent_update_n only: 1 = co-schedule the actor phase of
-                             step i with the critic phase of step i+1 (they are independent: the
-                             critic phase reads the TARGET actor); same arithmetic, fewer launches */
+  int32_t pipeline_steps; /* DDPG: 0 = one launch per layer and phase after phase; 1 = co-schedule the
+                             actor phase of step i with the critic phase of step i+1 in
+                             gcrl_agent_update_n (they are independent: the critic phase reads the
+                             TARGET actor; same arithmetic, fewer launches); 2 = additionally run
+                             each phase's forward / input-gradient chain as ONE row-block launch
+                             (csrc/rowchain.h; needs hidden_dim % 4 == 0, else falls back to 1) */
   int32_t reserved;
 } gcrl_agent_config;
 
 gcrl_agent* gcrl_agent_create(const gcrl_agent_config* cfg);
+
+/* Measurement (bench.py's roofline leg): while enabled, gcrl_agent_update_n issues the row-block
+ * DDPG step (pipeline_steps = 2) as plain launches instead of graph replays and brackets every
+ * overlapped row-block launch (actor phase of step i || critic phase of step i+1) with two hipEvents
+ * on its stream and a device wall-clock stamp pair.  _read waits for the pending events and returns
+ * the launches since enabling, their summed hipEvent time (ms, includes the dispatch overhead of a
+ * bracketed launch) and their summed in-kernel time (last block end - first block start, the
+ * duration rocprofv3 reports).  Results are unchanged; only the issue path differs. */
+int gcrl_agent_profile_enable(gcrl_agent* a, int on);
+int gcrl_agent_profile_read(gcrl_agent* a, int64_t* launches_out, double* total_ms_out,
+                            double* device_clock_ms_out);
 void gcrl_agent_destroy(gcrl_agent* a);
 void* gcrl_agent_stream(const gcrl_agent* a);
 
