@@ -115,7 +115,8 @@ struct gcrl_agent {
   bool rowchain = false, wt_dirty = true;
   int row_rg = 1, row_ldl = 0;
   float *wt = nullptr, *rc_gC = nullptr, *rc_gA = nullptr, *ybuf = nullptr;
-  long long wt_net[4] = {};   // offsets of the four nets inside wt
+  long long wt_net[4] = {};   // offsets of actor | target actor | critic 0 | target critic 0 inside wt
+  long long wt_cstride = 0;   // critic c / target critic c at wt_net[2|3] + c*wt_cstride
   // measurement hooks (gcrl_agent_profile_*): event pair + device clock around each row-block launch
   bool prof = false;
   static constexpr int kProfPairs = 64;
@@ -335,10 +336,22 @@ int sac_actor_forward(gcrl_agent* a, hipStream_t st, const float* X0, long long 
 // one graph); off in data-parallel runs, where the norm is of the all-reduced gradients
 enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32, V_FUSED_NORM = 64 };
 
+int adam_common(gcrl_agent* a, AdamArgs& ad);
+
+#include "agent_rowchain.inc"
+
 // ---------------------------------------------------------------- phase 0
 int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
   const int kind = a->cfg.kind, B = a->B, C = a->C, S = a->S, L = a->L, H = a->H;
   TRY(launch_begin_step(st, a->ctrl()));
+  if (a->rowchain) {
+    // row-block form: the whole critic phase up to the input gradients in one launch, then every dW|db
+    const PipeCtx kc{a->cur(), a->slot_ptr()};
+    TRY(rc_launch_chain(a, st, kc, kc, 1, (variant & V_NOISE) ? a->noise_in : nullptr));
+    Launches dw;
+    rc_add_dw(a, dw, kc, true, (variant & V_FUSED_NORM) != 0);
+    return dw.run(st);
+  }
   Launches crit;  // online critics on [s|a], activations kept for the backward
   for (int c = 0; c < C; ++c)
     chain_mlp(a, crit, 0, a->critic, a->P_critic(c), a->sa, a->ldx, a->slot_x, hid_C, c, a->q + (long long)c * B, 1, 0, EPI_NONE, B);
@@ -435,6 +448,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     if (kind == GCRL_AGENT_TD3) ad.clip[0] = -1.f;  // critic_1 is not clipped (src/agent.py:201)
     ad.polyak = (variant & V_POLYAK_C) ? 1 : 0;
     ad.metric_index = MET_CRITIC_GRAD;
+    if (a->rowchain) rc_adam_extras(a, ad, true);
     TRY(launch_adam(st, ad));
   }
   if (kind == GCRL_AGENT_TQC) {
@@ -445,9 +459,22 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     TRY(re.run(st));
     TRY(launch_mean_metric(st, a->cur(), a->qt, C * B, 1.0f, a->metrics_dev, MET_Q));
   }
-  if (kind == GCRL_AGENT_DDPG && (variant & V_POLYAK_A))  // before the actor step (src/agent.py:1397-1401)
+  if (kind == GCRL_AGENT_DDPG && (variant & V_POLYAK_A)) {  // before the actor step (src/agent.py:1397-1401)
     TRY(launch_polyak(st, a->P_actor(), a->P_tactor(), a->actor.numel, a->cfg.tau));
+    if (a->rowchain) {
+      const RowNet r = make_rownet(a, a->actor, a->P_tactor(), 1);
+      TRY(launch_wt_rebuild(st, r, const_cast<float*>(r.Wt)));
+    }
+  }
   if (!(variant & V_ACTOR)) return GCRL_OK;
+  if (a->rowchain) {
+    // row-block form of the actor phase: actor, stepped critic 0, both input-gradient chains; then dW|db
+    const PipeCtx pc{a->cur(), a->slot_ptr()};
+    TRY(rc_launch_chain(a, st, pc, pc, 2));
+    Launches dw;
+    rc_add_dw(a, dw, pc, false, (variant & V_FUSED_NORM) != 0);
+    return dw.run(st);
+  }
 
   const int nac = a->n_actor_critics();
   // actor forward on s; its action lands in the action columns of spa
@@ -569,6 +596,7 @@ int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   if (!a->sac) {  // actor_loss = -Q.mean() (dq2 holds the constant -1/B), folded into this launch
     ad.mean_x = a->q2; ad.mean_n = a->B; ad.mean_scale = -1.0f; ad.mean_index = MET_ACTOR_LOSS;
   }
+  if (a->rowchain) rc_adam_extras(a, ad, false);
   TRY(launch_adam(st, ad));
   if (a->sac) {
     AlphaArgs al;
@@ -591,7 +619,7 @@ int enqueue_phases(gcrl_agent* a, hipStream_t st, int variant, int mask) {
 }
 
 int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask) {
-  a->wt_dirty = true;   // this path steps / Polyak-averages parameters without their [in][out] copies
+  if (a->rowchain && a->wt_dirty) TRY(rc_rebuild_wt(a, st));
   if (!a->cfg.use_graph) return enqueue_phases(a, st, variant, mask);
   const int key = variant | (mask << 8);
   auto it = a->graphs.find(key);
@@ -817,20 +845,22 @@ int build(gcrl_agent* a) {
       {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH},
       {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
       {&a->hC2, L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H},
-      {&a->rc_gC, L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}};
+      {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}};
   // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
   {
     const long long per_a = (long long)round_up(S, 4) * H + (long long)(L - 1) * H * H;
     const long long per_c = (long long)a->ldx * H + (long long)(L - 1) * H * H;
+    a->wt_cstride = align_up(per_c, 64);
     a->wt_net[0] = 0; a->wt_net[1] = align_up(per_a, 64);
-    a->wt_net[2] = 2 * align_up(per_a, 64); a->wt_net[3] = a->wt_net[2] + align_up(per_c, 64);
-    wants.push_back({&a->wt, a->wt_net[3] + align_up(per_c, 64)});
+    a->wt_net[2] = 2 * align_up(per_a, 64); a->wt_net[3] = a->wt_net[2] + C * a->wt_cstride;
+    wants.push_back({&a->wt, a->wt_net[3] + C * a->wt_cstride});
     a->row_ldl = round_up(std::max(H, a->ldx), 4) + 4;
-    // fewest rows per block that keep both phases of a pipelined step within one wave of blocks
+    // fewest rows per block that keep a launch within one wave of blocks (DDPG launches both phases together)
+    const int phases = c.kind == GCRL_AGENT_DDPG ? 2 : 1;
     a->row_rg = 1;
-    while (a->row_rg < 4 && 2 * ((B + 4 * a->row_rg - 1) / (4 * a->row_rg)) > 256) a->row_rg *= 2;
-    a->rowchain = c.kind == GCRL_AGENT_DDPG && H % 4 == 0 && c.pipeline_steps >= 2 &&
-                  rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H) <= 160 * 1024;
+    while (a->row_rg < 4 && phases * ((B + 4 * a->row_rg - 1) / (4 * a->row_rg)) > 256) a->row_rg *= 2;
+    a->rowchain = (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3) && H % 4 == 0 && c.pipeline_steps >= 2 &&
+                  rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H, C) <= 160 * 1024;
   }
   long long total = 0;
   for (auto& w : wants) total += align_up(w.second, 64);

@@ -33,6 +33,8 @@ int launch_shape(hipStream_t st, GemmBatch& gb) {
 //   larger                 : 32x32 per wave
 int shape_of(const GemmDesc& d) {
   const long long tiles16 = (long long)((d.M + 15) / 16) * ((d.N + 15) / 16);
+  // (tried: LDS-tiled for every long reduction, i.e. dW at batch >= 1024 — 20 tiles of 64x64 per problem
+  // each walking K alone was 2x slower than 272 k-split tiles; the k-split form stays)
   if (tiles16 <= 1024) return 1;
   // LDS-tiled 64x64 workgroup tiles (gemm_tiled.h) once a problem alone fills most CUs with
   // them (>= 192 tiles of 64x64); in between, one 16x16 tile per wave keeps more CUs busy

@@ -83,6 +83,20 @@ int launch_td3_smooth(hipStream_t st, const StepCtrl* cur, float* act, long long
                       int ld, int B, int A, const float* eps, float policy_noise,
                       float noise_clamp, unsigned long long seed);
 
+// counter-hash normals of the device-RNG mode (TD3 smoothing noise, SAC eps when not injected)
+__device__ inline unsigned long long mix64d(unsigned long long z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__device__ inline float hash_normal(unsigned long long seed, unsigned long long ctr) {
+  const unsigned long long h = mix64d(mix64d(seed) + ctr);
+  const float u1 = ((float)((h >> 40) + 1)) * (1.0f / 16777217.0f);  // (0,1]
+  const float u2 = (float)((h >> 8) & 0xffffff) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
+}
+
 // ---- optimiser -------------------------------------------------------------------------
 constexpr int kNormBlocks = 64;
 constexpr int kMaxTransposed = 8;
@@ -110,14 +124,16 @@ struct AdamArgs {
   const float* mean_x; int mean_n; float mean_scale; int mean_index;
   // optional TD metrics of a DDPG critic step whose loss was formed inside the row-block kernel:
   // critic loss mean((q-y)^2), mean |q-y|, mean q from the per-row q / y it left behind (block (0,0))
-  const float* td_q; const float* td_y; int td_n;
+  // (td_q: [td_C][td_n], td_loss_kind LOSS_*; the sums td_loss_kernel would have formed)
+  const float* td_q; const float* td_y; int td_n; int td_C; int td_loss_kind;
   // optional [in][out] copies of weight matrices (rowchain.h streams them in the forward pass):
   // element i of tensor t = [tr_beg, tr_beg + out*in) also lands at wt[tr_dst + k*out + o]
   // optional end-of-step control advance: thread 0 of block (0,0) does what begin_step(shift)
   // would do for the next step (prev <- cur, cur <- table[cursor++]), saving that launch.  Legal
   // only when this launch reads the copies cur_b / prev_b (CtrlBlock)
   CtrlBlock* advance;
-  float* wt; int n_tr;
+  // net i's copies live at wt + i*wt_net_stride; wt_target: the same for the Polyak destination
+  float* wt; float* wt_target; long long wt_net_stride; int n_tr;
   long long tr_beg[kMaxTransposed], tr_dst[kMaxTransposed];
   int tr_out[kMaxTransposed], tr_in[kMaxTransposed];
 };

@@ -137,20 +137,6 @@ __global__ void fill_kernel(float* x, long long n, float v) {
   if (i < n) x[i] = v;
 }
 
-__device__ inline unsigned long long mix64d(unsigned long long z) {
-  z += 0x9e3779b97f4a7c15ull;
-  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-  return z ^ (z >> 31);
-}
-// standard normal from a 64-bit counter hash (Box-Muller); device-RNG mode only
-__device__ inline float hash_normal(unsigned long long seed, unsigned long long ctr) {
-  const unsigned long long h = mix64d(mix64d(seed) + ctr);
-  const float u1 = ((float)((h >> 40) + 1)) * (1.0f / 16777217.0f);  // (0,1]
-  const float u2 = (float)((h >> 8) & 0xffffff) * (1.0f / 16777216.0f);
-  return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
-}
-
 __global__ void td3_smooth_kernel(const StepCtrl* cur, float* act, long long slot_stride, int ld, int B,
                                   int A, const float* eps, float pn, float nc, unsigned long long seed) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,24 +215,40 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
       a.metrics[(long long)c.metrics_slot * kMetricFloats + a.mean_index] = a.mean_scale * (s / (float)a.mean_n);
   }
   if (a.td_q && blockIdx.x == 0 && net == 0) {
-    // same sums, in the same order, as td_loss_kernel forms for one critic
+    // same sums, in the same order, as td_loss_kernel forms
     __shared__ float scratch[4];
-    float loss = 0.f, td = 0.f, qs = 0.f;
+    const int C = a.td_C;
+    float loss[2] = {0.f, 0.f}, td = 0.f, qs = 0.f;
     for (int i = threadIdx.x; i < a.td_n; i += 256) {
-      const float q = a.td_q[i];
-      const float diff = __fsub_rn(q, a.td_y[i]);
-      loss += diff * diff;
-      td += fabsf(diff);
-      qs += q;
+      const float y = a.td_y[i];
+      float tdmax = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k < C) {
+          const float q = a.td_q[(long long)k * a.td_n + i];
+          const float diff = __fsub_rn(q, y);
+          const float ad = fabsf(diff);
+          if (a.td_loss_kind == LOSS_MSE) loss[k] += diff * diff;
+          else loss[k] += (ad < 1.0f) ? 0.5f * diff * diff : ad - 0.5f;
+          tdmax = fmaxf(tdmax, ad);
+          qs += q;
+        }
+      }
+      td += tdmax;
     }
-    loss = block_sum_256(loss, scratch);
+    float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k < C) {
+        const float s = block_sum_256(loss[k], scratch);
+        if (threadIdx.x == 0) met[MET_CRITIC_LOSS + k] = s / (float)a.td_n;
+      }
+    }
     td = block_sum_256(td, scratch);
     qs = block_sum_256(qs, scratch);
     if (threadIdx.x == 0) {
-      float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
-      met[MET_CRITIC_LOSS] = loss / (float)a.td_n;
       met[MET_TD] = td / (float)a.td_n;
-      met[MET_Q] = qs / (float)a.td_n;
+      met[MET_Q] = qs / (float)(a.td_n * C);
     }
   }
   const float gmul = gscale * s_coef;
@@ -261,6 +263,9 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2s), a.eps);
     pi = __fadd_rn(pi, __fdiv_rn(__fmul_rn(-step_size, mi), denom));
     p[i] = pi; m[i] = mi; v[i] = vi;
+    float ti = 0.f;
+    const bool pk = tp && a.polyak;
+    if (pk) { ti = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, tp[i])); tp[i] = ti; }
     if (a.wt) {
       // small code on purpose (the kernel's instructions are cold every step): a real loop
 #pragma unroll 1
@@ -268,11 +273,12 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
         const long long rel = i - a.tr_beg[t];
         if (rel >= 0 && rel < (long long)a.tr_out[t] * a.tr_in[t]) {
           const int o = (int)(rel / a.tr_in[t]), k = (int)(rel - (long long)o * a.tr_in[t]);
-          a.wt[a.tr_dst[t] + (long long)k * a.tr_out[t] + o] = pi;
+          const long long at = (long long)net * a.wt_net_stride + a.tr_dst[t] + (long long)k * a.tr_out[t] + o;
+          a.wt[at] = pi;
+          if (pk && a.wt_target) a.wt_target[at] = ti;
         }
       }
     }
-    if (tp && a.polyak) tp[i] = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, tp[i]));
   }
 }
 

@@ -177,12 +177,16 @@ struct RowNet {
 struct RowChainArgs {
   const StepCtrl* cur_k; const StepCtrl* cur_p;
   CtrlBlock* cb;   // block 0 refreshes cb->cur_b / prev_b (the optimiser launch reads those)
-  RowNet actor, tactor, critic, tcritic;
+  RowNet actor, tactor, critic[2], tcritic[2];
+  int C;                      // critics in the K role (1 DDPG, 2 TD3); the P role uses critic[0]
+  int target_kind, loss_kind; // TGT_DDPG (clamped) / TGT_MIN; LOSS_MSE / LOSS_SMOOTH_L1
+  // TD3 target-policy smoothing (src/agent.py:174-179): injected N(0,1) [B][A] or null (device RNG)
+  const float* noise; float policy_noise, noise_clamp; unsigned long long seed;
   const float* sa; const float* nsa; const float* rbuf; const float* dbuf;   // + batch_slot * slot_*
   long long slot_x, slot_rd;
   int ldx, ldl, B, S, A, Apad;
   int nblk_k, nblk_p;
-  float *hC, *gC, *q, *y, *dq;      // K: activations / pre-activation gradients [L][B][H], per-row scalars [B]
+  float *hC, *gC, *q, *y, *dq;      // K: activations / pre-activation gradients [C][L][B][H], q / dq [C][B], y [B]
   float *hA, *gA, *hC2, *q2, *dz;   // P: ..., critic activations (scratch), Q(s, pi(s)), d(pre-tanh) [B][Apad]
   float gamma, clamp_lo;
   unsigned long long* clk;   // profiling: {first block start, last block end} in wall_clock64 ticks, or null
@@ -190,7 +194,7 @@ struct RowChainArgs {
 
 // rows per workgroup = 4*rg, rg in {1, 2, 4}
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg);
-size_t rowchain_lds_bytes(int rg, int ldl, int A, int H);
+size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C);
 
 // (re)build the [in][out] copies of one net's hidden-layer weights from its parameter block
 int launch_wt_rebuild(hipStream_t st, const RowNet& net, float* Wt);

@@ -10,6 +10,8 @@
 //       d(pre-tanh) = da*(1-a^2); actor gradient chain, saved for dW.
 #include "rowchain.h"
 
+#include <algorithm>
+
 namespace gcrl {
 namespace {
 
@@ -77,17 +79,17 @@ template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int R = 4 * RG;
-  const int ldl = a.ldl, H = a.critic.H, S = a.S, A = a.A, B = a.B;
+  const int ldl = a.ldl, H = a.critic[0].H, S = a.S, A = a.A, B = a.B;
   float* X0 = lds;
   float* X1 = X0 + R * ldl;
   float* X2 = X1 + R * ldl;
   float* XS = X2 + R * ldl;               // second input rows (K) / last actor activation (P)
   float* part = XS + R * ldl;
-  float* sm = part + 4 * R * kRowChunk;   // [R][16] head outputs
+  float* sm = part + R * 16 + 4 * R * kRowChunk;   // [R][16] head outputs (part[0..R*16): smoothing noise)
   float* sm2 = sm + R * 16;               // [R][16] second small array
   float* sm3 = sm2 + R * 16;              // [R][16] reward / done
   float* hw = sm3 + R * 16;               // head weights of the role: [A*H | H | max(A*H, H)], then head biases [16 | 16]
-  float* hb = hw + (2 * A + 1) * H;
+  float* hb = hw + max(2 * A + 1, A + 2 * a.C) * H;
   const bool role_k = (int)blockIdx.x < a.nblk_k;
   const int blk = role_k ? (int)blockIdx.x : (int)blockIdx.x - a.nblk_k;
   const long long row0 = (long long)blk * R;
@@ -102,65 +104,93 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   // middle of the chain.
   if (role_k) {
     const StepCtrl c = *a.cur_k;
+    const int C = a.C;
     const float* ns_rows = a.nsa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
     const float* rr = a.rbuf + (long long)c.batch_slot * a.slot_rd + row0;
     const float* dd = a.dbuf + (long long)c.batch_slot * a.slot_rd + row0;
-    load_rows<RG>(X0, ldl, ns_rows, a.ldx, S, max(a.tactor.jpad0, a.tcritic.jpad0), rv);
-    load_rows<RG>(XS, ldl, sa_rows, a.ldx, S + A, a.critic.jpad0, rv);
+    load_rows<RG>(X0, ldl, ns_rows, a.ldx, S, max(a.tactor.jpad0, a.tcritic[0].jpad0), rv);
+    load_rows<RG>(XS, ldl, sa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
     if (tid < R) { sm3[tid * 16] = tid < rv ? rr[tid] : 0.f; sm3[tid * 16 + 1] = tid < rv ? dd[tid] : 0.f; }
-    float* hw_ta = hw; float* hw_tc = hw + A * H; float* hw_c = hw_tc + H;
+    float* hw_ta = hw; float* hw_tc = hw + A * H; float* hw_c = hw_tc + C * H;
     stage(hw_ta, a.tactor.P + a.tactor.w[a.tactor.L], A * H);
-    stage(hw_tc, a.tcritic.P + a.tcritic.w[a.tcritic.L], H);
-    stage(hw_c, a.critic.P + a.critic.w[a.critic.L], H);
+    for (int k = 0; k < C; ++k) {
+      stage(hw_tc + k * H, a.tcritic[k].P + a.tcritic[k].w[a.tcritic[k].L], H);
+      stage(hw_c + k * H, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
+    }
     if (tid < A) hb[tid] = a.tactor.P[a.tactor.b[a.tactor.L] + tid];
-    if (tid == 32) hb[16] = a.tcritic.P[a.tcritic.b[a.tcritic.L]];
-    if (tid == 33) hb[17] = a.critic.P[a.critic.b[a.critic.L]];
+    if (tid >= 32 && tid < 32 + C) hb[16 + (tid - 32)] = a.tcritic[tid - 32].P[a.tcritic[tid - 32].b[a.tcritic[tid - 32].L]];
+    if (tid >= 64 && tid < 64 + C) hb[18 + (tid - 64)] = a.critic[tid - 64].P[a.critic[tid - 64].b[a.critic[tid - 64].L]];
+    if (a.target_kind == TGT_MIN && tid < R * A) {
+      // smoothing noise of this block's rows, same draw as td3_smooth_kernel (element i = row*A + j)
+      const int r = tid / A, o = tid - r * A;
+      const long long i = (row0 + r) * A + o;
+      float e = 0.f;
+      if (r < rv) e = a.noise ? a.noise[i] : hash_normal(a.seed, (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
+      part[tid] = fminf(fmaxf(__fmul_rn(e, a.policy_noise), -a.noise_clamp), a.noise_clamp);
+    }
     __syncthreads();
-    // target actor on ns
-    float* h = mlp_hidden<RG>(a.tactor, X0, X1, X2, ldl, part, nullptr, BH, row0, rv);
+    // target actor on ns (+ clipped smoothing noise, TD3)
+    float* h = mlp_hidden<RG>(a.tactor, X0, X1, X2, ldl, part + R * 16, nullptr, BH, row0, rv);
     rows_head<RG>(h, ldl, H, hw_ta, H, hb, A, EPI_TANH, sm);
     __syncthreads();
-    if (tid < R * A) { const int r = tid / A, o = tid - r * A; X0[r * ldl + S + o] = sm[r * 16 + o]; }
+    if (tid < R * A) {
+      const int r = tid / A, o = tid - r * A;
+      float act = sm[r * 16 + o];
+      if (a.target_kind == TGT_MIN) act = fminf(fmaxf(__fadd_rn(act, part[tid]), -1.0f), 1.0f);
+      X0[r * ldl + S + o] = act;
+    }
     __syncthreads();
-    // target critic on [ns | a']
-    h = mlp_hidden<RG>(a.tcritic, X0, X1, X2, ldl, part, nullptr, BH, row0, rv);
-    rows_head<RG>(h, ldl, H, hw_tc, H, hb + 16, 1, EPI_NONE, sm);
-    __syncthreads();
+    // target critic(s) on [ns | a']
+    for (int k = 0; k < C; ++k) {
+      h = mlp_hidden<RG>(a.tcritic[k], X0, X1, X2, ldl, part + R * 16, nullptr, BH, row0, rv);
+      rows_head<RG>(h, ldl, H, hw_tc + k * H, H, hb + 16 + k, 1, EPI_NONE, sm + 4 + k);   // sm[r*16 + 4 + k]
+      __syncthreads();
+    }
     if (tid < R) {
-      // y = clamp(r + gamma*(1-d)*Q'(ns, pi'(ns)), -1/(1-gamma), 0): same roundings as td_loss_kernel
+      // y = r + gamma*(1-d)*tq, tq = Q' (DDPG, y clamped to [-1/(1-gamma), 0]) or min(Q1', Q2') (TD3):
+      // same roundings as td_loss_kernel
       const int r = tid;
-      float y = __fadd_rn(sm3[r * 16], __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, sm3[r * 16 + 1])), sm[r * 16]));
-      y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
+      const float tq = a.target_kind == TGT_MIN ? fminf(sm[r * 16 + 4], sm[r * 16 + 5]) : sm[r * 16 + 4];
+      float y = __fadd_rn(sm3[r * 16], __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, sm3[r * 16 + 1])), tq));
+      if (a.target_kind == TGT_DDPG) y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
       sm2[r * 16 + 1] = y;
+      if (r < rv) a.y[row0 + r] = y;
     }
-    // online critic on [s | a]
-    h = mlp_hidden<RG>(a.critic, XS, X1, X2, ldl, part, a.hC, BH, row0, rv);
-    rows_head<RG>(h, ldl, H, hw_c, H, hb + 17, 1, EPI_NONE, sm);
-    __syncthreads();
-    if (tid < R) {
-      const int r = tid;
-      const float q = sm[r * 16], y = sm2[r * 16 + 1];
-      const float g = (r < rv) ? (2.0f / (float)B) * __fsub_rn(q, y) : 0.f;   // d mse_loss / dq
-      sm2[r * 16] = g;
-      if (r < rv) { a.q[row0 + r] = q; a.y[row0 + r] = y; a.dq[row0 + r] = g; }
+    // online critic(s) on [s | a]: forward (activations saved), loss gradient, input-gradient chain
+    for (int k = 0; k < C; ++k) {
+      h = mlp_hidden<RG>(a.critic[k], XS, X1, X2, ldl, part + R * 16, a.hC + (long long)k * a.critic[k].L * BH, BH, row0, rv);
+      rows_head<RG>(h, ldl, H, hw_c + k * H, H, hb + 18 + k, 1, EPI_NONE, sm);
+      __syncthreads();
+      if (tid < R) {
+        const int r = tid;
+        const float q = sm[r * 16], y = sm2[r * 16 + 1];
+        const float diff = __fsub_rn(q, y);
+        float g;
+        if (a.loss_kind == LOSS_MSE) g = (2.0f / (float)B) * diff;            // d mse_loss / dq
+        else { const float n1 = 1.0f / (float)B; g = (diff < -1.0f) ? -n1 : (diff > 1.0f ? n1 : n1 * diff); }   // smooth-L1
+        if (r >= rv) g = 0.f;
+        sm2[r * 16] = g;
+        if (r < rv) { a.q[(long long)k * B + row0 + r] = q; a.dq[(long long)k * B + row0 + r] = g; }
+      }
+      __syncthreads();
+      float* gsave = a.gC + (long long)k * a.critic[k].L * BH;
+      head_backward<RG>(h, ldl, H, hw_c + k * H, 1, sm2, gsave + (a.critic[k].L - 1) * BH + row0 * H, rv);
+      __syncthreads();
+      grad_chain<RG>(a.critic[k], h, X1, X2, ldl, part + R * 16, a.hC + (long long)k * a.critic[k].L * BH, gsave, BH, row0, rv);
     }
-    __syncthreads();
-    head_backward<RG>(h, ldl, H, hw_c, 1, sm2, a.gC + (a.critic.L - 1) * BH + row0 * H, rv);
-    __syncthreads();
-    grad_chain<RG>(a.critic, h, X1, X2, ldl, part, a.hC, a.gC, BH, row0, rv);
   } else {
     const StepCtrl c = *a.cur_p;
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
-    load_rows<RG>(X0, ldl, sa_rows, a.ldx, S, max(a.actor.jpad0, a.critic.jpad0), rv);
+    load_rows<RG>(X0, ldl, sa_rows, a.ldx, S, max(a.actor.jpad0, a.critic[0].jpad0), rv);
     float* hw_a = hw; float* hw_c = hw + A * H; float* hw_da = hw_c + H;
     stage(hw_a, a.actor.P + a.actor.w[a.actor.L], A * H);
-    stage(hw_c, a.critic.P + a.critic.w[a.critic.L], H);
-    stage(hw_da, a.critic.Wt + a.critic.wt[0] + (long long)S * H, A * H);   // rows S..S+A-1 of W0^T
+    stage(hw_c, a.critic[0].P + a.critic[0].w[a.critic[0].L], H);
+    stage(hw_da, a.critic[0].Wt + a.critic[0].wt[0] + (long long)S * H, A * H);   // rows S..S+A-1 of W0^T
     if (tid < A) hb[tid] = a.actor.P[a.actor.b[a.actor.L] + tid];
-    if (tid == 32) hb[16] = a.critic.P[a.critic.b[a.critic.L]];
+    if (tid == 32) hb[16] = a.critic[0].P[a.critic[0].b[a.critic[0].L]];
     __syncthreads();
-    float* h = mlp_hidden<RG>(a.actor, X0, X1, X2, ldl, part, a.hA, BH, row0, rv);
+    float* h = mlp_hidden<RG>(a.actor, X0, X1, X2, ldl, part + R * 16, a.hA, BH, row0, rv);
     rows_head<RG>(h, ldl, H, hw_a, H, hb, A, EPI_TANH, sm);
     // keep the last actor activation: the critic chain reuses X1 / X2
     for (int i = tid; i < R * H; i += kRowThreads) { const int r = i / H, k = i - r * H; XS[r * ldl + k] = h[r * ldl + k]; }
@@ -168,7 +198,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     if (tid < R * A) { const int r = tid / A, o = tid - r * A; X0[r * ldl + S + o] = sm[r * 16 + o]; }
     __syncthreads();
     // critic on [s | pi(s)]
-    h = mlp_hidden<RG>(a.critic, X0, X1, X2, ldl, part, a.hC2, BH, row0, rv);
+    h = mlp_hidden<RG>(a.critic[0], X0, X1, X2, ldl, part + R * 16, a.hC2, BH, row0, rv);
     rows_head<RG>(h, ldl, H, hw_c, H, hb + 16, 1, EPI_NONE, sm2);
     __syncthreads();
     if (tid < R) {
@@ -178,7 +208,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     __syncthreads();
     head_backward<RG>(h, ldl, H, hw_c, 1, sm2, nullptr, rv);
     __syncthreads();
-    float* g0 = grad_chain<RG>(a.critic, h, X1, X2, ldl, part, a.hC2, nullptr, BH, row0, rv);
+    float* g0 = grad_chain<RG>(a.critic[0], h, X1, X2, ldl, part + R * 16, a.hC2, nullptr, BH, row0, rv);
     // da[r][j] = g0[r][:] . W0[:, S+j]  (row S+j of the [in][out] copy), then through the tanh
     rows_head<RG>(g0, ldl, H, hw_da, H, nullptr, A, EPI_NONE, sm2);
     __syncthreads();
@@ -192,7 +222,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     __syncthreads();
     head_backward<RG>(XS, ldl, H, hw_a, A, sm2, a.gA + (a.actor.L - 1) * BH + row0 * H, rv);
     __syncthreads();
-    grad_chain<RG>(a.actor, XS, X1, X2, ldl, part, a.hA, a.gA, BH, row0, rv);
+    grad_chain<RG>(a.actor, XS, X1, X2, ldl, part + R * 16, a.hA, a.gA, BH, row0, rv);
   }
   if (a.clk && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
@@ -210,15 +240,16 @@ __global__ void wt_rebuild_kernel(RowNet net, float* Wt) {
 
 }  // namespace
 
-size_t rowchain_lds_bytes(int rg, int ldl, int A, int H) {
+size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C) {
   const int R = 4 * rg;
-  return (size_t)(4 * R * ldl + 4 * R * kRowChunk + 3 * R * 16 + (2 * A + 1) * H + 32) * sizeof(float);
+  return (size_t)(4 * R * ldl + 4 * R * kRowChunk + 4 * R * 16 + std::max(2 * A + 1, A + 2 * C) * H + 32) * sizeof(float);
 }
 
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
   GCRL_CHECK_ARG(rg == 1 || rg == 2 || rg == 4, "rowchain: rows per block must be 4, 8 or 16");
-  GCRL_CHECK_ARG(a.critic.H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16, "rowchain: unsupported shape (H=%d, A=%d)", a.critic.H, a.A);
-  const size_t lds = rowchain_lds_bytes(rg, a.ldl, a.A, a.critic.H);
+  GCRL_CHECK_ARG(a.critic[0].H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16 && a.C >= 1 && a.C <= 2,
+                 "rowchain: unsupported shape (H=%d, A=%d, C=%d)", a.critic[0].H, a.A, a.C);
+  const size_t lds = rowchain_lds_bytes(rg, a.ldl, a.A, a.critic[0].H, a.C);
   GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain: %zu bytes of LDS needed", lds);
   const int grid = a.nblk_k + a.nblk_p;
   if (grid < 1) return GCRL_OK;
