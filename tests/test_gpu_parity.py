@@ -385,6 +385,48 @@ def test_row_block_ddpg_tracks_the_layer_per_launch_path(gcrl, H, L, B):
         assert np.array_equal(v1.flat(), v2.flat())
 
 
+@pytest.mark.parametrize("kind,H,L,B,S,A", [("TD3", 32, 2, 32, 10, 3), ("TD3", 128, 3, 1030, 23, 4), ("TD3", 64, 1, 7, 5, 16),
+                                              ("DDPG", 4, 2, 3, 3, 1), ("DDPG", 128, 8, 17, 30, 6), ("DDPG", 520, 2, 40, 12, 2)])
+def test_row_block_path_against_the_layer_per_launch_path_one_step(gcrl, kind, H, L, B, S, A):
+    """Shape sweep of the row-block kernels (ragged last row block, 1..8 hidden layers, 1..16
+    action dims, hidden width below / across the 256-column chunk, 4-/8-/16-row blocks): one update
+    with injected batches and noise from identical parameters must give the layer-per-launch
+    path's gradients, parameters and metrics to fp32 reordering accuracy."""
+    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent)[kind]
+    cfg = make_config(kind, hidden_dim=H, layer_count=L, batch_size=B, max_len=2000, grad_clip=0.7, ac_update_freq=1,
+                      policy_noise=0.2, noise_clamp=0.5)
+    gen = np.random.default_rng(H + L + B)
+    batch = (gen.standard_normal((B, S)).astype(np.float32), gen.uniform(-1, 1, (B, A)).astype(np.float32),
+             -(gen.uniform(size=(B, 1)) > 0.3).astype(np.float32), gen.standard_normal((B, S)).astype(np.float32),
+             (gen.uniform(size=(B, 1)) > 0.9).astype(np.float32))
+    noise = gen.standard_normal((B, A)).astype(np.float32)
+    agents = []
+    for level in (0, 2):
+        ag = cls(S, A, cfg, None, nenvs=1, gradient_step=40, rng="engine", seed=3, pipeline=level)
+        g2 = np.random.default_rng(9)
+        ag.actor.set_flat((0.3 * g2.standard_normal(ag.actor.numel())).astype(np.float32))
+        for c in ag.critics:
+            c.set_flat((0.3 * g2.standard_normal(c.numel())).astype(np.float32))
+        ag.update_target_network()
+        agents.append(ag)
+    outs = []
+    for ag in agents:
+        kw = dict(noise=torch.from_numpy(noise).cuda()) if kind == "TD3" else {}
+        tup = ag.update(1, batch=tuple(torch.from_numpy(x).cuda() for x in batch), **kw)
+        outs.append(np.array([float(x) for x in tup]))
+    assert np.allclose(outs[0], outs[1], rtol=1e-4, atol=1e-6), (outs[0], outs[1])
+    a0, a1 = agents
+    views = lambda ag: [("actor", ag.actor)] + [(f"critic_{i}", c) for i, c in enumerate(ag.critics)]
+    for (nm, v0), (_, v1) in zip(views(a0), views(a1)):
+        g0, g1 = v0.grad_flat(), v1.grad_flat()
+        scale = max(1e-6, float(np.abs(g0).max()))
+        assert float(np.abs(g0 - g1).max()) <= 2e-5 * scale + 1e-7, (nm, float(np.abs(g0 - g1).max()), scale)
+    for v0, v1 in [(a0.actor, a1.actor), (a0.critics[0], a1.critics[0]), (a0.target_critics[0], a1.target_critics[0]),
+                   (a0.target_actor, a1.target_actor)]:
+        d = np.abs(v0.flat() - v1.flat())
+        assert float(np.mean(d > 2e-5)) < 0.02 and float(d.max()) < 3e-3      # Adam turns ~0 gradients into +-lr
+
+
 def test_tuple_contract_and_td_error_array(gcrl):
     cfg = make_config("TD3", hidden_dim=32, layer_count=2, batch_size=16, ac_update_freq=2)
     ag = gcrl.TD3Agent(10, 3, cfg, None, nenvs=1, gradient_step=4, sync_metrics=True, rng="engine", seed=1)
