@@ -100,6 +100,12 @@ __device__ inline float hash_normal(unsigned long long seed, unsigned long long 
 // ---- optimiser -------------------------------------------------------------------------
 constexpr int kNormBlocks = 64;
 constexpr int kMaxTransposed = 8;
+constexpr int kMaxAdamSeg = 2 * kMaxTransposed + 2;
+// A net's parameter vector cut into block-sized work items: FLAT segments (256 consecutive elements per
+// block) and TILED [rows][cols] weight matrices (one 16x16 tile per block) whose updated values are also
+// written, through an LDS transpose, to an [cols][rows] copy (rowchain.h streams those): 64-byte runs
+// instead of 4-byte scattered stores (the scattered form cost 3.2 us of a 10.8 us launch).
+struct AdamSeg { long long beg, dst; int rows, cols; int blk0, nblk; int tiled, pad; };
 // partial[net][kNormBlocks] = sum of squares of block-strided chunks of g[net][n]
 int launch_sumsq(hipStream_t st, const float* g, long long n, long long net_stride, int nets,
                  float* partial);
@@ -127,15 +133,16 @@ struct AdamArgs {
   // (td_q: [td_C][td_n], td_loss_kind LOSS_*; the sums td_loss_kernel would have formed)
   const float* td_q; const float* td_y; int td_n; int td_C; int td_loss_kind;
   // optional [in][out] copies of weight matrices (rowchain.h streams them in the forward pass):
-  // element i of tensor t = [tr_beg, tr_beg + out*in) also lands at wt[tr_dst + k*out + o]
+  // element (o, k) of a tiled segment also lands at wt[seg.dst + k*rows + o].  With n_seg > 0 the
+  // launch covers the net by segments (seg_blocks blocks) instead of a flat grid-stride loop
   // optional end-of-step control advance: thread 0 of block (0,0) does what begin_step(shift)
   // would do for the next step (prev <- cur, cur <- table[cursor++]), saving that launch.  Legal
   // only when this launch reads the copies cur_b / prev_b (CtrlBlock)
   CtrlBlock* advance;
   // net i's copies live at wt + i*wt_net_stride; wt_target: the same for the Polyak destination
-  float* wt; float* wt_target; long long wt_net_stride; int n_tr;
-  long long tr_beg[kMaxTransposed], tr_dst[kMaxTransposed];
-  int tr_out[kMaxTransposed], tr_in[kMaxTransposed];
+  float* wt; float* wt_target; long long wt_net_stride;
+  int n_seg, seg_blocks;
+  AdamSeg seg[kMaxAdamSeg];
 };
 int launch_adam(hipStream_t st, const AdamArgs& a);
 int launch_adam_pair(hipStream_t st, const AdamArgs& a0, const AdamArgs& a1);  // two single-net steps, one launch

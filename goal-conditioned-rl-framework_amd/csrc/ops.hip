@@ -254,7 +254,9 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
   }
   const float gmul = gscale * s_coef;
   const float w1 = a.w1, w2 = a.w2, one_m_tau = a.one_m_tau;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+  const bool pk = tp && a.polyak;
+  // one element: torch's single-tensor Adam(W) op order; returns the new parameter, *ti the new target
+  auto step_one = [&](long long i, float* ti) -> float {
     const float gi = __fmul_rn(g[i], gmul);
     float pi = p[i];
     if (decay != 1.0f) pi = __fmul_rn(pi, decay);
@@ -264,21 +266,45 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2s), a.eps);
     pi = __fadd_rn(pi, __fdiv_rn(__fmul_rn(-step_size, mi), denom));
     p[i] = pi; m[i] = mi; v[i] = vi;
-    float ti = 0.f;
-    const bool pk = tp && a.polyak;
-    if (pk) { ti = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, tp[i])); tp[i] = ti; }
-    if (a.wt) {
-      // small code on purpose (the kernel's instructions are cold every step): a real loop
-#pragma unroll 1
-      for (int t = 0; t < a.n_tr; ++t) {
-        const long long rel = i - a.tr_beg[t];
-        if (rel >= 0 && rel < (long long)a.tr_out[t] * a.tr_in[t]) {
-          const int o = (int)(rel / a.tr_in[t]), k = (int)(rel - (long long)o * a.tr_in[t]);
-          const long long at = (long long)net * a.wt_net_stride + a.tr_dst[t] + (long long)k * a.tr_out[t] + o;
-          a.wt[at] = pi;
-          if (pk && a.wt_target) a.wt_target[at] = ti;
-        }
-      }
+    if (pk) { *ti = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, tp[i])); tp[i] = *ti; }
+    return pi;
+  };
+  if (a.n_seg == 0) {
+    float ti;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) step_one(i, &ti);
+    return;
+  }
+  int s = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxAdamSeg; ++q)
+    if (q < a.n_seg && (int)blockIdx.x >= a.seg[q].blk0) s = q;
+  const AdamSeg sg = a.seg[s];
+  const int lb = (int)blockIdx.x - sg.blk0;
+  if (lb >= sg.nblk) return;   // paired launches are sized for the larger net
+  if (!sg.tiled) {
+    const long long i = sg.beg + (long long)lb * 256 + threadIdx.x;
+    float ti;
+    if (i < sg.beg + (long long)sg.rows * sg.cols) step_one(i, &ti);
+    return;
+  }
+  __shared__ float tile_p[16][17], tile_t[16][17];
+  const int tiles_k = (sg.cols + 15) >> 4;
+  const int o0 = (lb / tiles_k) << 4, k0 = (lb % tiles_k) << 4;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  {
+    const int o = o0 + ty, k = k0 + tx;
+    float ti = 0.f, pi = 0.f;
+    if (o < sg.rows && k < sg.cols) pi = step_one(sg.beg + (long long)o * sg.cols + k, &ti);
+    tile_p[ty][tx] = pi;
+    tile_t[ty][tx] = ti;
+  }
+  __syncthreads();
+  {
+    const int k = k0 + ty, o = o0 + tx;   // 16 consecutive o per copy row: 64-byte runs
+    if (k < sg.cols && o < sg.rows) {
+      const long long at = (long long)net * a.wt_net_stride + sg.dst + (long long)k * sg.rows + o;
+      a.wt[at] = tile_p[tx][ty];
+      if (pk && a.wt_target) a.wt_target[at] = tile_t[tx][ty];
     }
   }
 }
@@ -366,14 +392,16 @@ static unsigned adam_blocks(long long n) {
 
 int launch_adam(hipStream_t st, const AdamArgs& a) {
   GCRL_CHECK_ARG(a.nets >= 1 && a.nets <= kMaxCritics, "adam: bad net count %d", a.nets);
-  hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(a.n), a.nets), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(adam_kernel, dim3(a.n_seg ? (unsigned)a.seg_blocks : adam_blocks(a.n), a.nets), dim3(256), 0, st, a);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
 
 int launch_adam_pair(hipStream_t st, const AdamArgs& a0, const AdamArgs& a1) {
   GCRL_CHECK_ARG(a0.nets == 1 && a1.nets == 1, "adam_pair: single-net argument sets only");
-  hipLaunchKernelGGL(adam_pair_kernel, dim3(adam_blocks(std::max(a0.n, a1.n)), 2), dim3(256), 0, st, a0, a1);
+  const unsigned b0 = a0.n_seg ? (unsigned)a0.seg_blocks : adam_blocks(a0.n);
+  const unsigned b1 = a1.n_seg ? (unsigned)a1.seg_blocks : adam_blocks(a1.n);
+  hipLaunchKernelGGL(adam_pair_kernel, dim3(std::max(b0, b1), 2), dim3(256), 0, st, a0, a1);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
