@@ -87,20 +87,67 @@ __device__ inline void rows_matmul_wave(const float* xs, int ldx, __amdgpu_buffe
 }
 
 // y = act(x . M + bias) [* act'(hprev)] for the block's rows; all kRowThreads threads call it.
-//   part   LDS scratch [4 waves][4*RG][kRowChunk]
+//   part   LDS scratch 2 x [4 waves][4*RG][kRowChunk] (two buffers, `pbuf` picks one)
 //   ys     LDS output [4*RG][ldy]   (must not alias xs)
 //   save   optional global copy of y: row r of the block at save[r*ld_save + c]
 //   mulH   dX form: y *= act'(mulH[r*ld_mul + c]) (saved post-activation of the layer below, global)
+//   chained (N <= kRowChunk only): wave w finishes exactly the columns that are ITS j-share of the
+//          next pass (whose J is this N), so the next pass may start without a second barrier — a
+//          wave reads back only what it wrote itself.  `part` alternates between two buffers (a fast
+//          wave's next exchange must not overwrite what a slow wave is still summing); whoever reads
+//          ys across waves afterwards (heads, element-wise steps) must __syncthreads() first.
 template <int RG>
 __device__ inline void rows_linear(const float* xs, int ldx, int J, const float* M, int ldm, int N, const float* bias,
                                    int epi, float* part, float* ys, int ldy, float* save, long long ld_save,
-                                   int rows_valid, const float* mulH = nullptr, long long ld_mul = 0, int mul = MUL_NONE) {
+                                   int rows_valid, const float* mulH = nullptr, long long ld_mul = 0, int mul = MUL_NONE,
+                                   bool chained = false, int pbuf = 0) {
   constexpr int R = 4 * RG;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const __amdgpu_buffer_rsrc_t rs = bounded_rsrc(M, (long long)J * ldm);
   const int per = ((J + 3) / 4 + 3) & ~3;
   const int jb = wave * per, je = min(J, jb + per);
+  if (chained) {
+    part += pbuf * (4 * R * kRowChunk);
+    // this wave's outputs: all rows x its share [cb, ce) of the next pass
+    const int pern = ((N + 3) / 4 + 3) & ~3, q4 = pern >> 2;   // float4 items per row
+    const int cb = wave * pern;
+    v4f eb[RG], eh[RG];
+#pragma unroll
+    for (int it = 0; it < RG; ++it) {
+      const int idx = lane + 64 * it, r = idx / q4, cc = cb + 4 * (idx - r * q4);
+      const bool ok = idx < R * q4 && cc < N;
+      eb[it] = (bias && ok) ? *(const v4f*)(bias + cc) : (v4f){0.f, 0.f, 0.f, 0.f};
+      eh[it] = (mulH && ok && r < rows_valid) ? *(const v4f*)(mulH + (long long)r * ld_mul + cc) : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    v4f acc[RG][4];
+    rows_matmul_wave<RG>(xs, ldx, rs, ldm, 0, jb, je, acc);
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *(v4f*)(part + ((wave * R + 4 * g + i) * kRowChunk) + 4 * lane) =
+            (v4f){acc[g][0][i], acc[g][1][i], acc[g][2][i], acc[g][3][i]};
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RG; ++it) {
+      const int idx = lane + 64 * it, r = idx / q4, cc = cb + 4 * (idx - r * q4);
+      if (idx < R * q4 && cc < N) {
+        v4f v = *(const v4f*)(part + r * kRowChunk + cc);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *(const v4f*)(part + (w * R + r) * kRowChunk + cc);
+        v += eb[it];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = act_apply(v[q], epi);
+          if (mul != MUL_NONE) v[q] *= act_deriv(eh[it][q], mul);
+        }
+        *(v4f*)(ys + r * ldy + cc) = v;
+        if (save && r < rows_valid) *(v4f*)(save + (long long)r * ld_save + cc) = v;
+      }
+    }
+    return;
+  }
   for (int c0 = 0; c0 < N; c0 += kRowChunk) {
     const int c = c0 + 4 * lane;
     // epilogue operands first: their latency hides behind the weight stream

@@ -31,12 +31,15 @@ __device__ inline float* mlp_hidden(const RowNet& net, const float* X0, float* X
                                     float* save, long long BH, long long row0, int rv) {
   const float* in = X0;
   float* out = X1;
+  const bool chained = RG == 1 && net.H <= kRowChunk;   // one barrier per layer (rows_linear); measured slower at 8 rows
   for (int l = 0; l < net.L; ++l) {
     rows_linear<RG>(in, ldl, l == 0 ? net.jpad0 : net.H, net.Wt + net.wt[l], net.H, net.H, net.P + net.b[l], EPI_LEAKY,
-                    part, out, ldl, save ? save + l * BH + row0 * net.H : nullptr, net.H, rv);
+                    part, out, ldl, save ? save + l * BH + row0 * net.H : nullptr, net.H, rv, nullptr, 0, MUL_NONE,
+                    chained, l & 1);
     in = out;
     out = (out == X1) ? X2 : X1;
   }
+  if (chained) __syncthreads();   // the callers read the result across waves
   return (float*)in;
 }
 
@@ -60,13 +63,15 @@ template <int RG>
 __device__ inline float* grad_chain(const RowNet& net, float* G, float* X1, float* X2, int ldl, float* part,
                                     const float* hsaved, float* gsave, long long BH, long long row0, int rv) {
   float* in = G;
+  const bool chained = RG == 1 && net.H <= kRowChunk;
   for (int l = net.L - 1; l >= 1; --l) {
     float* out = (in == X1) ? X2 : X1;
     rows_linear<RG>(in, ldl, net.H, net.P + net.w[l], net.H, net.H, nullptr, EPI_NONE, part, out, ldl,
                     gsave ? gsave + (l - 1) * BH + row0 * net.H : nullptr, net.H, rv,
-                    hsaved + (l - 1) * BH + row0 * net.H, net.H, MUL_DLEAKY);
+                    hsaved + (l - 1) * BH + row0 * net.H, net.H, MUL_DLEAKY, chained, l & 1);
     in = out;
   }
+  if (chained) __syncthreads();
   return in;
 }
 
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   float* X2 = X1 + R * ldl;
   float* XS = X2 + R * ldl;               // second input rows (K) / last actor activation (P)
   float* part = XS + R * ldl;
-  float* sm = part + R * 16 + 4 * R * kRowChunk;   // [R][16] head outputs (part[0..R*16): smoothing noise)
+  float* sm = part + R * 16 + (RG == 1 ? 2 : 1) * 4 * R * kRowChunk;   // [R][16] head outputs (part[0..R*16): smoothing noise; then 2 exchange buffers)
   float* sm2 = sm + R * 16;               // [R][16] second small array
   float* sm3 = sm2 + R * 16;              // [R][16] reward / done
   float* hw = sm3 + R * 16;               // head weights of the role: [A*H | H | max(A*H, H)], then head biases [16 | 16]
@@ -242,7 +247,7 @@ __global__ void wt_rebuild_kernel(RowNet net, float* Wt) {
 
 size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C) {
   const int R = 4 * rg;
-  return (size_t)(4 * R * ldl + 4 * R * kRowChunk + 4 * R * 16 + std::max(2 * A + 1, A + 2 * C) * H + 32) * sizeof(float);
+  return (size_t)(4 * R * ldl + (rg == 1 ? 2 : 1) * 4 * R * kRowChunk + 4 * R * 16 + std::max(2 * A + 1, A + 2 * C) * H + 32) * sizeof(float);
 }
 
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
