@@ -338,6 +338,12 @@ enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_
 
 int adam_common(gcrl_agent* a, AdamArgs& ad);
 
+// hipGraph replay pays when a step is many launches (31 per DDPG step launch-per-layer: 1.8 us per
+// dependent kernel in a graph vs ~5 us issued one by one); the row-block step is 3-7 launches issued
+// from a native loop, where plain launches measured 1.5-4 % faster than replaying graphs (a graph
+// launch itself idles the GPU ~8 us).  use_graph = 2 forces graphs everywhere.
+bool graph_on(const gcrl_agent* a) { return a->cfg.use_graph >= 2 || (a->cfg.use_graph == 1 && !a->rowchain); }
+
 #include "agent_rowchain.inc"
 
 // ---------------------------------------------------------------- phase 0
@@ -620,7 +626,7 @@ int enqueue_phases(gcrl_agent* a, hipStream_t st, int variant, int mask) {
 
 int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask) {
   if (a->rowchain && a->wt_dirty) TRY(rc_rebuild_wt(a, st));
-  if (!a->cfg.use_graph) return enqueue_phases(a, st, variant, mask);
+  if (!graph_on(a)) return enqueue_phases(a, st, variant, mask);
   const int key = variant | (mask << 8);
   auto it = a->graphs.find(key);
   if (it == a->graphs.end()) {

@@ -124,7 +124,7 @@ class _EngineAgent:
             alpha_lr=float(getattr(config, "alpha_lr", 0.0003)),
             ac_scheduler_steps=config.ac_scheduler_steps, cr_scheduler_steps=config.cr_scheduler_steps,
             alpha_min_steps=float(getattr(config, "alpha_min_steps", 10000)),
-            device=device_index, use_graph=1 if use_graph else 0, pipeline_steps=(2 if pipeline is True else int(pipeline)),
+            device=device_index, use_graph=int(use_graph), pipeline_steps=(2 if pipeline is True else int(pipeline)),
             seed=0 if seed is None else int(seed))
         self._h = _ffi.check_ptr(lib.gcrl_agent_create(C.byref(cfg)), "gcrl_agent_create")
         self._metric_cache: dict[int, list[float]] = {}

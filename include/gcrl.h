@@ -207,7 +207,8 @@ typedef struct gcrl_agent_config {
   int64_t ac_scheduler_steps, cr_scheduler_steps;
   double alpha_min_steps; /* SACAgentConfig.alpha_min_steps is a float (src/utils.py:39) */
   int32_t device;
-  int32_t use_graph;      /* 1: replay the step as a hipGraph */
+  int32_t use_graph;      /* 0: plain launches; 1: replay the step as a hipGraph where that pays (not on the
+                             3-7-launch row-block path, measured faster issued one by one); 2: always */
   uint64_t seed;          /* device RNG for TD3 noise / SAC eps when not injected */
   int32_t pipeline_steps; /* DDPG: 0 = one launch per layer and phase after phase; 1 = co-schedule the
                              actor phase of step i with the critic phase of step i+1 in

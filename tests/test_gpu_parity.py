@@ -186,7 +186,7 @@ def make_agent(gcrl, g, use_graph):
     return ag, views
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("use_graph", [False, 2])   # plain launches / hipGraph replay everywhere
 @pytest.mark.parametrize("tag", ["ddpg_reach", "ddpg_cosine", "ddpg_pickplace_h256", "td3", "sac", "tqc"])
 def test_update_matches_reference(gcrl, tag, use_graph):
     g = load_golden(f"update_{tag}.npz")
@@ -321,11 +321,11 @@ def test_update_many_equals_repeated_update(gcrl):
     assert np.array_equal(a1.actor.flat(), a2.actor.flat())
 
 
-def _ddpg_for_schedules(gcrl, H, L, pipeline, B=32, S=10, A=3):
+def _ddpg_for_schedules(gcrl, H, L, pipeline, B=32, S=10, A=3, use_graph=True):
     cfg = make_config("DDPG", hidden_dim=H, layer_count=L, batch_size=B, max_len=3000, grad_clip=0.5)
     gen = np.random.default_rng(4)
     eps = [her_oracle.synthetic_episode(gen, 50, S, A) for _ in range(3)]
-    ag = gcrl.DDPG(S, A, cfg, None, nenvs=1, gradient_step=40, rng="engine", seed=11, pipeline=pipeline)
+    ag = gcrl.DDPG(S, A, cfg, None, nenvs=1, gradient_step=40, rng="engine", seed=11, pipeline=pipeline, use_graph=use_graph)
     for ep in eps:
         for st in ep:
             ag.push_her(0, *st)
@@ -345,13 +345,13 @@ def _run_many(ag):
 
 # (sequential agent, overlapped agent): layer-per-launch path vs its co-scheduled form, and the
 # row-block path's update() (K then P) vs its overlapped update_many
-@pytest.mark.parametrize("levels", [(0, 1), (2, 2)])
+@pytest.mark.parametrize("levels", [(0, 1, True), (2, 2, True), (2, 2, 2)])   # (sequential, overlapped, use_graph of the latter)
 @pytest.mark.parametrize("H,L", [(32, 2), (64, 3)])
 def test_pipelined_ddpg_is_bitwise_the_sequential_path(gcrl, H, L, levels):
     """Software-pipelined update_many (actor phase of step i co-scheduled with the critic phase of
     step i+1) vs one update() per step, across two Polyak boundaries (steps 40 and 80) and an
     update_many call that starts mid-stream: every returned tuple and every parameter bitwise equal."""
-    a_seq, a_pipe = _ddpg_for_schedules(gcrl, H, L, levels[0]), _ddpg_for_schedules(gcrl, H, L, levels[1])
+    a_seq, a_pipe = _ddpg_for_schedules(gcrl, H, L, levels[0]), _ddpg_for_schedules(gcrl, H, L, levels[1], use_graph=levels[2])
     seq = [tuple(float(x) for x in a_seq.update(s)) for s in range(1, 91)]
     pipe = _run_many(a_pipe)
     assert len(seq) == len(pipe) == 90
