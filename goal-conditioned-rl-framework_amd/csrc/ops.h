@@ -110,6 +110,9 @@ struct AdamSeg { long long beg, dst; int rows, cols; int blk0, nblk; int tiled, 
 int launch_sumsq(hipStream_t st, const float* g, long long n, long long net_stride, int nets,
                  float* partial);
 
+int launch_sumsq2(hipStream_t st, const float* g0, long long n0, float* partial0, const float* g1, long long n1,
+                  float* partial1);
+
 struct AdamArgs {
   const StepCtrl* cur;
   int which;            // 0 actor, 1 critic, 2 alpha : selects the StepCtrl triple

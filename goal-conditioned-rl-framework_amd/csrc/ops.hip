@@ -164,6 +164,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long long n,
   if (threadIdx.x == 0) partial[blockIdx.y * kNormBlocks + blockIdx.x] = s;
 }
 
+// two vectors of different length, one launch (data-parallel overlapped step: critic and actor norms)
+__global__ __launch_bounds__(256) void sumsq2_kernel(const float* g0, long long n0, const float* g1, long long n1,
+                                                     float* partial0, float* partial1) {
+  __shared__ float scratch[4];
+  const float* gp = blockIdx.y ? g1 : g0;
+  const long long n = blockIdx.y ? n1 : n0;
+  const long long chunk = (n + kNormBlocks - 1) / kNormBlocks;
+  const long long beg = (long long)blockIdx.x * chunk;
+  const long long end = beg + chunk < n ? beg + chunk : n;
+  float s = 0.f;
+  for (long long i = beg + threadIdx.x; i < end; i += 256) s += gp[i] * gp[i];
+  s = block_sum_256(s, scratch);
+  if (threadIdx.x == 0) (blockIdx.y ? partial1 : partial0)[blockIdx.x] = s;
+}
+
 // ------------------------------------------------------------------ Adam / AdamW
 __device__ inline void adam_body(const AdamArgs& a, const int net) {
   __shared__ float s_coef;
@@ -388,6 +403,13 @@ static unsigned adam_blocks(long long n) {
   if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
   return (unsigned)blocks;
+}
+
+int launch_sumsq2(hipStream_t st, const float* g0, long long n0, float* partial0, const float* g1, long long n1,
+                  float* partial1) {
+  hipLaunchKernelGGL(sumsq2_kernel, dim3(kNormBlocks, 2), dim3(256), 0, st, g0, n0, g1, n1, partial0, partial1);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
 }
 
 int launch_adam(hipStream_t st, const AdamArgs& a) {
