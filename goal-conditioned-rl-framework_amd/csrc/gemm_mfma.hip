@@ -33,8 +33,10 @@ int launch_shape(hipStream_t st, GemmBatch& gb) {
 //   larger                 : 32x32 per wave
 int shape_of(const GemmDesc& d) {
   const long long tiles16 = (long long)((d.M + 15) / 16) * ((d.N + 15) / 16);
-  // (tried: LDS-tiled for every long reduction, i.e. dW at batch >= 1024 — 20 tiles of 64x64 per problem
-  // each walking K alone was 2x slower than 272 k-split tiles; the k-split form stays)
+  // (tried for long reductions, i.e. dW at batch >= 1024: LDS-tiled 64x64 — 20 tiles per problem each
+  // walking K alone, 2x slower; LDS-tiled 64x64 split over k-ranges of 256 plus a reduce pass — 41 + 5 us
+  // vs 32 us for TD3's 12 problems at B=2048: both forms move ~150 MB through L2, i.e. are L2-bound at
+  // this tile size; a 128x128 tile would halve that.  The k-split 16x16 form stays.)
   if (tiles16 <= 1024) return 1;
   // LDS-tiled 64x64 workgroup tiles (gemm_tiled.h) once a problem alone fills most CUs with
   // them (>= 192 tiles of 64x64); in between, one 16x16 tile per wave keeps more CUs busy
