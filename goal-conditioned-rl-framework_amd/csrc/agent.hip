@@ -342,7 +342,8 @@ int adam_common(gcrl_agent* a, AdamArgs& ad);
 // dependent kernel in a graph vs ~5 us issued one by one); the row-block step is 3-7 launches issued
 // from a native loop, where plain launches measured 1.5-4 % faster than replaying graphs (a graph
 // launch itself idles the GPU ~8 us).  use_graph = 2 forces graphs everywhere.
-bool graph_on(const gcrl_agent* a) { return a->cfg.use_graph >= 2 || (a->cfg.use_graph == 1 && !a->rowchain); }
+// (SAC keeps ~35 BatchNorm / head launches per step around its two row-block launches: graphs stay on)
+bool graph_on(const gcrl_agent* a) { return a->cfg.use_graph >= 2 || (a->cfg.use_graph == 1 && (!a->rowchain || a->sac)); }
 
 #include "agent_rowchain.inc"
 
@@ -352,6 +353,10 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
   TRY(launch_begin_step(st, a->ctrl()));
   if (a->rowchain) {
     // row-block form: the whole critic phase up to the input gradients in one launch, then every dW|db
+    // (SAC: the BatchNorm actor samples the next action first, into the action columns of nsa)
+    if (a->sac)
+      TRY(sac_actor_forward(a, st, a->nsa, a->slot_x, false, a->nsa + S, a->slot_x, a->logp_next,
+                            (variant & V_EPSN) ? a->eps_next_in : nullptr, 1, nullptr));
     const PipeCtx kc{a->cur(), a->slot_ptr()};
     TRY(rc_launch_chain(a, st, kc, kc, 1, (variant & V_NOISE) ? a->noise_in : nullptr));
     Launches dw;
@@ -473,7 +478,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     }
   }
   if (!(variant & V_ACTOR)) return GCRL_OK;
-  if (a->rowchain) {
+  if (a->rowchain && !a->sac) {
     // row-block form of the actor phase: actor, stepped critic 0, both input-gradient chains; then dW|db
     const PipeCtx pc{a->cur(), a->slot_ptr()};
     TRY(rc_launch_chain(a, st, pc, pc, 2));
@@ -492,9 +497,13 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     TRY(sac_actor_forward(a, st, a->spa, a->slot_x, true, a->spa + S, a->slot_x, a->logp,
                           (variant & V_EPSC) ? a->eps_cur_in : nullptr, 2, nullptr));
   }
+  if (a->rowchain) {   // SAC: both stepped critics, the min-selection gradient and their action gradients, one launch
+    const PipeCtx pc{a->cur(), a->slot_ptr()};
+    TRY(rc_launch_chain(a, st, pc, pc, 2));
+  }
   // stepped critic(s) on [s | pi(s)]
   Launches c2;
-  for (int c = 0; c < nac; ++c)
+  for (int c = 0; c < (a->rowchain ? 0 : nac); ++c)
     chain_mlp(a, c2, 0, a->critic, a->P_critic(c), a->spa, a->ldx, a->slot_x, hid_C, c, a->q2 + (long long)c * B, 1, 0, EPI_NONE, B);
   TRY(c2.run(st));
   if (a->sac) {
@@ -508,7 +517,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
   }
   // input gradient of the critic(s) down to the action columns
   Launches cb;
-  for (int c = 0; c < nac; ++c) {
+  for (int c = 0; c < (a->rowchain ? 0 : nac); ++c) {
     const float* P = a->P_critic(c);
     for (int l = L; l >= 1; --l) {
       const float* G = l == L ? a->dq2 + (long long)c * B : a->gC_at(c, l & 1);
@@ -602,7 +611,7 @@ int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   if (!a->sac) {  // actor_loss = -Q.mean() (dq2 holds the constant -1/B), folded into this launch
     ad.mean_x = a->q2; ad.mean_n = a->B; ad.mean_scale = -1.0f; ad.mean_index = MET_ACTOR_LOSS;
   }
-  if (a->rowchain) rc_adam_extras(a, ad, false);
+  if (a->rowchain && !a->sac) rc_adam_extras(a, ad, false);
   TRY(launch_adam(st, ad));
   if (a->sac) {
     AlphaArgs al;
@@ -850,7 +859,7 @@ int build(gcrl_agent* a) {
       {&a->norm_partial, (long long)kMaxCritics * kNormBlocks}, {&a->act_in, (long long)B * a->ldx},
       {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH},
       {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
-      {&a->hC2, L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H},
+      {&a->hC2, (long long)C * L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H},
       {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}};
   // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
   {
@@ -865,7 +874,8 @@ int build(gcrl_agent* a) {
     const int phases = c.kind == GCRL_AGENT_DDPG ? 2 : 1;
     a->row_rg = 1;
     while (a->row_rg < 4 && phases * ((B + 4 * a->row_rg - 1) / (4 * a->row_rg)) > 256) a->row_rg *= 2;
-    a->rowchain = (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3) && H % 4 == 0 && c.pipeline_steps >= 2 &&
+    a->rowchain = (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3 || c.kind == GCRL_AGENT_SAC) && H % 4 == 0 &&
+                  c.pipeline_steps >= 2 &&
                   rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H, C) <= 160 * 1024;
   }
   long long total = 0;
@@ -1125,7 +1135,7 @@ int gcrl_agent_update(gcrl_agent* a, gcrl_her* her, int64_t step, const gcrl_upd
   TRY(begin_call(a, her, step, 1, in, 1.0f, st, plans, ticket_out, &len));
   int variant = plans[0].variant | V_FUSED_NORM;
   if (in) TRY(stage_injected(a, in, st, &variant));
-  if (a->rowchain && variant == (V_ACTOR | V_FUSED_NORM)) {
+  if (a->rowchain && a->cfg.kind == GCRL_AGENT_DDPG && variant == (V_ACTOR | V_FUSED_NORM)) {
     TRY(run_ddpg_pipe(a, st, 1));   // the phases of a plain DDPG step, row-block kernels
     TRY(run_ddpg_pipe(a, st, 2));
   } else {

@@ -229,12 +229,19 @@ struct RowChainArgs {
   int target_kind, loss_kind; // TGT_DDPG (clamped) / TGT_MIN; LOSS_MSE / LOSS_SMOOTH_L1
   // TD3 target-policy smoothing (src/agent.py:174-179): injected N(0,1) [B][A] or null (device RNG)
   const float* noise; float policy_noise, noise_clamp; unsigned long long seed;
+  // SAC (the BatchNorm actor runs outside, src/agent.py:557-570, :516-521): the K role takes the next
+  // action from the action columns of nsa (given_next) and subtracts alpha*logp_next in the target
+  // (TGT_MIN_ENT); the P role is critic-only (p_critic_only): both critics on the rows of spa
+  // = [s | pi(s)], d(-min(q1,q2))/dq, each critic's input gradient w.r.t. the action into dz[c]
+  int given_next, p_critic_only;
+  const float* logp_next; float alpha;
+  const float* spa;
   const float* sa; const float* nsa; const float* rbuf; const float* dbuf;   // + batch_slot * slot_*
   long long slot_x, slot_rd;
   int ldx, ldl, B, S, A, Apad;
   int nblk_k, nblk_p;
   float *hC, *gC, *q, *y, *dq;      // K: activations / pre-activation gradients [C][L][B][H], q / dq [C][B], y [B]
-  float *hA, *gA, *hC2, *q2, *dz;   // P: ..., critic activations (scratch), Q(s, pi(s)), d(pre-tanh) [B][Apad]
+  float *hA, *gA, *hC2, *q2, *dz;   // P: ..., critic activations (scratch) [C][L][B][H], Q(s, pi(s)) [C][B], d(pre-tanh) [C][B][Apad]
   float gamma, clamp_lo;
   unsigned long long* clk;   // profiling: {first block start, last block end} in wall_clock64 ticks, or null
 };

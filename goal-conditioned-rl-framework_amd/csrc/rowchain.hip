@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   float* sm2 = sm + R * 16;               // [R][16] second small array
   float* sm3 = sm2 + R * 16;              // [R][16] reward / done
   float* hw = sm3 + R * 16;               // head weights of the role: [A*H | H | max(A*H, H)], then head biases [16 | 16]
-  float* hb = hw + max(2 * A + 1, A + 2 * a.C) * H;
+  float* hb = hw + max(max(2 * A + 1, A + 2 * a.C), a.C * (A + 1)) * H;
   const bool role_k = (int)blockIdx.x < a.nblk_k;
   const int blk = role_k ? (int)blockIdx.x : (int)blockIdx.x - a.nblk_k;
   const long long row0 = (long long)blk * R;
@@ -114,19 +114,22 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
     const float* rr = a.rbuf + (long long)c.batch_slot * a.slot_rd + row0;
     const float* dd = a.dbuf + (long long)c.batch_slot * a.slot_rd + row0;
-    load_rows<RG>(X0, ldl, ns_rows, a.ldx, S, max(a.tactor.jpad0, a.tcritic[0].jpad0), rv);
+    load_rows<RG>(X0, ldl, ns_rows, a.ldx, a.given_next ? S + A : S, max(a.tactor.jpad0, a.tcritic[0].jpad0), rv);
     load_rows<RG>(XS, ldl, sa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
-    if (tid < R) { sm3[tid * 16] = tid < rv ? rr[tid] : 0.f; sm3[tid * 16 + 1] = tid < rv ? dd[tid] : 0.f; }
+    if (tid < R) {
+      sm3[tid * 16] = tid < rv ? rr[tid] : 0.f; sm3[tid * 16 + 1] = tid < rv ? dd[tid] : 0.f;
+      sm3[tid * 16 + 2] = (a.logp_next && tid < rv) ? a.logp_next[row0 + tid] : 0.f;
+    }
     float* hw_ta = hw; float* hw_tc = hw + A * H; float* hw_c = hw_tc + C * H;
-    stage(hw_ta, a.tactor.P + a.tactor.w[a.tactor.L], A * H);
+    if (!a.given_next) stage(hw_ta, a.tactor.P + a.tactor.w[a.tactor.L], A * H);
     for (int k = 0; k < C; ++k) {
       stage(hw_tc + k * H, a.tcritic[k].P + a.tcritic[k].w[a.tcritic[k].L], H);
       stage(hw_c + k * H, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
     }
-    if (tid < A) hb[tid] = a.tactor.P[a.tactor.b[a.tactor.L] + tid];
+    if (tid < A && !a.given_next) hb[tid] = a.tactor.P[a.tactor.b[a.tactor.L] + tid];
     if (tid >= 32 && tid < 32 + C) hb[16 + (tid - 32)] = a.tcritic[tid - 32].P[a.tcritic[tid - 32].b[a.tcritic[tid - 32].L]];
     if (tid >= 64 && tid < 64 + C) hb[18 + (tid - 64)] = a.critic[tid - 64].P[a.critic[tid - 64].b[a.critic[tid - 64].L]];
-    if (a.target_kind == TGT_MIN && tid < R * A) {
+    if (a.target_kind == TGT_MIN && !a.given_next && tid < R * A) {
       // smoothing noise of this block's rows, same draw as td3_smooth_kernel (element i = row*A + j)
       const int r = tid / A, o = tid - r * A;
       const long long i = (row0 + r) * A + o;
@@ -135,17 +138,20 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
       part[tid] = fminf(fmaxf(__fmul_rn(e, a.policy_noise), -a.noise_clamp), a.noise_clamp);
     }
     __syncthreads();
-    // target actor on ns (+ clipped smoothing noise, TD3)
-    float* h = mlp_hidden<RG>(a.tactor, X0, X1, X2, ldl, part + R * 16, nullptr, BH, row0, rv);
-    rows_head<RG>(h, ldl, H, hw_ta, H, hb, A, EPI_TANH, sm);
-    __syncthreads();
-    if (tid < R * A) {
-      const int r = tid / A, o = tid - r * A;
-      float act = sm[r * 16 + o];
-      if (a.target_kind == TGT_MIN) act = fminf(fmaxf(__fadd_rn(act, part[tid]), -1.0f), 1.0f);
-      X0[r * ldl + S + o] = act;
+    float* h;
+    if (!a.given_next) {
+      // target actor on ns (+ clipped smoothing noise, TD3)
+      h = mlp_hidden<RG>(a.tactor, X0, X1, X2, ldl, part + R * 16, nullptr, BH, row0, rv);
+      rows_head<RG>(h, ldl, H, hw_ta, H, hb, A, EPI_TANH, sm);
+      __syncthreads();
+      if (tid < R * A) {
+        const int r = tid / A, o = tid - r * A;
+        float act = sm[r * 16 + o];
+        if (a.target_kind == TGT_MIN) act = fminf(fmaxf(__fadd_rn(act, part[tid]), -1.0f), 1.0f);
+        X0[r * ldl + S + o] = act;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // target critic(s) on [ns | a']
     for (int k = 0; k < C; ++k) {
       h = mlp_hidden<RG>(a.tcritic[k], X0, X1, X2, ldl, part + R * 16, nullptr, BH, row0, rv);
@@ -156,7 +162,8 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
       // y = r + gamma*(1-d)*tq, tq = Q' (DDPG, y clamped to [-1/(1-gamma), 0]) or min(Q1', Q2') (TD3):
       // same roundings as td_loss_kernel
       const int r = tid;
-      const float tq = a.target_kind == TGT_MIN ? fminf(sm[r * 16 + 4], sm[r * 16 + 5]) : sm[r * 16 + 4];
+      float tq = a.target_kind == TGT_DDPG ? sm[r * 16 + 4] : fminf(sm[r * 16 + 4], sm[r * 16 + 5]);
+      if (a.target_kind == TGT_MIN_ENT) tq = __fsub_rn(tq, __fmul_rn(a.alpha, sm3[r * 16 + 2]));
       float y = __fadd_rn(sm3[r * 16], __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, sm3[r * 16 + 1])), tq));
       if (a.target_kind == TGT_DDPG) y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
       sm2[r * 16 + 1] = y;
@@ -183,6 +190,53 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
       head_backward<RG>(h, ldl, H, hw_c + k * H, 1, sm2, gsave + (a.critic[k].L - 1) * BH + row0 * H, rv);
       __syncthreads();
       grad_chain<RG>(a.critic[k], h, X1, X2, ldl, part + R * 16, a.hC + (long long)k * a.critic[k].L * BH, gsave, BH, row0, rv);
+    }
+  } else if (a.p_critic_only) {
+    const StepCtrl c = *a.cur_p;
+    const int C = a.C;
+    const float* spa_rows = a.spa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
+    load_rows<RG>(X0, ldl, spa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
+    float* hw_c = hw; float* hw_da = hw + C * H;   // heads [C][H], then rows S..S+A-1 of each W0^T [C][A][H]
+    for (int k = 0; k < C; ++k) {
+      stage(hw_c + k * H, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
+      stage(hw_da + k * A * H, a.critic[k].Wt + a.critic[k].wt[0] + (long long)S * H, A * H);
+    }
+    if (tid < C) hb[tid] = a.critic[tid].P[a.critic[tid].b[a.critic[tid].L]];
+    __syncthreads();
+    for (int k = 0; k < C; ++k) {
+      float* h = mlp_hidden<RG>(a.critic[k], X0, X1, X2, ldl, part + R * 16, a.hC2 + (long long)k * a.critic[k].L * BH, BH, row0, rv);
+      rows_head<RG>(h, ldl, H, hw_c + k * H, H, hb + k, 1, EPI_NONE, sm + k);   // sm[r*16 + k]
+      __syncthreads();
+    }
+    if (tid < R) {
+      // d(-mean min(q1, q2))/dq: to the smaller, split on ties (actor_select_kernel)
+      const int r = tid;
+      const float q0 = sm[r * 16], q1 = C > 1 ? sm[r * 16 + 1] : INFINITY;
+      const float gb = r < rv ? -1.0f / (float)B : 0.f;
+      const float w0 = q0 < q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
+      sm2[r * 16] = gb * w0;
+      sm2[r * 16 + 1] = gb * (1.f - w0);
+      if (r < rv) { a.q2[row0 + r] = q0; if (C > 1) a.q2[(long long)B + row0 + r] = q1; }
+    }
+    __syncthreads();
+    for (int k = 0; k < C; ++k) {
+      const float* hs = a.hC2 + (long long)k * a.critic[k].L * BH;
+      const float* hsrc = hs + (a.critic[k].L - 1) * BH + row0 * H;
+      for (int i = tid; i < R * H; i += kRowThreads) {
+        const int r = i / H, kk = i - r * H;
+        XS[r * ldl + kk] = r < rv ? hsrc[(long long)r * H + kk] : 0.f;
+      }
+      __syncthreads();
+      head_backward<RG>(XS, ldl, H, hw_c + k * H, 1, sm2 + k, nullptr, rv);
+      __syncthreads();
+      float* g0 = grad_chain<RG>(a.critic[k], XS, X1, X2, ldl, part + R * 16, hs, nullptr, BH, row0, rv);
+      rows_head<RG>(g0, ldl, H, hw_da + k * A * H, H, nullptr, A, EPI_NONE, sm);
+      __syncthreads();
+      if (tid < R * A) {
+        const int r = tid / A, o = tid - r * A;
+        if (r < rv) a.dz[((long long)k * B + row0 + r) * a.Apad + o] = sm[r * 16 + o];
+      }
+      __syncthreads();
     }
   } else {
     const StepCtrl c = *a.cur_p;
@@ -247,7 +301,7 @@ __global__ void wt_rebuild_kernel(RowNet net, float* Wt) {
 
 size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C) {
   const int R = 4 * rg;
-  return (size_t)(4 * R * ldl + (rg == 1 ? 2 : 1) * 4 * R * kRowChunk + 4 * R * 16 + std::max(2 * A + 1, A + 2 * C) * H + 32) * sizeof(float);
+  return (size_t)(4 * R * ldl + (rg == 1 ? 2 : 1) * 4 * R * kRowChunk + 4 * R * 16 + std::max(std::max(2 * A + 1, A + 2 * C), C * (A + 1)) * H + 32) * sizeof(float);
 }
 
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
