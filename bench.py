@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=-1, help="schedule level (see gcrl_agent_config.pipeline_steps); -1: the default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,7 +190,7 @@ def main():
     cls = dict(DDPG=gcrl_amd.DDPG, TD3=gcrl_amd.TD3Agent, SAC=gcrl_amd.SACAgent, TQC=gcrl_amd.TQCAgent)[w["kind"]]
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        agent = cls(w["S"], w["A"], cfg, None, nenvs=8, gradient_step=w["gstep"], use_graph=not args.no_graph,
+        agent = cls(w["S"], w["A"], cfg, None, nenvs=8, gradient_step=w["gstep"], use_graph=not args.no_graph, pipeline=(True if args.pipeline < 0 else args.pipeline),
                     rng="engine", seed=rank_seed(1898, rank), device_index=local_rank)
         pool = episode_pool(w, 64, seed=1898 + rank)
         arrays = [episode_arrays(ep) for ep in pool]
