@@ -176,6 +176,11 @@ def check_ptr(p, what: str):
 def stream_handle(torch_stream=None) -> int:
     """hipStream_t of torch's current stream as the ABI wants it (0 -> legacy sentinel)."""
     import torch
-    s = torch_stream if torch_stream is not None else torch.cuda.current_stream()
-    h = int(s.cuda_stream)
+    if torch_stream is None:
+        try:   # raw handle straight from the C extension: torch.cuda.current_stream() costs ~10 us per call
+            h = int(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+            return h if h != 0 else STREAM_LEGACY
+        except AttributeError:
+            torch_stream = torch.cuda.current_stream()
+    h = int(torch_stream.cuda_stream)
     return h if h != 0 else STREAM_LEGACY
