@@ -295,33 +295,36 @@ __global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p)
   const int sub = lane >> 4, v4 = lane & 15;
   const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nwaves = (long long)gridDim.x * 4;
-  const int c0 = v4 * 4;
   const int o_r = p.SA4 + p.S4;
   clk_begin(p.clk);
-  for (long long r0 = wave_id * (4 * kUnroll); r0 < p.n; r0 += nwaves * (4 * kUnroll)) {
-    float4 val[kUnroll];
-    long long row[kUnroll];
+  // records wider than 64 floats (state dims above ~28) take further 64-float column passes
+  for (int cc = 0; cc < p.RS; cc += 64) {
+    const int c0 = cc + v4 * 4;
+    for (long long r0 = wave_id * (4 * kUnroll); r0 < p.n; r0 += nwaves * (4 * kUnroll)) {
+      float4 val[kUnroll];
+      long long row[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      row[u] = r0 + u * 4 + sub;
-      val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row[u] < p.n && c0 < p.RS) {
-        const long long phys = (p.head + (long long)p.idx[row[u]]) % p.cap;
-        val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
+      for (int u = 0; u < kUnroll; ++u) {
+        row[u] = r0 + u * 4 + sub;
+        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row[u] < p.n && c0 < p.RS) {
+          const long long phys = (p.head + (long long)p.idx[row[u]]) % p.cap;
+          val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
+        }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      if (row[u] >= p.n) continue;
-      const long long ro = row[u] * p.ldx;
-      if (c0 < p.SA4) {
-        *reinterpret_cast<float4*>(p.sa + ro + c0) = val[u];
-        if (c0 < p.S4) *reinterpret_cast<float4*>(p.spa + ro + c0) = val[u];
-      } else if (c0 < o_r) {
-        *reinterpret_cast<float4*>(p.nsa + ro + (c0 - p.SA4)) = val[u];
-      } else if (c0 == o_r) {
-        p.r[row[u]] = val[u].x;
-        p.d[row[u]] = val[u].y;
+      for (int u = 0; u < kUnroll; ++u) {
+        if (row[u] >= p.n) continue;
+        const long long ro = row[u] * p.ldx;
+        if (c0 < p.SA4) {
+          *reinterpret_cast<float4*>(p.sa + ro + c0) = val[u];
+          if (c0 < p.S4) *reinterpret_cast<float4*>(p.spa + ro + c0) = val[u];
+        } else if (c0 < o_r) {
+          *reinterpret_cast<float4*>(p.nsa + ro + (c0 - p.SA4)) = val[u];
+        } else if (c0 == o_r) {
+          p.r[row[u]] = val[u].x;
+          p.d[row[u]] = val[u].y;
+        }
       }
     }
   }
@@ -485,7 +488,6 @@ int her_upload_indices(gcrl_her* h, int B, int M, const uint32_t* idx_host, hipS
 int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa, float* nsa,
                       float* spa, int ldx, float* r, float* d, hipStream_t st) {
   if (ldx != h->SA4) return fail(GCRL_ERR_ARG, "her_gather_update: batch row stride %d != roundup(S+A,4) = %d", ldx, h->SA4);
-  if (h->RS > 64) return fail(GCRL_ERR_ARG, "her_gather_update: records wider than 64 floats are not supported by the engine gather");
   if (int rc = prof_begin(h, st)) return rc;
   GatherUpdArgs ga{h->ring, idx_dev, n, h->head, h->cfg.capacity, h->SA4, h->S4, h->RS, ldx, sa, nsa, spa, r, d, prof_slot(h)};
   constexpr int kUnroll = 4;

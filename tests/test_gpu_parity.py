@@ -269,11 +269,12 @@ def test_adam_moments_match_reference(gcrl):
 
 
 # ------------------------------------------------------------------ end to end vs the oracle, sampling path
-@pytest.mark.parametrize("kind", ["DDPG", "TD3"])
-def test_sampled_updates_track_oracle(gcrl, kind):
+@pytest.mark.parametrize("kind,S,A", [("DDPG", 10, 3), ("TD3", 10, 3), ("DDPG", 41, 7), ("TD3", 62, 2)])
+def test_sampled_updates_track_oracle(gcrl, kind, S, A):
     """push -> flush -> sample -> update, three steps, engine RNG == oracle RNG; deterministic
-    agents only (SAC/TQC draw device noise when nothing is injected)."""
-    S, A, B = 10, 3, 64
+    agents only (SAC/TQC draw device noise when nothing is injected).  The wide state dims put the
+    ring record past 64 floats (second column pass of the engine's batch gather)."""
+    B = 64
     cfg = make_config(kind, hidden_dim=32, layer_count=2, batch_size=B, max_len=5000, ac_update_freq=1,
                       policy_noise=0.0, noise_clamp=0.5, grad_clip=5.0)
     cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent)[kind]
