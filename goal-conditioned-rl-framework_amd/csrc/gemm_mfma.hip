@@ -36,7 +36,9 @@ int shape_of(const GemmDesc& d) {
   // (tried for long reductions, i.e. dW at batch >= 1024: LDS-tiled 64x64 — 20 tiles per problem each
   // walking K alone, 2x slower; LDS-tiled 64x64 split over k-ranges of 256 plus a reduce pass — 41 + 5 us
   // vs 32 us for TD3's 12 problems at B=2048: both forms move ~150 MB through L2, i.e. are L2-bound at
-  // this tile size; a 128x128 tile would halve that.  The k-split 16x16 form stays.)
+  // this tile size.  Also tried: a dW-specialised kernel with 128x128 tiles, batch-major operand rows copied to
+  // LDS as they lie in memory and 4-byte fragment reads — correct, but 1.8 us per 16-row stage with one
+  // workgroup per CU (2x its MFMA time) and slower end to end.  The k-split 16x16 form stays.)
   if (tiles16 <= 1024) return 1;
   // LDS-tiled 64x64 workgroup tiles (gemm_tiled.h) once a problem alone fills most CUs with
   // them (>= 192 tiles of 64x64); in between, one 16x16 tile per wave keeps more CUs busy
