@@ -1005,6 +1005,11 @@ void gcrl_agent_destroy(gcrl_agent* a) {
   for (int i = 0; i < kEventRing; ++i) if (a->call_ev[i]) (void)hipEventDestroy(a->call_ev[i]);
   if (a->metrics_host) (void)hipHostFree(a->metrics_host);
   if (a->metrics_dev) (void)hipFree(a->metrics_dev);
+  if (a->prof_clk) (void)hipFree(a->prof_clk);
+  for (int i = 0; i < gcrl_agent::kProfPairs; ++i) {
+    if (a->prof_a[i]) (void)hipEventDestroy(a->prof_a[i]);
+    if (a->prof_b[i]) (void)hipEventDestroy(a->prof_b[i]);
+  }
   if (a->stream) (void)hipStreamDestroy(a->stream);
   if (a->cap_stream) (void)hipStreamDestroy(a->cap_stream);
   delete a;
