@@ -28,11 +28,12 @@ __device__ inline void load_rows(float* X, int ldl, const float* src, long long 
 // buffer holding the last hidden activation.  save: [L][B][H] global, row r0 of the block.
 template <int RG>
 __device__ inline float* mlp_hidden(const RowNet& net, const float* X0, float* X1, float* X2, int ldl, float* part,
-                                    float* save, long long BH, long long row0, int rv) {
+                                    float* save, long long BH, long long row0, int rv, float* last_out = nullptr) {
   const float* in = X0;
   float* out = X1;
   const bool chained = RG == 1 && net.H <= kRowChunk;   // one barrier per layer (rows_linear); measured slower at 8 rows
   for (int l = 0; l < net.L; ++l) {
+    if (last_out && l == net.L - 1) out = last_out;   // e.g. kept aside while the ping-pong buffers are reused
     rows_linear<RG>(in, ldl, l == 0 ? net.jpad0 : net.H, net.Wt + net.wt[l], net.H, net.H, net.P + net.b[l], EPI_LEAKY,
                     part, out, ldl, save ? save + l * BH + row0 * net.H : nullptr, net.H, rv, nullptr, 0, MUL_NONE,
                     chained, l & 1);
@@ -76,8 +77,53 @@ __device__ inline float* grad_chain(const RowNet& net, float* G, float* X1, floa
 }
 
 // stage `n` floats of global memory into LDS (all threads)
+// Prologue staging in two phases — every global load of the block's inputs is requested (into registers)
+// before the first LDS store waits for any of them: the phases used to alternate per region and the
+// prologue was seven memory round trips (4.9 us) long.
+template <int N>
+struct Staged { float v[N]; };
+
+template <int N>
+__device__ inline void seg_load(Staged<N>& s, const float* src, int n) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) { const int i = threadIdx.x + u * kRowThreads; s.v[u] = i < n ? src[i] : 0.f; }
+}
+template <int N>
+__device__ inline void seg_store(const Staged<N>& s, float* dst, const float* src, int n) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) { const int i = threadIdx.x + u * kRowThreads; if (i < n) dst[i] = s.v[u]; }
+  for (int i = threadIdx.x + N * kRowThreads; i < n; i += kRowThreads) dst[i] = src[i];   // oversize regions: the rest directly
+}
+template <int RG, int N>
+__device__ inline void rows_load(Staged<N>& s, const float* src, long long ld_src, int ncols, int jpad, int rv) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int i = threadIdx.x + u * kRowThreads, r = i / jpad, c = i - r * jpad;
+    s.v[u] = (i < 4 * RG * jpad && r < rv && c < ncols) ? src[(long long)r * ld_src + c] : 0.f;
+  }
+}
+template <int RG, int N>
+__device__ inline void rows_store(const Staged<N>& s, float* X, int ldl, const float* src, long long ld_src, int ncols, int jpad, int rv) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int i = threadIdx.x + u * kRowThreads, r = i / jpad, c = i - r * jpad;
+    if (i < 4 * RG * jpad) X[r * ldl + c] = s.v[u];
+  }
+  for (int i = threadIdx.x + N * kRowThreads; i < 4 * RG * jpad; i += kRowThreads) {
+    const int r = i / jpad, c = i - r * jpad;
+    X[r * ldl + c] = (r < rv && c < ncols) ? src[(long long)r * ld_src + c] : 0.f;
+  }
+}
+
+// (eight loads in flight per thread before the first LDS store: one memory round trip per 2048 floats)
 __device__ inline void stage(float* dst, const float* src, int n) {
-  for (int i = threadIdx.x; i < n; i += kRowThreads) dst[i] = src[i];
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * kRowThreads) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * kRowThreads; v[u] = i < n ? src[i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * kRowThreads; if (i < n) dst[i] = v[u]; }
+  }
 }
 
 template <int RG>
@@ -114,21 +160,41 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
     const float* rr = a.rbuf + (long long)c.batch_slot * a.slot_rd + row0;
     const float* dd = a.dbuf + (long long)c.batch_slot * a.slot_rd + row0;
-    load_rows<RG>(X0, ldl, ns_rows, a.ldx, a.given_next ? S + A : S, max(a.tactor.jpad0, a.tcritic[0].jpad0), rv);
-    load_rows<RG>(XS, ldl, sa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
-    if (tid < R) {
-      sm3[tid * 16] = tid < rv ? rr[tid] : 0.f; sm3[tid * 16 + 1] = tid < rv ? dd[tid] : 0.f;
-      sm3[tid * 16 + 2] = (a.logp_next && tid < rv) ? a.logp_next[row0 + tid] : 0.f;
-    }
+    constexpr int NX = 2 * RG;   // covers row widths up to 128 floats
+    const int jp_ns = max(a.tactor.jpad0, a.tcritic[0].jpad0), nc_ns = a.given_next ? S + A : S;
     float* hw_ta = hw; float* hw_tc = hw + A * H; float* hw_c = hw_tc + C * H;
-    if (!a.given_next) stage(hw_ta, a.tactor.P + a.tactor.w[a.tactor.L], A * H);
-    for (int k = 0; k < C; ++k) {
-      stage(hw_tc + k * H, a.tcritic[k].P + a.tcritic[k].w[a.tcritic[k].L], H);
-      stage(hw_c + k * H, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
-    }
-    if (tid < A && !a.given_next) hb[tid] = a.tactor.P[a.tactor.b[a.tactor.L] + tid];
-    if (tid >= 32 && tid < 32 + C) hb[16 + (tid - 32)] = a.tcritic[tid - 32].P[a.tcritic[tid - 32].b[a.tcritic[tid - 32].L]];
-    if (tid >= 64 && tid < 64 + C) hb[18 + (tid - 64)] = a.critic[tid - 64].P[a.critic[tid - 64].b[a.critic[tid - 64].L]];
+    const float* src_ta = a.tactor.P + a.tactor.w[a.tactor.L];
+    // phase 1: request everything
+    Staged<NX> s_ns, s_sa;
+    rows_load<RG>(s_ns, ns_rows, a.ldx, nc_ns, jp_ns, rv);
+    rows_load<RG>(s_sa, sa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
+    float v_r = 0.f, v_d = 0.f, v_lp = 0.f, v_hb = 0.f;
+    if (tid < R && tid < rv) { v_r = rr[tid]; v_d = dd[tid]; if (a.logp_next) v_lp = a.logp_next[row0 + tid]; }
+    if (tid < A && !a.given_next) v_hb = a.tactor.P[a.tactor.b[a.tactor.L] + tid];
+    if (tid >= 32 && tid < 32 + C) v_hb = a.tcritic[tid - 32].P[a.tcritic[tid - 32].b[a.tcritic[tid - 32].L]];
+    if (tid >= 64 && tid < 64 + C) v_hb = a.critic[tid - 64].P[a.critic[tid - 64].b[a.critic[tid - 64].L]];
+    Staged<8> s_ta, s_tc[2], s_c[2];
+    if (!a.given_next) seg_load(s_ta, src_ta, A * H);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (k < C) {
+        seg_load(s_tc[k], a.tcritic[k].P + a.tcritic[k].w[a.tcritic[k].L], H);
+        seg_load(s_c[k], a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
+      }
+    // phase 2: into LDS
+    rows_store<RG>(s_ns, X0, ldl, ns_rows, a.ldx, nc_ns, jp_ns, rv);
+    rows_store<RG>(s_sa, XS, ldl, sa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
+    if (tid < R) { sm3[tid * 16] = v_r; sm3[tid * 16 + 1] = v_d; sm3[tid * 16 + 2] = v_lp; }
+    if (tid < A && !a.given_next) hb[tid] = v_hb;
+    if (tid >= 32 && tid < 32 + C) hb[16 + (tid - 32)] = v_hb;
+    if (tid >= 64 && tid < 64 + C) hb[18 + (tid - 64)] = v_hb;
+    if (!a.given_next) seg_store(s_ta, hw_ta, src_ta, A * H);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (k < C) {
+        seg_store(s_tc[k], hw_tc + k * H, a.tcritic[k].P + a.tcritic[k].w[a.tcritic[k].L], H);
+        seg_store(s_c[k], hw_c + k * H, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
+      }
     if (a.target_kind == TGT_MIN && !a.given_next && tid < R * A) {
       // smoothing noise of this block's rows, same draw as td3_smooth_kernel (element i = row*A + j)
       const int r = tid / A, o = tid - r * A;
@@ -241,18 +307,31 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   } else {
     const StepCtrl c = *a.cur_p;
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
-    load_rows<RG>(X0, ldl, sa_rows, a.ldx, S, max(a.actor.jpad0, a.critic[0].jpad0), rv);
+    constexpr int NX = 2 * RG;
+    const int jp_s = max(a.actor.jpad0, a.critic[0].jpad0);
     float* hw_a = hw; float* hw_c = hw + A * H; float* hw_da = hw_c + H;
-    stage(hw_a, a.actor.P + a.actor.w[a.actor.L], A * H);
-    stage(hw_c, a.critic[0].P + a.critic[0].w[a.critic[0].L], H);
-    stage(hw_da, a.critic[0].Wt + a.critic[0].wt[0] + (long long)S * H, A * H);   // rows S..S+A-1 of W0^T
-    if (tid < A) hb[tid] = a.actor.P[a.actor.b[a.actor.L] + tid];
-    if (tid == 32) hb[16] = a.critic[0].P[a.critic[0].b[a.critic[0].L]];
+    const float* src_a = a.actor.P + a.actor.w[a.actor.L];
+    const float* src_c = a.critic[0].P + a.critic[0].w[a.critic[0].L];
+    const float* src_da = a.critic[0].Wt + a.critic[0].wt[0] + (long long)S * H;   // rows S..S+A-1 of W0^T
+    Staged<NX> s_s;
+    rows_load<RG>(s_s, sa_rows, a.ldx, S, jp_s, rv);
+    Staged<8> s_a, s_hc, s_da;
+    seg_load(s_a, src_a, A * H);
+    seg_load(s_hc, src_c, H);
+    seg_load(s_da, src_da, A * H);
+    float v_hb = 0.f;
+    if (tid < A) v_hb = a.actor.P[a.actor.b[a.actor.L] + tid];
+    if (tid == 32) v_hb = a.critic[0].P[a.critic[0].b[a.critic[0].L]];
+    rows_store<RG>(s_s, X0, ldl, sa_rows, a.ldx, S, jp_s, rv);
+    seg_store(s_a, hw_a, src_a, A * H);
+    seg_store(s_hc, hw_c, src_c, H);
+    seg_store(s_da, hw_da, src_da, A * H);
+    if (tid < A) hb[tid] = v_hb;
+    if (tid == 32) hb[16] = v_hb;
     __syncthreads();
-    float* h = mlp_hidden<RG>(a.actor, X0, X1, X2, ldl, part + R * 16, a.hA, BH, row0, rv);
+    // the last actor activation lands in XS and stays there: the critic chain reuses X1 / X2
+    float* h = mlp_hidden<RG>(a.actor, X0, X1, X2, ldl, part + R * 16, a.hA, BH, row0, rv, XS);
     rows_head<RG>(h, ldl, H, hw_a, H, hb, A, EPI_TANH, sm);
-    // keep the last actor activation: the critic chain reuses X1 / X2
-    for (int i = tid; i < R * H; i += kRowThreads) { const int r = i / H, k = i - r * H; XS[r * ldl + k] = h[r * ldl + k]; }
     __syncthreads();
     if (tid < R * A) { const int r = tid / A, o = tid - r * A; X0[r * ldl + S + o] = sm[r * 16 + o]; }
     __syncthreads();
