@@ -47,6 +47,9 @@ __device__ inline float hash_normal(unsigned long long seed, unsigned long long 
 //   stage 2  grid (H/64, B/64): every block merges the <= B/64 partials of its columns in the same
 //            fixed order (Chan's parallel-variance merge / plain sums), then transforms its rows.
 // A block = 64 columns x 4 row groups of 16 rows; every wave-load is one coalesced 256-B row segment.
+// (Measured alternatives, both slower at B = 512 / H = 256: one launch with a block owning 16 columns and all
+// rows — 16 blocks, 2 695 vs 2 773 SAC steps/s; one launch on this grid with every block re-reducing its
+// columns over all rows — 128 dependent-latency loads per thread, 2 176 steps/s.)
 constexpr int kBnRows = 64;
 
 __device__ inline float col_sum4(float v, float (*red)[64], int cl, int rg) {
