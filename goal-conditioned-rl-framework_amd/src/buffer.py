@@ -28,13 +28,18 @@ class MTStream:
     HER picks, batch draws and the reference's own random.random() calls (src/agent.py:1348)
     interleave exactly as in the reference.  mode "engine": a private stream seeded once —
     bit-identical to the reference as long as nothing else consumes `random` in between,
-    without the ~30 us state round trip per call.
+    without the ~30 us state round trip per call.  mode "device": no MT stream at all — HER future
+    indices come from a counter hash evaluated inside the flush kernel (keyed by seed, episode number,
+    pick number) and batch indices from the same hash (keyed by draw number) with duplicates rejected;
+    NOT the reference's index stream (restated in oracle/her_oracle.py HashRng), for runs that do not
+    need index-level parity with a reference run.
     """
 
     def __init__(self, mode: str = "python", seed: int | None = None):
-        if mode not in ("python", "engine"):
-            raise ValueError(f"rng mode must be 'python' or 'engine', got {mode!r}")
+        if mode not in ("python", "engine", "device"):
+            raise ValueError(f"rng mode must be 'python', 'engine' or 'device', got {mode!r}")
         self.mode = mode
+        self.seed_value = 0 if seed is None else int(seed)
         self.handle = _ffi.check_ptr(lib.gcrl_mt_create(), "gcrl_mt_create")
         self._buf = (C.c_uint32 * 625)()
         if mode == "engine":
@@ -64,7 +69,7 @@ class MTStream:
         _pyrandom.setstate((3, tuple(self._buf), self._gauss))
 
     def random(self) -> float:
-        if self.mode == "python":
+        if self.mode in ("python", "device"):   # device mode: the ring never touches an MT stream
             return _pyrandom.random()
         return float(lib.gcrl_mt_random(self.handle))
 
@@ -134,7 +139,7 @@ class HERBuffer:
         cfg = _ffi.HerConfig(state_dim=S, action_dim=A, goal_dim=G, capacity=self.max_mem_len,
                              nenvs=self.nenvs, k_future=self.k_future, flush_len=FLUSH_LEN,
                              reward_kind=kind, reward_threshold=thr, device=self.device_index,
-                             rng_mode=0, seed=0)
+                             rng_mode=1 if self.rng.mode == "device" else 0, seed=self.rng.seed_value)
         self._h = _ffi.check_ptr(lib.gcrl_her_create(C.byref(cfg), self.rng.handle), "gcrl_her_create")
         self._dims = (S, A, G)
 

@@ -61,6 +61,8 @@ class HERBufferOracle:
         """:143-179 — original row, then k_future 'future' relabels for every step but the last."""
         episode = self.staged[idx]
         T = len(episode)
+        if hasattr(self.rng, "begin_episode"):      # HashRng: picks are keyed by episode number
+            self.rng.begin_episode()
         for i, (s, a, ns, r, d, dg, ag) in enumerate(episode):
             self.rows.append((s, a, ns, r, d, dg, ag))
             if i >= T - 1:
@@ -124,6 +126,38 @@ def mix64(z: int) -> int:
 def hash_below(seed: int, stream: int, ctr: int, n: int) -> int:
     h = mix64((mix64(seed ^ ((stream * 0xD1342543DE82EF95) & _M)) + ctr) & _M)
     return ((h >> 32) * n) >> 32
+
+
+class HashRng:
+    """The engine's device-RNG mode (GCRL_RNG_DEVICE) as a `random`-like object for HERBufferOracle:
+    randint() = the flush kernel's future pick (csrc/her_ring.hip her_flush_kernel: stream = episode
+    number, counter = pick number inside the episode), sample() = the batch draw (csrc/her_ring.hip /
+    agent.hip begin_call: stream = draw number, duplicates rejected)."""
+
+    def __init__(self, seed: int):
+        self.seed = int(seed)
+        self.episode = -1
+        self.pick = 0
+        self.draws = 0
+
+    def begin_episode(self):
+        self.episode += 1
+        self.pick = 0
+
+    def randint(self, a: int, b: int) -> int:
+        v = a + hash_below(self.seed, self.episode, self.pick, b - a + 1)
+        self.pick += 1
+        return v
+
+    def sample(self, population, k: int):
+        n, out, ctr = len(population), [], 0
+        while len(out) < k:
+            j = hash_below(self.seed ^ 0x5BD1E995, self.draws, ctr, n)
+            ctr += 1
+            if j not in out:
+                out.append(j)
+        self.draws += 1
+        return [population[j] for j in out]
 
 
 def synthetic_episode(rng: np.random.Generator, T: int, S: int, A: int, G: int = 3):

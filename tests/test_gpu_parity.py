@@ -137,6 +137,47 @@ def test_her_engine_rng_equals_python_rng_and_oracle(gcrl):
             assert np.array_equal(bits(gt.cpu().numpy()), bits(w))
 
 
+def test_device_rng_mode_equals_its_restatement(gcrl):
+    """rng="device": future picks by a counter hash inside the flush kernel, batch draws by the same hash
+    with duplicates rejected.  Not the reference's stream — pinned against oracle/her_oracle.py HashRng:
+    stored rows, sampled batches and the batches update_many consumes, bit-exact."""
+    S, A, B = 10, 3, 48
+    seed = 77
+    buf = gcrl.HERBuffer(5000, 50, 3, k_future=4, rng="device", seed=seed)
+    orc = her_oracle.HERBufferOracle(5000, 50, 3, k_future=4, rng=her_oracle.HashRng(seed))
+    buf.compute_reward = her_oracle.sparse_reward
+    gen = np.random.default_rng(8)
+    eps = [her_oracle.synthetic_episode(gen, T, S, A) for T in (50, 50, 50, 50, 50)]
+    # envs 0 and 1 finish together (flushed in env order), then three more episodes
+    for t in range(50):
+        for env in (0, 1):
+            buf.push(env, *eps[env][t]); orc.push(env, *eps[env][t])
+    for k, env in ((2, 2), (3, 0), (4, 1)):
+        for st in eps[k]:
+            buf.push(env, *st); orc.push(env, *st)
+    assert len(buf) == len(orc) == 5 * 246
+    for g, w in zip(buf.rows(), orc.as_arrays()):
+        assert np.array_equal(np.asarray(g).view(np.uint32), np.asarray(w).view(np.uint32))
+    for _ in range(3):
+        got = buf.sample(B)
+        want = orc.sample(B)
+        for g, w in zip(got, want):
+            assert np.array_equal(g.cpu().numpy(), np.asarray(w, dtype=np.float32).reshape(g.shape))
+    # the update engine draws with the same hash stream (its own draw counter continues the ring's)
+    cfg = make_config("DDPG", hidden_dim=32, layer_count=2, batch_size=B, max_len=5000)
+    ag = gcrl.DDPG(S, A, cfg, None, nenvs=2, gradient_step=3, rng="device", seed=seed)
+    orc2 = OracleAgent("DDPG", S, A, cfg, nenvs=2, gradient_step=3, rng=her_oracle.HashRng(seed))
+    for k in range(4):
+        for st in eps[k]:
+            ag.push_her(k % 2, torch.from_numpy(st[0]).cuda(), *st[1:]); orc2.push_her(k % 2, *st)
+    ag.actor.set_flat(orc2.flat_params(orc2.actor))
+    ag.critic.set_flat(orc2.flat_params(orc2.critics[0]))
+    ag.update_target_network(); orc2.hard_update()
+    for step, info in zip((1, 2, 3), ag.update_many(1, 3)):
+        ref = orc2.update(step)
+        assert np.allclose([float(x) for x in info], [float(np.asarray(x)) for x in ref], rtol=5e-5, atol=5e-6)
+
+
 def test_sample_errors_and_multi_batch(gcrl):
     buf = gcrl.HERBuffer(1000, 50, 1, rng="engine", seed=1)
     gen = np.random.default_rng(0)
