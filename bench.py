@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--rng", default="engine", choices=["engine", "device"], help="index streams: CPython-exact MT (default) or the counter hash")
     ap.add_argument("--pipeline", type=int, default=-1, help="schedule level (see gcrl_agent_config.pipeline_steps); -1: the default")
     args = ap.parse_args()
 
@@ -191,7 +192,7 @@ def main():
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         agent = cls(w["S"], w["A"], cfg, None, nenvs=8, gradient_step=w["gstep"], use_graph=not args.no_graph, pipeline=(True if args.pipeline < 0 else args.pipeline),
-                    rng="engine", seed=rank_seed(1898, rank), device_index=local_rank)
+                    rng=args.rng, seed=rank_seed(1898, rank), device_index=local_rank)
         pool = episode_pool(w, 64, seed=1898 + rank)
         arrays = [episode_arrays(ep) for ep in pool]
         rows_per_ep = 50 + w["k"] * 49
@@ -276,7 +277,8 @@ def main():
             "config": {"workload": args.workload, "agent": w["kind"], "batch_per_gpu": w["B"], "buffer_rows": len(agent.buffer),
                        "state_dim": w["S"], "action_dim": w["A"], "hidden": w["H"], "layers": w["L"], "k_future": w["k"],
                        "gradient_step": gstep, "parallelism": f"dp{world}" if world > 1 else "single",
-                       "hip_graph": not args.no_graph, "rng": "cpython-mt19937 (host) indices"},
+                       "hip_graph": not args.no_graph,
+                       "rng": "cpython-mt19937 (host) indices" if args.rng == "engine" else "counter-hash indices (in-kernel HER picks)"},
             "roofline_gather": {"kernel": "her_gather_update_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": launches.value, "avg_launch_us": avg_us, "rows_per_launch": rows_per_launch,

@@ -765,14 +765,8 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
       if (her->cfg.rng_mode == GCRL_RNG_CPYTHON_MT) {
         TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)a->B, idx + (size_t)i * a->B));
       } else {
-        uint32_t* out = idx + (size_t)i * a->B;
-        uint64_t ctr = 0;
-        for (int k = 0; k < a->B;) {
-          uint32_t j = hash_below(her->cfg.seed ^ 0x5bd1e995u, her->draws_done, ctr++, (uint32_t)her->len);
-          bool dup = false;
-          for (int q = 0; q < k; ++q) if (out[q] == j) { dup = true; break; }
-          if (!dup) out[k++] = j;
-        }
+        std::vector<uint32_t> table;
+        hash_draw_batch(her->cfg.seed, her->draws_done, (uint32_t)her->len, a->B, idx + (size_t)i * a->B, table);
         her->draws_done++;
       }
     }

@@ -37,6 +37,28 @@ __host__ __device__ inline uint32_t hash_below(uint64_t seed, uint64_t stream, u
   return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);  // multiply-high range reduction
 }
 
+// device-RNG batch draw (host side): the first B DISTINCT values of hash_below(seed, draw, ctr = 0, 1, ...)
+// in draw order (what oracle/her_oracle.py HashRng.sample restates); duplicates found through a small
+// open-addressing table instead of a scan of the batch so far (B = 2048: 4 M compares per batch)
+inline void hash_draw_batch(uint64_t seed, uint64_t draw, uint32_t n, int B, uint32_t* out, std::vector<uint32_t>& table) {
+  size_t cap = 64;
+  while (cap < (size_t)B * 2) cap <<= 1;
+  table.assign(cap, 0xffffffffu);
+  uint64_t ctr = 0;
+  for (int i = 0; i < B;) {
+    const uint32_t j = hash_below(seed ^ 0x5bd1e995u, draw, ctr++, n);
+    size_t slot = (j * 2654435761u) & (cap - 1);
+    bool dup = false;
+    while (table[slot] != 0xffffffffu) {
+      if (table[slot] == j) { dup = true; break; }
+      slot = (slot + 1) & (cap - 1);
+    }
+    if (dup) continue;
+    table[slot] = j;
+    out[i++] = j;
+  }
+}
+
 }  // namespace gcrl
 
 struct gcrl_her {

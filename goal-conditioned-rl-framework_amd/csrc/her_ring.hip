@@ -467,15 +467,9 @@ int her_upload_indices(gcrl_her* h, int B, int M, const uint32_t* idx_host, hipS
   } else {
     // device-RNG mode: uniform WITH the hash stream; exact without-replacement comes from
     // rejecting duplicates inside a batch, in draw order (restated in oracle/her_oracle.py)
+    std::vector<uint32_t> table;
     for (int m = 0; m < M; ++m) {
-      uint32_t* out = dst + (size_t)m * B;
-      uint64_t ctr = 0;
-      for (int i = 0; i < B;) {
-        uint32_t j = hash_below(h->cfg.seed ^ 0x5bd1e995u, h->draws_done, ctr++, (uint32_t)h->len);
-        bool dup = false;
-        for (int q = 0; q < i; ++q) if (out[q] == j) { dup = true; break; }
-        if (!dup) out[i++] = j;
-      }
+      hash_draw_batch(h->cfg.seed, h->draws_done, (uint32_t)h->len, B, dst + (size_t)m * B, table);
       h->draws_done++;
     }
   }
