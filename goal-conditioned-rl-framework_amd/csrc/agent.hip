@@ -760,22 +760,20 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
   }
   ub->cb.cur = table[0];
   size_t bytes = sizeof(UploadBlock);
-  if (!injected) {
-    for (int i = 0; i < n; ++i) {
-      if (her->cfg.rng_mode == GCRL_RNG_CPYTHON_MT) {
-        TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)a->B, idx + (size_t)i * a->B));
-      } else {
-        std::vector<uint32_t> table;
-        hash_draw_batch(her->cfg.seed, her->draws_done, (uint32_t)her->len, a->B, idx + (size_t)i * a->B, table);
-        her->draws_done++;
-      }
-    }
+  const bool device_rng = !injected && her->cfg.rng_mode != GCRL_RNG_CPYTHON_MT;
+  if (!injected && !device_rng) {
+    for (int i = 0; i < n; ++i)
+      TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)a->B, idx + (size_t)i * a->B));
     bytes += (size_t)n * a->B * sizeof(uint32_t);
+  }
+  if (device_rng) {   // the gather kernel computes the indices itself: nothing to draw or upload here
+    her->last_gen = IdxGen{her->cfg.seed, her->draws_done, (uint32_t)her->len, a->B, feistel_half_bits((uint32_t)her->len)};
+    her->draws_done += n;
   }
   GCRL_HIP(hipMemcpyAsync(a->upload_dev, ub, bytes, hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(a->upload_ev[slot], st));
   if (!injected)
-    TRY(her_gather_update(her, a->idx_dev(), (int64_t)n * a->B, a->sa, a->nsa, a->spa, a->ldx, a->rbuf, a->dbuf, st));
+    TRY(her_gather_update(her, device_rng ? nullptr : a->idx_dev(), (int64_t)n * a->B, a->sa, a->nsa, a->spa, a->ldx, a->rbuf, a->dbuf, st));
   return GCRL_OK;
 }
 

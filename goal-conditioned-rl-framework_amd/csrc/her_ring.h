@@ -37,26 +37,44 @@ __host__ __device__ inline uint32_t hash_below(uint64_t seed, uint64_t stream, u
   return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);  // multiply-high range reduction
 }
 
-// device-RNG batch draw (host side): the first B DISTINCT values of hash_below(seed, draw, ctr = 0, 1, ...)
-// in draw order (what oracle/her_oracle.py HashRng.sample restates); duplicates found through a small
-// open-addressing table instead of a scan of the batch so far (B = 2048: 4 M compares per batch)
-inline void hash_draw_batch(uint64_t seed, uint64_t draw, uint32_t n, int B, uint32_t* out, std::vector<uint32_t>& table) {
-  size_t cap = 64;
-  while (cap < (size_t)B * 2) cap <<= 1;
-  table.assign(cap, 0xffffffffu);
-  uint64_t ctr = 0;
-  for (int i = 0; i < B;) {
-    const uint32_t j = hash_below(seed ^ 0x5bd1e995u, draw, ctr++, n);
-    size_t slot = (j * 2654435761u) & (cap - 1);
-    bool dup = false;
-    while (table[slot] != 0xffffffffu) {
-      if (table[slot] == j) { dup = true; break; }
-      slot = (slot + 1) & (cap - 1);
+// device-RNG batch draw: batch element t of draw d is pi_{seed,d}(t), pi a keyed permutation of [0, n)
+// (a 4-round balanced Feistel network over the next even power of two, cycle-walked back into range).
+// A permutation gives the batch its without-replacement property by construction — no rejection, no
+// communication between the elements: every gather lane computes its own row index, so the device mode
+// needs neither a host RNG nor an index upload.  Restated in oracle/her_oracle.py (HashRng.sample).
+struct IdxGen {
+  uint64_t seed, draw0;   // draw number of the launch's first batch
+  uint32_t n;             // population (ring length)
+  int B, half_bits;       // batch size; the Feistel halves are half_bits wide
+};
+
+__host__ __device__ inline int feistel_half_bits(uint32_t n) {
+  int bits = 2;
+  while (bits < 32 && (1ull << bits) < (uint64_t)n) ++bits;
+  return (bits + 1) >> 1;
+}
+
+__host__ __device__ inline uint32_t feistel_index(uint64_t seed, uint64_t draw, uint32_t n, int hb, uint32_t t) {
+  const uint32_t mask = hb >= 32 ? 0xffffffffu : ((1u << hb) - 1u);
+  const uint64_t key = mix64(seed ^ (draw * 0xd1342543de82ef95ull) ^ 0x5bd1e995ull);
+  uint64_t x = t;
+  do {
+    uint32_t L = (uint32_t)(x >> hb) & mask, R = (uint32_t)x & mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t f = (uint32_t)(mix64(key + (uint64_t)r * 0x9e3779b97f4a7c15ull + R) >> 32) & mask;
+      const uint32_t nl = R;
+      R = L ^ f;
+      L = nl;
     }
-    if (dup) continue;
-    table[slot] = j;
-    out[i++] = j;
-  }
+    x = ((uint64_t)L << hb) | R;
+  } while (x >= (uint64_t)n);
+  return (uint32_t)x;
+}
+
+__host__ __device__ inline uint32_t idxgen_at(const IdxGen& g, long long row) {
+  const long long m = row / g.B;
+  return feistel_index(g.seed, g.draw0 + (uint64_t)m, g.n, g.half_bits, (uint32_t)(row - m * g.B));
 }
 
 }  // namespace gcrl
@@ -74,6 +92,8 @@ struct gcrl_her {
   std::vector<int> staged;
   uint64_t episodes_flushed = 0;  // stream id of the device RNG
   uint64_t draws_done = 0;        // batch-draw counter of the device RNG
+  gcrl::IdxGen last_gen{};        // device-RNG mode: what the next gather launch computes its indices from
+  bool idx_on_device = true;      // false: no index array was uploaded (device-RNG mode)
   uint64_t mutation_epoch = 0;    // bumped by every flush
 
   // index upload: pinned host slots -> idx_dev

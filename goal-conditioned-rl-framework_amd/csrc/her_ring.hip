@@ -180,7 +180,8 @@ __device__ inline void clk_end(unsigned long long* clk) {
 // ---------------------------------------------------------------- gather (public sample)
 struct GatherArgs {
   const float* ring;
-  const uint32_t* idx;  // logical indices
+  const uint32_t* idx;  // logical indices (null: computed per row from `gen`, device-RNG mode)
+  gcrl::IdxGen gen;
   long long n, head, cap;
   int S, A, SA4, S4, RS;
   float *out_s, *out_a, *out_r, *out_ns, *out_d;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void her_gather_kernel(GatherArgs p) {
       const long long row = r0 + wave * 16 + u * 4 + sub;
       val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < p.n && c0 < p.RS) {
-        const long long phys = (p.head + (long long)p.idx[row]) % p.cap;
+        const long long phys = (p.head + (long long)(p.idx ? p.idx[row] : gcrl::idxgen_at(p.gen, row))) % p.cap;
         val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
       }
     }
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void her_gather_wide_kernel(GatherArgs p) {
         val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c0 = ch * 64 + v4 * 4;
         if (row[u] < p.n && c0 < p.RS) {
-          long long phys = (p.head + (long long)p.idx[row[u]]) % p.cap;
+          long long phys = (p.head + (long long)(p.idx ? p.idx[row[u]] : gcrl::idxgen_at(p.gen, row[u]))) % p.cap;
           val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
         }
       }
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(256) void her_gather_wide_kernel(GatherArgs p) {
 // ---------------------------------------------------------------- gather (update engine)
 struct GatherUpdArgs {
   const float* ring;
-  const uint32_t* idx;
+  const uint32_t* idx;   // null: computed per row from `gen`
+  gcrl::IdxGen gen;
   long long n, head, cap;
   int SA4, S4, RS, ldx;   // ldx == SA4
   float *sa, *nsa, *spa, *r, *d;
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p)
         row[u] = r0 + u * 4 + sub;
         val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row[u] < p.n && c0 < p.RS) {
-          const long long phys = (p.head + (long long)p.idx[row[u]]) % p.cap;
+          const long long phys = (p.head + (long long)(p.idx ? p.idx[row[u]] : gcrl::idxgen_at(p.gen, row[u]))) % p.cap;
           val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
         }
       }
@@ -465,14 +467,20 @@ int her_upload_indices(gcrl_her* h, int B, int M, const uint32_t* idx_host, hipS
     for (int m = 0; m < M; ++m)
       if (int rc = gcrl_mt_sample_indices(h->rng, (uint32_t)h->len, (uint32_t)B, dst + (size_t)m * B)) return rc;
   } else {
-    // device-RNG mode: uniform WITH the hash stream; exact without-replacement comes from
-    // rejecting duplicates inside a batch, in draw order (restated in oracle/her_oracle.py)
-    std::vector<uint32_t> table;
-    for (int m = 0; m < M; ++m) {
-      hash_draw_batch(h->cfg.seed, h->draws_done, (uint32_t)h->len, B, dst + (size_t)m * B, table);
-      h->draws_done++;
+    // device-RNG mode: the gather kernels compute the indices themselves (her_ring.h idxgen_at); the host
+    // restates them only when the caller wants to see them
+    if (host_copy) {
+      const int hb = feistel_half_bits((uint32_t)h->len);
+      for (size_t i = 0; i < rows; ++i)
+        dst[i] = feistel_index(h->cfg.seed, h->draws_done + i / B, (uint32_t)h->len, hb, (uint32_t)(i % B));
+      *host_copy = dst;
     }
+    h->last_gen = IdxGen{h->cfg.seed, h->draws_done, (uint32_t)h->len, B, feistel_half_bits((uint32_t)h->len)};
+    h->draws_done += M;
+    h->idx_on_device = false;
+    return GCRL_OK;
   }
+  h->idx_on_device = true;
   GCRL_HIP(hipMemcpyAsync(h->idx_dev, dst, rows * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(h->slot_ev[slot], st));
   if (host_copy) *host_copy = dst;
@@ -483,7 +491,7 @@ int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa
                       float* spa, int ldx, float* r, float* d, hipStream_t st) {
   if (ldx != h->SA4) return fail(GCRL_ERR_ARG, "her_gather_update: batch row stride %d != roundup(S+A,4) = %d", ldx, h->SA4);
   if (int rc = prof_begin(h, st)) return rc;
-  GatherUpdArgs ga{h->ring, idx_dev, n, h->head, h->cfg.capacity, h->SA4, h->S4, h->RS, ldx, sa, nsa, spa, r, d, prof_slot(h)};
+  GatherUpdArgs ga{h->ring, idx_dev, h->last_gen, n, h->head, h->cfg.capacity, h->SA4, h->S4, h->RS, ldx, sa, nsa, spa, r, d, prof_slot(h)};
   constexpr int kUnroll = 4;
   int blocks = (int)std::min<int64_t>((n + 16 * kUnroll - 1) / (16 * kUnroll), 8192);
   hipLaunchKernelGGL(her_gather_update_kernel<kUnroll>, dim3(blocks), dim3(256), 0, st, ga);
@@ -709,10 +717,10 @@ int gcrl_her_sample(gcrl_her* h, int B, int M, const uint32_t* idx_host, float* 
   GCRL_CHECK_ARG(ld_s >= h->S && ld_ns >= h->S && ld_a >= h->A, "gcrl_her_sample: row stride smaller than the row");
   hipStream_t st = h->pick(stream);
   const uint32_t* host_copy = nullptr;
-  if (int rc = gcrl::her_upload_indices(h, B, M, idx_host, st, &host_copy)) return rc;
+  if (int rc = gcrl::her_upload_indices(h, B, M, idx_host, st, drawn_idx_host ? &host_copy : nullptr)) return rc;
   if (drawn_idx_host) std::memcpy(drawn_idx_host, host_copy, (size_t)B * M * sizeof(uint32_t));
   const long long n = (long long)B * M;
-  GatherArgs ga{h->ring, h->idx_dev, n, h->head, h->cfg.capacity, h->S, h->A, h->SA4, h->S4, h->RS,
+  GatherArgs ga{h->ring, h->idx_on_device ? h->idx_dev : nullptr, h->last_gen, n, h->head, h->cfg.capacity, h->S, h->A, h->SA4, h->S4, h->RS,
                 out_s, out_a, out_r, out_ns, out_d, ld_s, ld_a, ld_ns, nullptr};
   if (int rc = prof_begin(h, st)) return rc;
   ga.clk = prof_slot(h);

@@ -30,7 +30,8 @@ class MTStream:
     bit-identical to the reference as long as nothing else consumes `random` in between,
     without the ~30 us state round trip per call.  mode "device": no MT stream at all — HER future
     indices come from a counter hash evaluated inside the flush kernel (keyed by seed, episode number,
-    pick number) and batch indices from the same hash (keyed by draw number) with duplicates rejected;
+    pick number) and batch indices from a keyed permutation of the ring positions that the gather
+    kernels evaluate per row (no host RNG, no index upload);
     NOT the reference's index stream (restated in oracle/her_oracle.py HashRng), for runs that do not
     need index-level parity with a reference run.
     """

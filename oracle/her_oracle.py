@@ -131,8 +131,8 @@ def hash_below(seed: int, stream: int, ctr: int, n: int) -> int:
 class HashRng:
     """The engine's device-RNG mode (GCRL_RNG_DEVICE) as a `random`-like object for HERBufferOracle:
     randint() = the flush kernel's future pick (csrc/her_ring.hip her_flush_kernel: stream = episode
-    number, counter = pick number inside the episode), sample() = the batch draw (csrc/her_ring.hip /
-    agent.hip begin_call: stream = draw number, duplicates rejected)."""
+    number, counter = pick number inside the episode), sample() = the batch draw the gather kernels compute
+    per row (csrc/her_ring.h idxgen_at: a keyed Feistel permutation of the ring positions)."""
 
     def __init__(self, seed: int):
         self.seed = int(seed)
@@ -150,14 +150,30 @@ class HashRng:
         return v
 
     def sample(self, population, k: int):
-        n, out, ctr = len(population), [], 0
-        while len(out) < k:
-            j = hash_below(self.seed ^ 0x5BD1E995, self.draws, ctr, n)
-            ctr += 1
-            if j not in out:
-                out.append(j)
+        """Batch element t of draw d = feistel_index(seed, d, n, t) (csrc/her_ring.h): a keyed permutation of
+        [0, n), so the k picks are distinct by construction."""
+        n = len(population)
+        out = [feistel_index(self.seed, self.draws, n, t) for t in range(k)]
         self.draws += 1
         return [population[j] for j in out]
+
+
+def feistel_index(seed: int, draw: int, n: int, t: int) -> int:
+    bits = 2
+    while bits < 32 and (1 << bits) < n:
+        bits += 1
+    hb = (bits + 1) >> 1
+    mask = (1 << hb) - 1
+    key = mix64((seed ^ ((draw * 0xD1342543DE82EF95) & _M) ^ 0x5BD1E995) & _M)
+    x = t
+    while True:
+        L, R = (x >> hb) & mask, x & mask
+        for r in range(4):
+            f = (mix64((key + r * 0x9E3779B97F4A7C15 + R) & _M) >> 32) & mask
+            L, R = R, L ^ f
+        x = (L << hb) | R
+        if x < n:
+            return x
 
 
 def synthetic_episode(rng: np.random.Generator, T: int, S: int, A: int, G: int = 3):

@@ -167,3 +167,24 @@ def test_oracle_update_matches_reference(tag):
         if not ok:
             bad.append((name, float(np.max(np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))))))
     assert not bad, bad
+
+
+def test_device_rng_batch_draw_is_a_permutation_prefix():
+    """Device-RNG batch draws (oracle restatement of csrc/her_ring.h feistel_index): within a draw the picks
+    are distinct and in range for any population size (power of two or not, barely above the batch), different
+    draws differ, and over many draws the picks are spread evenly over the population."""
+    from oracle.her_oracle import feistel_index
+    for n, B in ((256, 256), (257, 256), (1000, 64), (5000, 256), (1_000_000, 256), (3, 2)):
+        for draw in (0, 1, 12345):
+            picks = [feistel_index(77, draw, n, t) for t in range(B)]
+            assert len(set(picks)) == B and min(picks) >= 0 and max(picks) < n
+        if n > 8:
+            assert [feistel_index(77, 0, n, t) for t in range(B)] != [feistel_index(77, 1, n, t) for t in range(B)]
+    n, B, draws = 1000, 50, 400
+    counts = np.zeros(n)
+    for d in range(draws):
+        for t in range(B):
+            counts[feistel_index(5, d, n, t)] += 1
+    expect = draws * B / n                      # 20 per position
+    assert abs(counts.mean() - expect) < 1e-9
+    assert counts.min() >= 3 and counts.max() <= 45 and abs(counts.std() - np.sqrt(expect)) < 1.5   # ~Poisson(20)
