@@ -49,7 +49,10 @@ template <int RG>
 __device__ inline void rows_matmul_wave(const float* xs, int ldx, __amdgpu_buffer_rsrc_t rs, int ldm, int c0,
                                         int jb, int je, v4f (&acc)[RG][4]) {
   const int lane = threadIdx.x & 63;
-  constexpr int U = 8;  // k per stage; two stages in flight
+  // k per stage; two stages in flight.  A sharp optimum: 16 loads per wave = 64 per CU in flight.  Measured end
+  // to end (headline bench): U = 4 -> 8.5k steps/s, 8 -> 17.0k, 12 -> 11.1k, 16 -> 10.6k — past 64 outstanding
+  // vector-memory instructions per CU the issue itself stalls, and the in-order wave cannot reach its MFMAs.
+  constexpr int U = 8;
 #pragma unroll
   for (int g = 0; g < RG; ++g)
 #pragma unroll
