@@ -15,4 +15,4 @@ def run(M, N, K, shape, reps=50):
     us = e0.elapsed_time(e1) * 1e3 / reps
     print(f"M={M} N={N} K={K} shape {shape}: {us:8.1f} us  {2*M*N*K/us/1e6:6.1f} TFLOP/s")
 for (M, N, K) in [(512, 513, 2048), (256, 257, 2048), (256, 257, 1024), (256, 257, 256)]:
-    for s in (1, 4, 5): run(M, N, K, s)
+    for s in (1, 2, 4): run(M, N, K, s)
