@@ -88,14 +88,15 @@ def test_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind):
         assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
 
 
-def _worker_cycle(rank, world, port, out_dir):
+def _worker_cycle(rank, world, port, out_dir, kind="DDPG"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     import gcrl_amd
     from gcrl_amd.src.dp import DataParallelUpdater
     from oracle import her_oracle
-    ag = gcrl_amd.DDPG(S, A, _cfg("DDPG", B), None, nenvs=1, gradient_step=45, rng="engine", seed=7)   # same seed on both ranks
+    cls = dict(DDPG=gcrl_amd.DDPG, TD3=gcrl_amd.TD3Agent)[kind]
+    ag = cls(S, A, _cfg(kind, B), None, nenvs=1, gradient_step=45, rng="engine", seed=7)   # same seed on both ranks
     gen = np.random.default_rng(3)
     for _ in range(3):
         for st in her_oracle.synthetic_episode(gen, 50, S, A):
@@ -106,30 +107,33 @@ def _worker_cycle(rank, world, port, out_dir):
     out = [[float(x) for x in t] for t in dp.update_many(1, 45)]      # crosses the Polyak step 40
     out += [[float(x) for x in t] for t in dp.update_many(46, 5)]
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, f"cycle{rank}.npz"), actor=ag.actor.flat(), critic=ag.critic.flat(),
-             tactor=ag.target_actor.flat(), tuples=np.array(out))
+    np.savez(os.path.join(out_dir, f"cycle{rank}.npz"), actor=ag.actor.flat(), critic=ag.critics[0].flat(),
+             tactor=ag.target_actor.flat(), tuples=np.array([t + [0.0] * (9 - len(t)) for t in out]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_dp_cycle_schedule_tracks_single_process(gcrl, tmp_path):
+@pytest.mark.parametrize("kind", ["DDPG", "TD3"])
+def test_dp_cycle_schedule_tracks_single_process(gcrl, tmp_path, kind):
     """Engine-scheduled DP cycle (pipelined DDPG segments with ONE exchange per step, ordinary
     phases around the Polyak step): two ranks holding IDENTICAL rings and RNG seeds draw identical
     batches, so the averaged gradients equal each rank's own and the run must track a single-process
     update_many (same math; the clip norm is summed by a different kernel, hence a tolerance)."""
     from oracle import her_oracle
     world = 2
-    mp.spawn(_worker_cycle, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_cycle, args=(world, _free_port(), str(tmp_path), kind), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "cycle0.npz"), np.load(tmp_path / "cycle1.npz")
     for k in ("actor", "critic", "tactor", "tuples"):
         assert np.array_equal(r0[k], r1[k]), k
-    ag = gcrl.DDPG(S, A, _cfg("DDPG", B), None, nenvs=1, gradient_step=45, rng="engine", seed=7)
+    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent)[kind]
+    ag = cls(S, A, _cfg(kind, B), None, nenvs=1, gradient_step=45, rng="engine", seed=7)
     gen = np.random.default_rng(3)
     for _ in range(3):
         for st in her_oracle.synthetic_episode(gen, 50, S, A):
             ag.push_her(0, *st)
     _init_params(ag)
     ref = [[float(x) for x in t] for t in ag.update_many(1, 45)] + [[float(x) for x in t] for t in ag.update_many(46, 5)]
-    assert np.allclose(r0["tuples"], np.array(ref), rtol=2e-4, atol=2e-5)
-    for k, v in (("actor", ag.actor), ("critic", ag.critic), ("tactor", ag.target_actor)):
+    ref = np.array([t + [0.0] * (9 - len(t)) for t in ref])
+    assert np.allclose(r0["tuples"], ref, rtol=2e-4, atol=2e-5)
+    for k, v in (("actor", ag.actor), ("critic", ag.critics[0]), ("tactor", ag.target_actor)):
         assert float(np.max(np.abs(r0[k] - v.flat()))) < 5e-4, k
