@@ -115,6 +115,7 @@ PROTOTYPES = {
     "gcrl_agent_dp_run": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i64), _vp]),
     "gcrl_agent_dev_ptr": (C.c_int, [_vp, _cp, C.POINTER(_vp), C.POINTER(_i64)]),
     "gcrl_agent_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "gcrl_agent_act_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "gcrl_sort_truncate_mean": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp]),
     "gcrl_gemm_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "gcrl_event_create": (_vp, []),

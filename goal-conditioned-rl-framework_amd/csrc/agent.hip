@@ -110,6 +110,7 @@ struct gcrl_agent {
   float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
   float *noise_in = nullptr, *eps_next_in = nullptr, *eps_cur_in = nullptr, *norm_partial = nullptr;
   float *act_in = nullptr, *act_tmp[2] = {};
+  float* act_pinned = nullptr;   // host staging of gcrl_agent_act_host
   // row-block DDPG path (rowchain.h): [in][out] weight copies of actor | target actor | critic 0 |
   // target critic 0, per-layer gradient buffers, TD targets
   bool rowchain = false, wt_dirty = true;
@@ -998,6 +999,7 @@ void gcrl_agent_destroy(gcrl_agent* a) {
   if (a->metrics_host) (void)hipHostFree(a->metrics_host);
   if (a->metrics_dev) (void)hipFree(a->metrics_dev);
   if (a->prof_clk) (void)hipFree(a->prof_clk);
+  if (a->act_pinned) (void)hipHostFree(a->act_pinned);
   for (int i = 0; i < gcrl_agent::kProfPairs; ++i) {
     if (a->prof_a[i]) (void)hipEventDestroy(a->prof_a[i]);
     if (a->prof_b[i]) (void)hipEventDestroy(a->prof_b[i]);
@@ -1295,6 +1297,15 @@ int gcrl_agent_act(gcrl_agent* a, const float* obs, int n, int ld_obs, float* ou
   GCRL_CHECK_ARG(a && obs && out && n >= 1 && ld_obs >= a->S && ld_out >= a->A, "gcrl_agent_act: bad arguments");
   hipStream_t st = a->pick(stream);
   const int H = a->H, L = a->L;
+  if (a->rowchain && !a->sac && !eps) {   // one row-block launch: hidden layers and tanh head for 4 rows per workgroup
+    if (a->wt_dirty) TRY(rc_rebuild_wt(a, st));
+    RowActArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.actor = make_rownet(a, a->actor, a->P_actor(), 0);
+    ra.obs = obs; ra.ld_obs = ld_obs; ra.out = out; ra.ld_out = ld_out;
+    ra.n = n; ra.S = a->S; ra.A = a->A; ra.ldl = a->row_ldl;
+    return launch_rowchain_act(st, ra);
+  }
   for (int r0 = 0; r0 < n; r0 += a->B) {
     const int rows = std::min(a->B, n - r0);
     const float* X = obs + (long long)r0 * ld_obs;
@@ -1326,6 +1337,24 @@ int gcrl_agent_act(gcrl_agent* a, const float* obs, int n, int ld_obs, float* ou
       TRY(launch_tanh_gauss_fwd(st, tg));
     }
   }
+  return GCRL_OK;
+}
+
+// select_action from host arrays in one call (src/agent.py:1345-1366 builds a tensor, moves it to the device,
+// runs the actor and copies the result back): pinned staging, H2D, gcrl_agent_act, D2H, stream sync.
+int gcrl_agent_act_host(gcrl_agent* a, const float* obs_host, int n, int ld_obs, float* out_host, int ld_out, void* stream) {
+  GCRL_CHECK_ARG(a && obs_host && out_host && n >= 1 && n <= a->B && ld_obs >= a->S && ld_out >= a->A,
+                 "gcrl_agent_act_host: bad arguments (n must be 1..batch_size)");
+  hipStream_t st = a->pick(stream);
+  if (!a->act_pinned) GCRL_HIP(hipHostMalloc((void**)&a->act_pinned, (size_t)a->B * (a->ldx + a->Apad) * sizeof(float), hipHostMallocDefault));
+  float* pin_in = a->act_pinned;
+  float* pin_out = a->act_pinned + (size_t)a->B * a->ldx;
+  for (int r = 0; r < n; ++r) std::memcpy(pin_in + (size_t)r * a->S, obs_host + (size_t)r * ld_obs, (size_t)a->S * sizeof(float));
+  GCRL_HIP(hipMemcpyAsync(a->act_in, pin_in, (size_t)n * a->S * sizeof(float), hipMemcpyHostToDevice, st));
+  TRY(gcrl_agent_act(a, a->act_in, n, a->S, a->dact, a->Apad, nullptr, stream));
+  GCRL_HIP(hipMemcpyAsync(pin_out, a->dact, (size_t)n * a->Apad * sizeof(float), hipMemcpyDeviceToHost, st));
+  GCRL_HIP(hipStreamSynchronize(st));
+  for (int r = 0; r < n; ++r) std::memcpy(out_host + (size_t)r * ld_out, pin_out + (size_t)r * a->Apad, (size_t)a->A * sizeof(float));
   return GCRL_OK;
 }
 

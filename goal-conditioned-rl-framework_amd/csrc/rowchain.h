@@ -260,6 +260,16 @@ struct RowChainArgs {
   unsigned long long* clk;   // profiling: {first block start, last block end} in wall_clock64 ticks, or null
 };
 
+// Batched actor inference (select_action, src/agent.py:1345-1366) as one row-block launch: 4 observation
+// rows per workgroup through the actor's hidden layers and its tanh head.
+struct RowActArgs {
+  RowNet actor;
+  const float* obs; int ld_obs;   // [n, >= S]
+  float* out; int ld_out;         // [n, >= A]
+  int n, S, A, ldl;
+};
+int launch_rowchain_act(hipStream_t st, const RowActArgs& a);
+
 // rows per workgroup = 4*rg, rg in {1, 2, 4}
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg);
 size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C);

@@ -365,6 +365,39 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   if (a.clk && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
 
+__global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int R = 4;
+  const int ldl = a.ldl, H = a.actor.H, A = a.A, tid = threadIdx.x;
+  float* X0 = lds;
+  float* X1 = X0 + R * ldl;
+  float* X2 = X1 + R * ldl;
+  float* part = X2 + R * ldl;                 // two exchange buffers (chained layers)
+  float* sm = part + 2 * 4 * R * kRowChunk;
+  float* hw = sm + R * 16;
+  float* hb = hw + A * H;
+  const long long row0 = (long long)blockIdx.x * R;
+  const int rv = min(R, a.n - (int)row0);
+  const float* rows = a.obs + row0 * a.ld_obs;
+  const float* src_h = a.actor.P + a.actor.w[a.actor.L];
+  Staged<2> s_x;
+  Staged<8> s_h;
+  rows_load<1>(s_x, rows, a.ld_obs, a.S, a.actor.jpad0, rv);
+  seg_load(s_h, src_h, A * H);
+  const float v_hb = tid < A ? a.actor.P[a.actor.b[a.actor.L] + tid] : 0.f;
+  rows_store<1>(s_x, X0, ldl, rows, a.ld_obs, a.S, a.actor.jpad0, rv);
+  seg_store(s_h, hw, src_h, A * H);
+  if (tid < A) hb[tid] = v_hb;
+  __syncthreads();
+  float* h = mlp_hidden<1>(a.actor, X0, X1, X2, ldl, part, nullptr, 0, row0, rv);
+  rows_head<1>(h, ldl, H, hw, H, hb, A, EPI_TANH, sm);
+  __syncthreads();
+  if (tid < R * A) {
+    const int r = tid / A, o = tid - r * A;
+    if (r < rv) a.out[(row0 + r) * a.ld_out + o] = sm[r * 16 + o];
+  }
+}
+
 // Wt[wt[l] + k*H + o] = P[w[l] + o*in_l + k]; layer 0 rows in..jpad0-1 are zero
 __global__ void wt_rebuild_kernel(RowNet net, float* Wt) {
   const int l = blockIdx.y;
@@ -404,6 +437,20 @@ int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
   if (rg == 1) return go(rowchain_ddpg_kernel<1>);
   if (rg == 2) return go(rowchain_ddpg_kernel<2>);
   return go(rowchain_ddpg_kernel<4>);
+}
+
+int launch_rowchain_act(hipStream_t st, const RowActArgs& a) {
+  GCRL_CHECK_ARG(a.actor.H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16 && a.n >= 1, "rowchain act: unsupported shape");
+  const size_t lds = (size_t)(3 * 4 * a.ldl + 2 * 4 * 4 * kRowChunk + 4 * 16 + a.A * a.actor.H + 32) * sizeof(float);
+  GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain act: %zu bytes of LDS needed", lds);
+  static thread_local size_t raised = 0;
+  if (lds > 64 * 1024 && lds > raised) {
+    GCRL_HIP(hipFuncSetAttribute((const void*)rowchain_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = lds;
+  }
+  hipLaunchKernelGGL(rowchain_act_kernel, dim3((a.n + 3) / 4), dim3(kRowThreads), lds, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
 }
 
 int launch_wt_rebuild(hipStream_t st, const RowNet& net, float* Wt) {

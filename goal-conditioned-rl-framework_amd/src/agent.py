@@ -254,6 +254,16 @@ class _EngineAgent:
 
     # ------------------------------------------------------------------ acting
     def _actor_forward(self, obs, eps=None) -> torch.Tensor:
+        if eps is None and not self._sac and not (isinstance(obs, torch.Tensor) and obs.is_cuda):
+            # host rows in, host actions out, one native call (staging, both copies and the sync inside)
+            x = np.ascontiguousarray(np.asarray(obs, dtype=np.float32))
+            if x.ndim == 1:
+                x = x[None, :]
+            if x.shape[0] <= int(self.config.batch_size):
+                out = np.empty((x.shape[0], self.ac_dim), dtype=np.float32)
+                _ffi.check(lib.gcrl_agent_act_host(self._h, x.ctypes.data, x.shape[0], x.shape[1], out.ctypes.data,
+                                                   self.ac_dim, _ffi.stream_handle()))
+                return torch.from_numpy(out)
         obs_t = torch.as_tensor(np.asarray(obs), dtype=torch.float32).to("cuda").contiguous()
         if obs_t.dim() == 1:
             obs_t = obs_t.unsqueeze(0)

@@ -318,6 +318,10 @@ int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr_dev_out, int
  * else tanh(mean + std*eps). */
 int gcrl_agent_act(gcrl_agent* a, const float* obs_dev, int n, int ld_obs, float* out_dev,
                    int ld_out, const float* eps_dev, void* stream);
+/* The same from and to HOST arrays (n <= batch_size rows): staging, both copies and the stream
+ * synchronisation happen inside; what select_action needs per vector-env step in one call. */
+int gcrl_agent_act_host(gcrl_agent* a, const float* obs_host, int n, int ld_obs, float* out_host,
+                        int ld_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stand-alone ops exposed for tests / reuse.
