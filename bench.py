@@ -58,7 +58,7 @@ WORKLOADS = {
 
 
 def make_cfg(w):
-    from oracle.agent_oracle import make_config
+    from gcrl_amd.src.synthetic import agent_config as make_config
     return make_config(w["kind"], hidden_dim=w["H"], layer_count=w["L"], batch_size=w["B"], max_len=w["cap"],
                        k_future=w["k"], gamma=w["gamma"], tau=w["tau"], grad_clip=w["grad_clip"],
                        ac_update_freq=w["freq"], actor_lr=w["lr"], actor_lr_min=w["lr"], critic_lr=w["lr"],
@@ -67,7 +67,7 @@ def make_cfg(w):
 
 
 def episode_pool(w, n, seed):
-    from oracle.her_oracle import synthetic_episode
+    from gcrl_amd.src.synthetic import synthetic_episode
     gen = np.random.default_rng(seed)
     return [synthetic_episode(gen, 50, w["S"], w["A"]) for _ in range(n)]
 

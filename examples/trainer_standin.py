@@ -71,7 +71,7 @@ def train(agent_name="DDPG", num_envs=8, cycles=60, max_episode=8, gradient_step
           seed=0, verbose=True):
     import gcrl_amd
     from gcrl_amd.src.utils import RunningNormalizer
-    from oracle.agent_oracle import make_config   # hyper-parameter container with the YAML field names
+    from gcrl_amd.src.synthetic import agent_config as make_config   # hyper-parameter container with the YAML field names
 
     np.random.seed(seed)
     env = PointReachVecEnv(num_envs, seed=seed)

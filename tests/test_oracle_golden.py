@@ -188,3 +188,18 @@ def test_device_rng_batch_draw_is_a_permutation_prefix():
     expect = draws * B / n                      # 20 per position
     assert abs(counts.mean() - expect) < 1e-9
     assert counts.min() >= 3 and counts.max() <= 45 and abs(counts.std() - np.sqrt(expect)) < 1.5   # ~Poisson(20)
+
+
+def test_synthetic_workload_helpers_agree_with_the_oracle_copies(gcrl):
+    """bench.py / examples build their synthetic inputs and configs with the package's own helpers (nothing
+    outside tests, smoke() and the CPU-baseline leg touches oracle/); the oracle keeps separate copies for the
+    tests — same streams, same defaults."""
+    from gcrl_amd.src import synthetic
+    from oracle import agent_oracle, her_oracle
+    a = synthetic.synthetic_episode(np.random.default_rng(3), 50, 13, 4)
+    b = her_oracle.synthetic_episode(np.random.default_rng(3), 50, 13, 4)
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+    for kind in ("DDPG", "TD3", "SAC", "TQC"):
+        assert vars(synthetic.agent_config(kind, batch_size=7)) == vars(agent_oracle.make_config(kind, batch_size=7))

@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gcrl_amd  # noqa: E402
 from gcrl_amd._ffi import check, lib  # noqa: E402
-from oracle.her_oracle import synthetic_episode  # noqa: E402
+from gcrl_amd.src.synthetic import synthetic_episode  # noqa: E402
 
 
 def main():
