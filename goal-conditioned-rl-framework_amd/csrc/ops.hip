@@ -194,6 +194,36 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
   float* __restrict__ m = a.m + base;
   float* __restrict__ v = a.v + base;
   float* __restrict__ tp = a.target ? a.target + base : nullptr;
+  // segmented launches: this thread's element is known before anything is loaded, so its operands are
+  // requested NOW and arrive while the norm partials are being reduced (one memory round trip less on the
+  // critical path of a kernel that is nothing but round trips)
+  AdamSeg sg;
+  sg.tiled = 0; sg.nblk = 0;
+  int lb = 0;
+  long long my_i = -1;
+  if (a.n_seg > 0) {
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxAdamSeg; ++q)
+      if (q < a.n_seg && (int)blockIdx.x >= a.seg[q].blk0) s = q;
+    sg = a.seg[s];
+    lb = (int)blockIdx.x - sg.blk0;
+    if (lb < sg.nblk) {
+      if (!sg.tiled) {
+        const long long i = sg.beg + (long long)lb * 256 + threadIdx.x;
+        if (i < sg.beg + (long long)sg.rows * sg.cols) my_i = i;
+      } else {
+        const int tiles_k = (sg.cols + 15) >> 4;
+        const int o = ((lb / tiles_k) << 4) + (threadIdx.x >> 4), k = ((lb % tiles_k) << 4) + (threadIdx.x & 15);
+        if (o < sg.rows && k < sg.cols) my_i = sg.beg + (long long)o * sg.cols + k;
+      }
+    }
+  }
+  float pre_g = 0.f, pre_p = 0.f, pre_m = 0.f, pre_v = 0.f, pre_t = 0.f;
+  if (my_i >= 0) {
+    pre_g = g[my_i]; pre_p = p[my_i]; pre_m = m[my_i]; pre_v = v[my_i];
+    if (tp && a.polyak) pre_t = tp[my_i];
+  }
   {
     // ||g||: every block sums the same partials in the same order (deterministic), in fp64
     __shared__ double dred[4];
@@ -271,48 +301,33 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
   const float w1 = a.w1, w2 = a.w2, one_m_tau = a.one_m_tau;
   const bool pk = tp && a.polyak;
   // one element: torch's single-tensor Adam(W) op order; returns the new parameter, *ti the new target
-  auto step_one = [&](long long i, float* ti) -> float {
-    const float gi = __fmul_rn(g[i], gmul);
-    float pi = p[i];
+  auto step_vals = [&](long long i, float g_raw, float pi, float mi, float v_old, float t_old, float* ti) -> float {
+    const float gi = __fmul_rn(g_raw, gmul);
     if (decay != 1.0f) pi = __fmul_rn(pi, decay);
-    float mi = m[i];
     mi = __fadd_rn(mi, __fmul_rn(w1, __fsub_rn(gi, mi)));
-    const float vi = __fadd_rn(__fmul_rn(v[i], a.beta2), __fmul_rn(__fmul_rn(w2, gi), gi));
+    const float vi = __fadd_rn(__fmul_rn(v_old, a.beta2), __fmul_rn(__fmul_rn(w2, gi), gi));
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2s), a.eps);
     pi = __fadd_rn(pi, __fdiv_rn(__fmul_rn(-step_size, mi), denom));
     p[i] = pi; m[i] = mi; v[i] = vi;
-    if (pk) { *ti = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, tp[i])); tp[i] = *ti; }
+    if (pk) { *ti = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, t_old)); tp[i] = *ti; }
     return pi;
   };
   if (a.n_seg == 0) {
     float ti;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) step_one(i, &ti);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256)
+      step_vals(i, g[i], p[i], m[i], v[i], pk ? tp[i] : 0.f, &ti);
     return;
   }
-  int s = 0;
-#pragma unroll
-  for (int q = 1; q < kMaxAdamSeg; ++q)
-    if (q < a.n_seg && (int)blockIdx.x >= a.seg[q].blk0) s = q;
-  const AdamSeg sg = a.seg[s];
-  const int lb = (int)blockIdx.x - sg.blk0;
   if (lb >= sg.nblk) return;   // paired launches are sized for the larger net
-  if (!sg.tiled) {
-    const long long i = sg.beg + (long long)lb * 256 + threadIdx.x;
-    float ti;
-    if (i < sg.beg + (long long)sg.rows * sg.cols) step_one(i, &ti);
-    return;
-  }
+  float ti = 0.f, pi = 0.f;
+  if (my_i >= 0) pi = step_vals(my_i, pre_g, pre_p, pre_m, pre_v, pre_t, &ti);
+  if (!sg.tiled) return;
   __shared__ float tile_p[16][17], tile_t[16][17];
   const int tiles_k = (sg.cols + 15) >> 4;
   const int o0 = (lb / tiles_k) << 4, k0 = (lb % tiles_k) << 4;
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  {
-    const int o = o0 + ty, k = k0 + tx;
-    float ti = 0.f, pi = 0.f;
-    if (o < sg.rows && k < sg.cols) pi = step_one(sg.beg + (long long)o * sg.cols + k, &ti);
-    tile_p[ty][tx] = pi;
-    tile_t[ty][tx] = ti;
-  }
+  tile_p[ty][tx] = pi;
+  tile_t[ty][tx] = ti;
   __syncthreads();
   {
     const int k = k0 + ty, o = o0 + tx;   // 16 consecutive o per copy row: 64-byte runs
