@@ -429,7 +429,7 @@ def test_row_block_ddpg_tracks_the_layer_per_launch_path(gcrl, H, L, B):
 
 @pytest.mark.parametrize("kind,H,L,B,S,A", [("TD3", 32, 2, 32, 10, 3), ("TD3", 128, 3, 1030, 23, 4), ("TD3", 64, 1, 7, 5, 16),
                                               ("DDPG", 4, 2, 3, 3, 1), ("DDPG", 128, 8, 17, 30, 6), ("DDPG", 520, 2, 40, 12, 2),
-                                              ("TD3-devnoise", 64, 2, 50, 9, 3)])
+                                              ("TD3-devnoise", 64, 2, 50, 9, 3), ("SAC", 64, 2, 40, 11, 3), ("SAC", 256, 3, 130, 22, 4)])
 def test_row_block_path_against_the_layer_per_launch_path_one_step(gcrl, kind, H, L, B, S, A):
     """Shape sweep of the row-block kernels (ragged last row block, 1..8 hidden layers, 1..16
     action dims, hidden width below / across the 256-column chunk, 4-/8-/16-row blocks): one update
@@ -437,7 +437,7 @@ def test_row_block_path_against_the_layer_per_launch_path_one_step(gcrl, kind, H
     path's gradients, parameters and metrics to fp32 reordering accuracy."""
     inject_noise = kind != "TD3-devnoise"     # else: the smoothing noise comes from the device counter hash in both paths
     kind = kind.split("-")[0]
-    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent)[kind]
+    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent, SAC=gcrl.SACAgent)[kind]
     cfg = make_config(kind, hidden_dim=H, layer_count=L, batch_size=B, max_len=2000, grad_clip=0.7, ac_update_freq=1,
                       policy_noise=0.2, noise_clamp=0.5)
     gen = np.random.default_rng(H + L + B)
@@ -457,6 +457,8 @@ def test_row_block_path_against_the_layer_per_launch_path_one_step(gcrl, kind, H
     outs = []
     for ag in agents:
         kw = dict(noise=torch.from_numpy(noise).cuda()) if (kind == "TD3" and inject_noise) else {}
+        if kind == "SAC":   # the two reparameterisation draws (next-state action, current action) injected
+            kw = dict(eps_next=torch.from_numpy(noise).cuda(), eps_cur=torch.from_numpy(noise[::-1].copy()).cuda())
         tup = ag.update(1, batch=tuple(torch.from_numpy(x).cuda() for x in batch), **kw)
         outs.append(np.array([float(x) for x in tup]))
     assert np.allclose(outs[0], outs[1], rtol=1e-4, atol=1e-6), (outs[0], outs[1])
@@ -466,8 +468,10 @@ def test_row_block_path_against_the_layer_per_launch_path_one_step(gcrl, kind, H
         g0, g1 = v0.grad_flat(), v1.grad_flat()
         scale = max(1e-6, float(np.abs(g0).max()))
         assert float(np.abs(g0 - g1).max()) <= 2e-5 * scale + 1e-7, (nm, float(np.abs(g0 - g1).max()), scale)
-    for v0, v1 in [(a0.actor, a1.actor), (a0.critics[0], a1.critics[0]), (a0.target_critics[0], a1.target_critics[0]),
-                   (a0.target_actor, a1.target_actor)]:
+    pairs = [(a0.actor, a1.actor), (a0.critics[0], a1.critics[0]), (a0.target_critics[0], a1.target_critics[0])]
+    if kind != "SAC":
+        pairs.append((a0.target_actor, a1.target_actor))
+    for v0, v1 in pairs:
         d = np.abs(v0.flat() - v1.flat())
         assert float(np.mean(d > 2e-5)) < 0.02 and float(d.max()) < 3e-3      # Adam turns ~0 gradients into +-lr
 
