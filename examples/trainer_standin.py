@@ -68,7 +68,7 @@ class PointReachVecEnv:
 
 
 def train(agent_name="DDPG", num_envs=8, cycles=60, max_episode=8, gradient_step=40, hidden=64, layers=3, batch=256,
-          seed=0, verbose=True):
+          seed=0, verbose=True, per_env_push=False):
     import gcrl_amd
     from gcrl_amd.src.utils import RunningNormalizer
     from gcrl_amd.src.synthetic import agent_config as make_config   # hyper-parameter container with the YAML field names
@@ -105,7 +105,13 @@ def train(agent_name="DDPG", num_envs=8, cycles=60, max_episode=8, gradient_step
                                       next_obs["achieved_goal"]], True, False)
             obs_b = torch.from_numpy(agent.normalize_state_batch(state["observation"], state["desired_goal"], True, False)).float().cuda()
             nxt_b = torch.from_numpy(agent.normalize_state_batch(next_obs["observation"], next_obs["desired_goal"], True, False)).float().cuda()
-            agent.buffer.push_batch(obs_b, actions, nxt_b, rewards, terminateds, next_obs["achieved_goal"])
+            if per_env_push:   # the reference's own loop (src/env.py:192-201): one push_her per env
+                for i in range(num_envs):
+                    agent.push_her(i, obs_b[i].detach(), actions[i], nxt_b[i].detach(), rewards[i], terminateds[i],
+                                   agent.normalize_goal(next_obs["desired_goal"][i], False),
+                                   agent.normalize_goal(next_obs["achieved_goal"][i], False))
+            else:
+                agent.buffer.push_batch(obs_b, actions, nxt_b, rewards, terminateds, next_obs["achieved_goal"])
             env_steps += num_envs
             if dones.any():
                 idx = np.nonzero(dones)[0]
@@ -137,8 +143,9 @@ if __name__ == "__main__":
     ap.add_argument("--cycles", type=int, default=60)
     ap.add_argument("--nenv", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--per-env-push", action="store_true", help="push one env at a time, exactly as the reference's trainer does")
     args = ap.parse_args()
-    out = train(args.agent, num_envs=args.nenv, cycles=args.cycles, seed=args.seed)
+    out = train(args.agent, num_envs=args.nenv, cycles=args.cycles, seed=args.seed, per_env_push=args.per_env_push)
     tail = out["success_per_cycle"][-10:]
     print(f"{args.agent}: success over the last 10 cycles {np.mean(tail):.2f}; {out['env_steps']} env steps "
           f"({out['env_steps_per_s']:.0f}/s in the acting phase), {out['gradient_steps']} gradient steps "
