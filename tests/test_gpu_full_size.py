@@ -1,0 +1,75 @@
+"""GPU (-m gpu): the HIP engine's DEFAULT schedule at BASELINE.json's cfg 2-5 shapes (and the headline
+shape) against the real reference, through the C ABI.
+
+These are the code paths only the benchmarked sizes select — the LDS-tiled GEMM inside the TQC step
+(H=512, B=2048), the k-split dW rule at K >= 1024, the 8-/16-row blocks of the row-chain kernel at
+B=1024/2048, BatchNorm over 512 rows — compared with fixtures captured from the reference itself
+(tests/golden/make_golden_full.py) in fp32 and fp64.  Criterion per quantity (tests/fullsize.py):
+|hip - ref64| <= max(3 * |ref32 - ref64|, 1e-5 * scale): the HIP error may not exceed the reference's
+own fp32 error (x3) or the north star's 1e-5, whichever is looser.  The measured errors are written to
+gpurun_out/parity_full_size.json (committed under profiles/ per round)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from fullsize import CASES, Case, Report, compare
+
+pytestmark = pytest.mark.gpu
+_rows = []
+
+
+def build(gcrl, c, **kw):
+    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent, SAC=gcrl.SACAgent, TQC=gcrl.TQCAgent)[c.kind]
+    ag = cls(c.S, c.A, c.cfg, None, nenvs=1, gradient_step=c.gstep, rng="engine", seed=0, **kw)
+    views = {"actor": ag.actor}
+    if c.kind in ("DDPG", "TD3"):
+        views["target_actor"] = ag.target_actor
+    for i, (q, t) in enumerate(zip(ag.critics, ag.target_critics)):
+        views[f"critic_{i}"], views[f"target_critic_{i}"] = q, t
+    assert sorted(views) == sorted(c.net_names)
+    for n, v in views.items():
+        v.set_flat(c.init_vector(n))
+    return ag, views
+
+
+def run(c, ag, views):
+    kw = {}
+    if c.noise is not None:
+        kw["noise"] = torch.from_numpy(c.noise)
+    if c.eps_next is not None:
+        kw["eps_next"], kw["eps_cur"] = torch.from_numpy(c.eps_next), torch.from_numpy(c.eps_cur)
+    info = ag.update(c.step, batch=tuple(torch.from_numpy(x).cuda() for x in c.batch), **kw)
+    tup = [float(x) for x in info]
+    actor_step = len(tup) in (6, 8, 9) and not (c.kind != "DDPG" and len(tup) == 6)
+    grads = {n: v.grad_flat() for n, v in views.items() if n.startswith("critic_")}
+    if actor_step:
+        grads["actor"] = views["actor"].grad_flat()
+    params = {n: v.flat() for n, v in views.items()}
+    extras = {}
+    if c.kind in ("SAC", "TQC"):
+        sd = ag.actor.state_dict()
+        extras = dict(bn_mean=np.concatenate([sd[f"base_net.{3 * l + 1}.running_mean"].numpy() for l in range(c.L)]),
+                      bn_var=np.concatenate([sd[f"base_net.{3 * l + 1}.running_var"].numpy() for l in range(c.L)]),
+                      log_alpha=ag.log_alpha.detach().numpy(), alpha=np.array([ag.alpha.item()]))
+    return tup, grads, params, extras
+
+
+@pytest.mark.parametrize("schedule", ["default", "layer_per_launch"])
+@pytest.mark.parametrize("name", CASES)
+def test_full_size_update_matches_reference(gcrl, name, schedule):
+    c = Case(name)
+    ag, views = build(gcrl, c, **({} if schedule == "default" else dict(pipeline=0)))
+    rep = Report(f"hip/{schedule}", name)
+    compare(c, rep, *run(c, ag, views))
+    print(rep.summary())
+    _rows.extend(rep.rows)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_full_size.json"), "w") as f:
+        json.dump(dict(criterion="|hip - ref64| <= max(3*|ref32 - ref64|, 1e-5*scale); all columns relative to the quantity's scale",
+                       rows=_rows), f, indent=1)
+    assert not rep.bad, rep.bad[:8]
