@@ -195,32 +195,37 @@ class _EngineAgent:
         ratio = step / self.beta_end
         self.beta = min(self.beta_max, self.beta_start + ratio * (self.beta_max - self.beta_start))
 
+    @staticmethod
+    def _inject(batch=None, noise=None, eps_next=None, eps_cur=None):
+        """-> (gcrl_update_inputs or None, tensors to keep alive) for an explicit batch / injected noise."""
+        if batch is None and noise is None and eps_next is None and eps_cur is None:
+            return None, []
+        inputs, keep = _ffi.UpdateInputs(), []
+
+        def dev(t):
+            t = torch.as_tensor(t).to(device="cuda", dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        if batch is not None:
+            s, a, r, ns, d = (dev(t) for t in batch)
+            inputs.s_dev, inputs.ld_s = s.data_ptr(), s.shape[1]
+            inputs.a_dev, inputs.ld_a = a.data_ptr(), a.shape[1]
+            inputs.r_dev, inputs.d_dev = r.data_ptr(), d.data_ptr()
+            inputs.ns_dev, inputs.ld_ns = ns.data_ptr(), ns.shape[1]
+        if noise is not None:
+            inputs.noise_dev = dev(noise).data_ptr()
+        if eps_next is not None:
+            inputs.eps_next_dev = dev(eps_next).data_ptr()
+        if eps_cur is not None:
+            inputs.eps_cur_dev = dev(eps_cur).data_ptr()
+        return inputs, keep
+
     def update(self, step: int, *, batch=None, noise=None, eps_next=None, eps_cur=None):
         """agent.update(step).  Keyword arguments inject an explicit batch / noise (parity tests):
         batch = (states, actions, rewards, next_states, dones) cuda float32 tensors."""
         self.set_train()
-        inputs = None
-        keep = []
-        if batch is not None or noise is not None or eps_next is not None or eps_cur is not None:
-            inputs = _ffi.UpdateInputs()
-
-            def dev(t):
-                t = t.to(device="cuda", dtype=torch.float32).contiguous()
-                keep.append(t)
-                return t
-
-            if batch is not None:
-                s, a, r, ns, d = (dev(t) for t in batch)
-                inputs.s_dev, inputs.ld_s = s.data_ptr(), s.shape[1]
-                inputs.a_dev, inputs.ld_a = a.data_ptr(), a.shape[1]
-                inputs.r_dev, inputs.d_dev = r.data_ptr(), d.data_ptr()
-                inputs.ns_dev, inputs.ld_ns = ns.data_ptr(), ns.shape[1]
-            if noise is not None:
-                inputs.noise_dev = dev(noise).data_ptr()
-            if eps_next is not None:
-                inputs.eps_next_dev = dev(eps_next).data_ptr()
-            if eps_cur is not None:
-                inputs.eps_cur_dev = dev(eps_cur).data_ptr()
+        inputs, keep = self._inject(batch, noise, eps_next, eps_cur)
         her = None
         if batch is None:
             her = self.buffer.handle

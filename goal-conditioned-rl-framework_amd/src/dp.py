@@ -122,21 +122,14 @@ class DataParallelUpdater:
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         return [a._tuple(int(t), int(l)) for t, l in zip(tickets, lens)]
 
-    def update(self, step: int, batch=None):
-        """One step.  `batch` = (s, a, r, ns, d) cuda tensors injects this rank's rows (tests)."""
+    def update(self, step: int, batch=None, noise=None, eps_next=None, eps_cur=None):
+        """One step.  `batch` = (s, a, r, ns, d) cuda tensors injects this rank's rows, `noise` / `eps_*` its
+        TD3 smoothing noise / SAC-TQC reparameterisation draws (tests)."""
         a, lib, ffi = self.agent, self._ffi.lib, self._ffi
         ticket = C.c_int64(-1)
-        inputs, keep, her = None, [], a.buffer.handle
-        if batch is not None:
-            inputs = ffi.UpdateInputs()
-            s, ac, r, ns, d = (t.to(device="cuda", dtype=torch.float32).contiguous() for t in batch)
-            keep = [s, ac, r, ns, d]
-            inputs.s_dev, inputs.ld_s = s.data_ptr(), s.shape[1]
-            inputs.a_dev, inputs.ld_a = ac.data_ptr(), ac.shape[1]
-            inputs.r_dev, inputs.d_dev = r.data_ptr(), d.data_ptr()
-            inputs.ns_dev, inputs.ld_ns = ns.data_ptr(), ns.shape[1]
-            her = None
-        else:
+        inputs, keep = a._inject(batch, noise, eps_next, eps_cur)
+        her = a.buffer.handle if batch is None else None
+        if batch is None:
             a.buffer.rng.pull()
         n = ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 0, C.byref(inputs) if inputs is not None else None,
                                                   self.scale, C.byref(ticket), ffi.stream_handle()))

@@ -146,6 +146,9 @@ class OracleAgent:
         self.buffer = HERBufferOracle(config.max_len, config.max_eps_len, nenvs, k_future=config.k_future, rng=rng)
         self.hard_update()
         self.last = {}
+        # data-parallel emulation hook (oracle/dp_oracle.py): called with (name, parameters) right after a
+        # network's backward pass, before clipping — where a DP run exchanges that network's gradients
+        self.grad_sync = None
 
     # ------------------------------------------------------------------ plumbing
     def hard_update(self):
@@ -218,6 +221,8 @@ class OracleAgent:
             opt.zero_grad()
             loss = loss_fn(q, y)
             loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync(f"critic_{i}", list(c.parameters()))
             pre.append(_flat(p.grad for p in c.parameters()))
             clip_this = cfg.grad_clip is not None and not (kind == "TD3" and i == 0)   # :201 commented out
             if clip_this:
@@ -267,6 +272,8 @@ class OracleAgent:
                 loss = (self.alpha.detach() * logp - mq).mean()
         self.actor_opt.zero_grad()
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync("actor", list(self.actor.parameters()))
         self.last["actor_grads_pre"] = _flat(p.grad for p in self.actor.parameters())
         if cfg.grad_clip is not None:
             torch.nn.utils.clip_grad_norm_(self.actor.parameters(), cfg.grad_clip)
@@ -283,6 +290,8 @@ class OracleAgent:
         loss = -(self.log_alpha * (logp + self.target_entropy).detach()).mean()
         self.alpha_opt.zero_grad()
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync("log_alpha", [self.log_alpha])
         self.last["alpha_grad"] = float(self.log_alpha.grad.item())
         self.alpha_opt.step()
         self.alpha = self.log_alpha.exp()

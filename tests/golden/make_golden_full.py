@@ -16,9 +16,21 @@ from seeds by tests/detdata.py on both sides; the fixture carries their checksum
   g32_<net> / g64_<net>      pre-clip gradient at those positions
   p32_<net> / p64_<net>      parameters after the optimiser (+ Polyak for targets) step, sampled
   bn_mean32/64, bn_var32/64, log_alpha32/64, alpha32/64   (SAC / TQC)
+  kink_units, kinku_<net>, kinkF_<net>, kinkdot_<net>, kinkgram_<net>   see "activation kinks" below
 The fp64 run is what lets the GPU test say "the HIP error is no larger than the reference's own
 fp32 error": |hip - f64| is compared with |ref32 - f64| per quantity.
 Every case starts from a FRESH agent (optimiser step count 0), so cases are independent.
+
+Activation kinks.  LeakyReLU / ReLU are discontinuous in their derivative at 0.  Among the ~16 M hidden
+pre-activations of a B=2048, H=512 step a few lie within fp32 rounding error of 0, and two correct fp32
+implementations with different summation orders may put such a unit on opposite sides: the unit's
+derivative flips (1 <-> 0.01), one batch row's contribution to every gradient below changes — a discrete,
+exactly computable change, not an accuracy defect (the reference itself flips between BLAS kernels / thread
+counts).  The generator therefore lists every unit of a gradient-carrying forward pass whose fp64
+pre-activation is within KINK_TAU x rms of zero, re-runs the fp64 step once per unit with that unit's
+derivative flipped, and stores the resulting gradient change ("flip vector") at the sampled positions plus
+its inner products with the gradient and the other flip vectors.  The tests explain a deviation as an
+integer combination of flip vectors (least squares) and hold the REMAINDER to the strict bound.
 """
 import os
 import random
@@ -87,7 +99,54 @@ def init_vector(case, name, kind, S, A, H, L):
     return detdata.net_params(f"{case}/{name}", "mlp", S + A, H, L, 1)
 
 
-def run_case(case, spec, dtype):
+KINK_TAU = 2e-6   # |z| < KINK_TAU * rms(z of the layer): ~10x the fp32 rounding error of a 512-term dot product
+
+
+class Kinks:
+    """Forward hooks on the activation modules of the gradient-carrying (online) networks: in detection mode
+    lists near-zero pre-activations of grad-enabled passes; in flip mode overrides the slope of given units."""
+
+    def __init__(self, nets, flips=()):
+        self.found, self.calls, self.flips = [], {}, set(flips)
+        self.handles = []
+        for name, (net, opt) in nets.items():
+            if opt is None:
+                continue
+            acts = [m for m in net.modules() if isinstance(m, (torch.nn.LeakyReLU, torch.nn.ReLU))]
+            for ai, m in enumerate(acts):
+                self.handles.append(m.register_forward_hook(self._hook(name, ai, m)))
+
+    def _hook(self, name, ai, mod):
+        slope = mod.negative_slope if isinstance(mod, torch.nn.LeakyReLU) else 0.0
+
+        def hook(module, inputs, output):
+            if not torch.is_grad_enabled():
+                return None
+            z = inputs[0]
+            call = self.calls.get((name, ai), 0)
+            self.calls[(name, ai)] = call + 1
+            if not self.flips:
+                thr = KINK_TAU * float(z.detach().pow(2).mean().sqrt())
+                for b, j in (z.detach().abs() < thr).nonzero().tolist():
+                    self.found.append((name, ai, call, b, j, float(z[b, j])))
+                return None
+            mine = [(b, j) for (n, a, c, b, j) in self.flips if (n, a, c) == (name, ai, call)]
+            if not mine:
+                return None
+            out = output.clone()
+            for b, j in mine:
+                other = slope if float(z[b, j]) > 0 else 1.0     # the slope of the OTHER side of the kink
+                out[b, j] = z[b, j] * other
+            return out
+
+        return hook
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+
+
+def run_case(case, spec, dtype, flips=(), detect=False):
     kind, (S, A), B, step = spec["kind"], spec["dims"], spec["B"], spec["step"]
     cfg = mg.load_her_config(os.path.join(mg.CFG_DIR, kind, spec["yaml"]), kind)
     acfg = cfg.agent.model_copy(update=dict(batch_size=B, **spec["over"]))
@@ -116,6 +175,7 @@ def run_case(case, spec, dtype):
         queue.append(torch.from_numpy(detdata.normalish(detdata.seed_of(case, "eps_next"), (B, A))).to(dtype))
         queue.append(torch.from_numpy(detdata.normalish(detdata.seed_of(case, "eps_cur"), (B, A))).to(dtype))
 
+    kinks = Kinks(nets, flips) if (detect or flips) else None
     rec = mg.Recorder()
     for name, (net, opt) in nets.items():
         if opt is not None:
@@ -128,6 +188,8 @@ def run_case(case, spec, dtype):
         info = agent.update(step=step)
     finally:
         torch.nn.utils.clip_grad_norm_, torch.randn_like, torch.distributions.Normal.rsample = orig_clip, orig_rl, orig_rs
+        if kinks is not None:
+            kinks.remove()
     assert not queue
     out = dict(tuple=np.array([float(np.asarray(x)) for x in info], dtype=np.float64))
     flat64 = lambda ts: np.concatenate([t.detach().numpy().reshape(-1).astype(np.float64) for t in ts])
@@ -141,6 +203,8 @@ def run_case(case, spec, dtype):
         out["bn_var"] = np.concatenate([m.running_var.numpy().astype(np.float64) for m in bns])
         out["log_alpha"] = agent.log_alpha.detach().numpy().astype(np.float64).copy()
         out["alpha"] = agent.alpha.detach().numpy().astype(np.float64).copy()
+    if detect:
+        out["kinks"] = kinks.found
     return out, acfg, sums, batch
 
 
@@ -186,7 +250,7 @@ def main():
         if only and case not in only:
             continue
         r32, acfg, sums, batch = run_case(case, spec, torch.float32)
-        r64, _, _, _ = run_case(case, spec, torch.float64)
+        r64, _, _, _ = run_case(case, spec, torch.float64, detect=True)
         kind, (S, A), B = spec["kind"], spec["dims"], spec["B"]
         out = dict(meta=np.array([str(mg.META)]), kind=np.array([kind]),
                    dims=np.array([S, A, B, spec["gstep"], acfg.hidden_dim, acfg.layer_count]), step=np.array([spec["step"]]),
@@ -216,10 +280,30 @@ def main():
             if k in r32:
                 out[k + "32"] = r32[k].astype(np.float32)
                 out[k + "64"] = r64[k]
+        # activation kinks: one fp64 re-run per near-zero unit with its derivative flipped
+        gnets = [n for n in names if f"g_{n}" in r64]
+        units, effects = [], []
+        for (net, ai, call, b, j, z) in r64["kinks"]:
+            rf, _, _, _ = run_case(case, spec, torch.float64, flips=[(net, ai, call, b, j)])
+            eff = {n: rf[f"g_{n}"] - r64[f"g_{n}"] for n in gnets}
+            if max(float(np.abs(e).max()) for e in eff.values()) == 0.0:
+                continue      # a pass that is never back-propagated (TQC's post-update metric forward)
+            units.append((gnets.index(net) if net in gnets else -1, ai, call, b, j, z))
+            effects.append(eff)
+        out["kink_units"] = np.array(units, dtype=np.float64).reshape(len(units), 6)
+        out["kink_nets"] = np.array(gnets)
+        for n in gnets:   # per network: the units that move its gradient, their flip vectors (sampled), inner products
+            rows = [u for u, e in enumerate(effects) if float(np.abs(e[n]).max()) > 0.0]
+            F = np.array([effects[u][n] for u in rows]).reshape(len(rows), r64[f"g_{n}"].size)
+            out[f"kinku_{n}"] = np.array(rows, dtype=np.int64)
+            out[f"kinkF_{n}"] = F[:, out[f"gidx_{n}"]].astype(np.float32)
+            out[f"kinkdot_{n}"] = F @ r64[f"g_{n}"]
+            out[f"kinkgram_{n}"] = F @ F.T
         path = os.path.join(HERE, f"full_{case}.npz")
         np.savez_compressed(path, **out)
         rel = np.abs(r32["tuple"] - r64["tuple"]) / np.maximum(1e-12, np.abs(r64["tuple"]))
-        print(case, "ok", os.path.getsize(path) // 1024, "KiB; ref32 vs ref64 tuple rel err max", float(rel.max()))
+        print(case, "ok", os.path.getsize(path) // 1024, "KiB; ref32 vs ref64 tuple rel err max", float(rel.max()),
+              "; near-kink units", len(r64["kinks"]), "with effect", len(units))
 
 
 if __name__ == "__main__":
