@@ -8,9 +8,14 @@ due, Polyak when due (reference src/agent.py:1378-1404 / src/env.py:384-385).  S
 as the trainer issues them, `gradient_step` (40) at a time with the buffer untouched in between.
 Inputs (the replay ring) are resident in HBM before the timed region.
 
-N > 1: one process per GPU (torchrun env), each rank owns a local ring and draws its own batch
-of B rows; gradients are all-reduced over RCCL — once per overlapped DDPG step (critic and actor
-blocks are adjacent), twice per step otherwise (critic, then actor).  Per-GPU work is fixed -> "scaling": "weak"; value = per-rank gradient steps summed over ranks / time.
+N > 1: one process per GPU — under torchrun (RANK / WORLD_SIZE in the environment) or, when started as
+plain `python bench.py --gpus N`, N rank processes spawned by this script before it touches the GPU.
+Each rank owns a local ring and draws its own batch of B rows; gradients are all-reduced over RCCL —
+once per overlapped DDPG step (critic and actor blocks are adjacent), twice per step otherwise.
+Per-GPU work is fixed -> "scaling": "weak"; value = N x synchronised optimiser steps / s (batch-B-equivalent
+steps: one synchronised step consumes N x B rows — `value_semantics` in the line says so).  Two extra
+untimed-by-the-headline legs at N > 1: `strong_scaling` (the batch of B rows split over the ranks) and
+`cfg5_sac_slide_b512` (BASELINE.json configs[4]).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline         the dominant kernel.  DDPG (row-block path): rowchain_ddpg_kernel, the forward and
@@ -143,9 +148,118 @@ def cpu_baseline(w, pool, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 2000:
             break
-    return dict(value=n / el, unit="gradient-steps/s", cores=threads, kind="port",
+    return dict(value=n / el, unit="gradient-steps/s", cores=threads, kind="port", host=host_info(),
                 sample=f"{n} oracle update() calls in {el:.1f}s after filling the deque to {len(orc.buffer)} rows "
                        f"({fill_s:.1f}s); {w['kind']} B={w['B']} H={w['H']} L={w['L']}; torch {threads} threads")
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE anything in
+    this process touches the GPU, wait for them, relay rank 0's JSON line, exit with the worst status.  (Never
+    exec: a process that has initialised the GPU must not be replaced, and this one has not even done that.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode("utf-8", "replace")
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) failed: {bad}")
+
+
+def host_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return dict(cpu_model=model, logical_cpus=os.cpu_count(), usable_cpus=avail)
+
+
+def build_agent(w, args, rank, local_rank, batch=None):
+    import gcrl_amd
+    from gcrl_amd.src.dp import rank_seed
+    cfg = make_cfg(dict(w, B=batch or w["B"]))
+    cls = dict(DDPG=gcrl_amd.DDPG, TD3=gcrl_amd.TD3Agent, SAC=gcrl_amd.SACAgent, TQC=gcrl_amd.TQCAgent)[w["kind"]]
+    agent = cls(w["S"], w["A"], cfg, None, nenvs=8, gradient_step=w["gstep"], use_graph=not args.no_graph,
+                pipeline=(True if args.pipeline < 0 else args.pipeline), rng=args.rng, seed=rank_seed(1898, rank),
+                device_index=local_rank)
+    pool = episode_pool(w, 64, seed=1898 + rank)
+    arrays = [episode_arrays(ep) for ep in pool]
+    rows_per_ep = 50 + w["k"] * 49
+    n_eps = -(-w["cap"] // rows_per_ep)          # fill to capacity before timing (SURVEY §8d)
+    t_fill = time.perf_counter()
+    for ep in range(n_eps):
+        s, a, ns, r, d, ag = arrays[ep % len(arrays)]
+        agent.buffer.push_episode(ep % 8, s, a, ns, r, d, ag)
+    torch.cuda.synchronize()
+    t_fill = time.perf_counter() - t_fill
+    assert len(agent.buffer) == min(w["cap"], n_eps * rows_per_ep)
+    return agent, pool, t_fill
+
+
+def timed_region(agent, dp, w, steps, warmup, step0=1):
+    """W warm-up steps, one untimed call of every chunk size the timed region will issue (lazily built graphs and
+    buffers exist before the clock starts), then exactly `steps` steps between barrier + synchronize pairs."""
+    import torch.distributed as dist
+    gstep = w["gstep"]
+
+    def run(s0, n):
+        done = 0
+        while done < n:
+            m = min(gstep, n - done)
+            (agent if dp is None else dp).update_many(s0 + done, m)
+            done += m
+
+    run(step0, warmup)
+    extra = 0
+    for m in sorted({min(gstep, steps), steps % gstep} - {0}):
+        run(step0 + warmup + extra, m)
+        extra += m
+    s0 = step0 + warmup + extra
+    torch.cuda.synchronize()
+    if dp is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(s0, steps)
+    torch.cuda.synchronize()
+    if dp is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, s0 + steps, extra, run
+
+
+def pmc_traffic(workload, kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r02_pmc_traffic_<workload>.json, made by tools/pmc_traffic.sh: FETCH_SIZE x 2 + WRITE_SIZE per the
+    guide's gfx950 correction).  bench.py cannot run the counter tool on itself."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{workload}.json")
+    if not os.path.exists(path):
+        return None
+    for name, d in json.load(open(path)).items():
+        if kernel_substr in name and "hbm_bytes_per_launch_corrected" in d:
+            return d
+    return None
 
 
 def main():
@@ -159,16 +273,26 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--rng", default="engine", choices=["engine", "device"], help="index streams: CPython-exact MT (default) or the counter hash")
     ap.add_argument("--pipeline", type=int, default=-1, help="schedule level (see gcrl_agent_config.pipeline_steps); -1: the default")
+    ap.add_argument("--no-extra-legs", action="store_true", help="N > 1: skip the strong-scaling and cfg-5 (SAC) legs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)       # nothing above has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torchrun with WORLD_SIZE={args.gpus} (got {world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("GCRL_BENCH_SPAWN_ECHO"):   # CPU test of the launch plumbing: report the rank environment, touch nothing
+        if rank == 0:
+            print(json.dumps(dict(rank=rank, world=world, master=os.environ.get("MASTER_ADDR"), port=os.environ.get("MASTER_PORT"))))
+        raise SystemExit(int(os.environ["GCRL_BENCH_SPAWN_ECHO"]) if rank == world - 1 else 0)
     # one rank per GPU; GCRL_DIST_BACKEND=gloo lets several ranks rehearse the DP path on ONE GPU
     backend = os.environ.get("GCRL_DIST_BACKEND", "nccl")
-    local_rank = local_rank % max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > max(1, ndev):
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} GPUs, {ndev} visible (GCRL_DIST_BACKEND=gloo shares one GPU)")
+    local_rank = local_rank % max(1, ndev)
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     # GCRL_FORCE_DP=1: take the data-parallel path (process group + exchanges) even at world size 1,
@@ -182,93 +306,82 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    import gcrl_amd
+    import gcrl_amd  # noqa: F401
     from gcrl_amd._ffi import lib, check
-    from gcrl_amd.src.dp import DataParallelUpdater, rank_seed
+    from gcrl_amd.src.dp import DataParallelUpdater
 
     w = WORKLOADS[args.workload]
-    cfg = make_cfg(w)
-    cls = dict(DDPG=gcrl_amd.DDPG, TD3=gcrl_amd.TD3Agent, SAC=gcrl_amd.SACAgent, TQC=gcrl_amd.TQCAgent)[w["kind"]]
+    gstep = w["gstep"]
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        agent = cls(w["S"], w["A"], cfg, None, nenvs=8, gradient_step=w["gstep"], use_graph=not args.no_graph, pipeline=(True if args.pipeline < 0 else args.pipeline),
-                    rng=args.rng, seed=rank_seed(1898, rank), device_index=local_rank)
-        pool = episode_pool(w, 64, seed=1898 + rank)
-        arrays = [episode_arrays(ep) for ep in pool]
-        rows_per_ep = 50 + w["k"] * 49
-        n_eps = -(-w["cap"] // rows_per_ep)          # fill to capacity before timing
-        t_fill = time.perf_counter()
-        for ep in range(n_eps):
-            s, a, ns, r, d, ag = arrays[ep % len(arrays)]
-            agent.buffer.push_episode(ep % 8, s, a, ns, r, d, ag)
-        torch.cuda.synchronize()
-        t_fill = time.perf_counter() - t_fill
-        assert len(agent.buffer) == min(w["cap"], n_eps * rows_per_ep)
-
+        agent, pool, t_fill = build_agent(w, args, rank, local_rank)
         dp = DataParallelUpdater(agent) if (world > 1 or force_dp) else None
-        gstep = w["gstep"]
+        elapsed, next_step, extra_warm, run = timed_region(agent, dp, w, args.steps, args.warmup)
 
-        def run(step0, n):
-            done = 0
-            while done < n:
-                m = min(gstep, n - done)
-                (agent if dp is None else dp).update_many(step0 + done, m)
-                done += m
-
-        run(1, args.warmup)
-        torch.cuda.synchronize()
+        # ---- untimed measurement legs -------------------------------------------------------
+        # HER gather kernel: hipEvent pairs + device clock around every gather launch of 10 trainer cycles
         her = agent.buffer.handle
         check(lib.gcrl_her_profile_enable(her, 1))
-        if dp is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(1 + args.warmup, args.steps)
-        torch.cuda.synchronize()
-        if dp is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
+        run(next_step, 10 * gstep)
+        next_step += 10 * gstep
         launches, ms, rows, dev_ms = C.c_int64(), C.c_double(), C.c_int64(), C.c_double()
         check(lib.gcrl_her_profile_read(her, C.byref(launches), C.byref(ms), C.byref(rows), C.byref(dev_ms)))
         check(lib.gcrl_her_profile_enable(her, 0))
-        # roofline leg for the row-block kernel: a short untimed run with the engine's measurement
-        # hooks on (plain launches, each overlapped row-block launch bracketed by hipEvents on its
-        # stream + device clock stamps)
+        # row-chain kernel: the engine's measurement hooks (plain launches, every row-chain launch bracketed by
+        # hipEvents on its stream + device clock stamps)
         rc = None
-        if w["kind"] == "DDPG" and dp is None and w["H"] % 4 == 0:
+        if w["kind"] in ("DDPG", "TD3") and dp is None and w["H"] % 4 == 0:
             check(lib.gcrl_agent_profile_enable(agent._h, 1))
-            run(1 + args.warmup + args.steps, 10 * gstep)
+            run(next_step, 10 * gstep)
+            next_step += 10 * gstep
             n_l, ev_ms, clk_ms = C.c_int64(), C.c_double(), C.c_double()
             check(lib.gcrl_agent_profile_read(agent._h, C.byref(n_l), C.byref(ev_ms), C.byref(clk_ms)))
             check(lib.gcrl_agent_profile_enable(agent._h, 0))
             if n_l.value:
                 rc = (n_l.value, ev_ms.value * 1e3 / n_l.value, clk_ms.value * 1e3 / n_l.value)
         # a last metrics fetch proves the steps really ran to completion
-        last = [float(x) for x in (agent.update_many(1 + args.warmup + args.steps + 10 * gstep, 1)[0] if dp is None
-                                   else dp.update(1 + args.warmup + args.steps))]
+        last = [float(x) for x in (agent.update_many(next_step, 1)[0] if dp is None else dp.update(next_step))]
+        next_step += 1
         assert all(np.isfinite(last)), last
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        legs = {}
+        if world > 1 and not args.no_extra_legs:
+            # strong scaling: the metric's batch of B rows split over the ranks (B/N rows each), same ring size
+            if w["B"] % world == 0:
+                ag_s, _, _ = build_agent(w, args, rank, local_rank, batch=w["B"] // world)
+                dp_s = DataParallelUpdater(ag_s)
+                el_s, _, _, _ = timed_region(ag_s, dp_s, w, max(gstep, min(args.steps, 10 * gstep)), min(args.warmup, 2 * gstep))
+                n_s = max(gstep, min(args.steps, 10 * gstep))
+                legs["strong_scaling"] = dict(global_batch=w["B"], batch_per_gpu=w["B"] // world, steps=n_s,
+                                              value=n_s / el_s, unit="gradient-steps/s", ms_per_step=1e3 * el_s / n_s,
+                                              note="fixed global batch: a latency-bound chain of 256-wide layers does not get "
+                                                   "shorter with fewer rows per GPU, and gains two exchanges (DESIGN.md §6)")
+                del dp_s, ag_s
+            # BASELINE cfg 5: SAC Slide, B=512 per GPU, 64 env streams over the ranks
+            w5 = WORKLOADS["sac_slide_b512"]
+            ag5, _, _ = build_agent(w5, args, rank, local_rank)
+            dp5 = DataParallelUpdater(ag5)
+            n5 = max(w5["gstep"], min(args.steps, 5 * w5["gstep"]))
+            el5, _, _, _ = timed_region(ag5, dp5, w5, n5, min(args.warmup, 2 * w5["gstep"]))
+            legs["cfg5_sac_slide_b512"] = dict(batch_per_gpu=w5["B"], steps=n5, sync_optimizer_steps_per_s=n5 / el5,
+                                               value=world * n5 / el5, unit="gradient-steps/s (batch-512 equivalents)",
+                                               ms_per_step=1e3 * el5 / n5, batchnorm="local statistics per rank (DESIGN.md §6)")
+            del dp5, ag5
 
     if rank == 0:
         R = (2 * w["S"] + w["A"] + 2) * 4
         alg_bytes_per_row = 2 * R                      # read the record + write the batch row
         rows_per_launch = rows.value / max(1, launches.value)
         avg_us = ms.value * 1e3 / max(1, launches.value)
+        dev_us = dev_ms.value * 1e3 / max(1, launches.value)
         achieved = (alg_bytes_per_row * rows_per_launch) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-        # (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section); bench.py cannot run the
-        # counter tool on itself, so the per-row figure measured there is scaled to this run's rows
+        achieved_dev = (alg_bytes_per_row * rows_per_launch) / (dev_us * 1e-6) / 1e9 if dev_us > 0 else 0.0
+        g_pmc = pmc_traffic(args.workload, "her_gather")
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", f"r01_e_bench_pmc_traffic_{args.workload}.json")
-        if os.path.exists(pmc_file):
-            g = json.load(open(pmc_file)).get("her_gather_update_kernel", {})
-            if g.get("rows_per_launch"):
-                traffic = g["hbm_bytes_corrected"] / g["rows_per_launch"] * rows_per_launch
-        value = world * args.steps / elapsed
+        if g_pmc and g_pmc.get("rows_per_launch"):
+            traffic = g_pmc["hbm_bytes_per_launch_corrected"] / g_pmc["rows_per_launch"] * rows_per_launch
+        sync_rate = args.steps / elapsed
+        value = world * sync_rate
         out = {
             "metric": "gradient-steps/sec (HER sample + critic+actor update)",
             "value": value, "unit": "gradient-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -278,37 +391,56 @@ def main():
                        "state_dim": w["S"], "action_dim": w["A"], "hidden": w["H"], "layers": w["L"], "k_future": w["k"],
                        "gradient_step": gstep, "parallelism": f"dp{world}" if world > 1 else "single",
                        "hip_graph": not args.no_graph,
-                       "rng": "cpython-mt19937 (host) indices" if args.rng == "engine" else "counter-hash indices (in-kernel HER picks)"},
-            "roofline_gather": {"kernel": "her_gather_update_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches": launches.value, "avg_launch_us": avg_us, "rows_per_launch": rows_per_launch,
-                         "algorithmic_bytes_per_row": alg_bytes_per_row,
-                         "timing": "hipEvent pair around each launch on its stream (includes event/dispatch overhead)",
-                         "kernel_us_device_clock": dev_ms.value * 1e3 / max(1, launches.value),
-                         "achieved_device_clock": (alg_bytes_per_row * rows_per_launch) / max(1e-9, dev_ms.value * 1e-3 / max(1, launches.value)) / 1e9},
+                       "rng": "cpython-mt19937 (host) indices" if args.rng == "engine" else "counter-hash indices (in-kernel HER picks)",
+                       "reward": "built-in sparse goal-distance reward (panda-gym absent: the only parity-unpinned seam, DESIGN.md §2)"},
+            "value_semantics": ("one agent.update(step) on a batch of %d rows per second" % w["B"]) if world == 1 else
+                               ("weak scaling: every rank draws its own batch of %d rows and the gradients are all-reduced, so ONE "
+                                "synchronised optimiser step consumes %d x %d rows; value = samples/s / %d = n_gpus x "
+                                "sync_optimizer_steps_per_s (batch-%d-equivalent gradient steps)" % (w["B"], world, w["B"], w["B"], w["B"])),
+            "sync_optimizer_steps_per_s": sync_rate,
+            "warmup_extra_steps": extra_warm,
+            "roofline_gather": {"kernel": "her_gather_update_kernel", "bound": "hbm", "achieved": achieved_dev, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": achieved_dev / HBM_PEAK_GBS, "traffic": traffic,
+                                "launches": launches.value, "avg_launch_us": dev_us, "rows_per_launch": rows_per_launch,
+                                "algorithmic_bytes_per_row": alg_bytes_per_row,
+                                "timing": "device wall clock inside the kernel (last block end - first block start = rocprofv3's "
+                                          "kernel duration), separate untimed leg of 10 trainer cycles",
+                                "hip_event_us": avg_us, "achieved_hip_event": achieved,
+                                "note": "one launch per trainer cycle gathers gradient_step x B rows; below ~1e5 rows the launch is "
+                                        "latency-bound (DESIGN.md §4)"},
             "update_flops": {"gflop_per_step": flops_per_step(w) / 1e9,
                              "achieved_tflops": flops_per_step(w) * args.steps / elapsed / 1e12,
                              "peak_tflops": FP32_MFMA_PEAK_TF},
-            "fill_s": t_fill, "last_metrics": last,
+            "fill_s": t_fill, "last_metrics": last, "host": host_info(),
         }
-        if rc is not None:
+        out.update(legs)
+        if rc is not None and w["kind"] == "DDPG":
             fl = chain_flops_per_launch(w)
+            r_pmc = pmc_traffic(args.workload, "rowchain")
             out["roofline"] = {
-                "kernel": "rowchain_ddpg_kernel", "bound": "mfma", "achieved": fl / (rc[1] * 1e-6) / 1e12,
-                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / (rc[1] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF,
-                "traffic": None, "launches": rc[0], "avg_launch_us": rc[1], "algorithmic_flops_per_launch": fl,
-                "timing": "hipEvent pair around each launch on its stream, separate untimed leg of 10 trainer cycles "
-                          "(includes event/dispatch overhead)",
-                "kernel_us_device_clock": rc[2], "achieved_device_clock": fl / (rc[2] * 1e-6) / 1e12,
+                "kernel": "rowchain_ddpg_kernel", "bound": "mfma", "achieved": fl / (rc[2] * 1e-6) / 1e12,
+                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / (rc[2] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF,
+                "traffic": r_pmc["hbm_bytes_per_launch_corrected"] if r_pmc else None,
+                "l2_to_cu_read_requests_per_launch": r_pmc.get("TCP_TCC_READ_REQ_sum") if r_pmc else None,
+                "launches": rc[0], "avg_launch_us": rc[2], "algorithmic_flops_per_launch": fl,
+                "timing": "device wall clock inside the kernel (= rocprofv3's kernel duration; profiles/), separate untimed leg of "
+                          "10 trainer cycles with every launch also bracketed by a hipEvent pair on its stream",
+                "hip_event_us": rc[1], "achieved_hip_event": fl / (rc[1] * 1e-6) / 1e12,
                 "share_of_step_time": rc[2] / (1e6 * elapsed / args.steps),
-                "note": "latency-bound chain (8 dependent 256-wide layer passes per phase, 128 of 256 CUs at B=256), see DESIGN.md §4"}
+                "note": "latency-bound chain (10 dependent 256-wide layer passes per phase, 128 of 256 CUs at B=256), see DESIGN.md §4"}
         else:
-            out["roofline"] = dict(out["roofline_gather"])
+            # many-kernel steps (TD3 / SAC / TQC): the step as a whole against the MFMA roofline, not one kernel
+            tf = flops_per_step(w) * args.steps / elapsed / 1e12
+            out["roofline"] = {"kernel": "whole update step (all launches; per-kernel shares in profiles/)", "bound": "mfma",
+                               "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
+                               "traffic": None, "timing": "algorithmic flops per step / measured step time"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, pool, args.cpu_seconds)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

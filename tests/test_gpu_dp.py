@@ -202,8 +202,10 @@ def test_two_ranks_local_batchnorm_matches_the_dp_oracle(gcrl, tmp_path, kind):
         w = np.array([t + [0.0] * (9 - len(t)) for t in (want[s][i] for s in range(3))])
         assert np.allclose(r[i]["tuples"], w, rtol=2e-4, atol=2e-5), (kind, i, np.abs(r[i]["tuples"] - w).max())
         bns = [m for m in reps[i].actor.base_net if isinstance(m, torch.nn.BatchNorm1d)]
-        assert np.allclose(r[i]["bn_mean"], np.concatenate([m.running_mean.numpy() for m in bns]), rtol=1e-4, atol=1e-5)
-        assert np.allclose(r[i]["bn_var"], np.concatenate([m.running_var.numpy() for m in bns]), rtol=1e-4, atol=1e-5)
+        # a Linear bias in front of a BatchNorm has an analytically zero gradient: Adam moves it by +-lr per step on
+        # rounding noise, and the batch mean moves with it (0.1 * lr per step into the running mean)
+        assert np.allclose(r[i]["bn_mean"], np.concatenate([m.running_mean.numpy() for m in bns]), rtol=1e-3, atol=1e-3)
+        assert np.allclose(r[i]["bn_var"], np.concatenate([m.running_var.numpy() for m in bns]), rtol=1e-3, atol=1e-4)
     assert not np.array_equal(r[0]["bn_mean"], r[1]["bn_mean"])      # local statistics: the ranks saw different rows
     o = reps[0]
     for k, v in (("actor", o.flat_params(o.actor)), ("critic", o.flat_params(o.critics[0])),

@@ -142,3 +142,23 @@ def test_device_entry_points_fail_loudly_without_gpu(gcrl, lib):
     assert b"no CPU fallback" in lib.gcrl_last_error()
     with pytest.raises(gcrl._ffi.GcrlError):
         gcrl.HERBuffer(100, 50, 1)
+
+
+def test_bench_spawns_one_process_per_gpu_without_a_launcher():
+    """`python bench.py --gpus N` as the driver runs it: N fresh rank processes with RANK / WORLD_SIZE / MASTER_*
+    set, rank 0's line relayed, a failing rank turns into a non-zero exit (launch plumbing only: no GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GCRL_BENCH_SPAWN_ECHO="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "5", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["rank"] == 0 and line["world"] == 3 and line["master"] == "127.0.0.1" and int(line["port"]) > 0
+    env["GCRL_BENCH_SPAWN_ECHO"] = "7"       # the last rank exits 7
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "rank(s) failed" in r.stderr
