@@ -113,6 +113,13 @@ PROTOTYPES = {
     "gcrl_agent_dp_phase": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "gcrl_agent_dp_end": (C.c_int, [_vp, _vp]),
     "gcrl_agent_dp_run": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i64), _vp]),
+    "gcrl_dp_unique_id": (C.c_int, [_vp, _cp]),
+    "gcrl_dp_create": (_vp, [C.c_int, C.c_int, _vp, C.c_int, _cp]),
+    "gcrl_dp_destroy": (None, [_vp]),
+    "gcrl_dp_world": (C.c_int, [_vp]),
+    "gcrl_dp_allreduce_sum": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "gcrl_dp_broadcast": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
+    "gcrl_agent_dp_run_all": (C.c_int, [_vp, _vp, _vp]),
     "gcrl_agent_dev_ptr": (C.c_int, [_vp, _cp, C.POINTER(_vp), C.POINTER(_i64)]),
     "gcrl_agent_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "gcrl_agent_act_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),

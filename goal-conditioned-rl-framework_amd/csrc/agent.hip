@@ -1213,6 +1213,18 @@ int gcrl_agent_dp_run(gcrl_agent* a, float** reduce_ptr_out, int64_t* reduce_num
   return 0;
 }
 
+int gcrl_agent_dp_run_all(gcrl_agent* a, gcrl_dp* d, void* stream) {
+  GCRL_CHECK_ARG(a && d, "gcrl_agent_dp_run_all: null handle");
+  for (;;) {
+    float* ptr = nullptr;
+    int64_t n = 0;
+    const int more = gcrl_agent_dp_run(a, &ptr, &n, stream);
+    if (more < 0) return more;
+    if (n > 0) TRY(gcrl_dp_allreduce_sum(d, ptr, n, stream ? stream : (void*)a->stream));
+    if (!more) return GCRL_OK;
+  }
+}
+
 int gcrl_agent_dp_phase(gcrl_agent* a, int i, int phase, void* stream) {
   GCRL_CHECK_ARG(a && phase >= 0 && phase <= 2, "gcrl_agent_dp_phase: bad arguments");
   GCRL_CHECK_ARG(i >= 0 && i < (int)a->dp_plans.size(), "gcrl_agent_dp_phase: step %d outside the begun cycle of %d", i, (int)a->dp_plans.size());

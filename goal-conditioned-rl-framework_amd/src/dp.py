@@ -17,6 +17,12 @@ statistics per rank (stated divergence from a single big batch).  Each exchange 
 buffer: messages are 37 KB - 11 MB, latency-bound on point-to-point xGMI, so fewer, larger
 collectives beat per-tensor ones.
 
+Over RCCL the exchange itself lives in the engine too: `DataParallelUpdater` creates a library-owned
+communicator (`gcrl_dp_create`, csrc/dp_rccl.cc; the 128-byte id travels through torch.distributed's store)
+and a whole trainer cycle is ONE native call (`gcrl_agent_dp_run_all`) that enqueues every graph segment and
+every all-reduce on the engine's stream — no Python round trip per exchange.  With any other backend (gloo in
+the tests) the Python loop below moves the bytes instead; the schedule is the same.
+
 For runs of plain DDPG steps the engine schedules the software-pipelined form instead (actor phase
 of step i in the same launches as the critic phase of step i+1): both gradient blocks are ready at
 the same point and adjacent in memory, so a step costs ONE all-reduce.  The schedule lives in the
@@ -26,6 +32,7 @@ moves the bytes, with whatever torch.distributed backend the process group has.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -79,11 +86,36 @@ class DataParallelUpdater:
         lib = _ffi.lib
         self._views = {}
         self._blocks = []
+        self._block_ptrs = []
+        self._native = None
+        if dist.get_backend(group) == "nccl" and not int(os.environ.get("GCRL_DP_PYTHON_EXCHANGE", "0")):
+            # the librccl PyTorch itself uses (two RCCL / HIP runtime copies in one process do not mix)
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
+            uid = (C.c_uint8 * 128)()
+            if dist.get_rank(group) == 0:
+                _ffi.check(lib.gcrl_dp_unique_id(uid, path))
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            self._native = _ffi.check_ptr(lib.gcrl_dp_create(dist.get_rank(group), self.world, box[0], agent.device_index, path),
+                                          "gcrl_dp_create")
         for phase in (0, 1):
             p, n = C.c_void_p(), C.c_int64()
             _ffi.check(lib.gcrl_agent_grad_ptr(agent._h, phase, C.byref(p), C.byref(n)))
             self._blocks.append(device_view(p.value, n.value))
+            self._block_ptrs.append((p.value, n.value))
         self.sync_parameters()
+
+    def __del__(self):
+        h, self._native = getattr(self, "_native", None), None
+        if h:
+            self._ffi.lib.gcrl_dp_destroy(h)
+
+    def _allreduce_block(self, i: int, st):
+        if self._native:
+            p, n = self._block_ptrs[i]
+            self._ffi.check(self._ffi.lib.gcrl_dp_allreduce_sum(self._native, p, n, st))
+        else:
+            dist.all_reduce(self._blocks[i], op=dist.ReduceOp.SUM, group=self.group)
 
     def sync_parameters(self):
         """Rank 0's parameters (and BN statistics, log_alpha) become everyone's."""
@@ -109,6 +141,9 @@ class DataParallelUpdater:
         a.buffer.rng.pull()
         ffi.check(lib.gcrl_agent_dp_begin(a._h, her, int(step0), int(n), self.scale, tickets, lens, st))
         a.buffer.rng.push_back()
+        if self._native:   # segments and collectives enqueued by one native call
+            ffi.check(lib.gcrl_agent_dp_run_all(a._h, self._native, st))
+            return [a._tuple(int(t), int(l)) for t, l in zip(tickets, lens)]
         # the engine owns the schedule: run a segment, all-reduce the gradient block it names, repeat
         ptr, numel = C.c_void_p(), C.c_int64()
         more = 1
@@ -131,15 +166,16 @@ class DataParallelUpdater:
         her = a.buffer.handle if batch is None else None
         if batch is None:
             a.buffer.rng.pull()
+        st = ffi.stream_handle()
         n = ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 0, C.byref(inputs) if inputs is not None else None,
-                                                  self.scale, C.byref(ticket), ffi.stream_handle()))
+                                                  self.scale, C.byref(ticket), st))
         if batch is None:
             a.buffer.rng.push_back()
-        dist.all_reduce(self._blocks[0], op=dist.ReduceOp.SUM, group=self.group)
-        ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 1, None, self.scale, None, ffi.stream_handle()))
+        self._allreduce_block(0, st)
+        ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 1, None, self.scale, None, st))
         if n == {0: 6, 1: 8, 2: 9, 3: 9}[ffi_kind(a)]:   # tuple length of an actor step
-            dist.all_reduce(self._blocks[1], op=dist.ReduceOp.SUM, group=self.group)
-        ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 2, None, self.scale, None, ffi.stream_handle()))
+            self._allreduce_block(1, st)
+        ffi.check(lib.gcrl_agent_update_phase(a._h, her, int(step), 2, None, self.scale, None, st))
         return a._tuple(ticket.value, n)
 
 

@@ -309,6 +309,21 @@ int gcrl_agent_dp_end(gcrl_agent* a, void* stream);
  * of plain DDPG steps the software-pipelined form, where the critic gradients of step i+1 and the
  * actor gradients of step i are adjacent in memory and travel in ONE all-reduce per step. */
 int gcrl_agent_dp_run(gcrl_agent* a, float** reduce_ptr_out, int64_t* reduce_numel_out, void* stream);
+/* In-engine gradient exchange: an RCCL communicator owned by the library (one process per GPU; RCCL is bound at
+ * run time from `rccl_path` — the librccl the host process already uses — or the default soname when NULL).
+ * Rank 0 makes the 128-byte id and hands it to the other ranks by any side channel (torch.distributed's store,
+ * MPI, a file).  New design: the reference has no distributed code. */
+typedef struct gcrl_dp gcrl_dp;
+int gcrl_dp_unique_id(uint8_t* id128_out, const char* rccl_path);
+gcrl_dp* gcrl_dp_create(int rank, int world, const uint8_t* id128, int device, const char* rccl_path);
+void gcrl_dp_destroy(gcrl_dp* d);
+int gcrl_dp_world(const gcrl_dp* d);
+int gcrl_dp_allreduce_sum(gcrl_dp* d, float* buf_dev, int64_t n, void* stream); /* in place, fp32 */
+int gcrl_dp_broadcast(gcrl_dp* d, float* buf_dev, int64_t n, int root, void* stream);
+/* The whole data-parallel trainer cycle begun by gcrl_agent_dp_begin as ONE host call: every segment of the
+ * engine's schedule and, after each, the all-reduce(sum) of the gradient block it names, all enqueued on `stream`
+ * (what the caller of gcrl_agent_dp_run does one Python round trip at a time). */
+int gcrl_agent_dp_run_all(gcrl_agent* a, gcrl_dp* d, void* stream);
 /* device pointer of a named vector (parameters / grads), for zero-copy interop */
 int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr_dev_out, int64_t* numel_out);
 

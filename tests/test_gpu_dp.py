@@ -208,8 +208,67 @@ def test_two_ranks_local_batchnorm_matches_the_dp_oracle(gcrl, tmp_path, kind):
         assert np.allclose(r[i]["bn_var"], np.concatenate([m.running_var.numpy() for m in bns]), rtol=1e-3, atol=1e-4)
     assert not np.array_equal(r[0]["bn_mean"], r[1]["bn_mean"])      # local statistics: the ranks saw different rows
     o = reps[0]
+    # Linear biases in front of a BatchNorm: zero gradient, moved by +-lr per step on rounding noise -> left out
+    keep, off = np.ones(probe.actor.numel(), bool), 0
+    for key, shape in probe.actor._param_layout():
+        n = int(np.prod(shape))
+        if key.startswith("base_net") and key.endswith("bias") and int(key.split(".")[1]) % 3 == 0:
+            keep[off:off + n] = False
+        off += n
     for k, v in (("actor", o.flat_params(o.actor)), ("critic", o.flat_params(o.critics[0])),
                  ("critic_last", o.flat_params(o.critics[-1])), ("target", o.flat_params(o.target_critics[0]))):
         err = np.abs(r[0][k].astype(np.float64) - v)
+        if k == "actor":
+            err = err[keep]
         assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
     assert abs(float(r[0]["log_alpha"][0]) - float(o.log_alpha.detach())) < 1e-5
+
+
+def _worker_rccl(rank, world, port, out_dir, kind):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    import gcrl_amd
+    from gcrl_amd.src.dp import DataParallelUpdater
+    from oracle import her_oracle
+    cls = dict(DDPG=gcrl_amd.DDPG, SAC=gcrl_amd.SACAgent)[kind]
+    ag = cls(S, A, _cfg(kind, B), None, nenvs=1, gradient_step=45, rng="engine", seed=7)
+    gen = np.random.default_rng(3)
+    for _ in range(3):
+        for st in her_oracle.synthetic_episode(gen, 50, S, A):
+            ag.push_her(0, *st)
+    _init_params(ag)
+    dp = DataParallelUpdater(ag)
+    assert dp._native, "the RCCL process group must select the in-engine exchange"
+    out = [[float(x) for x in t] for t in dp.update_many(1, 45)]      # one native call: segments + all-reduces
+    out += [[float(x) for x in dp.update(46)]]                        # the per-phase entry, collectives native too
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rccl.npz"), actor=ag.actor.flat(), critic=ag.critics[0].flat(),
+             tuples=np.array([t + [0.0] * (9 - len(t)) for t in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["DDPG", "SAC"])
+def test_in_engine_rccl_exchange_world_size_one(gcrl, tmp_path, kind):
+    """The library-owned RCCL communicator (csrc/dp_rccl.cc) and the one-call trainer cycle
+    (gcrl_agent_dp_run_all) on the one GPU this box has: a single-rank all-reduce is the identity, so the run
+    must track a single-process update_many (the clip norm is summed by a different kernel: tolerance)."""
+    from oracle import her_oracle
+    mp.spawn(_worker_rccl, args=(1, _free_port(), str(tmp_path), kind), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    cls = dict(DDPG=gcrl.DDPG, SAC=gcrl.SACAgent)[kind]
+    ag = cls(S, A, _cfg(kind, B), None, nenvs=1, gradient_step=45, rng="engine", seed=7)
+    gen = np.random.default_rng(3)
+    for _ in range(3):
+        for st in her_oracle.synthetic_episode(gen, 50, S, A):
+            ag.push_her(0, *st)
+    _init_params(ag)
+    ref = [[float(x) for x in t] for t in ag.update_many(1, 45)] + [[float(x) for x in ag.update(46)]]
+    ref = np.array([t + [0.0] * (9 - len(t)) for t in ref])
+    if kind == "DDPG":
+        assert np.allclose(r["tuples"], ref, rtol=2e-4, atol=2e-5), np.abs(r["tuples"] - ref).max()
+        assert float(np.max(np.abs(r["actor"] - ag.actor.flat()))) < 5e-4
+    else:   # SAC draws its exploration noise from the device counter hash: same counters, same draws
+        assert np.allclose(r["tuples"][:5], ref[:5], rtol=5e-4, atol=5e-5), np.abs(r["tuples"][:5] - ref[:5]).max()
