@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <random>
 #include <string>
@@ -110,10 +111,12 @@ struct gcrl_agent {
   float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
   float *noise_in = nullptr, *eps_next_in = nullptr, *eps_cur_in = nullptr, *norm_partial = nullptr;
   float *act_in = nullptr, *act_tmp[2] = {};
+  float* pi_buf = nullptr;   // SAC row-chain path: pi(s) [B][Apad] (the layer-per-launch paths keep it in spa's action columns)
   float* act_pinned = nullptr;   // host staging of gcrl_agent_act_host
   // row-block DDPG path (rowchain.h): [in][out] weight copies of actor | target actor | critic 0 |
   // target critic 0, per-layer gradient buffers, TD targets
   bool rowchain = false, wt_dirty = true;
+  bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
   int row_rg = 1, row_ldl = 0;
   float *wt = nullptr, *rc_gC = nullptr, *rc_gA = nullptr, *ybuf = nullptr;
   long long wt_net[4] = {};   // offsets of actor | target actor | critic 0 | target critic 0 inside wt
@@ -197,7 +200,7 @@ __global__ void pack_batch_kernel(const float* s, int ld_s, const float* a, int 
   if (c < S) {
     const float v = s[(long long)b * ld_s + c];
     sa[(long long)b * ldx + c] = v;
-    spa[(long long)b * ldx + c] = v;
+    if (spa) spa[(long long)b * ldx + c] = v;
   } else if (c < S + A) sa[(long long)b * ldx + c] = a[(long long)b * ld_a + (c - S)];
   else if (c < W - 2) nsa[(long long)b * ldx + (c - S - A)] = ns[(long long)b * ld_ns + (c - S - A)];
   else if (c == W - 2) rb[b] = r[b];
@@ -293,7 +296,7 @@ void chain_mlp(gcrl_agent* a, Launches& ls, size_t at, const NetSpec& net, const
 // heads, tanh-Gaussian sample.  save: keep what the backward needs.  extra: critic-chain
 // launches co-scheduled with the actor's GEMM launches (may be null).
 int sac_actor_forward(gcrl_agent* a, hipStream_t st, const float* X0, long long x_slot, bool save, float* act_dst,
-                      long long act_slot, float* logp_dst, const float* eps_in, int rng_stream, Launches* extra) {
+                      long long act_slot, float* logp_dst, const float* eps_in, int rng_stream, Launches* extra, int ld_act = 0) {
   const NetSpec& net = a->actor;
   const float* P = a->P_actor();
   const int B = a->B, H = a->H;
@@ -323,7 +326,7 @@ int sac_actor_forward(gcrl_agent* a, hipStream_t st, const float* X0, long long 
   tg.cur = a->cur();
   tg.mu = a->headA; tg.ls_raw = a->headA + a->Apad; tg.ld_head = 2 * a->Apad;
   tg.eps = eps_in;
-  tg.act = act_dst; tg.act_slot_stride = act_slot; tg.ld_act = a->ldx;
+  tg.act = act_dst; tg.act_slot_stride = act_slot; tg.ld_act = ld_act ? ld_act : a->ldx;
   tg.logp = logp_dst;
   tg.save_eps = save ? a->epsbuf : nullptr;
   tg.save_std = save ? a->stdbuf : nullptr;
@@ -495,8 +498,12 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     chain_mlp(a, af, 0, a->actor, a->P_actor(), a->spa, a->ldx, a->slot_x, hid_A, 0, a->spa + S, a->ldx, a->slot_x, EPI_TANH, B);
     TRY(af.run(st));
   } else {
-    TRY(sac_actor_forward(a, st, a->spa, a->slot_x, true, a->spa + S, a->slot_x, a->logp,
-                          (variant & V_EPSC) ? a->eps_cur_in : nullptr, 2, nullptr));
+    if (a->rowchain)   // s is read from sa's rows, pi(s) goes to its own [B][Apad] matrix (no spa on this path)
+      TRY(sac_actor_forward(a, st, a->sa, a->slot_x, true, a->pi_buf, 0, a->logp, (variant & V_EPSC) ? a->eps_cur_in : nullptr, 2,
+                            nullptr, a->Apad));
+    else
+      TRY(sac_actor_forward(a, st, a->spa, a->slot_x, true, a->spa + S, a->slot_x, a->logp,
+                            (variant & V_EPSC) ? a->eps_cur_in : nullptr, 2, nullptr));
   }
   if (a->rowchain) {   // SAC: both stepped critics, the min-selection gradient and their action gradients, one launch
     const PipeCtx pc{a->cur(), a->slot_ptr()};
@@ -552,6 +559,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     std::memset(&tb, 0, sizeof(tb));
     tb.dact = a->dact; tb.C = nac; tb.ld_dact = a->Apad; tb.dact_stride = (long long)B * a->Apad;
     tb.act = a->spa + S; tb.act_slot_stride = a->slot_x; tb.ld_act = a->ldx; tb.cur = a->cur();
+    if (a->rowchain) { tb.act = a->pi_buf; tb.act_slot_stride = 0; tb.ld_act = a->Apad; }
     tb.eps = a->epsbuf; tb.std = a->stdbuf; tb.ls_raw = a->headA + a->Apad; tb.ld_head = 2 * a->Apad;
     if (kind == GCRL_AGENT_SAC) tb.alpha_const = 0.2f; else tb.alpha_dev = a->alpha_dev;
     tb.gmu = a->ghead; tb.gls = a->ghead + a->Apad; tb.ld_g = 2 * a->Apad;
@@ -573,7 +581,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
                              a->invstdA + (long long)l * H, Pa + a->actor.bn_g[l], B, H, a->zA, Ga + a->actor.bn_g[l],
                              Ga + a->actor.bn_b[l], a->bn_part));
       std::vector<GemmDesc> v;
-      GemmDesc dw = bwd_dw(a->zA, H, l == 0 ? a->spa : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
+      GemmDesc dw = bwd_dw(a->zA, H, l == 0 ? (a->rowchain ? a->sa : a->spa) : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
       v.push_back(dw);
       if (l > 0) v.push_back(bwd_dx(a->zA, H, Pa, a->actor.lin[l], 0, H, a->gA[l & 1], H, B, MUL_NONE, nullptr, 0));
@@ -722,7 +730,7 @@ int stage_injected(gcrl_agent* a, const gcrl_update_inputs* in, hipStream_t st, 
     GCRL_CHECK_ARG(in->ld_s >= S && in->ld_ns >= S && in->ld_a >= A, "update: injected batch row stride too small");
     const int n = B * (2 * S + A + 2);
     hipLaunchKernelGGL(pack_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in->s_dev, in->ld_s, in->a_dev,
-                       in->ld_a, in->r_dev, in->ns_dev, in->ld_ns, in->d_dev, B, S, A, a->ldx, a->sa, a->nsa, a->spa,
+                       in->ld_a, in->r_dev, in->ns_dev, in->ld_ns, in->d_dev, B, S, A, a->ldx, a->sa, a->nsa, a->rowchain ? nullptr : a->spa,
                        a->rbuf, a->dbuf);
     GCRL_HIP(hipGetLastError());
   }
@@ -774,7 +782,7 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
   GCRL_HIP(hipMemcpyAsync(a->upload_dev, ub, bytes, hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(a->upload_ev[slot], st));
   if (!injected)
-    TRY(her_gather_update(her, device_rng ? nullptr : a->idx_dev(), (int64_t)n * a->B, a->sa, a->nsa, a->spa, a->ldx, a->rbuf, a->dbuf, st));
+    TRY(her_gather_update(her, device_rng ? nullptr : a->idx_dev(), (int64_t)n * a->B, a->sa, a->nsa, a->rowchain ? nullptr : a->spa, a->ldx, a->rbuf, a->dbuf, st));
   return GCRL_OK;
 }
 
@@ -853,7 +861,7 @@ int build(gcrl_agent* a) {
       {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH},
       {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
       {&a->hC2, (long long)C * L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H},
-      {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}};
+      {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}, {&a->pi_buf, (long long)B * a->Apad}};
   // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
   {
     const long long per_a = (long long)round_up(S, 4) * H + (long long)(L - 1) * H * H;
@@ -870,6 +878,10 @@ int build(gcrl_agent* a) {
     a->rowchain = (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3 || c.kind == GCRL_AGENT_SAC) && H % 4 == 0 &&
                   c.pipeline_steps >= 2 &&
                   rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H, C) <= 160 * 1024;
+    // SAC (the BatchNorm actor runs outside the chain kernels, both phases are critic-only): split by roles while the
+    // fused form leaves CUs idle, i.e. up to ~one workgroup per CU per role pair
+    a->split_roles = a->rowchain && c.kind == GCRL_AGENT_SAC && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) <= 256 &&
+                     !std::getenv("GCRL_NO_SPLIT_ROLES");
   }
   long long total = 0;
   for (auto& w : wants) total += align_up(w.second, 64);

@@ -138,7 +138,7 @@ int her_upload_indices(gcrl_her* h, int B, int M, const uint32_t* idx_host, hipS
                        const uint32_t** host_copy);
 
 // Gather for the update engine: rows idx_dev[0..n) -> three GEMM-ready matrices with row
-// stride ldx = roundup(S+A,4): sa = [s|a], nsa = [ns|0..], spa = [s|0..]; r[n], d[n].
+// stride ldx = roundup(S+A,4): sa = [s|a], nsa = [ns|0..], spa = [s|0..] (may be null: not written); r[n], d[n].
 int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa, float* nsa,
                       float* spa, int ldx, float* r, float* d, hipStream_t st);
 

@@ -289,7 +289,8 @@ struct GatherUpdArgs {
 };
 
 // 16 lanes x 16 B cover one record; every batch matrix is a 16-byte-aligned slice of it, so each
-// lane's float4 goes out as float4: sa <- [0,SA4), spa <- [0,S4), nsa <- [SA4,SA4+S4), (r,d).
+// lane's float4 goes out as float4: sa <- [0,SA4), nsa <- [SA4,SA4+S4), (r,d); spa <- [0,S4) only for the
+// layer-per-launch schedules (null otherwise: the row-chain kernels read s from sa, 92 fewer bytes written per row).
 // kRows records per wave are fetched before any store (independent loads in flight).
 template <int kUnroll>
 __global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p) {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p)
         const long long ro = row[u] * p.ldx;
         if (c0 < p.SA4) {
           *reinterpret_cast<float4*>(p.sa + ro + c0) = val[u];
-          if (c0 < p.S4) *reinterpret_cast<float4*>(p.spa + ro + c0) = val[u];
+          if (p.spa && c0 < p.S4) *reinterpret_cast<float4*>(p.spa + ro + c0) = val[u];
         } else if (c0 < o_r) {
           *reinterpret_cast<float4*>(p.nsa + ro + (c0 - p.SA4)) = val[u];
         } else if (c0 == o_r) {

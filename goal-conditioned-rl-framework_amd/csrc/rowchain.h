@@ -245,11 +245,11 @@ struct RowChainArgs {
   const float* noise; float policy_noise, noise_clamp; unsigned long long seed;
   // SAC (the BatchNorm actor runs outside, src/agent.py:557-570, :516-521): the K role takes the next
   // action from the action columns of nsa (given_next) and subtracts alpha*logp_next in the target
-  // (TGT_MIN_ENT); the P role is critic-only (p_critic_only): both critics on the rows of spa
-  // = [s | pi(s)], d(-min(q1,q2))/dq, each critic's input gradient w.r.t. the action into dz[c]
+  // (TGT_MIN_ENT); the P role is critic-only (p_critic_only): both critics on the rows
+  // [s (from sa) | pi(s) (from pi)], d(-min(q1,q2))/dq, each critic's input gradient w.r.t. the action into dz[c]
   int given_next, p_critic_only;
   const float* logp_next; float alpha;
-  const float* spa;
+  const float* pi;   // pi(s) [B][Apad] (P role, critic-only form)
   const float* sa; const float* nsa; const float* rbuf; const float* dbuf;   // + batch_slot * slot_*
   long long slot_x, slot_rd;
   int ldx, ldl, B, S, A, Apad;
@@ -258,7 +258,19 @@ struct RowChainArgs {
   float *hA, *gA, *hC2, *q2, *dz;   // P: ..., critic activations (scratch) [C][L][B][H], Q(s, pi(s)) [C][B], d(pre-tanh) [C][B][Apad]
   float gamma, clamp_lo;
   unsigned long long* clk;   // profiling: {first block start, last block end} in wall_clock64 ticks, or null
+  // split form (launch_rowchain_split): the roles of a phase run in DIFFERENT workgroups, two launches per phase
+  float* qt;       // [C][B] target-critic outputs (written by the forward launch, read by the backward launch)
 };
+
+// Twin-critic phases as role-parallel launches (SAC; TD3 at small batches).  In the fused kernel a workgroup
+// walks its rows through BOTH critics and BOTH target critics one after the other (16 dependent layer passes
+// at L = 3); the chains of different networks are independent until the TD target / the min-selection, so
+//   part 1 (forward)    K: roles [target critic k | online critic k], P: roles [critic k on [s|pi(s)]]
+//   part 2 (backward)   K: y, dq, input-gradient chain of critic k;   P: min-selection, chain, action gradient
+// run each role in its own workgroups: L passes + (L-1) passes on the critical path, the whole chip busy.
+// Same per-row arithmetic in the same order as the fused kernel (bitwise the same results).
+//   phase 0 = K (critic phase), 1 = P (actor phase, critic-only form); part 1 | 2
+int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part);
 
 // Batched actor inference (select_action, src/agent.py:1345-1366) as one row-block launch: 4 observation
 // rows per workgroup through the actor's hidden layers and its tanh head.

@@ -260,8 +260,19 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   } else if (a.p_critic_only) {
     const StepCtrl c = *a.cur_p;
     const int C = a.C;
-    const float* spa_rows = a.spa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
-    load_rows<RG>(X0, ldl, spa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
+    const float* s_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
+    {
+      const int jpad = a.critic[0].jpad0;
+      for (int i = tid; i < R * jpad; i += kRowThreads) {
+        const int r = i / jpad, cc = i - r * jpad;
+        float v = 0.f;
+        if (r < rv) {
+          if (cc < S) v = s_rows[(long long)r * a.ldx + cc];
+          else if (cc < S + A) v = a.pi[(row0 + r) * a.Apad + (cc - S)];
+        }
+        X0[r * ldl + cc] = v;
+      }
+    }
     float* hw_c = hw; float* hw_da = hw + C * H;   // heads [C][H], then rows S..S+A-1 of each W0^T [C][A][H]
     for (int k = 0; k < C; ++k) {
       stage(hw_c + k * H, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
@@ -365,6 +376,175 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   if (a.clk && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
 
+// ---- role-parallel form (rowchain.h: launch_rowchain_split) -------------------------------------------------
+template <int RG>
+__global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArgs a, int phase, int part) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int R = 4 * RG;
+  const int ldl = a.ldl, H = a.critic[0].H, S = a.S, A = a.A, B = a.B, C = a.C;
+  float* X0 = lds;
+  float* X1 = X0 + R * ldl;
+  float* X2 = X1 + R * ldl;
+  float* XS = X2 + R * ldl;
+  float* part_ = XS + R * ldl;
+  float* sm = part_ + R * 16 + (RG == 1 ? 2 : 1) * 4 * R * kRowChunk;
+  float* sm2 = sm + R * 16;
+  float* sm3 = sm2 + R * 16;
+  float* hw = sm3 + R * 16;
+  float* hb = hw + max(max(2 * A + 1, A + 2 * C), C * (A + 1)) * H;
+  const int nblk = (B + R - 1) / R;
+  const int role = (int)blockIdx.x / nblk;
+  const int blk = (int)blockIdx.x - role * nblk;
+  const long long row0 = (long long)blk * R;
+  const int rv = min(R, B - (int)row0);
+  const long long BH = (long long)B * H;
+  const int tid = threadIdx.x;
+  const StepCtrl c = phase == 0 ? *a.cur_k : *a.cur_p;
+  if (phase == 0 && part == 1 && blockIdx.x == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
+
+  if (phase == 0 && part == 1 && role < C) {
+    // ---- target critic `role` on [ns | a'] (a' given: SAC; else the target actor runs first: TD3)
+    const int k = role;
+    const float* ns_rows = a.nsa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
+    const int jp_ns = max(a.tactor.jpad0, a.tcritic[0].jpad0), nc_ns = a.given_next ? S + A : S;
+    float* hw_ta = hw; float* hw_tc = hw + A * H;
+    load_rows<RG>(X0, ldl, ns_rows, a.ldx, nc_ns, jp_ns, rv);
+    stage(hw_tc, a.tcritic[k].P + a.tcritic[k].w[a.tcritic[k].L], H);
+    if (tid == 0) hb[16] = a.tcritic[k].P[a.tcritic[k].b[a.tcritic[k].L]];
+    if (!a.given_next) {
+      stage(hw_ta, a.tactor.P + a.tactor.w[a.tactor.L], A * H);
+      if (tid < A) hb[tid] = a.tactor.P[a.tactor.b[a.tactor.L] + tid];
+      if (a.target_kind == TGT_MIN && tid < R * A) {
+        const int r = tid / A, o = tid - r * A;
+        const long long i = (row0 + r) * A + o;
+        float e = 0.f;
+        if (r < rv) e = a.noise ? a.noise[i] : hash_normal(a.seed, (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
+        part_[tid] = fminf(fmaxf(__fmul_rn(e, a.policy_noise), -a.noise_clamp), a.noise_clamp);
+      }
+    }
+    __syncthreads();
+    float* h;
+    if (!a.given_next) {
+      h = mlp_hidden<RG>(a.tactor, X0, X1, X2, ldl, part_ + R * 16, nullptr, BH, row0, rv);
+      rows_head<RG>(h, ldl, H, hw_ta, H, hb, A, EPI_TANH, sm);
+      __syncthreads();
+      if (tid < R * A) {
+        const int r = tid / A, o = tid - r * A;
+        float act = sm[r * 16 + o];
+        if (a.target_kind == TGT_MIN) act = fminf(fmaxf(__fadd_rn(act, part_[tid]), -1.0f), 1.0f);
+        X0[r * ldl + S + o] = act;
+      }
+      __syncthreads();
+    }
+    h = mlp_hidden<RG>(a.tcritic[k], X0, X1, X2, ldl, part_ + R * 16, nullptr, BH, row0, rv);
+    rows_head<RG>(h, ldl, H, hw_tc, H, hb + 16, 1, EPI_NONE, sm);
+    __syncthreads();
+    if (tid < rv) a.qt[(long long)k * B + row0 + tid] = sm[tid * 16];
+  } else if (phase == 0 && part == 1) {
+    // ---- online critic `role - C` on [s | a]: forward, activations saved
+    const int k = role - C;
+    const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
+    load_rows<RG>(XS, ldl, sa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
+    stage(hw, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
+    if (tid == 0) hb[18] = a.critic[k].P[a.critic[k].b[a.critic[k].L]];
+    __syncthreads();
+    float* h = mlp_hidden<RG>(a.critic[k], XS, X1, X2, ldl, part_ + R * 16, a.hC + (long long)k * a.critic[k].L * BH, BH, row0, rv);
+    rows_head<RG>(h, ldl, H, hw, H, hb + 18, 1, EPI_NONE, sm);
+    __syncthreads();
+    if (tid < rv) a.q[(long long)k * B + row0 + tid] = sm[tid * 16];
+  } else if (phase == 0) {
+    // ---- part 2: TD target, loss gradient and input-gradient chain of critic `role`
+    const int k = role;
+    const int L = a.critic[k].L;
+    const float* hs = a.hC + (long long)k * L * BH;
+    const float* hsrc = hs + (L - 1) * BH + row0 * H;
+    stage(hw, a.critic[k].P + a.critic[k].w[L], H);
+    for (int i = tid; i < R * H; i += kRowThreads) {
+      const int r = i / H, kk = i - r * H;
+      XS[r * ldl + kk] = r < rv ? hsrc[(long long)r * H + kk] : 0.f;
+    }
+    if (tid < R) {
+      const int r = tid;
+      float g = 0.f;
+      if (r < rv) {
+        const float rew = a.rbuf[(long long)c.batch_slot * a.slot_rd + row0 + r], dn = a.dbuf[(long long)c.batch_slot * a.slot_rd + row0 + r];
+        const float t0 = a.qt[row0 + r], t1 = C > 1 ? a.qt[(long long)B + row0 + r] : t0;
+        float tq = a.target_kind == TGT_DDPG ? t0 : fminf(t0, t1);
+        if (a.target_kind == TGT_MIN_ENT) tq = __fsub_rn(tq, __fmul_rn(a.alpha, a.logp_next[row0 + r]));
+        float y = __fadd_rn(rew, __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, dn)), tq));
+        if (a.target_kind == TGT_DDPG) y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
+        const float q = a.q[(long long)k * B + row0 + r];
+        const float diff = __fsub_rn(q, y);
+        if (a.loss_kind == LOSS_MSE) g = (2.0f / (float)B) * diff;
+        else { const float n1 = 1.0f / (float)B; g = (diff < -1.0f) ? -n1 : (diff > 1.0f ? n1 : n1 * diff); }
+        if (k == 0) a.y[row0 + r] = y;
+        a.dq[(long long)k * B + row0 + r] = g;
+      }
+      sm2[r * 16] = g;
+    }
+    __syncthreads();
+    float* gsave = a.gC + (long long)k * L * BH;
+    head_backward<RG>(XS, ldl, H, hw, 1, sm2, gsave + (L - 1) * BH + row0 * H, rv);
+    __syncthreads();
+    grad_chain<RG>(a.critic[k], XS, X1, X2, ldl, part_ + R * 16, hs, gsave, BH, row0, rv);
+  } else if (part == 1) {
+    // ---- P, part 1: critic `role` forward on [s | pi(s)]
+    const int k = role;
+    const float* s_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
+    const int jpad = a.critic[0].jpad0;
+    for (int i = tid; i < R * jpad; i += kRowThreads) {
+      const int r = i / jpad, cc = i - r * jpad;
+      float v = 0.f;
+      if (r < rv) {
+        if (cc < S) v = s_rows[(long long)r * a.ldx + cc];
+        else if (cc < S + A) v = a.pi[(row0 + r) * a.Apad + (cc - S)];
+      }
+      X0[r * ldl + cc] = v;
+    }
+    stage(hw, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
+    if (tid == 0) hb[0] = a.critic[k].P[a.critic[k].b[a.critic[k].L]];
+    __syncthreads();
+    float* h = mlp_hidden<RG>(a.critic[k], X0, X1, X2, ldl, part_ + R * 16, a.hC2 + (long long)k * a.critic[k].L * BH, BH, row0, rv);
+    rows_head<RG>(h, ldl, H, hw, H, hb, 1, EPI_NONE, sm);
+    __syncthreads();
+    if (tid < rv) a.q2[(long long)k * B + row0 + tid] = sm[tid * 16];
+  } else {
+    // ---- P, part 2: d(-mean min(q1, q2))/dq_k, input-gradient chain of critic `role` down to the action columns
+    const int k = role;
+    const int L = a.critic[k].L;
+    const float* hs = a.hC2 + (long long)k * L * BH;
+    const float* hsrc = hs + (L - 1) * BH + row0 * H;
+    float* hw_da = hw + H;
+    stage(hw, a.critic[k].P + a.critic[k].w[L], H);
+    stage(hw_da, a.critic[k].Wt + a.critic[k].wt[0] + (long long)S * H, A * H);
+    for (int i = tid; i < R * H; i += kRowThreads) {
+      const int r = i / H, kk = i - r * H;
+      XS[r * ldl + kk] = r < rv ? hsrc[(long long)r * H + kk] : 0.f;
+    }
+    if (tid < R) {
+      const int r = tid;
+      float g = 0.f;
+      if (r < rv) {
+        const float q0 = a.q2[row0 + r], q1 = C > 1 ? a.q2[(long long)B + row0 + r] : INFINITY;
+        const float gb = -1.0f / (float)B;
+        const float w0 = q0 < q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
+        g = k == 0 ? gb * w0 : gb * (1.f - w0);
+      }
+      sm2[r * 16] = g;
+    }
+    __syncthreads();
+    head_backward<RG>(XS, ldl, H, hw, 1, sm2, nullptr, rv);
+    __syncthreads();
+    float* g0 = grad_chain<RG>(a.critic[k], XS, X1, X2, ldl, part_ + R * 16, hs, nullptr, BH, row0, rv);
+    rows_head<RG>(g0, ldl, H, hw_da, H, nullptr, A, EPI_NONE, sm);
+    __syncthreads();
+    if (tid < R * A) {
+      const int r = tid / A, o = tid - r * A;
+      if (r < rv) a.dz[((long long)k * B + row0 + r) * a.Apad + o] = sm[r * 16 + o];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int R = 4;
@@ -437,6 +617,30 @@ int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
   if (rg == 1) return go(rowchain_ddpg_kernel<1>);
   if (rg == 2) return go(rowchain_ddpg_kernel<2>);
   return go(rowchain_ddpg_kernel<4>);
+}
+
+int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part) {
+  GCRL_CHECK_ARG(rg == 1 || rg == 2 || rg == 4, "rowchain: rows per block must be 4, 8 or 16");
+  GCRL_CHECK_ARG(a.critic[0].H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16 && a.C >= 1 && a.C <= 2 && (phase == 0 || phase == 1) &&
+                     (part == 1 || part == 2) && (phase == 0 || a.p_critic_only) && a.qt,
+                 "rowchain split: unsupported shape (H=%d, A=%d, C=%d, phase %d part %d)", a.critic[0].H, a.A, a.C, phase, part);
+  const size_t lds = rowchain_lds_bytes(rg, a.ldl, a.A, a.critic[0].H, a.C);
+  GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain: %zu bytes of LDS needed", lds);
+  const int nblk = (a.B + 4 * rg - 1) / (4 * rg);
+  const int roles = (phase == 0 && part == 1) ? 2 * a.C : a.C;
+  auto go = [&](auto kern) -> int {
+    static thread_local size_t raised = 0;
+    if (lds > 64 * 1024 && lds > raised) {
+      GCRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      raised = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(roles * nblk), dim3(kRowThreads), lds, st, a, phase, part);
+    GCRL_HIP(hipGetLastError());
+    return GCRL_OK;
+  };
+  if (rg == 1) return go(rowchain_split_kernel<1>);
+  if (rg == 2) return go(rowchain_split_kernel<2>);
+  return go(rowchain_split_kernel<4>);
 }
 
 int launch_rowchain_act(hipStream_t st, const RowActArgs& a) {
