@@ -521,7 +521,15 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     as.B = B; as.C = nac;
     if (kind == GCRL_AGENT_SAC) { as.alpha_const = 0.2f; as.drop = 0; }
     else { as.alpha_dev = a->alpha_dev; as.drop = a->cfg.top_drop; }
-    TRY(launch_actor_select(st, as));
+    // ... and, in the same launch, the log-alpha gradient + loss metric (the optimiser step itself is in phase 2)
+    AlphaArgs al;
+    std::memset(&al, 0, sizeof(al));
+    al.cur = a->cur(); al.logp = a->logp; al.B = B;
+    al.target_entropy = kind == GCRL_AGENT_SAC ? -0.5f * (float)A : -(float)A;  // src/agent.py:424, :820
+    al.log_alpha = a->P_logalpha(); al.m = a->adam_m + a->goff_alpha; al.v = a->adam_v + a->goff_alpha;
+    al.alpha = a->alpha_dev; al.grad_out = a->grads + a->goff_alpha;
+    al.metrics = a->metrics_dev; al.phase = 0;
+    TRY(launch_actor_select_alpha(st, as, al));
   }
   // input gradient of the critic(s) down to the action columns
   Launches cb;
@@ -587,15 +595,6 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
       if (l > 0) v.push_back(bwd_dx(a->zA, H, Pa, a->actor.lin[l], 0, H, a->gA[l & 1], H, B, MUL_NONE, nullptr, 0));
       TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
     }
-    // log-alpha gradient + loss metric (the optimiser step itself is in phase 2)
-    AlphaArgs al;
-    std::memset(&al, 0, sizeof(al));
-    al.cur = a->cur(); al.logp = a->logp; al.B = B;
-    al.target_entropy = kind == GCRL_AGENT_SAC ? -0.5f * (float)A : -(float)A;  // src/agent.py:424, :820
-    al.log_alpha = a->P_logalpha(); al.m = a->adam_m + a->goff_alpha; al.v = a->adam_v + a->goff_alpha;
-    al.alpha = a->alpha_dev; al.grad_out = a->grads + a->goff_alpha;
-    al.metrics = a->metrics_dev; al.phase = 0;
-    TRY(launch_alpha_update(st, al));
   }
   return GCRL_OK;
 }

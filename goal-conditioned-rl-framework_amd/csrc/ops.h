@@ -220,6 +220,8 @@ struct AlphaArgs {
   int phase;  // 0: gradient + loss metric only, 1: optimiser step only, 2: both
 };
 int launch_alpha_update(hipStream_t st, const AlphaArgs& a);
+// actor_select + the gradient / loss-metric half of alpha_update (phase 0) as one launch
+int launch_actor_select_alpha(hipStream_t st, const ActorSelArgs& a, const AlphaArgs& al);
 
 // one wavefront per row: bitonic sort of width<=64 values by cross-lane exchange, mean of the
 // lowest width-drop

@@ -59,6 +59,11 @@ __device__ inline float col_sum4(float v, float (*red)[64], int cl, int rg) {
   return red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
+// Every thread owns kBnPer = 16 rows of one column (rows r0 + rg + 4 i).  All of a thread's operands are requested
+// before the first one is used: these kernels move 0.5 MB and are nothing but memory round trips — with the loads
+// inside the accumulation loops they were 16-32 DEPENDENT round trips long (6-10 us per launch, profiles/r02e).
+constexpr int kBnPer = kBnRows / 4;
+
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int B, int H,
                                                        float* __restrict__ part_mean, float* __restrict__ part_m2) {
   __shared__ float red[4][64];
@@ -66,17 +71,27 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   const int col = blockIdx.x * 64 + cl;
   const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
   const bool ok = col < H;
+  float v[kBnPer];
+#pragma unroll
+  for (int i = 0; i < kBnPer; ++i) {
+    const int b = r0 + rg + 4 * i;
+    v[i] = (ok && b < r1) ? z[(long long)b * H + col] : 0.f;
+  }
   float s = 0.f;
-  if (ok) for (int b = r0 + rg; b < r1; b += 4) s += z[(long long)b * H + col];
+#pragma unroll
+  for (int i = 0; i < kBnPer; ++i) if (r0 + rg + 4 * i < r1) s += v[i];
   const float mean = col_sum4(s, red, cl, rg) / (float)(r1 - r0);
   float q = 0.f;
-  if (ok) for (int b = r0 + rg; b < r1; b += 4) { const float df = z[(long long)b * H + col] - mean; q += df * df; }
+#pragma unroll
+  for (int i = 0; i < kBnPer; ++i) if (r0 + rg + 4 * i < r1) { const float df = v[i] - mean; q += df * df; }
   const float m2 = col_sum4(q, red, cl, rg);
   if (ok && rg == 0) {
     part_mean[(long long)blockIdx.y * H + col] = mean;
     part_m2[(long long)blockIdx.y * H + col] = m2;
   }
 }
+
+constexpr int kBnMaxPart = 32;   // row-block partials held in registers (B <= 2048); more fall back to a loop
 
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, int B, int H,
                                                             const float* gamma, const float* beta,
@@ -87,12 +102,27 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
   if (col >= H) return;
-  // merge the row-block partials (Chan et al.), same order in every block
   const int nrb = (B + kBnRows - 1) / kBnRows;
+  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
+  // request everything first: the partials, the affine pair, this thread's rows
+  float pm[kBnMaxPart], pq[kBnMaxPart], v[kBnPer];
+#pragma unroll
+  for (int rb = 0; rb < kBnMaxPart; ++rb) {
+    pm[rb] = rb < nrb ? part_mean[(long long)rb * H + col] : 0.f;
+    pq[rb] = rb < nrb ? part_m2[(long long)rb * H + col] : 0.f;
+  }
+  const float g = gamma[col], bt = beta[col];
+#pragma unroll
+  for (int i = 0; i < kBnPer; ++i) {
+    const int b = r0 + rg + 4 * i;
+    v[i] = b < r1 ? z[(long long)b * H + col] : 0.f;
+  }
+  // merge the row-block partials (Chan et al.), same order in every block
   float n = 0.f, mean = 0.f, m2 = 0.f;
   for (int rb = 0; rb < nrb; ++rb) {
     const float nb = (float)(min(B, (rb + 1) * kBnRows) - rb * kBnRows);
-    const float mb = part_mean[(long long)rb * H + col], qb = part_m2[(long long)rb * H + col];
+    const float mb = rb < kBnMaxPart ? pm[rb] : part_mean[(long long)rb * H + col];
+    const float qb = rb < kBnMaxPart ? pq[rb] : part_m2[(long long)rb * H + col];
     const float delta = mb - mean, tot = n + nb;
     mean += delta * (nb / tot);
     m2 += qb + delta * delta * (n * nb / tot);
@@ -100,14 +130,16 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
   }
   const float var = m2 / (float)B;  // biased: what normalises the batch
   const float invstd = 1.0f / sqrtf(var + kBnEps);
-  const float g = gamma[col], bt = beta[col];
-  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
-  for (int b = r0 + rg; b < r1; b += 4) {
-    const long long i = (long long)b * H + col;
-    const float xh = (z[i] - mean) * invstd;
-    const float y = xh * g + bt;
-    h[i] = y > 0.f ? y : 0.f;
-    if (xhat) xhat[i] = xh;
+#pragma unroll
+  for (int i = 0; i < kBnPer; ++i) {
+    const int b = r0 + rg + 4 * i;
+    if (b < r1) {
+      const long long idx = (long long)b * H + col;
+      const float xh = (v[i] - mean) * invstd;
+      const float y = xh * g + bt;
+      h[idx] = y > 0.f ? y : 0.f;
+      if (xhat) xhat[idx] = xh;
+    }
   }
   if (blockIdx.y == 0 && rg == 0) {
     if (invstd_out) invstd_out[col] = invstd;
@@ -135,14 +167,26 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
   const int col = blockIdx.x * 64 + cl;
   const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
   const bool ok = col < H;
+  float vd[kBnPer], vd2[kBnPer], vh[kBnPer], vx[kBnPer];
+#pragma unroll
+  for (int i = 0; i < kBnPer; ++i) {
+    const int b = r0 + rg + 4 * i;
+    const bool in = ok && b < r1;
+    const long long idx = (long long)b * H + col;
+    vd[i] = in ? dh[idx] : 0.f;
+    vd2[i] = (in && dh2) ? dh2[idx] : 0.f;
+    vh[i] = in ? h[idx] : 0.f;
+    vx[i] = in ? xhat[idx] : 0.f;
+  }
   float s1 = 0.f, s2 = 0.f;
-  if (ok)
-    for (int b = r0 + rg; b < r1; b += 4) {
-      const long long i = (long long)b * H + col;
-      const float dy = h[i] > 0.f ? (dh2 ? dh[i] + dh2[i] : dh[i]) : 0.f;
+#pragma unroll
+  for (int i = 0; i < kBnPer; ++i) {
+    if (ok && r0 + rg + 4 * i < r1) {
+      const float dy = vh[i] > 0.f ? (dh2 ? vd[i] + vd2[i] : vd[i]) : 0.f;
       s1 += dy;
-      s2 += dy * xhat[i];
+      s2 += dy * vx[i];
     }
+  }
   const float sum_dy = col_sum4(s1, red, cl, rg);
   const float sum_dyx = col_sum4(s2, red, cl, rg);
   if (ok && rg == 0) {
@@ -161,18 +205,37 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
   const int col = blockIdx.x * 64 + cl;
   if (col >= H) return;
   const int nrb = (B + kBnRows - 1) / kBnRows;
-  float sum_dy = 0.f, sum_dyx = 0.f;
-  for (int rb = 0; rb < nrb; ++rb) {
-    sum_dy += part_dy[(long long)rb * H + col];
-    sum_dyx += part_dyx[(long long)rb * H + col];
+  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
+  float p1[kBnMaxPart], p2[kBnMaxPart], vd[kBnPer], vd2[kBnPer], vh[kBnPer], vx[kBnPer];
+#pragma unroll
+  for (int rb = 0; rb < kBnMaxPart; ++rb) {
+    p1[rb] = rb < nrb ? part_dy[(long long)rb * H + col] : 0.f;
+    p2[rb] = rb < nrb ? part_dyx[(long long)rb * H + col] : 0.f;
   }
   const float k = gamma[col] * invstd[col];
+#pragma unroll
+  for (int i = 0; i < kBnPer; ++i) {
+    const int b = r0 + rg + 4 * i;
+    const bool in = b < r1;
+    const long long idx = (long long)b * H + col;
+    vd[i] = in ? dh[idx] : 0.f;
+    vd2[i] = (in && dh2) ? dh2[idx] : 0.f;
+    vh[i] = in ? h[idx] : 0.f;
+    vx[i] = in ? xhat[idx] : 0.f;
+  }
+  float sum_dy = 0.f, sum_dyx = 0.f;
+  for (int rb = 0; rb < nrb; ++rb) {
+    sum_dy += rb < kBnMaxPart ? p1[rb] : part_dy[(long long)rb * H + col];
+    sum_dyx += rb < kBnMaxPart ? p2[rb] : part_dyx[(long long)rb * H + col];
+  }
   const float m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B;
-  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
-  for (int b = r0 + rg; b < r1; b += 4) {
-    const long long i = (long long)b * H + col;
-    const float dy = h[i] > 0.f ? (dh2 ? dh[i] + dh2[i] : dh[i]) : 0.f;
-    dz[i] = (dy - m1 - xhat[i] * m2) * k;
+#pragma unroll
+  for (int i = 0; i < kBnPer; ++i) {
+    const int b = r0 + rg + 4 * i;
+    if (b < r1) {
+      const float dy = vh[i] > 0.f ? (dh2 ? vd[i] + vd2[i] : vd[i]) : 0.f;
+      dz[(long long)b * H + col] = (dy - m1 - vx[i] * m2) * k;
+    }
   }
   if (blockIdx.y == 0 && rg == 0) { dgamma[col] = sum_dyx; dbeta[col] = sum_dy; }
 }
@@ -210,8 +273,7 @@ __global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) {
   if (!a.deterministic && a.logp) a.logp[b] = lp;
 }
 
-__global__ __launch_bounds__(256) void actor_select_kernel(ActorSelArgs a) {
-  __shared__ float scratch[4];
+__device__ inline void actor_select_body(const ActorSelArgs& a, float* scratch) {
   const StepCtrl c = *a.cur;
   const float alpha = a.alpha_dev ? *a.alpha_dev : a.alpha_const;
   const int B = a.B, C = a.C, keep = a.C - a.drop;
@@ -259,6 +321,11 @@ __global__ __launch_bounds__(256) void actor_select_kernel(ActorSelArgs a) {
   if (threadIdx.x == 0) a.metrics[(long long)c.metrics_slot * kMetricFloats + MET_ACTOR_LOSS] = acc / (float)B;
 }
 
+__global__ __launch_bounds__(256) void actor_select_kernel(ActorSelArgs a) {
+  __shared__ float scratch[4];
+  actor_select_body(a, scratch);
+}
+
 __global__ void tanh_gauss_bwd_kernel(TanhGaussBwdArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.B * a.A) return;
@@ -279,8 +346,7 @@ __global__ void tanh_gauss_bwd_kernel(TanhGaussBwdArgs a) {
   a.gls[(long long)b * a.ld_g + j] = in_range ? (dx * a.eps[i] * a.std[i] - wlp) : 0.f;
 }
 
-__global__ __launch_bounds__(256) void alpha_update_kernel(AlphaArgs a) {
-  __shared__ float scratch[4];
+__device__ inline void alpha_body(const AlphaArgs& a, float* scratch) {
   const StepCtrl c = *a.cur;
   float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
   if (!c.do_alpha) {  // `gradient_step <= alpha_min_steps: return 0.0`
@@ -310,6 +376,19 @@ __global__ __launch_bounds__(256) void alpha_update_kernel(AlphaArgs a) {
     *a.alpha = expf(p);
     met[MET_ALPHA] = expf(p);
   }
+}
+
+__global__ __launch_bounds__(256) void alpha_update_kernel(AlphaArgs a) {
+  __shared__ float scratch[4];
+  alpha_body(a, scratch);
+}
+
+// actor-loss selection and the log-alpha gradient (both single-block passes over logp) in one launch
+__global__ __launch_bounds__(256) void actor_select_alpha_kernel(ActorSelArgs s, AlphaArgs al) {
+  __shared__ float scratch[4];
+  actor_select_body(s, scratch);
+  __syncthreads();
+  alpha_body(al, scratch);
 }
 
 // lane i holds element i of the row (+inf beyond `width`): 21 compare-exchange rounds with the
@@ -386,6 +465,13 @@ int launch_tanh_gauss_fwd(hipStream_t st, const TanhGaussArgs& a) {
 int launch_actor_select(hipStream_t st, const ActorSelArgs& a) {
   GCRL_CHECK_ARG(a.C >= 1 && a.C <= kMaxCritics && a.drop >= 0 && a.drop < a.C, "actor_select: bad C=%d drop=%d", a.C, a.drop);
   hipLaunchKernelGGL(actor_select_kernel, dim3(1), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_actor_select_alpha(hipStream_t st, const ActorSelArgs& a, const AlphaArgs& al) {
+  GCRL_CHECK_ARG(a.C >= 1 && a.C <= kMaxCritics && a.drop >= 0 && a.drop < a.C, "actor_select: bad C=%d drop=%d", a.C, a.drop);
+  hipLaunchKernelGGL(actor_select_alpha_kernel, dim3(1), dim3(256), 0, st, a, al);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
