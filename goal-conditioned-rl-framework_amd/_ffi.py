@@ -92,6 +92,9 @@ PROTOTYPES = {
     "gcrl_her_push_episode": (_i64, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_her_sample": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "gcrl_her_read_rows": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gcrl_her_state_size": (_i64, [_vp]),
+    "gcrl_her_save_state": (C.c_int, [_vp, _vp, _i64]),
+    "gcrl_her_load_state": (C.c_int, [_vp, _vp, _i64]),
     "gcrl_her_profile_enable": (C.c_int, [_vp, C.c_int]),
     "gcrl_her_profile_read": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_f64)]),
     "gcrl_agent_create": (_vp, [C.POINTER(AgentConfig)]),
@@ -104,6 +107,10 @@ PROTOTYPES = {
     "gcrl_agent_set": (C.c_int, [_vp, _cp, _vp, _i64]),
     "gcrl_agent_init_weights": (C.c_int, [_vp, _u64, C.c_int]),
     "gcrl_agent_hard_update_targets": (C.c_int, [_vp]),
+    "gcrl_agent_soft_update_targets": (C.c_int, [_vp, _f64, _vp]),
+    "gcrl_agent_state_size": (_i64, [_vp]),
+    "gcrl_agent_save_state": (C.c_int, [_vp, _vp, _i64]),
+    "gcrl_agent_load_state": (C.c_int, [_vp, _vp, _i64]),
     "gcrl_agent_update": (C.c_int, [_vp, _vp, _i64, C.POINTER(UpdateInputs), C.POINTER(_i64), _vp]),
     "gcrl_agent_update_n": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp, _vp]),
     "gcrl_agent_metrics": (C.c_int, [_vp, _i64, _vp, C.c_int]),

@@ -1113,6 +1113,76 @@ int gcrl_agent_hard_update_targets(gcrl_agent* a) {
   return GCRL_OK;
 }
 
+// ---- full resume state (SURVEY.md §8f-2 extension: the reference saves weights + normalisers only, src/env.py:430-440)
+namespace {
+struct AgentStateHeader {
+  uint32_t magic, version;
+  int32_t kind, S, A, H, L, B, C, pad;
+  int64_t n_params, n_grads, bn_n;
+  int64_t t_actor, t_critic, t_alpha;
+  double lr_actor, lr_critic;
+  uint64_t rng_ctr;
+};
+constexpr uint32_t kAgentMagic = 0x4c524347u;   // "GCRL"
+size_t agent_state_bytes(const gcrl_agent* a) {
+  const long long bn = std::max(1, a->L * a->H);
+  return sizeof(AgentStateHeader) + (size_t)(a->n_params + 2 * a->n_grads + 2 * bn + 1) * sizeof(float);
+}
+}  // namespace
+
+int64_t gcrl_agent_state_size(const gcrl_agent* a) { return a ? (int64_t)agent_state_bytes(a) : -1; }
+
+int gcrl_agent_save_state(gcrl_agent* a, void* dst_host, int64_t n) {
+  GCRL_CHECK_ARG(a && dst_host && n == (int64_t)agent_state_bytes(a), "gcrl_agent_save_state: buffer must be gcrl_agent_state_size() bytes");
+  GCRL_HIP(hipDeviceSynchronize());
+  const long long bn = std::max(1, a->L * a->H);
+  AgentStateHeader h{kAgentMagic, 1, a->cfg.kind, a->S, a->A, a->H, a->L, a->B, a->C, 0, a->n_params, a->n_grads, bn,
+                     a->t_actor, a->t_critic, a->t_alpha, a->lr_actor, a->lr_critic, a->rng_ctr};
+  char* o = (char*)dst_host;
+  std::memcpy(o, &h, sizeof(h)); o += sizeof(h);
+  auto put = [&](const float* dev, long long cnt) -> int {
+    GCRL_HIP(hipMemcpy(o, dev, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost));
+    o += (size_t)cnt * sizeof(float);
+    return GCRL_OK;
+  };
+  TRY(put(a->params, a->n_params)); TRY(put(a->adam_m, a->n_grads)); TRY(put(a->adam_v, a->n_grads));
+  TRY(put(a->bn_rmean, bn)); TRY(put(a->bn_rvar, bn)); TRY(put(a->alpha_dev, 1));
+  return GCRL_OK;
+}
+
+int gcrl_agent_load_state(gcrl_agent* a, const void* src_host, int64_t n) {
+  GCRL_CHECK_ARG(a && src_host && n == (int64_t)agent_state_bytes(a), "gcrl_agent_load_state: the blob does not have this agent's size");
+  AgentStateHeader h;
+  std::memcpy(&h, src_host, sizeof(h));
+  GCRL_CHECK_ARG(h.magic == kAgentMagic && h.version == 1, "gcrl_agent_load_state: not an agent state blob");
+  GCRL_CHECK_ARG(h.kind == a->cfg.kind && h.S == a->S && h.A == a->A && h.H == a->H && h.L == a->L && h.C == a->C &&
+                     h.n_params == a->n_params && h.n_grads == a->n_grads,
+                 "gcrl_agent_load_state: the blob was saved by a different agent shape");
+  GCRL_HIP(hipDeviceSynchronize());
+  const char* o = (const char*)src_host + sizeof(h);
+  auto get = [&](float* dev, long long cnt) -> int {
+    GCRL_HIP(hipMemcpy(dev, o, (size_t)cnt * sizeof(float), hipMemcpyHostToDevice));
+    o += (size_t)cnt * sizeof(float);
+    return GCRL_OK;
+  };
+  TRY(get(a->params, a->n_params)); TRY(get(a->adam_m, a->n_grads)); TRY(get(a->adam_v, a->n_grads));
+  TRY(get(a->bn_rmean, h.bn_n)); TRY(get(a->bn_rvar, h.bn_n)); TRY(get(a->alpha_dev, 1));
+  a->t_actor = h.t_actor; a->t_critic = h.t_critic; a->t_alpha = h.t_alpha;
+  a->lr_actor = h.lr_actor; a->lr_critic = h.lr_critic; a->rng_ctr = h.rng_ctr;
+  a->wt_dirty = true;
+  return GCRL_OK;
+}
+
+// update_target_network(hard_update=False, tau) (src/agent.py:1259-1271 and its copies): every target <- tau*net + (1-tau)*target
+int gcrl_agent_soft_update_targets(gcrl_agent* a, double tau, void* stream) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_soft_update_targets: null handle");
+  hipStream_t st = a->pick(stream);
+  if (a->has_target_actor) TRY(launch_polyak(st, a->P_actor(), a->P_tactor(), a->actor.numel, tau));
+  for (int c = 0; c < a->C; ++c) TRY(launch_polyak(st, a->P_critic(c), a->P_tcritic(c), a->critic.numel, tau));
+  if (a->rowchain) TRY(rc_rebuild_wt(a, st, true));
+  return GCRL_OK;
+}
+
 int gcrl_agent_profile_enable(gcrl_agent* a, int on) {
   GCRL_CHECK_ARG(a, "gcrl_agent_profile_enable: null handle");
   if (on && !a->prof_clk) {

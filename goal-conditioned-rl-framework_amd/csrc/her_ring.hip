@@ -549,7 +549,8 @@ gcrl_her* gcrl_her_create(const gcrl_her_config* cfg, gcrl_mt* rng) {
            ok(hipEventCreateWithFlags(&h->epi_ev[i], hipEventDisableTiming), "hipEventCreate") &&
            ok(hipHostMalloc((void**)&h->epi_pinned[i], (size_t)cfg->flush_len * h->RG * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
   }
-  if (good) good = ok(hipMemsetAsync(h->stage, 0, (size_t)cfg->nenvs * cfg->flush_len * h->RG * sizeof(float), h->stream), "hipMemset");
+  if (good) good = ok(hipMemset(h->stage, 0, (size_t)cfg->nenvs * cfg->flush_len * h->RG * sizeof(float)), "hipMemset") &&
+                   ok(hipDeviceSynchronize(), "hipDeviceSynchronize");   // the first stage kernel runs on the CALLER's stream
   if (!good) { gcrl_her_destroy(h); return nullptr; }
   return h;
 }
@@ -767,11 +768,69 @@ int gcrl_her_profile_read(gcrl_her* h, int64_t* launches, double* total_ms, int6
   return GCRL_OK;
 }
 
+// ---- full resume state: ring rows in logical (oldest-first) order, staged partial episodes, counters
+namespace {
+struct HerStateHeader {
+  uint32_t magic, version;
+  int32_t S, A, G, nenvs, k_future, flush_len, RS, RG;
+  int64_t capacity, len;
+  uint64_t episodes_flushed, draws_done, mutation_epoch;
+};
+constexpr uint32_t kHerMagic = 0x52454847u;   // "GHER"
+size_t her_state_bytes(const gcrl_her* h) {
+  return sizeof(HerStateHeader) + (size_t)h->cfg.nenvs * sizeof(int32_t) +
+         ((size_t)h->cfg.nenvs * h->cfg.flush_len * h->RG + (size_t)h->len * h->RS) * sizeof(float);
+}
+}  // namespace
+
+int64_t gcrl_her_state_size(const gcrl_her* h) { return h ? (int64_t)her_state_bytes(h) : -1; }
+
+int gcrl_her_save_state(gcrl_her* h, void* dst_host, int64_t n) {
+  GCRL_CHECK_ARG(h && dst_host && n == (int64_t)her_state_bytes(h), "gcrl_her_save_state: buffer must be gcrl_her_state_size() bytes");
+  GCRL_HIP(hipDeviceSynchronize());
+  HerStateHeader hd{kHerMagic, 1, h->S, h->A, h->G, h->cfg.nenvs, h->cfg.k_future, h->cfg.flush_len, h->RS, h->RG,
+                    h->cfg.capacity, h->len, h->episodes_flushed, h->draws_done, h->mutation_epoch};
+  char* o = (char*)dst_host;
+  std::memcpy(o, &hd, sizeof(hd)); o += sizeof(hd);
+  for (int e = 0; e < h->cfg.nenvs; ++e) { const int32_t v = h->staged[e]; std::memcpy(o, &v, sizeof(v)); o += sizeof(v); }
+  const size_t stage_bytes = (size_t)h->cfg.nenvs * h->cfg.flush_len * h->RG * sizeof(float);
+  GCRL_HIP(hipMemcpy(o, h->stage, stage_bytes, hipMemcpyDeviceToHost)); o += stage_bytes;
+  // logical order = physical order from `head`, wrapping once
+  const int64_t first = std::min<int64_t>(h->len, h->cfg.capacity - h->head);
+  GCRL_HIP(hipMemcpy(o, h->ring + (size_t)h->head * h->RS, (size_t)first * h->RS * sizeof(float), hipMemcpyDeviceToHost));
+  o += (size_t)first * h->RS * sizeof(float);
+  if (h->len > first) GCRL_HIP(hipMemcpy(o, h->ring, (size_t)(h->len - first) * h->RS * sizeof(float), hipMemcpyDeviceToHost));
+  return GCRL_OK;
+}
+
+int gcrl_her_load_state(gcrl_her* h, const void* src_host, int64_t n) {
+  GCRL_CHECK_ARG(h && src_host && n >= (int64_t)sizeof(HerStateHeader), "gcrl_her_load_state: null / short blob");
+  HerStateHeader hd;
+  std::memcpy(&hd, src_host, sizeof(hd));
+  GCRL_CHECK_ARG(hd.magic == kHerMagic && hd.version == 1, "gcrl_her_load_state: not a replay-ring state blob");
+  GCRL_CHECK_ARG(hd.S == h->S && hd.A == h->A && hd.G == h->G && hd.nenvs == h->cfg.nenvs && hd.flush_len == h->cfg.flush_len &&
+                     hd.RS == h->RS && hd.RG == h->RG && hd.k_future == h->cfg.k_future,
+                 "gcrl_her_load_state: the blob was saved by a ring of another shape");
+  GCRL_CHECK_ARG(hd.len >= 0 && hd.len <= h->cfg.capacity, "gcrl_her_load_state: %lld saved rows do not fit capacity %lld", (long long)hd.len, (long long)h->cfg.capacity);
+  const size_t stage_bytes = (size_t)h->cfg.nenvs * h->cfg.flush_len * h->RG * sizeof(float);
+  const size_t want = sizeof(hd) + (size_t)h->cfg.nenvs * sizeof(int32_t) + stage_bytes + (size_t)hd.len * h->RS * sizeof(float);
+  GCRL_CHECK_ARG((size_t)n == want, "gcrl_her_load_state: blob size %lld, expected %zu", (long long)n, want);
+  GCRL_HIP(hipDeviceSynchronize());
+  const char* o = (const char*)src_host + sizeof(hd);
+  for (int e = 0; e < h->cfg.nenvs; ++e) { int32_t v; std::memcpy(&v, o, sizeof(v)); o += sizeof(v); h->staged[e] = v; }
+  GCRL_HIP(hipMemcpy(h->stage, o, stage_bytes, hipMemcpyHostToDevice)); o += stage_bytes;
+  GCRL_HIP(hipMemcpy(h->ring, o, (size_t)hd.len * h->RS * sizeof(float), hipMemcpyHostToDevice));
+  h->head = 0; h->len = hd.len;
+  h->episodes_flushed = hd.episodes_flushed; h->draws_done = hd.draws_done; h->mutation_epoch = hd.mutation_epoch + 1;
+  return GCRL_OK;
+}
+
 int gcrl_her_read_rows(gcrl_her* h, int64_t first, int64_t n, float* s, float* a, float* ns,
                        float* r, float* d) {
   GCRL_CHECK_ARG(h, "gcrl_her_read_rows: null handle");
   GCRL_CHECK_ARG(first >= 0 && n >= 0 && first + n <= h->len, "gcrl_her_read_rows: range [%lld,+%lld) outside len %lld", (long long)first, (long long)n, (long long)h->len);
   if (n == 0) return GCRL_OK;
+  GCRL_HIP(hipDeviceSynchronize());   // pushes / flushes run on the caller's stream, this copy on the handle's own
   float* tmp = nullptr;
   GCRL_HIP(hipMalloc((void**)&tmp, (size_t)n * h->RS * sizeof(float)));
   long long total = n * h->RS;

@@ -12,8 +12,10 @@ as a 0-d numpy array, exactly like the reference (src/agent.py:1342).
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -28,13 +30,17 @@ KIND = {"DDPG": 0, "TD3": 1, "SAC": 2, "TQC": 3}
 
 class LazyScalar:
     """One entry of an update()'s return tuple, fetched from the device on first use."""
-    __slots__ = ("_agent", "_ticket", "_n", "_i", "_as_array")
+    __slots__ = ("_agent", "_ticket", "_n", "_i", "_as_array", "_val", "__weakref__")
 
     def __init__(self, agent, ticket, n, i, as_array=False):
         self._agent, self._ticket, self._n, self._i, self._as_array = agent, ticket, n, i, as_array
+        self._val = None
 
     def _value(self) -> float:
-        return self._agent._metrics(self._ticket, self._n)[self._i]
+        if self._val is None:   # kept: the engine's metric slots are a ring, a trainer may hold this object for long
+            self._val = self._agent._metrics(self._ticket, self._n)[self._i]
+            self._agent = None
+        return self._val
 
     def __float__(self):
         return float(self._value())
@@ -128,6 +134,8 @@ class _EngineAgent:
             seed=0 if seed is None else int(seed))
         self._h = _ffi.check_ptr(lib.gcrl_agent_create(C.byref(cfg)), "gcrl_agent_create")
         self._metric_cache: dict[int, list[float]] = {}
+        self._live = collections.deque()      # (ticket, n) of returned tuples, oldest first
+        self._lazy: dict[int, list] = {}      # ticket -> weak references to its unresolved LazyScalars
 
         self.noise_std = config.noise_std
         self.noise_clamp = config.noise_clamp
@@ -186,10 +194,20 @@ class _EngineAgent:
 
     def _tuple(self, ticket: int, n: int):
         td = self.TD_INDEX[n]
+        self._live.append((ticket, n))
+        # the engine keeps 4096 metric records: resolve what the caller still holds before its slot comes round again
+        while self._live and self._live[0][0] <= ticket - 2048:
+            t0, n0 = self._live.popleft()
+            for ref in self._lazy.pop(t0, ()):
+                ls = ref()
+                if ls is not None:
+                    ls._value()
         if self.sync_metrics:
             vals = self._metrics(ticket, n)
             return tuple(np.asarray(v, dtype=np.float32) if i == td else v for i, v in enumerate(vals))
-        return tuple(LazyScalar(self, ticket, n, i, i == td) for i in range(n))
+        out = tuple(LazyScalar(self, ticket, n, i, i == td) for i in range(n))
+        self._lazy[ticket] = [weakref.ref(x) for x in out]
+        return out
 
     def beta_scheduler(self, step: int):
         ratio = step / self.beta_end
@@ -321,9 +339,51 @@ class _EngineAgent:
 
     # ------------------------------------------------------------------ targets / reset
     def update_target_network(self, hard_update: bool = True, tau: float = 0.005):
-        if not hard_update:
-            raise NotImplementedError("soft target updates happen inside update(), fused into the optimiser kernel")
-        _ffi.check(lib.gcrl_agent_hard_update_targets(self._h))
+        """src/agent.py:1255-1271: hard copy, or tau*net + (1-tau)*target for every target network."""
+        if hard_update:
+            _ffi.check(lib.gcrl_agent_hard_update_targets(self._h))
+        else:
+            _ffi.check(lib.gcrl_agent_soft_update_targets(self._h, float(tau), _ffi.stream_handle()))
+
+    # ------------------------------------------------------------------ full resume state (SURVEY.md §8f-2 extension)
+    def save_state(self, path: str):
+        """Everything a bitwise-identical continuation needs, which the reference's checkpoints (weights + normalisers,
+        src/env.py:430-440) do not hold: parameters and targets, Adam moments, scheduler positions and step counts,
+        BatchNorm statistics, alpha, the replay ring's rows + staged partial episodes, the MT19937 stream."""
+        import json
+        os.makedirs(path, exist_ok=True)
+        n = int(lib.gcrl_agent_state_size(self._h))
+        blob = np.empty(n, np.uint8)
+        _ffi.check(lib.gcrl_agent_save_state(self._h, blob.ctypes.data, n))
+        blob.tofile(os.path.join(path, "agent.bin"))
+        meta = dict(kind=self.KIND_NAME, beta=self.beta, num_batches_tracked=int(self.actor.num_batches_tracked),
+                    ring=self.buffer.save_state(os.path.join(path, "ring.bin")))
+        for name in ("obs_normalizer", "dg_normalizer"):
+            nz = getattr(self.buffer, name, None)
+            if nz is not None:
+                meta[name] = dict(mean=np.asarray(nz.mean, np.float64).tolist(), var=np.asarray(nz.var, np.float64).tolist(),
+                                  count=float(nz.count), clip_range=float(nz.clip_range))
+        with open(os.path.join(path, "meta.json"), "w") as f:
+            json.dump(meta, f)
+
+    def load_state(self, path: str):
+        import json
+        blob = np.fromfile(os.path.join(path, "agent.bin"), dtype=np.uint8)
+        _ffi.check(lib.gcrl_agent_load_state(self._h, blob.ctypes.data, blob.size))
+        with open(os.path.join(path, "meta.json")) as f:
+            meta = json.load(f)
+        if meta["kind"] != self.KIND_NAME:
+            raise ValueError(f"state of a {meta['kind']} agent loaded into a {self.KIND_NAME}")
+        self.beta = meta["beta"]
+        self.actor.num_batches_tracked = meta["num_batches_tracked"]
+        self.buffer.load_state(os.path.join(path, "ring.bin"), meta["ring"])
+        for name in ("obs_normalizer", "dg_normalizer"):
+            nz = getattr(self.buffer, name, None)
+            if name in meta and nz is not None:
+                d = meta[name]
+                nz.mean, nz.var = np.array(d["mean"]), np.array(d["var"])
+                nz.count, nz.clip_range = d["count"], d["clip_range"]
+        self._metric_cache.clear()
 
     def reset(self):
         """Re-initialise Linear layers (src/agent.py:1461-1465, :760-769)."""

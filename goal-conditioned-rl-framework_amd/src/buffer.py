@@ -116,19 +116,54 @@ class HERBuffer:
         if not torch.cuda.is_available() or lib.gcrl_device_count() <= 0:
             raise _ffi.GcrlError("HERBuffer needs a HIP device: the replay ring lives in HBM and "
                                  "there is no CPU fallback")
+        if int(max_eps_len) < FLUSH_LEN:
+            # the reference's staging deque(maxlen=max_eps_len) would silently drop the oldest transitions and never
+            # reach the len >= 50 flush (src/buffer.py:102,117); the ring's staging always holds 50: refuse, do not diverge
+            raise ValueError(f"max_eps_len={max_eps_len} < {FLUSH_LEN}: the reference flushes at the literal 50 "
+                             "(src/buffer.py:117) and would drop staged transitions; not emulated")
         self.max_mem_len = int(max_mem_len)
         self.max_eps_len = int(max_eps_len)
         self.nenvs = int(nenvs)
         self.device = "cuda"
         self.device_index = device_index
-        self.threshold = threshold
+        self._h = None
+        self._threshold = threshold
         self.k_future = int(k_future)
-        self.compute_reward = None
+        self._compute_reward = None
         self.obs_normalizer = None
         self.dg_normalizer = None
         self.rng = MTStream(rng, seed)
-        self._h = None
         self._dims = None
+        self._reward_cfg = None
+
+    # the trainer assigns compute_reward after construction (src/env.py:105); classification into a built-in reward
+    # kind happens when the ring is created — a later reassignment that changes the kind / threshold is refused
+    # rather than silently ignored
+    @property
+    def compute_reward(self):
+        return self._compute_reward
+
+    @compute_reward.setter
+    def compute_reward(self, fn):
+        self._compute_reward = fn
+        self._recheck_reward()
+
+    @property
+    def threshold(self):
+        return self._threshold
+
+    @threshold.setter
+    def threshold(self, v):
+        self._threshold = v
+        self._recheck_reward()
+
+    def _recheck_reward(self):
+        if self._h is None or self._reward_cfg is None:
+            return
+        now = _classify_reward(self._compute_reward, self._dims[2], self._threshold)
+        if now != self._reward_cfg:
+            raise ValueError(f"compute_reward / threshold changed after the replay ring was created with reward config "
+                             f"{self._reward_cfg} (now {now}): create a new buffer")
 
     # ------------------------------------------------------------------ handle management
     def _ensure(self, S: int, A: int, G: int):
@@ -137,6 +172,7 @@ class HERBuffer:
                 raise ValueError(f"transition dims {(S, A, G)} differ from the ring's {self._dims}")
             return
         kind, thr = _classify_reward(self.compute_reward, G, self.threshold)
+        self._reward_cfg = (kind, thr)
         cfg = _ffi.HerConfig(state_dim=S, action_dim=A, goal_dim=G, capacity=self.max_mem_len,
                              nenvs=self.nenvs, k_future=self.k_future, flush_len=FLUSH_LEN,
                              reward_kind=kind, reward_threshold=thr, device=self.device_index,
@@ -250,6 +286,37 @@ class HERBuffer:
             self.rng.push_back()
         out = (states, actions, rewards, next_states, dones)
         return out + (drawn,) if return_indices else out
+
+    # ------------------------------------------------------------------ full resume state
+    def save_state(self, path: str) -> dict:
+        """Ring rows (logical order), staged partial episodes and the MT19937 stream -> `path`; returns the metadata
+        load_state needs.  An untouched buffer (no transition pushed yet) saves as empty."""
+        meta = dict(dims=self._dims, rng_mode=self.rng.mode, py_random=None, mt=None, bytes=0)
+        if self.rng.mode == "python":
+            st = _pyrandom.getstate()
+            meta["py_random"] = [st[0], list(st[1]), st[2]]
+        elif self.rng.mode == "engine":
+            _ffi.check(lib.gcrl_mt_get_state(self.rng.handle, self.rng._buf))
+            meta["mt"] = list(self.rng._buf)
+        if self._h is not None:
+            n = int(lib.gcrl_her_state_size(self._h))
+            blob = np.empty(n, np.uint8)
+            _ffi.check(lib.gcrl_her_save_state(self._h, blob.ctypes.data, n))
+            blob.tofile(path)
+            meta["bytes"] = n
+        return meta
+
+    def load_state(self, path: str, meta: dict):
+        if meta["bytes"]:
+            self._ensure(*meta["dims"])
+            blob = np.fromfile(path, dtype=np.uint8)
+            _ffi.check(lib.gcrl_her_load_state(self._h, blob.ctypes.data, blob.size))
+        if meta.get("py_random") is not None and self.rng.mode == "python":
+            v, words, gauss = meta["py_random"]
+            _pyrandom.setstate((v, tuple(words), gauss))
+        if meta.get("mt") is not None and self.rng.mode == "engine":
+            self.rng._buf[:] = meta["mt"]
+            _ffi.check(lib.gcrl_mt_set_state(self.rng.handle, self.rng._buf))
 
     def rows(self, first: int = 0, count: int | None = None):
         """Test helper: ring rows in logical (oldest-first) order as numpy arrays."""

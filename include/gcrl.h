@@ -174,6 +174,14 @@ int gcrl_her_profile_enable(gcrl_her* h, int on);
 int gcrl_her_profile_read(gcrl_her* h, int64_t* launches_out, double* total_ms_out,
                           int64_t* rows_out, double* device_clock_ms_out);
 
+/* Full resume state of the ring (extension of SURVEY.md §8f-2: the reference checkpoints weights + normalisers only,
+ * src/env.py:430-440): every stored row in logical order, the per-env staged partial episodes, the counters of the
+ * device-RNG mode.  The CPython-MT stream is saved with gcrl_mt_get_state.  Load into a ring of the same shape (any
+ * capacity >= the saved row count); logical indices — what sample() draws — are preserved. */
+int64_t gcrl_her_state_size(const gcrl_her* h);
+int gcrl_her_save_state(gcrl_her* h, void* dst_host, int64_t nbytes);
+int gcrl_her_load_state(gcrl_her* h, const void* src_host, int64_t nbytes);
+
 /* Test/debug: copy `n` ring rows starting at logical index `first` to host arrays
  * (any may be NULL).  Synchronises the handle's stream. */
 int gcrl_her_read_rows(gcrl_her* h, int64_t first, int64_t n, float* s_host, float* a_host,
@@ -254,6 +262,16 @@ int gcrl_agent_set(gcrl_agent* a, const char* name, const float* src_host, int64
 int gcrl_agent_init_weights(gcrl_agent* a, uint64_t seed, int recreate_alpha);
 /* update_target_network(hard_update=True) */
 int gcrl_agent_hard_update_targets(gcrl_agent* a);
+
+/* update_target_network(hard_update=False, tau): every target <- tau*net + (1-tau)*target
+ * (src/agent.py:1259-1271, :117-132, :487-496, :888-895) */
+int gcrl_agent_soft_update_targets(gcrl_agent* a, double tau, void* stream);
+/* Full resume state of the agent (extension): parameters and targets, Adam moments, BatchNorm running
+ * statistics, alpha, optimiser step counts and scheduler positions, device-RNG counter.  One host blob of
+ * gcrl_agent_state_size() bytes; loads only into an agent of the same shape. */
+int64_t gcrl_agent_state_size(const gcrl_agent* a);
+int gcrl_agent_save_state(gcrl_agent* a, void* dst_host, int64_t nbytes);
+int gcrl_agent_load_state(gcrl_agent* a, const void* src_host, int64_t nbytes);
 
 /* Optional injected inputs for one update (parity tests; all device pointers, may be NULL). */
 typedef struct gcrl_update_inputs {

@@ -177,3 +177,90 @@ def test_push_batch_equals_per_env_pushes_and_oracle(gcrl, k, nenvs):
     want = orc.sample(64)
     for g, w in zip(got, want):
         assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32))
+
+
+# ------------------------------------------------------------------ full resume state (SURVEY.md §8f-2 extension)
+def resume_agent(gcrl, kind):
+    from oracle.agent_oracle import make_config
+    cfg = make_config(kind, hidden_dim=32, layer_count=2, batch_size=32, max_len=1000, ac_update_freq=2 if kind == "TD3" else 1,
+                      policy_noise=0.2, actor_lr_min=1e-4, ac_scheduler_steps=25, critic_lr_min=2e-4, cr_scheduler_steps=30)
+    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent, SAC=gcrl.SACAgent, TQC=gcrl.TQCAgent)[kind]
+    return cls(10, 3, cfg, None, nenvs=2, gradient_step=10, rng="engine", seed=5)
+
+
+@pytest.mark.parametrize("kind", ["DDPG", "TD3", "SAC", "TQC"])
+def test_full_state_resume_in_a_new_process(gcrl, tmp_path, kind):
+    """save_state after 30 steps (ring wrapped, one episode half staged, cosine schedules mid-way, device-noise counter
+    advanced), load into a fresh agent in a NEW process, continue 20 steps there and here: tuples, parameters, targets
+    and ring contents bitwise equal."""
+    import os
+    import subprocess
+    import sys
+    from oracle import her_oracle
+    ag = resume_agent(gcrl, kind)
+    gen = np.random.default_rng(9)
+    for ep in range(6):                      # 6 x 246 rows into a 1000-row ring: wraps
+        for st in her_oracle.synthetic_episode(gen, 50, 10, 3):
+            ag.push_her(ep % 2, *st)
+    for st in her_oracle.synthetic_episode(gen, 50, 10, 3)[:17]:   # a partial episode stays staged
+        ag.push_her(1, *st)
+    ag.update_many(1, 10); ag.update_many(11, 10); ag.update_many(21, 10)
+    state = str(tmp_path / "state")
+    ag.save_state(state)
+    want = [[float(x) for x in t] for t in ag.update_many(31, 10)] + [[float(x) for x in t] for t in ag.update_many(41, 10)]
+    out = str(tmp_path / "child.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys; sys.argv = ['x', %r, %r, '31', '10', %r]; exec(open(%r).read().replace(\"update_many(step0, n)\", "
+              "\"update_many(31, 10)] + [t for t in ag.update_many(41, 10)\"))" % (kind, state, out, os.path.join(root, "tests", "resume_child.py")))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    width = got["tuples"].shape[1]
+    want = np.array([t + [0.0] * (width - len(t)) for t in want])
+    assert np.array_equal(got["tuples"], want), np.abs(got["tuples"] - want).max()
+    assert np.array_equal(got["actor"], ag.actor.flat()) and np.array_equal(got["critic"], ag.critics[-1].flat())
+    assert np.array_equal(got["target"], ag.target_critics[0].flat())
+    assert int(got["n"]) == len(ag.buffer) == 1000 and np.array_equal(got["rows"], ag.buffer.rows()[0])
+
+
+def test_soft_target_update_matches_reference_formula(gcrl):
+    """update_target_network(hard_update=False, tau) = tau*p + (1-tau)*p_target on every target (src/agent.py:1259-1271)."""
+    ag = resume_agent(gcrl, "TD3")
+    gen = np.random.default_rng(1)
+    new = {}
+    for v in [ag.actor] + ag.critics:
+        new[v.name] = (0.3 * gen.standard_normal(v.numel())).astype(np.float32)
+    old = {v.name: v.flat() for v in [ag.target_actor] + ag.target_critics}
+    for v in [ag.actor] + ag.critics:
+        v.set_flat(new[v.name])
+    ag.update_target_network(hard_update=False, tau=0.25)
+    torch.cuda.synchronize()
+    for v in [ag.target_actor] + ag.target_critics:
+        src = new[v.name.replace("target_", "")]
+        want = (np.float32(0.25) * src + np.float32(0.75) * old[v.name]).astype(np.float32)
+        assert np.array_equal(v.flat(), want), v.name
+    # the row-chain kernels' [in][out] copies of the targets follow: one more update must still track the layer-per-launch path
+    info = ag.update_many(1, 2)
+    assert all(np.isfinite([float(x) for x in t]).all() for t in info)
+
+
+def test_lazy_scalars_outlive_the_metrics_ring(gcrl):
+    """A trainer keeps update() outputs in history containers (src/env.py:521-537): entries read long after 4096 later
+    steps must still resolve, and np.mean over a deque of them equals the eager path."""
+    from collections import deque
+    from oracle import her_oracle
+    ag = resume_agent(gcrl, "DDPG")
+    gen = np.random.default_rng(2)
+    for ep in range(3):
+        for st in her_oracle.synthetic_episode(gen, 50, 10, 3):
+            ag.push_her(0, *st)
+    first = ag.update(1)
+    hist = deque(maxlen=100)
+    step = 2
+    for _ in range(110):
+        for t in ag.update_many(step, 40):
+            hist.append(t[0])
+        step += 40
+    assert np.isfinite(float(first[0])) and np.isfinite(np.asarray(first[2]))      # 4400 steps later
+    m = np.mean(hist)
+    assert np.isfinite(m) and abs(m - np.mean([float(x) for x in hist])) < 1e-12
