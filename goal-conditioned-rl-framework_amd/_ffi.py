@@ -130,6 +130,15 @@ PROTOTYPES = {
     "gcrl_agent_dev_ptr": (C.c_int, [_vp, _cp, C.POINTER(_vp), C.POINTER(_i64)]),
     "gcrl_agent_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "gcrl_agent_act_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
+    "gcrl_normalizer_create": (_vp, [C.c_int, _f64, _f64, C.c_int]),
+    "gcrl_normalizer_destroy": (None, [_vp]),
+    "gcrl_normalizer_size": (C.c_int, [_vp]),
+    "gcrl_normalizer_update": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "gcrl_normalizer_normalize": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "gcrl_normalizer_get": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gcrl_normalizer_set": (C.c_int, [_vp, _vp, _vp, _f64, _f64]),
+    "gcrl_agent_observe_act": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "gcrl_her_process_step": (_i64, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "gcrl_sort_truncate_mean": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp]),
     "gcrl_gemm_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "gcrl_event_create": (_vp, []),

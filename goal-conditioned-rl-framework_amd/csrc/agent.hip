@@ -113,6 +113,8 @@ struct gcrl_agent {
   float *act_in = nullptr, *act_tmp[2] = {};
   float* pi_buf = nullptr;   // SAC row-chain path: pi(s) [B][Apad] (the layer-per-launch paths keep it in spa's action columns)
   float* act_pinned = nullptr;   // host staging of gcrl_agent_act_host
+  char *oa_pinned = nullptr, *oa_dev = nullptr;   // staging of gcrl_agent_observe_act (raw rows, noise, actions)
+  size_t oa_bytes = 0;
   // row-block DDPG path (rowchain.h): [in][out] weight copies of actor | target actor | critic 0 |
   // target critic 0, per-layer gradient buffers, TD targets
   bool rowchain = false, wt_dirty = true;
@@ -205,6 +207,22 @@ __global__ void pack_batch_kernel(const float* s, int ld_s, const float* a, int 
   else if (c < W - 2) nsa[(long long)b * ldx + (c - S - A)] = ns[(long long)b * ld_ns + (c - S - A)];
   else if (c == W - 2) rb[b] = r[b];
   else db[b] = d[b];
+}
+
+// select_action's arithmetic after the network (src/agent.py:1345-1366, :253-270): mode 0 clip(tanh(x), -1, 1) (DDPG eval),
+// 1 clip(tanh(x) + noise, -1, 1) (DDPG / TD3 exploration; float32 tanh + float64 noise like numpy), 2 x as it is
+__global__ void act_post_kernel(const float* x, int ld, int n, int A, const double* noise, int mode, double* out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * A) return;
+  const int i = t / A, j = t - i * A;
+  const float v = x[(long long)i * ld + j];
+  double r = (double)v;
+  if (mode != 2) {
+    r = (double)tanhf(v);
+    if (mode == 1 && noise) r += noise[t];
+    r = fmin(fmax(r, -1.0), 1.0);
+  }
+  out[t] = r;
 }
 
 __global__ void copy_rows_kernel(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols) {
@@ -1011,6 +1029,8 @@ void gcrl_agent_destroy(gcrl_agent* a) {
   if (a->metrics_dev) (void)hipFree(a->metrics_dev);
   if (a->prof_clk) (void)hipFree(a->prof_clk);
   if (a->act_pinned) (void)hipHostFree(a->act_pinned);
+  if (a->oa_pinned) (void)hipHostFree(a->oa_pinned);
+  if (a->oa_dev) (void)hipFree(a->oa_dev);
   for (int i = 0; i < gcrl_agent::kProfPairs; ++i) {
     if (a->prof_a[i]) (void)hipEventDestroy(a->prof_a[i]);
     if (a->prof_b[i]) (void)hipEventDestroy(a->prof_b[i]);
@@ -1448,6 +1468,51 @@ int gcrl_agent_act_host(gcrl_agent* a, const float* obs_host, int n, int ld_obs,
   GCRL_HIP(hipMemcpyAsync(pin_out, a->dact, (size_t)n * a->Apad * sizeof(float), hipMemcpyDeviceToHost, st));
   GCRL_HIP(hipStreamSynchronize(st));
   for (int r = 0; r < n; ++r) std::memcpy(out_host + (size_t)r * ld_out, pin_out + (size_t)r * a->Apad, (size_t)a->A * sizeof(float));
+  return GCRL_OK;
+}
+
+// One vector-env step of the acting side as ONE call: raw observation / desired-goal rows from the
+// host -> normalize_state_batch (src/agent.py:1435-1447) with the device normalisers (null: that part stays raw) ->
+// actor -> select_action's post-processing (modes: act_post_kernel; SAC / TQC: noise = the rsample eps, null = eval)
+// -> float64 actions on the host, as the reference returns them.  The epsilon-random branch of DDPG
+// (src/agent.py:1348) is the caller's: it consumes the shared Python `random` stream.
+int gcrl_agent_observe_act(gcrl_agent* a, gcrl_normalizer* nz_obs, gcrl_normalizer* nz_dg, const float* obs_host, int obs_dim,
+                           const float* dg_host, int goal_dim, int n, const double* noise_host, int mode, double* out_host,
+                           void* stream) {
+  GCRL_CHECK_ARG(a && obs_host && dg_host && out_host && n >= 1 && n <= a->B, "gcrl_agent_observe_act: bad arguments (n must be 1..batch_size)");
+  GCRL_CHECK_ARG(obs_dim >= 1 && goal_dim >= 0 && obs_dim + goal_dim == a->S, "gcrl_agent_observe_act: obs_dim %d + goal_dim %d != %d", obs_dim, goal_dim, a->S);
+  GCRL_CHECK_ARG(mode >= 0 && mode <= 2, "gcrl_agent_observe_act: mode must be 0, 1 or 2");
+  hipStream_t st = a->pick(stream);
+  const int D = obs_dim, G = goal_dim, A = a->A;
+  const size_t f_raw = (size_t)a->B * (D + G + A), d_cnt = (size_t)a->B * A;
+  const size_t bytes = f_raw * sizeof(float) + 2 * d_cnt * sizeof(double) + 64;
+  if (!a->oa_pinned) {
+    GCRL_HIP(hipHostMalloc((void**)&a->oa_pinned, bytes, hipHostMallocDefault));
+    GCRL_HIP(hipMalloc((void**)&a->oa_dev, bytes));
+    a->oa_bytes = bytes;
+  }
+  // layout: doubles first (alignment): noise [B*A], out [B*A]; then floats: obs, dg, eps
+  double* p_noise = (double*)a->oa_pinned; double* p_out = p_noise + d_cnt; float* p_f = (float*)(p_out + d_cnt);
+  double* d_noise = (double*)a->oa_dev; double* d_out = d_noise + d_cnt; float* d_f = (float*)(d_out + d_cnt);
+  std::memcpy(p_f, obs_host, sizeof(float) * n * D);
+  std::memcpy(p_f + (size_t)n * D, dg_host, sizeof(float) * n * G);
+  const bool eps_act = a->sac && noise_host;
+  if (noise_host) {
+    if (eps_act) for (int i = 0; i < n * A; ++i) p_f[(size_t)n * (D + G) + i] = (float)noise_host[i];
+    else std::memcpy(p_noise, noise_host, sizeof(double) * n * A);
+  }
+  if (noise_host && !eps_act) GCRL_HIP(hipMemcpyAsync(d_noise, p_noise, sizeof(double) * n * A, hipMemcpyHostToDevice, st));
+  GCRL_HIP(hipMemcpyAsync(d_f, p_f, sizeof(float) * ((size_t)n * (D + G) + (eps_act ? (size_t)n * A : 0)), hipMemcpyHostToDevice, st));
+  TRY(gcrl::normalizer_apply_dev(nz_obs, d_f, n, D, D, a->act_in, a->S, 0, st));
+  if (G) TRY(gcrl::normalizer_apply_dev(nz_dg, d_f + (size_t)n * D, n, G, G, a->act_in, a->S, D, st));
+  TRY(gcrl_agent_act(a, a->act_in, n, a->S, a->dact, a->Apad, eps_act ? d_f + (size_t)n * (D + G) : nullptr, stream));
+  const int pm = a->sac ? 2 : mode;
+  hipLaunchKernelGGL(act_post_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, a->dact, a->Apad, n, A,
+                     (noise_host && !eps_act) ? d_noise : nullptr, pm, d_out);
+  GCRL_HIP(hipGetLastError());
+  GCRL_HIP(hipMemcpyAsync(p_out, d_out, sizeof(double) * n * A, hipMemcpyDeviceToHost, st));
+  GCRL_HIP(hipStreamSynchronize(st));
+  std::memcpy(out_host, p_out, sizeof(double) * n * A);
   return GCRL_OK;
 }
 

@@ -108,6 +108,15 @@ struct gcrl_her {
   float* epi_pinned[kSlots] = {};
   hipEvent_t epi_ev[kSlots] = {};
   int next_epi_slot = 0;
+  // future indices of a flush launch when they exceed the inline kernel-argument space (k_future >= 42)
+  uint8_t* fut_dev = nullptr;
+  uint8_t* fut_pinned[kSlots] = {};
+  hipEvent_t fut_ev[kSlots] = {};
+  int next_fut_slot = 0;
+  // raw observation rows of a vector-env step and their normalised [obs | goal] state matrices (gcrl_her_process_step)
+  float* ps_dev = nullptr;
+  float* ps_pinned[kSlots] = {};
+  size_t ps_floats = 0;
   // per-env payload of a vector-env step (gcrl_her_push_batch)
   float* pay_dev = nullptr;
   float* pay_pinned[kSlots] = {};
@@ -129,7 +138,15 @@ struct gcrl_her {
   }
 };
 
+struct gcrl_normalizer;
+
 namespace gcrl {
+
+// device RunningNormalizer (normalizer.hip): statistics update from device rows; out[:, col0:col0+D] = normalize(x)
+// (z == null: plain copy)
+int normalizer_update_dev(gcrl_normalizer* z, const float* x_dev, int n, int ld, hipStream_t st);
+int normalizer_apply_dev(const gcrl_normalizer* z, const float* x_dev, int n, int ld, int D, float* out_dev, int ld_out, int col0,
+                         hipStream_t st);
 
 // Draw M*B logical indices (random.sample semantics per batch) into a pinned slot and upload
 // them to h->idx_dev on `st`.  idx_host != NULL: use those instead of drawing.  Returns the

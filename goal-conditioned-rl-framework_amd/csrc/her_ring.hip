@@ -81,6 +81,7 @@ struct FlushArgs {
   int T[kMaxEp];
   unsigned long long epi_id[kMaxEp];
   int fut_off[kMaxEp];
+  const uint8_t* fut_ext;   // more than kMaxFut future indices in this launch: they were uploaded instead (k_future >= 42)
   uint8_t fut[kMaxFut];
 };
 
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
     const int o_ns = p.SA4, o_r = p.SA4 + p.S4;
     float rew = rec_lds[li][o_r], done = rec_lds[li][o_r + 1];
     if (rep > 0) {
-      if (p.rng_mode == GCRL_RNG_CPYTHON_MT) f = p.fut[p.fut_off[e] + i * p.k + (rep - 1)];
+      if (p.rng_mode == GCRL_RNG_CPYTHON_MT) f = (p.fut_ext ? p.fut_ext : p.fut)[p.fut_off[e] + i * p.k + (rep - 1)];
       else f = i + 1 + (int)gcrl::hash_below(p.seed, p.epi_id[e], (unsigned long long)(i * p.k + rep - 1), (uint32_t)(T - 1 - i));
       // compute_reward(ag_i, ag_f): d = ||ag_i - ag_f||_2 in fp32, one rounding per op
       float acc = 0.f;
@@ -412,6 +413,23 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
   fa.seed = c.seed;
   int64_t total = 0;
   int fut_used = 0, maxT = 0;
+  // future indices of the launch's episodes, in draw order (src/buffer.py:146-153): inline in the kernel arguments
+  // while they fit, uploaded through a pinned slot otherwise
+  size_t fut_need = 0;
+  for (int e = 0; e < nep; ++e) fut_need += (size_t)c.k_future * (Ts[e] - 1);
+  uint8_t* fut_host = fa.fut;
+  int fslot = -1;
+  if (c.rng_mode == GCRL_RNG_CPYTHON_MT && fut_need > (size_t)kMaxFut) {
+    const size_t cap = (size_t)kMaxEp * c.k_future * c.flush_len;
+    if (!h->fut_dev) {
+      GCRL_HIP(hipMalloc((void**)&h->fut_dev, cap));
+      for (int i = 0; i < gcrl_her::kSlots; ++i) GCRL_HIP(hipHostMalloc((void**)&h->fut_pinned[i], cap, hipHostMallocDefault));
+    }
+    fslot = h->next_fut_slot;
+    h->next_fut_slot = (fslot + 1) % gcrl_her::kSlots;
+    GCRL_HIP(hipEventSynchronize(h->fut_ev[fslot]));
+    fut_host = h->fut_pinned[fslot];
+  }
   for (int e = 0; e < nep; ++e) {
     const int T = Ts[e];
     fa.stage[e] = h->stage + ((size_t)envs[e] * c.flush_len) * h->RG;
@@ -420,14 +438,17 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
     fa.fut_off[e] = fut_used;
     const int nf = c.k_future * (T - 1);
     if (c.rng_mode == GCRL_RNG_CPYTHON_MT) {
-      if (fut_used + nf > kMaxFut)
-        return gcrl::fail(GCRL_ERR_ARG, "flush: k_future*(T-1) = %d exceeds the inline limit %d", fut_used + nf, kMaxFut);
-      if (futs && futs[e]) std::memcpy(fa.fut + fut_used, futs[e], nf);
-      else if (int rc = gcrl_mt_future_indices(h->rng, T, c.k_future, fa.fut + fut_used)) return rc;
+      if (futs && futs[e]) std::memcpy(fut_host + fut_used, futs[e], nf);
+      else if (int rc = gcrl_mt_future_indices(h->rng, T, c.k_future, fut_host + fut_used)) return rc;
       fut_used += nf;
     }
     total += T + (int64_t)c.k_future * (T - 1);
     maxT = std::max(maxT, T);
+  }
+  if (fslot >= 0) {
+    GCRL_HIP(hipMemcpyAsync(h->fut_dev, fut_host, (size_t)fut_used, hipMemcpyHostToDevice, st));
+    GCRL_HIP(hipEventRecord(h->fut_ev[fslot], st));
+    fa.fut_ext = h->fut_dev;
   }
   fa.skip = total > c.capacity ? total - c.capacity : 0;
   dim3 grid((maxT + kStepsPerBlock - 1) / kStepsPerBlock, nep);
@@ -547,6 +568,7 @@ gcrl_her* gcrl_her_create(const gcrl_her_config* cfg, gcrl_mt* rng) {
   for (int i = 0; good && i < gcrl_her::kSlots; ++i) {
     good = ok(hipEventCreateWithFlags(&h->slot_ev[i], hipEventDisableTiming), "hipEventCreate") &&
            ok(hipEventCreateWithFlags(&h->epi_ev[i], hipEventDisableTiming), "hipEventCreate") &&
+           ok(hipEventCreateWithFlags(&h->fut_ev[i], hipEventDisableTiming), "hipEventCreate") &&
            ok(hipHostMalloc((void**)&h->epi_pinned[i], (size_t)cfg->flush_len * h->RG * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
   }
   if (good) good = ok(hipMemset(h->stage, 0, (size_t)cfg->nenvs * cfg->flush_len * h->RG * sizeof(float)), "hipMemset") &&
@@ -568,6 +590,13 @@ void gcrl_her_destroy(gcrl_her* h) {
   for (hipEvent_t e : h->prof_b) (void)hipEventDestroy(e);
   if (h->prof_clk) (void)hipFree(h->prof_clk);
   if (h->pay_dev) (void)hipFree(h->pay_dev);
+  if (h->fut_dev) (void)hipFree(h->fut_dev);
+  if (h->ps_dev) (void)hipFree(h->ps_dev);
+  for (int i = 0; i < gcrl_her::kSlots; ++i) if (h->ps_pinned[i]) (void)hipHostFree(h->ps_pinned[i]);
+  for (int i = 0; i < gcrl_her::kSlots; ++i) {
+    if (h->fut_pinned[i]) (void)hipHostFree(h->fut_pinned[i]);
+    if (h->fut_ev[i]) (void)hipEventDestroy(h->fut_ev[i]);
+  }
   for (int i = 0; i < gcrl_her::kSlots; ++i) if (h->pay_pinned[i]) (void)hipHostFree(h->pay_pinned[i]);
   if (h->idx_dev) (void)hipFree(h->idx_dev);
   if (h->ring) (void)hipFree(h->ring);
@@ -671,13 +700,60 @@ int64_t gcrl_her_push_batch(gcrl_her* h, int env0, int n, const float* states_de
     h->staged[env] += 1;
     if (dones_host[i] || h->staged[env] >= h->cfg.flush_len) {
       const int need = h->cfg.k_future * (h->staged[env] - 1);  // inline future indices of this episode
-      if (cnt == kMaxEp || fut_acc + need > kMaxFut) if (int rc = flush_pending()) return rc;
+      if (cnt == kMaxEp) if (int rc = flush_pending()) return rc;
       envs[cnt] = env; Ts[cnt] = h->staged[env]; ++cnt;
       fut_acc += need;
     }
   }
   if (int rc = flush_pending()) return rc;
   return total;
+}
+
+// _process_step of the reference's trainer (src/env.py:163-201) for one vector-env step as ONE call: the observation
+// normaliser takes [obs ; next_obs] (src/agent.py:1425-1433 via :165-175), both state matrices are rebuilt from the
+// UPDATED statistics ([normalize(obs) | goal], src/env.py:177-188), and all n transitions are pushed (gcrl_her_push_batch).
+// Raw rows come from the host; nothing returns to it.  Goals stay raw (g_normalize is false in every shipped config;
+// a goal normaliser is refused here rather than half-applied — use the unfused calls for it).
+int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_stats, const float* obs_host,
+                              const float* next_obs_host, int obs_dim, const float* dg_host, const float* next_dg_host,
+                              const float* next_ag_host, const float* actions_host, const float* rewards_host,
+                              const uint8_t* dones_host, int env0, int n, void* stream) {
+  GCRL_CHECK_ARG(h && obs_host && next_obs_host && dg_host && next_dg_host && next_ag_host && actions_host && rewards_host && dones_host,
+                 "gcrl_her_process_step: null argument");
+  GCRL_CHECK_ARG(obs_dim >= 1 && obs_dim + h->G == h->S, "gcrl_her_process_step: obs_dim %d + goal_dim %d != state_dim %d", obs_dim, h->G, h->S);
+  GCRL_CHECK_ARG(n >= 1 && env0 >= 0 && env0 + n <= h->cfg.nenvs, "gcrl_her_process_step: envs [%d, %d) outside [0, %d)", env0, env0 + n, h->cfg.nenvs);
+  hipStream_t st = h->pick(stream);
+  const int D = obs_dim, G = h->G, S = h->S;
+  // staging layout (floats): raw [obs(n*D) | next_obs(n*D) | dg(n*G) | next_dg(n*G)], then s [n*S], ns [n*S]
+  const size_t raw = (size_t)n * (2 * D + 2 * G), need = raw + 2 * (size_t)n * S;
+  if (need > h->ps_floats) {
+    GCRL_HIP(hipDeviceSynchronize());
+    if (h->ps_dev) GCRL_HIP(hipFree(h->ps_dev));
+    const size_t want = std::max<size_t>(need, (size_t)h->cfg.nenvs * (2 * D + 2 * G + 2 * S));
+    GCRL_HIP(hipMalloc((void**)&h->ps_dev, want * sizeof(float)));
+    for (int i = 0; i < gcrl_her::kSlots; ++i) {
+      if (h->ps_pinned[i]) GCRL_HIP(hipHostFree(h->ps_pinned[i]));
+      GCRL_HIP(hipHostMalloc((void**)&h->ps_pinned[i], want * sizeof(float), hipHostMallocDefault));
+    }
+    h->ps_floats = want;
+  }
+  const int slot = h->next_epi_slot;   // shares the slot counter / events of the payload uploads of the same step
+  GCRL_HIP(hipEventSynchronize(h->epi_ev[slot]));
+  float* pin = h->ps_pinned[slot];
+  std::memcpy(pin, obs_host, sizeof(float) * n * D);
+  std::memcpy(pin + (size_t)n * D, next_obs_host, sizeof(float) * n * D);
+  std::memcpy(pin + (size_t)2 * n * D, dg_host, sizeof(float) * n * G);
+  std::memcpy(pin + (size_t)2 * n * D + (size_t)n * G, next_dg_host, sizeof(float) * n * G);
+  GCRL_HIP(hipMemcpyAsync(h->ps_dev, pin, raw * sizeof(float), hipMemcpyHostToDevice, st));
+  float* d_obs = h->ps_dev; float* d_nobs = d_obs + (size_t)n * D; float* d_dg = d_nobs + (size_t)n * D; float* d_ndg = d_dg + (size_t)n * G;
+  float* d_s = h->ps_dev + raw; float* d_ns = d_s + (size_t)n * S;
+  if (nz_obs && update_stats)
+    if (int rc = gcrl::normalizer_update_dev(nz_obs, d_obs, 2 * n, D, st)) return rc;   // np.concatenate([obs, next_obs]) is how they lie
+  if (int rc = gcrl::normalizer_apply_dev(nz_obs, d_obs, n, D, D, d_s, S, 0, st)) return rc;
+  if (int rc = gcrl::normalizer_apply_dev(nullptr, d_dg, n, G, G, d_s, S, D, st)) return rc;
+  if (int rc = gcrl::normalizer_apply_dev(nz_obs, d_nobs, n, D, D, d_ns, S, 0, st)) return rc;
+  if (int rc = gcrl::normalizer_apply_dev(nullptr, d_ndg, n, G, G, d_ns, S, D, st)) return rc;
+  return gcrl_her_push_batch(h, env0, n, d_s, S, actions_host, d_ns, S, rewards_host, dones_host, next_ag_host, stream);
 }
 
 int64_t gcrl_her_push_episode(gcrl_her* h, int env, int T, const float* s, const float* a,

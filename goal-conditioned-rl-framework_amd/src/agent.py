@@ -296,6 +296,78 @@ class _EngineAgent:
                                       _ffi.stream_handle()))
         return out
 
+    # ------------------------------------------------------------------ fused acting side
+    def _device_normalizers(self, obs_normalize: bool, g_normalize: bool):
+        """(obs handle, goal handle) when the normalisers this step needs live on the device, else None."""
+        from .utils import DeviceRunningNormalizer
+        on, gn = getattr(self.buffer, "obs_normalizer", None), getattr(self.buffer, "dg_normalizer", None)
+        if obs_normalize and not isinstance(on, DeviceRunningNormalizer):
+            return None
+        if g_normalize and not isinstance(gn, DeviceRunningNormalizer):
+            return None
+        return (on.handle if obs_normalize else None, gn.handle if g_normalize else None)
+
+    _ACT_MODE_EXPLORE, _ACT_MODE_EVAL = 1, 0      # DDPG; TD3 overrides eval (raw network output)
+
+    def observe_act(self, observation, desired_goal, eval_action: bool = False, obs_normalize: bool = True,
+                    g_normalize: bool = False):
+        """`select_action(normalize_state_batch(obs, dg, ...))` for one vector-env step (src/env.py:348-355) as ONE native
+        call: raw rows up, normalisation + actor + exploration noise on the device, float64 actions back.  The host
+        generators are consumed exactly as in the reference (`random.random()` for DDPG's epsilon branch, `np.random`
+        for the Gaussian noise, torch's for SAC / TQC eps).  Falls back to the two separate calls when the normalisers
+        are host objects."""
+        nz = self._device_normalizers(obs_normalize, g_normalize)
+        obs = np.ascontiguousarray(observation, np.float32)
+        dg = np.ascontiguousarray(desired_goal, np.float32)
+        if nz is None or obs.shape[0] > int(self.config.batch_size):
+            return self.select_action(self.normalize_state_batch(obs, dg, obs_normalize, g_normalize), eval_action)
+        self.set_eval()
+        n = obs.shape[0]
+        noise, mode = self._act_noise(n, eval_action)
+        if mode is None:
+            return noise                              # DDPG's epsilon-random action: no network involved
+        out = np.empty((n, self.ac_dim), np.float64)
+        _ffi.check(lib.gcrl_agent_observe_act(self._h, nz[0], nz[1], obs.ctypes.data, obs.shape[1], dg.ctypes.data, dg.shape[1], n,
+                                              noise.ctypes.data if noise is not None else None, mode, out.ctypes.data,
+                                              _ffi.stream_handle()))
+        return out
+
+    def _act_noise(self, n, eval_action):
+        """-> (noise or None, mode); DDPG overrides for the epsilon branch."""
+        if eval_action:
+            return None, self._ACT_MODE_EVAL
+        return np.ascontiguousarray(np.random.normal(0, self.noise_std, size=(n, self.ac_dim))), self._ACT_MODE_EXPLORE
+
+    def process_step(self, state, actions, next_obs_raw, rewards, dones, obs_normalize: bool = True, g_normalize: bool = False):
+        """The reference trainer's `_process_step` (src/env.py:163-201) for one vector-env step as ONE native call:
+        normaliser update with [obs ; next_obs], both normalised state matrices built on the device from the updated
+        statistics, all envs pushed (episode flush + HER relabel on the device when an env finishes).  `state` /
+        `next_obs_raw`: the env's dict observations; `dones` = `terminated` (src/env.py:372).  Falls back to the separate
+        calls when the observation normaliser is a host object or goals are normalised."""
+        nz = self._device_normalizers(obs_normalize, False)
+        buf = self.buffer
+        if nz is None or g_normalize:
+            self.update_normalizers([state["observation"], next_obs_raw["observation"]],
+                                    [state["desired_goal"], next_obs_raw["desired_goal"], state["achieved_goal"],
+                                     next_obs_raw["achieved_goal"]], obs_normalize, g_normalize)
+            s = torch.from_numpy(self.normalize_state_batch(state["observation"], state["desired_goal"], obs_normalize, g_normalize)).float().cuda()
+            ns = torch.from_numpy(self.normalize_state_batch(next_obs_raw["observation"], next_obs_raw["desired_goal"], obs_normalize, g_normalize)).float().cuda()
+            return buf.push_batch(s, actions, ns, rewards, dones, self.normalize_goal(next_obs_raw["achieved_goal"], g_normalize))
+        f32 = lambda x: np.ascontiguousarray(x, np.float32)
+        obs, nobs = f32(state["observation"]), f32(next_obs_raw["observation"])
+        dg, ndg, nag = f32(state["desired_goal"]), f32(next_obs_raw["desired_goal"]), f32(next_obs_raw["achieved_goal"])
+        act, rew = f32(actions), f32(rewards).reshape(-1)
+        dn = np.ascontiguousarray(np.asarray(dones).astype(np.uint8)).reshape(-1)
+        n = obs.shape[0]
+        buf._ensure(obs.shape[1] + dg.shape[1], act.shape[1], nag.shape[1])
+        buf.rng.pull()
+        rows = lib.gcrl_her_process_step(buf.handle, nz[0], 1 if obs_normalize else 0, obs.ctypes.data, nobs.ctypes.data, obs.shape[1],
+                                         dg.ctypes.data, ndg.ctypes.data, nag.ctypes.data, act.ctypes.data, rew.ctypes.data,
+                                         dn.ctypes.data, 0, n, _ffi.stream_handle())
+        _ffi.check(int(rows))
+        buf.rng.push_back()
+        return int(rows)
+
     def push(self, state, action, reward, next_state, done):
         # reference passes 5 args to a HERBuffer.push that takes 8 -> TypeError there too
         self.buffer.push(state, action, reward, next_state, done)
@@ -416,6 +488,11 @@ class DDPG(_EngineAgent):
             return np.clip(action + np.random.normal(0, self.noise_std, size=action.shape), -1, 1)
         return np.clip(torch.tanh(self._actor_forward(obs_tensor)).cpu().numpy(), -1, 1)
 
+    def _act_noise(self, n, eval_action):
+        if not eval_action and self.buffer.rng.random() < 0.2:      # src/agent.py:1348
+            return np.clip(np.random.randn(n, self.ac_dim), a_min=-1, a_max=1), None
+        return super()._act_noise(n, eval_action)
+
     def save_weights(self, path: str):
         self.actor.save(os.path.join(path, "actor.pth"))
         self.critic.save(os.path.join(path, "critic.pth"))
@@ -424,6 +501,7 @@ class DDPG(_EngineAgent):
 class TD3Agent(_EngineAgent):
     KIND_NAME = "TD3"
     TD_INDEX = {8: 3, 6: 2}
+    _ACT_MODE_EVAL = 2      # eval returns the network output as it is (src/agent.py:265-270)
 
     def _bind_names(self):
         self.critic_1, self.critic_2 = self.critics
@@ -449,6 +527,12 @@ class TD3Agent(_EngineAgent):
 
 class _StochasticAgent(_EngineAgent):
     TD_INDEX = {9: 3, 6: 2}
+
+    def _act_noise(self, n, eval_action):
+        if eval_action:
+            return None, 2
+        # rsample's eps (src/model.py:134); drawn on the host generator here — one fewer device round trip
+        return np.ascontiguousarray(torch.randn((n, self.ac_dim), dtype=torch.float32).numpy().astype(np.float64)), 2
 
     def select_action(self, obs_tensor, eval_action: bool = False):
         self.set_eval()

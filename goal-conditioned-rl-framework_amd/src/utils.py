@@ -139,6 +139,78 @@ class RunningNormalizer:
         self.clip_range = float(d["clip_range"])
 
 
+class DeviceRunningNormalizer:
+    """RunningNormalizer living on the GPU (csrc/normalizer.hip): same constructor, `update`, `normalize`, `save`,
+    `load`, `mean` / `var` / `count` / `clip_range` as the host class above (reference src/utils.py:68-117), same
+    arithmetic bit for bit.  Assign it where the trainer assigns the host one (`buffer.obs_normalizer = ...`,
+    src/env.py:93-98): the agents' fused entry points (`observe_act`, `process_step`) then keep a vector-env step's
+    observation rows on the device from normalisation to the replay ring.
+    `normalize` returns the float32-rounded values (as float64 arrays, like the reference) — the trainer casts the
+    result to float32 before anything consumes it (src/env.py:189-190, src/agent.py:1353)."""
+
+    def __init__(self, size, clip_range: float = 5.0, eps: float = 1e-8, device_index: int = 0):
+        import ctypes as C
+        from .. import _ffi
+        self._ffi, self._C = _ffi, C
+        self.size = int(size)
+        self._clip = float(clip_range)
+        self._h = _ffi.check_ptr(_ffi.lib.gcrl_normalizer_create(self.size, self._clip, float(eps), int(device_index)),
+                                 "gcrl_normalizer_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._ffi.lib.gcrl_normalizer_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _state(self):
+        C = self._C
+        mean, var, cnt = np.empty(self.size), np.empty(self.size), C.c_double()
+        self._ffi.check(self._ffi.lib.gcrl_normalizer_get(self._h, mean.ctypes.data, var.ctypes.data, C.byref(cnt)))
+        return mean, var, cnt.value
+
+    mean = property(lambda self: self._state()[0])
+    var = property(lambda self: self._state()[1])
+    count = property(lambda self: self._state()[2])
+    clip_range = property(lambda self: self._clip)
+
+    def set_state(self, mean, var, count, clip_range=None):
+        mean = np.ascontiguousarray(mean, np.float64).reshape(-1)
+        var = np.ascontiguousarray(var, np.float64).reshape(-1)
+        if clip_range is not None:
+            self._clip = float(clip_range)
+        self._ffi.check(self._ffi.lib.gcrl_normalizer_set(self._h, mean.ctypes.data, var.ctypes.data, float(count), self._clip))
+
+    def update(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        if x.ndim == 1:
+            x = x[None, :]
+        self._ffi.check(self._ffi.lib.gcrl_normalizer_update(self._h, x.ctypes.data, x.shape[0], x.shape[1], 0, self._ffi.stream_handle()))
+
+    def normalize(self, x):
+        x = np.asarray(x)
+        x2 = np.ascontiguousarray(x.reshape(-1, self.size), np.float32)
+        out = np.empty_like(x2)
+        self._ffi.check(self._ffi.lib.gcrl_normalizer_normalize(self._h, x2.ctypes.data, x2.shape[0], self.size, 0, out.ctypes.data,
+                                                                self.size, 0, self._ffi.stream_handle()))
+        return out.astype(np.float64).reshape(x.shape)
+
+    def save(self, path: str):
+        mean, var, count = self._state()
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            yaml.dump({"mean": mean.tolist(), "var": var.tolist(), "count": float(count), "clip_range": float(self._clip)}, fh)
+
+    def load(self, path: str):
+        with open(path, "r") as fh:
+            d = yaml.safe_load(fh)
+        # (the reference keeps float32 copies after load, src/utils.py:113-114; the values are the same)
+        self.set_state(np.array(d["mean"], dtype=np.float32), np.array(d["var"], dtype=np.float32), float(d["count"]), float(d["clip_range"]))
+
+
 def set_seed(seed: int, env=None):
     """Seeds the three host generators the reference seeds (src/utils.py:197-208)."""
     import torch

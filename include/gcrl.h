@@ -357,6 +357,38 @@ int gcrl_agent_act_host(gcrl_agent* a, const float* obs_host, int n, int ld_obs,
                         int ld_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The acting side: RunningNormalizer on the device (src/utils.py:68-98: float32 batch moments in
+ * numpy's order, float64 parallel-variance merge, clip to +-clip_range) and the two fused entry points of one
+ * vector-env step.  Rows are float32, `ld` floats apart; `on_device` says where they live.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gcrl_normalizer gcrl_normalizer;
+gcrl_normalizer* gcrl_normalizer_create(int size, double clip_range, double eps, int device);   /* __init__ :69-73 */
+void gcrl_normalizer_destroy(gcrl_normalizer* z);
+int gcrl_normalizer_size(const gcrl_normalizer* z);
+int gcrl_normalizer_update(gcrl_normalizer* z, const float* x, int n, int ld, int on_device, void* stream);   /* update :75-81 */
+/* normalize :95-97, result cast to float32 (what the trainer's torch.from_numpy(..).float() does, src/env.py:189-190) */
+int gcrl_normalizer_normalize(gcrl_normalizer* z, const float* x, int n, int ld, int on_device, float* out, int ld_out,
+                              int out_on_device, void* stream);
+int gcrl_normalizer_get(gcrl_normalizer* z, double* mean_host, double* var_host, double* count_host);   /* save :99-108 */
+int gcrl_normalizer_set(gcrl_normalizer* z, const double* mean_host, const double* var_host, double count, double clip_range);
+/* select_action for one vector-env step from RAW host rows (src/env.py:348-355 + src/agent.py:1345-1366 / :253-270 /
+ * :641-647): normalize_state_batch with the given normalisers (NULL: that part raw), actor, post-processing —
+ * mode 0: clip(tanh(net), -1, 1); 1: clip(tanh(net) + noise, -1, 1), noise = np.random.normal draws [n, A] float64;
+ * 2: the network output as it is.  SAC / TQC ignore `mode`: noise = rsample eps (NULL: deterministic tanh(mean)).
+ * out_host [n, A] float64.  DDPG's epsilon-random branch (:1348) stays with the caller (shared `random` stream). */
+int gcrl_agent_observe_act(gcrl_agent* a, gcrl_normalizer* nz_obs, gcrl_normalizer* nz_dg, const float* obs_host, int obs_dim,
+                           const float* dg_host, int goal_dim, int n, const double* noise_host, int mode, double* out_host,
+                           void* stream);
+/* _process_step for one vector-env step (src/env.py:163-201) from raw host rows: normaliser update with [obs ; next_obs]
+ * (when update_stats), state = [normalize(obs) | dg], next_state = [normalize(next_obs) | next_dg] built on the device
+ * from the UPDATED statistics, then the n pushes of gcrl_her_push_batch (achieved goal = next_ag, done = dones).
+ * Goals are not normalised (g_normalize is false in every shipped config).  Returns ring rows appended. */
+int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_stats, const float* obs_host,
+                              const float* next_obs_host, int obs_dim, const float* dg_host, const float* next_dg_host,
+                              const float* next_ag_host, const float* actions_host, const float* rewards_host,
+                              const uint8_t* dones_host, int env0, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Stand-alone ops exposed for tests / reuse.
  * ---------------------------------------------------------------------------------------- */
 /* Row-wise sort of `width` (<= 64) fp32 values per row in one wavefront (bitonic network via

@@ -1,0 +1,48 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product.
+
+CPU restatement of the reference's RunningNormalizer (src/utils.py:68-98), with the batch moments written out as
+the explicit float32 sequential sums numpy's axis-0 reductions perform — the order the device kernel
+(csrc/normalizer.hip) follows.  Pinned by tests/golden/normalizer.npz, captured from the reference's own class.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class RunningNormalizerOracle:
+    def __init__(self, size, clip_range=5.0, eps=1e-8):            # :69-73
+        self.mean = np.zeros(size)
+        self.var = np.ones(size)
+        self.count = eps
+        self.clip_range = clip_range
+
+    @staticmethod
+    def batch_moments(x):
+        """np.mean(x, axis=0), np.var(x, axis=0) of float32 rows: row after row, every operation rounded to float32."""
+        x = np.asarray(x, np.float32)
+        n, D = x.shape
+        s = np.zeros(D, np.float32)
+        for i in range(n):
+            s = s + x[i]
+        mean = s / np.float32(n)
+        q = np.zeros(D, np.float32)
+        for i in range(n):
+            d = x[i] - mean
+            q = q + d * d
+        return mean, q / np.float32(n), n
+
+    def update(self, x):                                            # :75-81
+        self._update_from_moments(*self.batch_moments(x))
+
+    def _update_from_moments(self, mean, var, count):              # :83-93
+        total_count = self.count + count
+        delta = mean - self.mean
+        new_mean = self.mean + delta * count / total_count
+        m_a = self.var * self.count
+        m_b = var * count
+        M2 = m_a + m_b + np.square(delta) * self.count * count / total_count
+        self.mean, self.var, self.count = new_mean, M2 / total_count, total_count
+
+    def normalize(self, x):                                         # :95-97
+        z = (x - self.mean) / (np.sqrt(self.var) + 1e-8)
+        return np.clip(z, -self.clip_range, self.clip_range)

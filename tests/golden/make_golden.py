@@ -286,7 +286,34 @@ def gen_update(kind, tag, yaml_name, overrides, dims, steps, B, gradient_step=40
     print(tag, "ok", {k: v.shape for k, v in out.items() if k.endswith("_tuple")})
 
 
+# --------------------------------------------------------------------------- G9: RunningNormalizer
+def gen_normalizer():
+    """The reference's RunningNormalizer (src/utils.py:68-98) over a sequence of float32 batches the way the trainer
+    feeds it (src/env.py:164-175: [obs ; next_obs] of a vector step), statistics after every update and the normalised
+    probe rows (float64, and as the float32 the trainer casts them to)."""
+    from src.utils import RunningNormalizer
+    gen = np.random.default_rng(77)
+    D = 7
+    nz = RunningNormalizer(D)
+    out = dict(D=np.array([D]))
+    sizes = [16, 16, 2, 128, 33, 16, 1000, 5]
+    out["sizes"] = np.array(sizes)
+    probe = (gen.standard_normal((9, D)) * np.array([1, 10, 0.1, 3, 1, 50, 1e-3]) + np.array([0, 5, -2, 0, 100, 0, 0])).astype(np.float32)
+    out["probe"] = probe
+    for i, n in enumerate(sizes):
+        x = (gen.standard_normal((n, D)) * np.array([1, 10, 0.1, 3, 1, 50, 1e-3]) + np.array([0, 5, -2, 0, 100, 0, 0])).astype(np.float32)
+        out[f"x{i}"] = x
+        nz.update(x)
+        out[f"mean{i}"], out[f"var{i}"], out[f"count{i}"] = nz.mean.copy(), nz.var.copy(), np.array([nz.count])
+        z = nz.normalize(probe)
+        out[f"norm64_{i}"] = z
+        out[f"norm32_{i}"] = torch.from_numpy(z).float().numpy()
+    np.savez_compressed(os.path.join(HERE, "normalizer.npz"), **out)
+    print("normalizer ok")
+
+
 def main():
+    gen_normalizer()
     gen_index_streams()
     gen_her_rows()
     # DDPG with the reference's Reach config (H=64, L=3); step 40 exercises the Polyak cadence

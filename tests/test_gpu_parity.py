@@ -549,3 +549,27 @@ def test_full_size_ring_properties(gcrl):
     assert len(small) == 1000
     for got, want in zip(small.rows(), orc.as_arrays()):
         assert np.array_equal(bits(got), bits(want))
+
+
+def test_large_k_future_flush_bit_exact(gcrl):
+    """k_future * (T - 1) beyond the flush kernel's inline argument space (2048 indices): the future indices travel
+    through an uploaded buffer instead; rows and RNG state still equal the oracle's, several envs finishing together."""
+    S, A, k = 10, 3, 48
+    eng = gcrl.HERBuffer(60000, 50, 3, k_future=k, rng="engine", seed=21)
+    orc = her_oracle.HERBufferOracle(60000, 50, 3, k_future=k, rng=random.Random(21))
+    gen = np.random.default_rng(6)
+    eps = [her_oracle.synthetic_episode(gen, 50, S, A) for _ in range(3)]
+    for t in range(50):
+        s = torch.from_numpy(np.stack([eps[e][t][0] for e in range(3)])).cuda()
+        ns = torch.from_numpy(np.stack([eps[e][t][2] for e in range(3)])).cuda()
+        eng.push_batch(s, np.stack([eps[e][t][1] for e in range(3)]), ns, np.array([eps[e][t][3] for e in range(3)], np.float32),
+                       np.zeros(3, bool), np.stack([eps[e][t][6] for e in range(3)]))
+        for e in range(3):
+            orc.push(e, *eps[e][t])
+    assert len(eng) == len(orc) == 3 * (50 + k * 49)
+    for got, want in zip(eng.rows(), orc.as_arrays()):
+        assert np.array_equal(bits(got), bits(want))
+    for st in her_oracle.synthetic_episode(gen, 50, S, A):     # and the single-push path
+        eng.push(1, *st); orc.push(1, *st)
+    for got, want in zip(eng.rows(), orc.as_arrays()):
+        assert np.array_equal(bits(got), bits(want))

@@ -210,9 +210,8 @@ def test_full_state_resume_in_a_new_process(gcrl, tmp_path, kind):
     want = [[float(x) for x in t] for t in ag.update_many(31, 10)] + [[float(x) for x in t] for t in ag.update_many(41, 10)]
     out = str(tmp_path / "child.npz")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = ("import sys; sys.argv = ['x', %r, %r, '31', '10', %r]; exec(open(%r).read().replace(\"update_many(step0, n)\", "
-              "\"update_many(31, 10)] + [t for t in ag.update_many(41, 10)\"))" % (kind, state, out, os.path.join(root, "tests", "resume_child.py")))
-    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, cwd=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "resume_child.py"), kind, state, out, "31", "10", "41", "10"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     got = np.load(out)
     width = got["tuples"].shape[1]
@@ -239,9 +238,19 @@ def test_soft_target_update_matches_reference_formula(gcrl):
         src = new[v.name.replace("target_", "")]
         want = (np.float32(0.25) * src + np.float32(0.75) * old[v.name]).astype(np.float32)
         assert np.array_equal(v.flat(), want), v.name
-    # the row-chain kernels' [in][out] copies of the targets follow: one more update must still track the layer-per-launch path
-    info = ag.update_many(1, 2)
-    assert all(np.isfinite([float(x) for x in t]).all() for t in info)
+    # the row-chain kernels' [in][out] copies of the targets follow the soft update: the next step equals the step of
+    # an agent whose targets were set to the same values through the parameter interface (which rebuilds the copies)
+    from oracle import her_oracle
+    twin = resume_agent(gcrl, "TD3")
+    for v, w in zip([ag.actor, ag.target_actor] + ag.critics + ag.target_critics,
+                    [twin.actor, twin.target_actor] + twin.critics + twin.target_critics):
+        w.set_flat(v.flat())
+    gen = np.random.default_rng(3)
+    for st in her_oracle.synthetic_episode(gen, 50, 10, 3):
+        ag.push_her(0, *st); twin.push_her(0, *st)
+    a = [[float(x) for x in t] for t in ag.update_many(1, 2)]
+    b = [[float(x) for x in t] for t in twin.update_many(1, 2)]
+    assert a == b
 
 
 def test_lazy_scalars_outlive_the_metrics_ring(gcrl):
@@ -264,3 +273,82 @@ def test_lazy_scalars_outlive_the_metrics_ring(gcrl):
     assert np.isfinite(float(first[0])) and np.isfinite(np.asarray(first[2]))      # 4400 steps later
     m = np.mean(hist)
     assert np.isfinite(m) and abs(m - np.mean([float(x) for x in hist])) < 1e-12
+
+
+# ------------------------------------------------------------------ acting side on the device
+def test_device_normalizer_bit_exact_vs_reference(gcrl):
+    """csrc/normalizer.hip against the golden captured from the reference's RunningNormalizer (src/utils.py:68-98):
+    mean / var / count (float64) after every update and the normalised probe rows, bit for bit."""
+    from conftest import load_golden
+    from gcrl_amd.src.utils import DeviceRunningNormalizer
+    g = load_golden("normalizer.npz")
+    nz = DeviceRunningNormalizer(int(g["D"][0]))
+    for i in range(len(g["sizes"])):
+        nz.update(g[f"x{i}"])
+        assert np.array_equal(nz.mean, g[f"mean{i}"]) and np.array_equal(nz.var, g[f"var{i}"]) and nz.count == g[f"count{i}"][0], i
+        z = nz.normalize(g["probe"])
+        assert np.array_equal(z.astype(np.float32), g[f"norm32_{i}"]), i
+    # save / load round trip through the reference's YAML layout
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        nz.save(d + "/n/obs.yaml")
+        other = DeviceRunningNormalizer(int(g["D"][0]))
+        other.load(d + "/n/obs.yaml")
+        assert np.allclose(other.mean, nz.mean, rtol=1e-6) and other.count == nz.count
+
+
+@pytest.mark.parametrize("kind", ["DDPG", "TD3", "SAC"])
+def test_fused_acting_entries_equal_the_separate_calls(gcrl, kind):
+    """observe_act / process_step (one native call each per vector-env step, device normalisers) against the reference's
+    call sequence made of the separate calls with host normalisers: same actions (same host RNG draws), same normaliser
+    statistics, same ring rows bit for bit — including the episode flushes (HER relabel) inside the steps."""
+    import random
+    from gcrl_amd.src.utils import DeviceRunningNormalizer, RunningNormalizer
+    from oracle import her_oracle
+    D, G, A, n = 7, 3, 3, 8
+    gen = np.random.default_rng(4)
+
+    def build(device):
+        ag = resume_agent(gcrl, kind)
+        Nz = DeviceRunningNormalizer if device else RunningNormalizer
+        ag.buffer.obs_normalizer, ag.buffer.dg_normalizer = Nz(D), Nz(G)
+        ag.buffer.compute_reward = her_oracle.sparse_reward
+        return ag
+
+    host, dev = build(False), build(True)
+    for v, w in zip([host.actor] + host.critics, [dev.actor] + dev.critics):
+        w.set_flat(v.flat())
+
+    def obs_dict():
+        return dict(observation=gen.standard_normal((n, D)).astype(np.float32) * 3 + 1,
+                    desired_goal=gen.uniform(-0.2, 0.2, (n, G)).astype(np.float32),
+                    achieved_goal=gen.uniform(-0.2, 0.2, (n, G)).astype(np.float32))
+
+    state = obs_dict()
+    for step in range(60):                    # episodes flush at 50 staged transitions per env
+        for ag, tag in ((host, "h"), (dev, "d")):
+            random.seed(100 + step); np.random.seed(100 + step); torch.manual_seed(100 + step)
+            if tag == "h":
+                x = ag.normalize_state_batch(state["observation"], state["desired_goal"], True, False)
+                act_h = np.asarray(ag.select_action(x, eval_action=(step % 7 == 3)), np.float64)
+            else:
+                act_d = np.asarray(ag.observe_act(state["observation"], state["desired_goal"], eval_action=(step % 7 == 3)), np.float64)
+        assert act_h.shape == act_d.shape == (n, A)
+        assert np.allclose(act_h, act_d, rtol=0, atol=2e-6), (step, np.abs(act_h - act_d).max())
+        nxt = obs_dict()
+        rewards = -(gen.uniform(size=n) > 0.3).astype(np.float32)
+        dones = np.zeros(n, bool)
+        actions = act_h.astype(np.float32)
+        # host: the reference's _process_step made of the separate calls
+        host.update_normalizers([state["observation"], nxt["observation"]],
+                                [state["desired_goal"], nxt["desired_goal"], state["achieved_goal"], nxt["achieved_goal"]], True, False)
+        s = torch.from_numpy(host.normalize_state_batch(state["observation"], state["desired_goal"], True, False)).float().cuda()
+        ns = torch.from_numpy(host.normalize_state_batch(nxt["observation"], nxt["desired_goal"], True, False)).float().cuda()
+        host.buffer.push_batch(s, actions, ns, rewards, dones, nxt["achieved_goal"])
+        dev.process_step(state, actions, nxt, rewards, dones)
+        state = nxt
+    hn, dn = host.buffer.obs_normalizer, dev.buffer.obs_normalizer
+    assert np.array_equal(np.asarray(hn.mean), dn.mean) and np.array_equal(np.asarray(hn.var), dn.var) and hn.count == dn.count
+    assert len(host.buffer) == len(dev.buffer) == n * 246
+    for a, b in zip(host.buffer.rows(), dev.buffer.rows()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -203,3 +203,15 @@ def test_synthetic_workload_helpers_agree_with_the_oracle_copies(gcrl):
             assert np.array_equal(np.asarray(u), np.asarray(v))
     for kind in ("DDPG", "TD3", "SAC", "TQC"):
         assert vars(synthetic.agent_config(kind, batch_size=7)) == vars(agent_oracle.make_config(kind, batch_size=7))
+
+
+# ---------------------------------------------------------------- G9: RunningNormalizer
+def test_normalizer_oracle_matches_reference_bitwise():
+    from oracle.normalizer_oracle import RunningNormalizerOracle
+    g = load_golden("normalizer.npz")
+    nz = RunningNormalizerOracle(int(g["D"][0]))
+    for i in range(len(g["sizes"])):
+        nz.update(g[f"x{i}"])
+        assert np.array_equal(nz.mean, g[f"mean{i}"]) and np.array_equal(nz.var, g[f"var{i}"]) and nz.count == g[f"count{i}"][0], i
+        z = nz.normalize(g["probe"])
+        assert np.array_equal(z, g[f"norm64_{i}"]) and np.array_equal(z.astype(np.float32), g[f"norm32_{i}"]), i
