@@ -68,9 +68,11 @@ class PointReachVecEnv:
 
 
 def train(agent_name="DDPG", num_envs=8, cycles=60, max_episode=8, gradient_step=40, hidden=64, layers=3, batch=256,
-          seed=0, verbose=True, per_env_push=False):
+          seed=0, verbose=True, per_env_push=False, fused=False):
     import gcrl_amd
-    from gcrl_amd.src.utils import RunningNormalizer
+    from gcrl_amd.src.utils import DeviceRunningNormalizer, RunningNormalizer
+    if fused:   # the normalisers live on the device; acting and _process_step are one native call each per vector step
+        RunningNormalizer = DeviceRunningNormalizer
     from gcrl_amd.src.synthetic import agent_config as make_config   # hyper-parameter container with the YAML field names
 
     np.random.seed(seed)
@@ -95,10 +97,25 @@ def train(agent_name="DDPG", num_envs=8, cycles=60, max_episode=8, gradient_step
         episode_count = 0
         tc = time.perf_counter()
         while episode_count < max_episode:
-            state_input = agent.normalize_state_batch(state["observation"], state["desired_goal"], True, False)
-            actions = np.asarray(agent.select_action(state_input), dtype=np.float32)
+            if fused:
+                actions = np.asarray(agent.observe_act(state["observation"], state["desired_goal"]), dtype=np.float32)
+            else:
+                state_input = agent.normalize_state_batch(state["observation"], state["desired_goal"], True, False)
+                actions = np.asarray(agent.select_action(state_input), dtype=np.float32)
             next_obs, rewards, terminateds, truncateds, _ = env.step(actions)
             dones = np.logical_or(terminateds, truncateds)
+            if fused:
+                agent.process_step(state, actions, next_obs, rewards, terminateds)
+                env_steps += num_envs
+                if dones.any():
+                    idx = np.nonzero(dones)[0]
+                    d = np.linalg.norm(next_obs["achieved_goal"][idx] - next_obs["desired_goal"][idx], axis=1)
+                    final_success.extend((d < env.thr).tolist())
+                    episode_count += len(idx)
+                    env._reset(idx)
+                    next_obs = env._obs()
+                state = next_obs
+                continue
             # _process_step: normaliser update, normalised [obs | goal] rows, one push for all envs
             agent.update_normalizers([state["observation"], next_obs["observation"]],
                                      [state["desired_goal"], next_obs["desired_goal"], state["achieved_goal"],
@@ -144,8 +161,9 @@ if __name__ == "__main__":
     ap.add_argument("--nenv", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--per-env-push", action="store_true", help="push one env at a time, exactly as the reference's trainer does")
+    ap.add_argument("--fused", action="store_true", help="device normalisers + one native call for acting and one for _process_step")
     args = ap.parse_args()
-    out = train(args.agent, num_envs=args.nenv, cycles=args.cycles, seed=args.seed, per_env_push=args.per_env_push)
+    out = train(args.agent, num_envs=args.nenv, cycles=args.cycles, seed=args.seed, per_env_push=args.per_env_push, fused=args.fused)
     tail = out["success_per_cycle"][-10:]
     print(f"{args.agent}: success over the last 10 cycles {np.mean(tail):.2f}; {out['env_steps']} env steps "
           f"({out['env_steps_per_s']:.0f}/s in the acting phase), {out['gradient_steps']} gradient steps "

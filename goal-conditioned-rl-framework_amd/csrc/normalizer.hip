@@ -48,7 +48,8 @@ __global__ void norm_update_kernel(const float* __restrict__ x, int n, int ld, i
   const double total = c0 + cb;
   const double delta = (double)bm - mean[j];
   const double new_mean = mean[j] + delta * cb / total;               // (delta * count) / total_count
-  const double m_a = var[j] * c0, m_b = (double)bv * cb;
+  // `var * count`: a float32 array times a Python int stays float32 in numpy (1.x value-based casting and 2.x alike)
+  const double m_a = var[j] * c0, m_b = (double)__fmul_rn(bv, (float)n);
   const double M2 = m_a + m_b + delta * delta * c0 * cb / total;      // ((square(delta) * self.count) * count) / total_count
   mean[j] = new_mean;
   var[j] = M2 / total;

@@ -49,7 +49,8 @@ class LazyScalar:
         return float(self._value())
 
     def __array__(self, dtype=None, copy=None):
-        return np.asarray(self._value(), dtype=dtype or np.float32)
+        # td_error is a 0-d float32 array in the reference (src/agent.py:1342), the other entries Python floats
+        return np.asarray(self._value(), dtype=dtype or (np.float32 if self._as_array else np.float64))
 
     def __repr__(self):
         return f"LazyScalar({self._value()!r})"
@@ -539,7 +540,9 @@ class _StochasticAgent(_EngineAgent):
         eps = None
         if not eval_action:
             n = np.asarray(obs_tensor).reshape(-1, self.obs_dim).shape[0]
-            eps = torch.randn((n, self.ac_dim), dtype=torch.float32, device="cuda")
+            # rsample's eps (src/model.py:134: loc + empty(shape).normal_() * scale on the module's device).  Drawn from
+            # torch's HOST generator here — what the reference itself uses on a CPU box, and one device round trip less
+            eps = torch.randn((n, self.ac_dim), dtype=torch.float32).cuda()
         return self._actor_forward(obs_tensor, eps).cpu().numpy()
 
     def _log_alpha_tensor(self):

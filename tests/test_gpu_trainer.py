@@ -23,3 +23,18 @@ def test_agents_learn_point_reach_through_the_engine(gcrl, agent, cycles, floor)
     assert early < 0.2                      # nothing is solved before learning
     assert late >= floor, (agent, late)     # (20 % of acting steps are random by construction: ~0.8-1.0 is solved)
     assert out["gradient_steps"] == cycles * 40
+
+
+def test_fused_acting_side_learns_and_is_faster(gcrl):
+    """The same loop with the acting side on the device (DeviceRunningNormalizer + observe_act + process_step: SURVEY.md
+    §8f-3): it must learn just the same, and the acting phase must run at >= 1.5x the env steps/s of the separate calls."""
+    import json
+    import trainer_standin
+    slow = trainer_standin.train("DDPG", cycles=150, seed=0, verbose=False)
+    fast = trainer_standin.train("DDPG", cycles=400, seed=0, verbose=False, fused=True)
+    assert float(np.mean(fast["success_per_cycle"][-10:])) >= 0.5
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "acting_rates.json"), "w") as f:
+        json.dump(dict(env_steps_per_s_separate_calls=slow["env_steps_per_s"], env_steps_per_s_fused=fast["env_steps_per_s"],
+                       gradient_steps_per_s=fast["gradient_steps_per_s"], envs=8), f)
+    assert fast["env_steps_per_s"] >= 1.5 * slow["env_steps_per_s"], (fast["env_steps_per_s"], slow["env_steps_per_s"])
