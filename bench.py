@@ -57,6 +57,10 @@ WORKLOADS = {
                                 tau=0.005, grad_clip=2.0, freq=2, gstep=40, lr=1e-3, policy_noise=0.2, noise_clamp=0.5),
     "tqc_push_b2048": dict(kind="TQC", S=22, A=3, H=512, L=3, B=2048, cap=1_000_000, k=4, gamma=0.95,
                            tau=0.05, grad_clip=5.0, freq=1, gstep=40, lr=3e-4),
+    # BASELINE.json configs[3] as WORDED ("25 quantiles x 2 critics, top-2 truncate"): the distributional variant, which the
+    # reference does not contain (its TQC is the 5-scalar-critic ensemble above) — no reference parity, oracle-pinned only
+    "tqc_quantile_push_b2048": dict(kind="TQC", S=22, A=3, H=512, L=3, B=2048, cap=1_000_000, k=4, gamma=0.95,
+                                    tau=0.05, grad_clip=5.0, freq=1, gstep=40, lr=3e-4, n_quantiles=25, num_critics=2, top_drop=2),
     "sac_slide_b512": dict(kind="SAC", S=22, A=3, H=256, L=3, B=512, cap=1_000_000, k=4, gamma=0.98,
                            tau=0.005, grad_clip=2.0, freq=1, gstep=40, lr=5e-4),
 }
@@ -95,6 +99,9 @@ def flops_per_step(w, actor_step=True):
         return 2 * B * ((4 * Pa + 10 * Pc) if actor_step else (Pa + 8 * Pc))
     if kind == "SAC":
         return 2 * B * (4 * Pa + 12 * Pc)
+    if w.get("n_quantiles", 1) > 1:
+        Pc += H * (w["n_quantiles"] - 1)
+        return 2 * B * (4 * Pa + 7 * w["num_critics"] * Pc)
     return 2 * B * (4 * Pa + 7 * 5 * Pc)
 
 
@@ -196,9 +203,12 @@ def build_agent(w, args, rank, local_rank, batch=None):
     from gcrl_amd.src.dp import rank_seed
     cfg = make_cfg(dict(w, B=batch or w["B"]))
     cls = dict(DDPG=gcrl_amd.DDPG, TD3=gcrl_amd.TD3Agent, SAC=gcrl_amd.SACAgent, TQC=gcrl_amd.TQCAgent)[w["kind"]]
+    extra = {}
+    if w.get("n_quantiles", 1) > 1:
+        extra = dict(n_quantiles=w["n_quantiles"], num_critics=w["num_critics"], top_quantiles_to_drop=w["top_drop"])
     agent = cls(w["S"], w["A"], cfg, None, nenvs=8, gradient_step=w["gstep"], use_graph=not args.no_graph,
                 pipeline=(True if args.pipeline < 0 else args.pipeline), rng=args.rng, seed=rank_seed(1898, rank),
-                device_index=local_rank)
+                device_index=local_rank, **extra)
     pool = episode_pool(w, 64, seed=1898 + rank)
     arrays = [episode_arrays(ep) for ep in pool]
     rows_per_ep = 50 + w["k"] * 49
@@ -434,7 +444,7 @@ def main():
             out["roofline"] = {"kernel": "whole update step (all launches; per-kernel shares in profiles/)", "bound": "mfma",
                                "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
                                "traffic": None, "timing": "algorithmic flops per step / measured step time"}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and w.get("n_quantiles", 1) == 1:
             out["cpu_baseline"] = cpu_baseline(w, pool, args.cpu_seconds)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))

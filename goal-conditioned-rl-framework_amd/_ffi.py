@@ -45,7 +45,7 @@ class AgentConfig(C.Structure):
         ("ac_scheduler_steps", C.c_int64), ("cr_scheduler_steps", C.c_int64),
         ("alpha_min_steps", C.c_double),
         ("device", C.c_int32), ("use_graph", C.c_int32), ("seed", C.c_uint64),
-        ("pipeline_steps", C.c_int32), ("reserved", C.c_int32),
+        ("pipeline_steps", C.c_int32), ("n_quantiles", C.c_int32),
     ]
 
 

@@ -89,6 +89,7 @@ struct DpSeg { int kind, a, b; float* reduce; long long reduce_n; };
 struct gcrl_agent {
   gcrl_agent_config cfg;
   int S = 0, A = 0, H = 0, L = 0, B = 0, C = 0, ldx = 0, Mmax = 0, Apad = 0;
+  int Q = 1;   // atoms per critic (distributional TQC variant: n_quantiles > 1; the reference's agents: 1)
   bool has_target_actor = false, sac = false;
   NetSpec actor, critic;
   hipStream_t stream = nullptr, cap_stream = nullptr;
@@ -111,6 +112,7 @@ struct gcrl_agent {
   float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
   float *noise_in = nullptr, *eps_next_in = nullptr, *eps_cur_in = nullptr, *norm_partial = nullptr;
   float *act_in = nullptr, *act_tmp[2] = {};
+  float *qy = nullptr, *q_row_loss = nullptr, *q_row_td = nullptr;   // distributional TQC: kept target atoms [B][64], per-row sums
   float* pi_buf = nullptr;   // SAC row-chain path: pi(s) [B][Apad] (the layer-per-launch paths keep it in spa's action columns)
   float* act_pinned = nullptr;   // host staging of gcrl_agent_act_host
   char *oa_pinned = nullptr, *oa_dev = nullptr;   // staging of gcrl_agent_observe_act (raw rows, noise, actions)
@@ -387,7 +389,7 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
   }
   Launches crit;  // online critics on [s|a], activations kept for the backward
   for (int c = 0; c < C; ++c)
-    chain_mlp(a, crit, 0, a->critic, a->P_critic(c), a->sa, a->ldx, a->slot_x, hid_C, c, a->q + (long long)c * B, 1, 0, EPI_NONE, B);
+    chain_mlp(a, crit, 0, a->critic, a->P_critic(c), a->sa, a->ldx, a->slot_x, hid_C, c, a->q + (long long)c * B * a->Q, a->Q, 0, EPI_NONE, B);
   if (!a->sac) {
     // target actor on ns, co-scheduled with the online critics; its tanh output lands in the
     // action columns of the target critics' input rows
@@ -405,7 +407,7 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
   }
   Launches tc;
   for (int c = 0; c < C; ++c)
-    chain_mlp(a, tc, 0, a->critic, a->P_tcritic(c), a->nsa, a->ldx, a->slot_x, hid_TC, c, a->qt + (long long)c * B, 1, 0, EPI_NONE, B);
+    chain_mlp(a, tc, 0, a->critic, a->P_tcritic(c), a->nsa, a->ldx, a->slot_x, hid_TC, c, a->qt + (long long)c * B * a->Q, a->Q, 0, EPI_NONE, B);
   TRY(tc.run(st));
 
   TdLossArgs td;
@@ -423,7 +425,17 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
     case GCRL_AGENT_SAC: td.target_kind = TGT_MIN_ENT; td.logp_next = a->logp_next; td.alpha_const = 0.2f; break;
     default: td.target_kind = TGT_TRUNC_ENT; td.logp_next = a->logp_next; td.alpha_dev = a->alpha_dev; td.drop = a->cfg.top_drop; break;
   }
-  TRY(launch_td_loss(st, td));
+  if (a->Q > 1) {   // distributional variant: pooled-atom sort + truncation, quantile-Huber loss (ops.h QuantileArgs)
+    QuantileArgs qa;
+    std::memset(&qa, 0, sizeof(qa));
+    qa.cur = a->cur(); qa.r = a->rbuf; qa.d = a->dbuf; qa.slot_stride = a->slot_rd;
+    qa.zt = a->qt; qa.z = a->q; qa.logp_next = a->logp_next; qa.alpha_dev = a->alpha_dev;
+    qa.y = a->qy; qa.dz = a->dq; qa.row_loss = a->q_row_loss; qa.row_td = a->q_row_td; qa.metrics = a->metrics_dev;
+    qa.B = B; qa.C = C; qa.Q = a->Q; qa.drop = a->cfg.top_drop; qa.gamma = (float)a->cfg.gamma;
+    TRY(launch_quantile_td(st, qa));
+  } else {
+    TRY(launch_td_loss(st, td));
+  }
 
   // critic backward, layer L..0: dW|db and dX of a layer share a launch
   Launches bw;
@@ -432,8 +444,8 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
     const float* P = a->P_critic(c);
     for (int l = L; l >= 0; --l) {
       const size_t at = (size_t)(L - l);
-      const float* G = l == L ? a->dq + (long long)c * B : a->gC_at(c, l & 1);
-      const long long ldg = l == L ? 1 : H;
+      const float* G = l == L ? a->dq + (long long)c * B * a->Q : a->gC_at(c, l & 1);
+      const long long ldg = l == L ? a->Q : H;
       GemmDesc dw = bwd_dw(G, ldg, l == 0 ? a->sa : a->hC_at(c, l - 1), l == 0 ? a->ldx : H, Gp, a->critic.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
       if (variant & V_FUSED_NORM) dw.sumsq_out = a->parts_c + (long long)c * a->nparts_c + a->part_off_c[l];
@@ -488,9 +500,9 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     // q_value metric from the UPDATED critics (src/agent.py:1016-1019)
     Launches re;
     for (int c = 0; c < C; ++c)
-      chain_mlp(a, re, 0, a->critic, a->P_critic(c), a->sa, a->ldx, a->slot_x, hid_TC, c, a->qt + (long long)c * B, 1, 0, EPI_NONE, B);
+      chain_mlp(a, re, 0, a->critic, a->P_critic(c), a->sa, a->ldx, a->slot_x, hid_TC, c, a->qt + (long long)c * B * a->Q, a->Q, 0, EPI_NONE, B);
     TRY(re.run(st));
-    TRY(launch_mean_metric(st, a->cur(), a->qt, C * B, 1.0f, a->metrics_dev, MET_Q));
+    TRY(launch_mean_metric(st, a->cur(), a->qt, C * B * a->Q, 1.0f, a->metrics_dev, MET_Q));
   }
   if (kind == GCRL_AGENT_DDPG && (variant & V_POLYAK_A)) {  // before the actor step (src/agent.py:1397-1401)
     TRY(launch_polyak(st, a->P_actor(), a->P_tactor(), a->actor.numel, a->cfg.tau));
@@ -530,7 +542,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
   // stepped critic(s) on [s | pi(s)]
   Launches c2;
   for (int c = 0; c < (a->rowchain ? 0 : nac); ++c)
-    chain_mlp(a, c2, 0, a->critic, a->P_critic(c), a->spa, a->ldx, a->slot_x, hid_C, c, a->q2 + (long long)c * B, 1, 0, EPI_NONE, B);
+    chain_mlp(a, c2, 0, a->critic, a->P_critic(c), a->spa, a->ldx, a->slot_x, hid_C, c, a->q2 + (long long)c * B * a->Q, a->Q, 0, EPI_NONE, B);
   TRY(c2.run(st));
   if (a->sac) {
     ActorSelArgs as;
@@ -547,15 +559,21 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     al.log_alpha = a->P_logalpha(); al.m = a->adam_m + a->goff_alpha; al.v = a->adam_v + a->goff_alpha;
     al.alpha = a->alpha_dev; al.grad_out = a->grads + a->goff_alpha;
     al.metrics = a->metrics_dev; al.phase = 0;
-    TRY(launch_actor_select_alpha(st, as, al));
+    if (a->Q > 1) {   // distributional variant: the actor maximises the mean of ALL atoms (no truncation on this side)
+      QuantileActorArgs qa{a->cur(), a->q2, a->logp, a->alpha_dev, a->dq2, a->metrics_dev, B, nac, a->Q};
+      TRY(launch_quantile_actor(st, qa));
+      TRY(launch_alpha_update(st, al));
+    } else {
+      TRY(launch_actor_select_alpha(st, as, al));
+    }
   }
   // input gradient of the critic(s) down to the action columns
   Launches cb;
   for (int c = 0; c < (a->rowchain ? 0 : nac); ++c) {
     const float* P = a->P_critic(c);
     for (int l = L; l >= 1; --l) {
-      const float* G = l == L ? a->dq2 + (long long)c * B : a->gC_at(c, l & 1);
-      cb.add((size_t)(L - l), bwd_dx(G, l == L ? 1 : H, P, a->critic.lin[l], 0, H, a->gC_at(c, (l - 1) & 1), H, B,
+      const float* G = l == L ? a->dq2 + (long long)c * B * a->Q : a->gC_at(c, l & 1);
+      cb.add((size_t)(L - l), bwd_dx(G, l == L ? a->Q : H, P, a->critic.lin[l], 0, H, a->gC_at(c, (l - 1) & 1), H, B,
                                      MUL_DLEAKY, a->hC_at(c, l - 1), H));
     }
     GemmDesc d0 = bwd_dx(a->gC_at(c, 0), H, P, a->critic.lin[0], S, A, a->dact + (long long)c * B * a->Apad, a->Apad, B,
@@ -824,7 +842,7 @@ int build(gcrl_agent* a) {
   GCRL_HIP(hipStreamCreateWithFlags(&a->cap_stream, hipStreamNonBlocking));
   const int S = a->S, A = a->A, H = a->H, L = a->L, B = a->B, C = a->C;
   a->actor = make_net(S, H, L, A, a->sac);
-  a->critic = make_net(S + A, H, L, 1, false);
+  a->critic = make_net(S + A, H, L, a->Q, false);
   a->critic_stride = align_up(a->critic.numel, 64);
   const long long na = align_up(a->actor.numel, 64);
   // params: actor | target_actor | critics | target critics | log_alpha
@@ -869,8 +887,8 @@ int build(gcrl_agent* a) {
       {&a->rbuf, (long long)a->Mmax * B}, {&a->dbuf, (long long)a->Mmax * B},
       {&a->hTA[0], BH}, {&a->hTA[1], BH}, {&a->hA, L * BH}, {&a->hC, (long long)C * L * BH},
       {&a->hTC, (long long)C * 2 * BH}, {&a->gC, (long long)C * 2 * BH}, {&a->gA[0], BH}, {&a->gA[1], BH},
-      {&a->q, (long long)C * B}, {&a->qt, (long long)C * B}, {&a->q2, (long long)C * B}, {&a->dq, (long long)C * B},
-      {&a->dq2, (long long)C * B}, {&a->dact, (long long)C * B * a->Apad}, {&a->zA, BH}, {&a->xhatA, L * BH},
+      {&a->q, (long long)C * B * a->Q}, {&a->qt, (long long)C * B * a->Q}, {&a->q2, (long long)C * B * a->Q}, {&a->dq, (long long)C * B * a->Q},
+      {&a->dq2, (long long)C * B * a->Q}, {&a->qy, (long long)B * 64}, {&a->q_row_loss, (long long)C * B}, {&a->q_row_td, B}, {&a->dact, (long long)C * B * a->Apad}, {&a->zA, BH}, {&a->xhatA, L * BH},
       {&a->invstdA, (long long)L * H}, {&a->headA, (long long)B * 2 * a->Apad}, {&a->ghead, (long long)B * 2 * a->Apad},
       {&a->dh2, BH}, {&a->logp, B}, {&a->logp_next, B}, {&a->epsbuf, (long long)B * A}, {&a->stdbuf, (long long)B * A},
       {&a->noise_in, (long long)B * A}, {&a->eps_next_in, (long long)B * A}, {&a->eps_cur_in, (long long)B * A},
@@ -927,7 +945,7 @@ int build(gcrl_agent* a) {
   a->ticket_len.assign(kMetricSlots, 0);
 
   // constant upstream gradient of -Q.mean()
-  TRY(launch_fill(a->stream, a->dq2, (long long)C * B, -1.0f / (float)B));
+  TRY(launch_fill(a->stream, a->dq2, (long long)C * B * a->Q, -1.0f / (float)B));
   TRY(launch_fill(a->stream, a->alpha_dev, 1, 1.0f));  // exp(log_alpha = 0)
   GCRL_HIP(hipStreamSynchronize(a->stream));
 
@@ -987,8 +1005,11 @@ gcrl_agent* gcrl_agent_create(const gcrl_agent_config* cfg) {
   if (cfg->kind == GCRL_AGENT_TQC) {
     C = cfg->num_critics;
     if (C < 2 || C > kMaxCritics) return bad("TQC needs 2..8 critics");
-    if (cfg->top_drop < 0 || cfg->top_drop >= C) return bad("top_drop must be in [0, num_critics)");
-  }
+    if (cfg->n_quantiles > 1) {   // distributional variant: top_drop atoms per critic are dropped from the pooled, sorted atoms
+      if (C * cfg->n_quantiles > 64) return bad("num_critics * n_quantiles must be <= 64 (one wavefront sorts a row's pooled atoms)");
+      if (cfg->top_drop < 0 || cfg->top_drop >= cfg->n_quantiles) return bad("top_drop must be in [0, n_quantiles)");
+    } else if (cfg->top_drop < 0 || cfg->top_drop >= C) return bad("top_drop must be in [0, num_critics)");
+  } else if (cfg->n_quantiles > 1) return bad("n_quantiles > 1 is the distributional TQC variant only");
   int ndev = gcrl_device_count();
   if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
     fail(GCRL_ERR_HIP, "gcrl_agent_create: no usable HIP device (count=%d, requested %d); there is no CPU fallback", ndev, cfg->device);
@@ -998,6 +1019,7 @@ gcrl_agent* gcrl_agent_create(const gcrl_agent_config* cfg) {
   a->cfg = *cfg;
   a->S = cfg->obs_dim; a->A = cfg->ac_dim; a->H = cfg->hidden_dim; a->L = cfg->layer_count;
   a->B = cfg->batch_size; a->C = C;
+  a->Q = cfg->n_quantiles > 1 ? cfg->n_quantiles : 1;
   a->ldx = round_up(a->S + a->A, 4);
   a->Apad = round_up(a->A, 4);
   a->Mmax = std::min(kMaxStepsPerCall, std::max(1, cfg->gradient_step));

@@ -223,6 +223,33 @@ int launch_alpha_update(hipStream_t st, const AlphaArgs& a);
 // actor_select + the gradient / loss-metric half of alpha_update (phase 0) as one launch
 int launch_actor_select_alpha(hipStream_t st, const ActorSelArgs& a, const AlphaArgs& al);
 
+// ---- distributional TQC (BASELINE.json configs[3]: "25 quantiles x 2 critics, top-2 truncate"; Kuznetsov et al. 2020).
+// NOT the reference's TQC (an ensemble of scalar critics, SURVEY.md headline facts): no reference parity, pinned to
+// oracle/quantile_tqc_oracle.py only.  Every critic outputs Q atoms; C*Q <= 64 so a row's pooled atoms sort in ONE wavefront.
+struct QuantileArgs {
+  const StepCtrl* cur;
+  const float* r; const float* d; long long slot_stride;   // + cur->batch_slot * slot_stride
+  const float* zt;         // [C][B][Q] target-critic atoms of (ns, a')
+  const float* z;          // [C][B][Q] online-critic atoms of (s, a)
+  const float* logp_next;  // [B]
+  const float* alpha_dev;  // device scalar alpha
+  float* y;                // [B][64] kept target atoms (K = C*Q - C*drop per row)
+  float* dz;               // [C][B][Q] dLoss_c / dz_c
+  float* row_loss;         // [C][B] per-row loss sums (reduced by the metrics pass)
+  float* row_td;           // [B] max_c |mean_K y - mean_Q z_c|
+  float* metrics;
+  int B, C, Q, drop;       // drop: atoms dropped PER CRITIC (top drop*C of the pooled, sorted atoms)
+  float gamma;
+};
+// pooled sort + truncation -> y; quantile-Huber loss (kappa = 1) of every critic against y and its gradient; metrics
+int launch_quantile_td(hipStream_t st, const QuantileArgs& a);
+// mean of z over all atoms of all critics per row: actor objective of the distributional variant
+//   loss = mean_b(alpha * logp_b - mean_{c,q} z_c(s_b, pi(s_b))_q);  dz = -1 / (B*C*Q) everywhere
+struct QuantileActorArgs {
+  const StepCtrl* cur; const float* z; const float* logp; const float* alpha_dev; float* dz; float* metrics; int B, C, Q;
+};
+int launch_quantile_actor(hipStream_t st, const QuantileActorArgs& a);
+
 // one wavefront per row: bitonic sort of width<=64 values by cross-lane exchange, mean of the
 // lowest width-drop
 int launch_sort_truncate_mean(hipStream_t st, const float* in, long long rows, int width, int drop,

@@ -415,7 +415,126 @@ __global__ __launch_bounds__(256) void sort_trunc_kernel(const float* in, long l
   if (lane == 0 && mean) mean[row] = s / (float)keep;
 }
 
+// ---- distributional TQC (ops.h QuantileArgs) -----------------------------------------------------------------
+__device__ inline float wave_bitonic_sort(float v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const float o = __shfl_xor(v, j, 64);
+      const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+      v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+    }
+  }
+  return v;
+}
+
+// One wavefront per batch row.  (1) lane l < C*Q holds atom l of the pooled target atoms: bitonic sort across the wave,
+// the lowest K = C*(Q - drop) kept, y_j = r + gamma*(1-d)*(z_(j) - alpha*logp').  (2) per critic c, lane i < Q owns atom
+// z_i with tau_i = (2i+1)/(2Q): over the K targets u = y_j - z_i, rho = |tau_i - 1(u<0)| * huber(u), loss_c = mean over
+// (B, Q, K), dz_i = -(1/(B*Q*K)) * sum_j |tau_i - 1(u<0)| * clamp(u, -1, 1).
+__global__ __launch_bounds__(256) void quantile_td_kernel(QuantileArgs a) {
+  __shared__ float ys[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + w;
+  if (b >= a.B) return;
+  const StepCtrl c = *a.cur;
+  const int C = a.C, Q = a.Q, N = C * Q, K = C * (Q - a.drop);
+  const float alpha = *a.alpha_dev;
+  float v = INFINITY;
+  if (lane < N) { const int cc = lane / Q, q = lane - cc * Q; v = a.zt[((long long)cc * a.B + b) * Q + q]; }
+  v = wave_bitonic_sort(v, lane);
+  const float rew = a.r[(long long)c.batch_slot * a.slot_stride + b], dn = a.d[(long long)c.batch_slot * a.slot_stride + b];
+  const float k1 = __fmul_rn(a.gamma, __fsub_rn(1.0f, dn)), ent = __fmul_rn(alpha, a.logp_next[b]);
+  const float y = lane < K ? __fadd_rn(rew, __fmul_rn(k1, __fsub_rn(v, ent))) : 0.f;
+  ys[w][lane] = y;
+  a.y[(long long)b * 64 + lane] = y;
+  float ysum = lane < K ? y : 0.f;
+  ysum = wave_sum(ysum);
+  ysum = __shfl(ysum, 0, 64);
+  const float ymean = ysum / (float)K;
+  const float norm = 1.0f / ((float)a.B * (float)Q * (float)K);
+  float tdmax = 0.f;
+  for (int cc = 0; cc < C; ++cc) {
+    float loss = 0.f, g = 0.f, z = 0.f;
+    if (lane < Q) {
+      z = a.z[((long long)cc * a.B + b) * Q + lane];
+      const float tau = (2.0f * (float)lane + 1.0f) / (2.0f * (float)Q);
+      for (int j = 0; j < K; ++j) {
+        const float u = ys[w][j] - z;
+        const float au = fabsf(u);
+        const float hub = au <= 1.0f ? 0.5f * u * u : au - 0.5f;
+        const float wgt = fabsf(tau - (u < 0.f ? 1.0f : 0.0f));
+        loss += wgt * hub;
+        g -= wgt * fminf(fmaxf(u, -1.0f), 1.0f);
+      }
+      a.dz[((long long)cc * a.B + b) * Q + lane] = g * norm;
+    }
+    loss = wave_sum(loss);
+    float zs = wave_sum(lane < Q ? z : 0.f);
+    if (lane == 0) {
+      a.row_loss[(long long)cc * a.B + b] = loss;
+      tdmax = fmaxf(tdmax, fabsf(ymean - zs / (float)Q));
+    }
+  }
+  if (lane == 0) a.row_td[b] = tdmax;
+}
+
+// metrics of the step from the per-row sums (one block, fixed order): critic losses, td, and — nothing else: q_value
+// is taken from the updated critics later, like the reference's TQC (src/agent.py:1016-1019)
+__global__ __launch_bounds__(256) void quantile_metrics_kernel(QuantileArgs a) {
+  __shared__ float scratch[4];
+  const StepCtrl c = *a.cur;
+  float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
+  const int K = a.C * (a.Q - a.drop);
+  for (int cc = 0; cc < a.C; ++cc) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < a.B; b += 256) s += a.row_loss[(long long)cc * a.B + b];
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) met[MET_CRITIC_LOSS + cc] = s / ((float)a.B * (float)a.Q * (float)K);
+  }
+  float t = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) t += a.row_td[b];
+  t = block_sum_256(t, scratch);
+  if (threadIdx.x == 0) met[MET_TD] = t / (float)a.B;
+}
+
+__global__ __launch_bounds__(256) void quantile_actor_kernel(QuantileActorArgs a) {
+  __shared__ float scratch[4];
+  const StepCtrl c = *a.cur;
+  const float alpha = *a.alpha_dev;
+  const int N = a.C * a.Q;
+  const float gz = -1.0f / ((float)a.B * (float)N);
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    float s = 0.f;
+    for (int cc = 0; cc < a.C; ++cc)
+      for (int q = 0; q < a.Q; ++q) {
+        const long long i = ((long long)cc * a.B + b) * a.Q + q;
+        s += a.z[i];
+        a.dz[i] = gz;
+      }
+    acc += __fsub_rn(__fmul_rn(alpha, a.logp[b]), s / (float)N);
+  }
+  acc = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) a.metrics[(long long)c.metrics_slot * kMetricFloats + MET_ACTOR_LOSS] = acc / (float)a.B;
+}
+
 }  // namespace
+
+int launch_quantile_td(hipStream_t st, const QuantileArgs& a) {
+  GCRL_CHECK_ARG(a.C >= 1 && a.Q >= 1 && a.C * a.Q <= 64 && a.drop >= 0 && a.drop < a.Q, "quantile_td: need C*Q <= 64 and 0 <= drop < Q (C=%d, Q=%d, drop=%d)", a.C, a.Q, a.drop);
+  hipLaunchKernelGGL(quantile_td_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(quantile_metrics_kernel, dim3(1), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_quantile_actor(hipStream_t st, const QuantileActorArgs& a) {
+  hipLaunchKernelGGL(quantile_actor_kernel, dim3(1), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
 
 int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
                        const float* beta, float* h, float* xhat, float* invstd, float* rmean,

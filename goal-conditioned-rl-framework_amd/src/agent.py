@@ -94,7 +94,7 @@ class _EngineAgent:
     def __init__(self, obs_dim: int, ac_dim: int, config, weights, nenvs: int, gradient_step: int, *,
                  use_graph: bool = True, pipeline: bool = True, sync_metrics: bool = False, rng: str = "python",
                  seed: int | None = None, device_index: int = 0, num_critics: int = 5,
-                 top_quantiles_to_drop: int = 2):
+                 top_quantiles_to_drop: int = 2, n_quantiles: int = 1):
         if not torch.cuda.is_available() or lib.gcrl_device_count() <= 0:
             raise _ffi.GcrlError(f"{type(self).__name__} needs a HIP device; there is no CPU fallback")
         self.device = "cuda"
@@ -117,6 +117,11 @@ class _EngineAgent:
         # reference, so getattr(config, ..., 5/2) always yields the defaults (src/agent.py:789-790)
         self.num_critics = int(getattr(config, "num_critics", num_critics)) if kind == 3 else (1 if kind == 0 else 2)
         self.top_quantiles_to_drop = int(getattr(config, "top_quantiles_to_drop", top_quantiles_to_drop))
+        # n_quantiles > 1: the DISTRIBUTIONAL TQC variant of BASELINE.json configs[3] (no reference counterpart: the reference's
+        # critics are scalar; include/gcrl.h gcrl_agent_config.n_quantiles, oracle/quantile_tqc_oracle.py)
+        self.n_quantiles = int(n_quantiles) if kind == 3 else 1
+        if self.n_quantiles > 1 and kind == 3:
+            self.num_critics = int(num_critics)
 
         cfg = _ffi.AgentConfig(
             kind=kind, obs_dim=obs_dim, ac_dim=ac_dim, hidden_dim=config.hidden_dim,
@@ -132,6 +137,7 @@ class _EngineAgent:
             ac_scheduler_steps=config.ac_scheduler_steps, cr_scheduler_steps=config.cr_scheduler_steps,
             alpha_min_steps=float(getattr(config, "alpha_min_steps", 10000)),
             device=device_index, use_graph=int(use_graph), pipeline_steps=(2 if pipeline is True else int(pipeline)),
+            n_quantiles=self.n_quantiles,
             seed=0 if seed is None else int(seed))
         self._h = _ffi.check_ptr(lib.gcrl_agent_create(C.byref(cfg)), "gcrl_agent_create")
         self._metric_cache: dict[int, list[float]] = {}
@@ -161,8 +167,8 @@ class _EngineAgent:
         else:
             self.actor = Actor(get, "actor", obs_dim, H, ac_dim, L)
             self.target_actor = Actor(get, "target_actor", obs_dim, H, ac_dim, L)
-        self.critics = [Critic(get, f"critic_{i}", obs_dim + ac_dim, H, 1, L) for i in range(self.num_critics)]
-        self.target_critics = [Critic(get, f"target_critic_{i}", obs_dim + ac_dim, H, 1, L)
+        self.critics = [Critic(get, f"critic_{i}", obs_dim + ac_dim, H, self.n_quantiles, L) for i in range(self.num_critics)]
+        self.target_critics = [Critic(get, f"target_critic_{i}", obs_dim + ac_dim, H, self.n_quantiles, L)
                                for i in range(self.num_critics)]
         self._bind_names()
         if weights:

@@ -224,7 +224,11 @@ typedef struct gcrl_agent_config {
                              TARGET actor; same arithmetic, fewer launches); 2 = additionally run
                              each phase's forward / input-gradient chain as ONE row-block launch
                              (csrc/rowchain.h; needs hidden_dim % 4 == 0, else falls back to 1) */
-  int32_t reserved;
+  int32_t n_quantiles;    /* TQC only; > 1 selects the DISTRIBUTIONAL variant of BASELINE.json configs[3] ("25 quantiles x 2
+                             critics"): every critic outputs n_quantiles atoms, the num_critics*n_quantiles (<= 64) pooled target
+                             atoms are sorted in one wavefront, the top top_drop PER CRITIC dropped, quantile-Huber loss.  NOT the
+                             reference's TQC (scalar-critic ensemble): no reference parity, pinned to its oracle restatement.
+                             0 / 1: the reference's semantics */
 } gcrl_agent_config;
 
 gcrl_agent* gcrl_agent_create(const gcrl_agent_config* cfg);

@@ -573,3 +573,54 @@ def test_large_k_future_flush_bit_exact(gcrl):
         eng.push(1, *st); orc.push(1, *st)
     for got, want in zip(eng.rows(), orc.as_arrays()):
         assert np.array_equal(bits(got), bits(want))
+
+
+# ------------------------------------------------------------------ distributional TQC (BASELINE.json configs[3]; no reference parity)
+@pytest.mark.parametrize("H,L,B,Q,C,drop", [(32, 2, 64, 25, 2, 2), (64, 3, 130, 8, 3, 1), (512, 3, 2048, 25, 2, 2)])
+def test_quantile_tqc_matches_its_oracle(gcrl, H, L, B, Q, C, drop):
+    """The 25-quantile x 2-critic TQC variant (n_quantiles > 1: pooled-atom wavefront sort, truncation, quantile-Huber
+    loss) against oracle/quantile_tqc_oracle.py — the reference has no quantile critic, so the oracle is the specification
+    (built from the reference's own networks / optimiser / cadence).  Two steps from identical parameters: returned tuples,
+    pre-clip gradients of every network, including the full BASELINE shape (H=512, B=2048)."""
+    from oracle.quantile_tqc_oracle import QuantileTQCOracle
+    S, A = 22, 3
+    cfg = make_config("TQC", hidden_dim=H, layer_count=L, batch_size=B, max_len=5000, grad_clip=5.0, gamma=0.95, tau=0.05,
+                      alpha_min_steps=0.0)
+    torch.manual_seed(3)
+    torch.set_num_threads(4)
+    orc = QuantileTQCOracle(S, A, cfg, n_quantiles=Q, num_critics=C, top_drop=drop)
+    ag = gcrl.TQCAgent(S, A, cfg, None, nenvs=1, gradient_step=40, rng="engine", seed=0, n_quantiles=Q, num_critics=C,
+                       top_quantiles_to_drop=drop)
+    gen = np.random.default_rng(H + B)
+    with torch.no_grad():   # moderate tanh-Gaussian heads (see tests/detdata.py), asymmetric everything else
+        for net in [orc.actor] + orc.critics:
+            for p in net.parameters():
+                p.add_(torch.from_numpy((0.02 * gen.standard_normal(tuple(p.shape))).astype(np.float32)))
+        orc.actor.log_std_head.weight.mul_(0.25); orc.actor.log_std_head.bias.fill_(-1.0); orc.actor.mean_head.weight.mul_(0.5)
+    orc.hard_update()
+    ag.actor.set_flat(orc.flat_params(orc.actor))
+    for v, c in zip(ag.critics, orc.critics):
+        v.set_flat(orc.flat_params(c))
+    ag.update_target_network()
+    for step in (1, 2):
+        batch = (gen.standard_normal((B, S)).astype(np.float32), gen.uniform(-1, 1, (B, A)).astype(np.float32),
+                 -(gen.uniform(size=(B, 1)) > 0.3).astype(np.float32), gen.standard_normal((B, S)).astype(np.float32),
+                 (gen.uniform(size=(B, 1)) > 0.9).astype(np.float32))
+        e1, e2 = gen.standard_normal((B, A)).astype(np.float32), gen.standard_normal((B, A)).astype(np.float32)
+        want = orc.update(step, tuple(torch.from_numpy(x) for x in batch), torch.from_numpy(e1), torch.from_numpy(e2))
+        got = ag.update(step, batch=tuple(torch.from_numpy(x).cuda() for x in batch), eps_next=torch.from_numpy(e1),
+                        eps_cur=torch.from_numpy(e2))
+        g = np.array([float(x) for x in got]); w = np.array([float(x) for x in want])
+        assert g.shape == w.shape == (9,)
+        assert np.allclose(g, w, rtol=5e-5, atol=2e-6), (step, g, w)
+        for v, pre in zip(ag.critics, orc.last["critic_grads_pre"]):
+            assert vec_close(v.grad_flat(), pre, rtol=5e-5), (step, v.name, float(np.abs(v.grad_flat() - pre).max()), float(np.abs(pre).max()))
+        assert vec_close(ag.actor.grad_flat(), orc.last["actor_grads_pre"], rtol=5e-5), step
+        # continue both from the oracle's state
+        ag.actor.set_flat(orc.flat_params(orc.actor))
+        for v, t, c, tc in zip(ag.critics, ag.target_critics, orc.critics, orc.target_critics):
+            v.set_flat(orc.flat_params(c)); t.set_flat(orc.flat_params(tc))
+        bns = [m for m in orc.actor.base_net if isinstance(m, torch.nn.BatchNorm1d)]
+        ag.actor._set("bn_running_mean", np.concatenate([m.running_mean.numpy() for m in bns]))
+        ag.actor._set("bn_running_var", np.concatenate([m.running_var.numpy() for m in bns]))
+        ag.actor._set("log_alpha", orc.log_alpha.detach().numpy())
