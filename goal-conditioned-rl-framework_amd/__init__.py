@@ -11,7 +11,7 @@ The directory name carries a hyphen, so import it through the repo-root shim: `i
 from . import _ffi  # noqa: F401  (loads the shared library; ImportError if it was not built)
 from .src import agent, buffer, model, utils  # noqa: F401
 from .src.agent import DDPG, SACAgent, TD3Agent, TQCAgent  # noqa: F401
-from .src.buffer import HERBuffer, MTStream  # noqa: F401
+from .src.buffer import HERBuffer, MTStream, PERBuffer, ReplayBuffer  # noqa: F401
 
-__all__ = ["DDPG", "TD3Agent", "SACAgent", "TQCAgent", "HERBuffer", "MTStream", "agent", "buffer",
+__all__ = ["DDPG", "TD3Agent", "SACAgent", "TQCAgent", "HERBuffer", "ReplayBuffer", "PERBuffer", "MTStream", "agent", "buffer",
            "model", "utils"]

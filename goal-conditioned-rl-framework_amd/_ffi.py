@@ -57,6 +57,7 @@ class UpdateInputs(C.Structure):
         ("ns_dev", C.c_void_p), ("ld_ns", C.c_int32),
         ("d_dev", C.c_void_p),
         ("noise_dev", C.c_void_p), ("eps_next_dev", C.c_void_p), ("eps_cur_dev", C.c_void_p),
+        ("idx_host", C.c_void_p), ("weights_host", C.c_void_p),
     ]
 
 
@@ -88,6 +89,7 @@ PROTOTYPES = {
     "gcrl_her_staged": (_i32, [_vp, C.c_int]),
     "gcrl_her_stream": (_vp, [_vp]),
     "gcrl_her_push": (_i64, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _f32, C.c_int, _vp, _vp, _vp]),
+    "gcrl_her_append": (_i64, [_vp, _vp, C.c_int, _vp, _f32, _vp, C.c_int, C.c_int, _vp]),
     "gcrl_her_push_batch": (_i64, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "gcrl_her_push_episode": (_i64, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_her_sample": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),

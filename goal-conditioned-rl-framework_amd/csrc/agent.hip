@@ -111,6 +111,7 @@ struct gcrl_agent {
   float *zA = nullptr, *xhatA = nullptr, *invstdA = nullptr, *headA = nullptr, *ghead = nullptr, *dh2 = nullptr;
   float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
   float *noise_in = nullptr, *eps_next_in = nullptr, *eps_cur_in = nullptr, *norm_partial = nullptr;
+  float *w_in = nullptr, *td_abs = nullptr;   // prioritised replay: IS weights of the batch [B], per-sample |td| [B]
   float *act_in = nullptr, *act_tmp[2] = {};
   float *qy = nullptr, *q_row_loss = nullptr, *q_row_td = nullptr;   // distributional TQC: kept target atoms [B][64], per-row sums
   float* pi_buf = nullptr;   // SAC row-chain path: pi(s) [B][Apad] (the layer-per-launch paths keep it in spa's action columns)
@@ -358,7 +359,7 @@ int sac_actor_forward(gcrl_agent* a, hipStream_t st, const float* X0, long long 
 
 // V_FUSED_NORM: gradient sum-of-squares partials come out of the dW GEMM epilogues (whole step in
 // one graph); off in data-parallel runs, where the norm is of the all-reduced gradients
-enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32, V_FUSED_NORM = 64 };
+enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32, V_FUSED_NORM = 64, V_WEIGHTS = 128 };
 
 int adam_common(gcrl_agent* a, AdamArgs& ad);
 
@@ -416,6 +417,8 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
   td.r = a->rbuf; td.d = a->dbuf; td.slot_stride = a->slot_rd;
   td.qt = a->qt; td.q = a->q; td.dq = a->dq;
   td.metrics = a->metrics_dev;
+  td.td_abs = a->td_abs;
+  td.w = (variant & V_WEIGHTS) ? a->w_in : nullptr;
   td.B = B; td.C = C; td.drop = 0;
   td.gamma = (float)a->cfg.gamma;
   td.loss_kind = LOSS_MSE;
@@ -773,6 +776,11 @@ int stage_injected(gcrl_agent* a, const gcrl_update_inputs* in, hipStream_t st, 
   if (in->noise_dev) { GCRL_HIP(hipMemcpyAsync(a->noise_in, in->noise_dev, nb, hipMemcpyDeviceToDevice, st)); *vbits |= V_NOISE; }
   if (in->eps_next_dev) { GCRL_HIP(hipMemcpyAsync(a->eps_next_in, in->eps_next_dev, nb, hipMemcpyDeviceToDevice, st)); *vbits |= V_EPSN; }
   if (in->eps_cur_dev) { GCRL_HIP(hipMemcpyAsync(a->eps_cur_in, in->eps_cur_dev, nb, hipMemcpyDeviceToDevice, st)); *vbits |= V_EPSC; }
+  if (in->weights_host) {
+    GCRL_CHECK_ARG(!a->rowchain && a->Q == 1, "update: importance-sampling weights need the layer-per-launch schedule (pipeline_steps = 0) and scalar critics");
+    GCRL_HIP(hipMemcpyAsync(a->w_in, in->weights_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));   // pageable source: staged synchronously
+    *vbits |= V_WEIGHTS;
+  }
   return GCRL_OK;
 }
 
@@ -805,19 +813,26 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
   ub->cb.cur = table[0];
   size_t bytes = sizeof(UploadBlock);
   const bool device_rng = !injected && her->cfg.rng_mode != GCRL_RNG_CPYTHON_MT;
-  if (!injected && !device_rng) {
+  const bool explicit_idx = !injected && in && in->idx_host;
+  if (explicit_idx) {   // prioritised replay: the caller drew the rows
+    for (int i = 0; i < a->B; ++i) {
+      GCRL_CHECK_ARG((int64_t)in->idx_host[i] < her->len, "update: row index %u outside the ring (len %lld)", in->idx_host[i], (long long)her->len);
+      idx[i] = in->idx_host[i];
+    }
+    bytes += (size_t)a->B * sizeof(uint32_t);
+  } else if (!injected && !device_rng) {
     for (int i = 0; i < n; ++i)
       TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)a->B, idx + (size_t)i * a->B));
     bytes += (size_t)n * a->B * sizeof(uint32_t);
   }
-  if (device_rng) {   // the gather kernel computes the indices itself: nothing to draw or upload here
+  if (device_rng && !explicit_idx) {   // the gather kernel computes the indices itself: nothing to draw or upload here
     her->last_gen = IdxGen{her->cfg.seed, her->draws_done, (uint32_t)her->len, a->B, feistel_half_bits((uint32_t)her->len)};
     her->draws_done += n;
   }
   GCRL_HIP(hipMemcpyAsync(a->upload_dev, ub, bytes, hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(a->upload_ev[slot], st));
   if (!injected)
-    TRY(her_gather_update(her, device_rng ? nullptr : a->idx_dev(), (int64_t)n * a->B, a->sa, a->nsa, a->rowchain ? nullptr : a->spa, a->ldx, a->rbuf, a->dbuf, st));
+    TRY(her_gather_update(her, (device_rng && !explicit_idx) ? nullptr : a->idx_dev(), (int64_t)n * a->B, a->sa, a->nsa, a->rowchain ? nullptr : a->spa, a->ldx, a->rbuf, a->dbuf, st));
   return GCRL_OK;
 }
 
@@ -896,7 +911,8 @@ int build(gcrl_agent* a) {
       {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH},
       {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
       {&a->hC2, (long long)C * L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H},
-      {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}, {&a->pi_buf, (long long)B * a->Apad}};
+      {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}, {&a->pi_buf, (long long)B * a->Apad},
+      {&a->w_in, B}, {&a->td_abs, B}};
   // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
   {
     const long long per_a = (long long)round_up(S, 4) * H + (long long)(L - 1) * H * H;
@@ -964,6 +980,7 @@ int build(gcrl_agent* a) {
     reg("adam_m:critic_" + s, a->adam_m + a->goff_critic + i * a->critic_stride, a->critic.numel);
     reg("adam_v:critic_" + s, a->adam_v + a->goff_critic + i * a->critic_stride, a->critic.numel);
   }
+  reg("td_abs", a->td_abs, B);
   if (a->sac) {
     reg("log_alpha", a->P_logalpha(), 1);
     reg("grad:log_alpha", a->grads + a->goff_alpha, 1);

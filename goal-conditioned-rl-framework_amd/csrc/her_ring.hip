@@ -648,6 +648,32 @@ int64_t gcrl_her_push(gcrl_her* h, int env, const float* state, int state_on_dev
   return 0;
 }
 
+int64_t gcrl_her_append(gcrl_her* h, const float* state, int state_on_device, const float* action_host, float reward,
+                        const float* next_state, int next_on_device, int done, void* stream) {
+  GCRL_CHECK_ARG(h && state && action_host && next_state, "gcrl_her_append: null argument");
+  if ((!state_on_device || !next_on_device) && h->S > kMaxInline)
+    return gcrl::fail(GCRL_ERR_ARG, "gcrl_her_append: host-pointer states support state_dim <= %d", kMaxInline);
+  hipStream_t st = h->pick(stream);
+  const int64_t cap = h->cfg.capacity;
+  const int64_t phys = (h->head + h->len) % cap;
+  StageArgs sa;
+  sa.dst = h->ring + (size_t)phys * h->RS;     // a ring record IS the leading RW floats of a staging record
+  sa.s_dev = state_on_device ? state : nullptr;
+  sa.ns_dev = next_on_device ? next_state : nullptr;
+  sa.S = h->S; sa.A = h->A; sa.G = 0; sa.SA4 = h->SA4; sa.S4 = h->S4;
+  sa.r = reward;
+  sa.d = done ? 1.0f : 0.0f;
+  std::memcpy(sa.a, action_host, sizeof(float) * h->A);
+  if (!state_on_device) std::memcpy(sa.s_inl, state, sizeof(float) * h->S);
+  if (!next_on_device) std::memcpy(sa.ns_inl, next_state, sizeof(float) * h->S);
+  hipLaunchKernelGGL(her_stage_kernel, dim3(1), dim3(64), 0, st, sa);
+  GCRL_HIP(hipGetLastError());
+  if (h->len == cap) h->head = (h->head + 1) % cap;   // deque(maxlen): the oldest row falls off
+  else h->len += 1;
+  h->mutation_epoch++;
+  return 1;
+}
+
 int64_t gcrl_her_push_batch(gcrl_her* h, int env0, int n, const float* states_dev, int ld_s,
                             const float* actions_host, const float* next_states_dev, int ld_ns,
                             const float* rewards_host, const uint8_t* dones_host,

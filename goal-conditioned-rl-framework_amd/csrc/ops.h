@@ -65,6 +65,8 @@ struct TdLossArgs {
   const float* alpha_dev;   // device scalar alpha (TQC) or null -> alpha_const
   float alpha_const;        // SAC: literal 0.2 (src/agent.py:569)
   float* dq;                // [C][B]  dLoss_c/dq_c
+  const float* w;           // [B] importance-sampling weights of a prioritised batch (src/agent.py:1320-1325 etc.) or null
+  float* td_abs;            // [B] max_c |q_c - y| per sample (what PERBuffer.update_priorities consumes) or null
   float* metrics;           // host-mapped records
   int B, C, drop, target_kind, loss_kind;
   float gamma, clamp_lo;

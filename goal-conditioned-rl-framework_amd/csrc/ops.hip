@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void td_loss_kernel(TdLossArgs a) {
     float y = __fadd_rn(r[b], __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, d[b])), tq));
     if (a.target_kind == TGT_DDPG) y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
     float tdmax = 0.f;
+    const float wb = a.w ? a.w[b] : 1.0f;   // (weights * loss).mean(): every per-sample term scaled before the mean
 #pragma unroll
     for (int k = 0; k < kMaxCritics; ++k) {
       if (k < C) {
@@ -95,18 +96,21 @@ __global__ __launch_bounds__(256) void td_loss_kernel(TdLossArgs a) {
         const float ad = fabsf(diff);
         float g;
         if (a.loss_kind == LOSS_MSE) {
-          loss[k] += diff * diff;
+          loss[k] += a.w ? wb * (diff * diff) : diff * diff;
           g = mse_norm * diff;
         } else {
-          loss[k] += (ad < 1.0f) ? 0.5f * diff * diff : ad - 0.5f;
+          const float l = (ad < 1.0f) ? 0.5f * diff * diff : ad - 0.5f;
+          loss[k] += a.w ? wb * l : l;
           g = (diff < -1.0f) ? -l1_norm : (diff > 1.0f ? l1_norm : l1_norm * diff);
         }
+        if (a.w) g *= wb;
         a.dq[(long long)k * B + b] = g;
         tdmax = fmaxf(tdmax, ad);
         qsum += qc;
       }
     }
     td += tdmax;
+    if (a.td_abs) a.td_abs[b] = tdmax;
   }
   float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
 #pragma unroll

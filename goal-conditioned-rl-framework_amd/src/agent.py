@@ -22,7 +22,7 @@ import torch
 
 from .. import _ffi
 from .._ffi import lib
-from .buffer import HERBuffer
+from .buffer import HERBuffer, PERBuffer, ReplayBuffer
 from .model import Actor, Critic, SACActorModel
 
 KIND = {"DDPG": 0, "TD3": 1, "SAC": 2, "TQC": 3}
@@ -106,12 +106,17 @@ class _EngineAgent:
         kind = KIND[self.KIND_NAME]
         self._sac = kind >= 2
 
-        if config.buffer_type != "HER":
-            # the reference also accepts "PER"/"REPLAY" (src/agent.py:1214-1228); no shipped config
-            # selects them and they are outside the hot path
+        # buffer factory of the reference (src/agent.py:1214-1228 and its copies)
+        if config.buffer_type == "PER":
+            self.buffer = PERBuffer(config.max_len, config.alpha, rng=rng, seed=seed, device_index=device_index)
+            pipeline = 0      # importance-sampling weights enter the loss in the layer-per-launch schedule
+        elif config.buffer_type == "REPLAY":
+            self.buffer = ReplayBuffer(config.max_len, rng=rng, seed=seed, device_index=device_index)
+        elif config.buffer_type == "HER":
+            self.buffer = HERBuffer(config.max_len, config.max_eps_len, nenvs, k_future=config.k_future,
+                                    rng=rng, seed=seed, device_index=device_index)
+        else:
             raise ValueError(f"[ERROR] Invalid Buffer type. Received {config.buffer_type}.")
-        self.buffer = HERBuffer(config.max_len, config.max_eps_len, nenvs, k_future=config.k_future,
-                                rng=rng, seed=seed, device_index=device_index)
 
         # the YAML keys num_critics / top_quantiles_to_drop are dropped by pydantic in the
         # reference, so getattr(config, ..., 5/2) always yields the defaults (src/agent.py:789-790)
@@ -252,6 +257,15 @@ class _EngineAgent:
         self.set_train()
         inputs, keep = self._inject(batch, noise, eps_next, eps_cur)
         her = None
+        per = isinstance(self.buffer, PERBuffer) and batch is None
+        if per:   # src/agent.py:1380-1387: the prioritised draw (host, numpy-exact), weights into the critic losses
+            indices, weights = self.buffer.draw(self.batch_size, self.beta)
+            if inputs is None:
+                inputs = _ffi.UpdateInputs()
+            idx32 = np.ascontiguousarray(indices, dtype=np.uint32)
+            w32 = np.ascontiguousarray(weights, dtype=np.float32)
+            keep += [idx32, w32]
+            inputs.idx_host, inputs.weights_host = idx32.ctypes.data, w32.ctypes.data
         if batch is None:
             her = self.buffer.handle
             assert her is not None and len(self.buffer) >= self.batch_size, "[ERROR] Not enough in buffer to sample"
@@ -261,14 +275,25 @@ class _EngineAgent:
                                              C.byref(ticket), _ffi.stream_handle()))
         if batch is None:
             self.buffer.rng.push_back()
+        if per:   # update_priorities(indices, td_error) with the per-sample |td| (src/agent.py:1387); td_error stays an array
+            td = np.empty(self.batch_size, np.float32)
+            _ffi.check(lib.gcrl_agent_get(self._h, b"td_abs", td.ctypes.data, td.size))
+            td = td.reshape(-1, 1)
+            self.buffer.update_priorities(indices=indices, priorities=td)
         self.beta_scheduler(step)
         if self._sac:
             self.actor.num_batches_tracked += 1 + (1 if n == 9 else 0)
-        return self._tuple(ticket.value, n)
+        out = self._tuple(ticket.value, n)
+        if per:
+            i = self.TD_INDEX[n]
+            out = out[:i] + (td,) + out[i + 1:]
+        return out
 
     def update_many(self, step0: int, n: int):
         """The trainer's `for _ in range(gradient_step): update(step)` loop (src/env.py:384-385) as
         one call: all n batches are drawn (same RNG stream order) and gathered by one launch."""
+        if isinstance(self.buffer, PERBuffer):   # the priorities change after every step: one draw per step (src/agent.py:1380-1387)
+            return [self.update(step0 + i) for i in range(n)]
         self.set_train()
         her = self.buffer.handle
         assert her is not None and len(self.buffer) >= self.batch_size, "[ERROR] Not enough in buffer to sample"
@@ -376,7 +401,7 @@ class _EngineAgent:
         return int(rows)
 
     def push(self, state, action, reward, next_state, done):
-        # reference passes 5 args to a HERBuffer.push that takes 8 -> TypeError there too
+        # (with a HERBuffer the reference passes 5 args to a push that takes 8 -> TypeError there too)
         self.buffer.push(state, action, reward, next_state, done)
 
     def push_her(self, idx, state, action, next_state, reward, done, desired_goal, achieved_goal):

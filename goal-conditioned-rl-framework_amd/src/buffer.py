@@ -109,7 +109,46 @@ def _classify_reward(fn, goal_dim: int, default_threshold: float):
         "only these two goal-distance rewards have a device implementation")
 
 
-class HERBuffer:
+class _RingState:
+    """save_state / load_state shared by the three buffers (extension of SURVEY.md §8f-2)."""
+
+    def save_state(self, path: str) -> dict:
+        """Ring rows (logical order), staged partial episodes and the MT19937 stream -> `path`; returns the metadata
+        load_state needs.  An untouched buffer (no transition pushed yet) saves as empty."""
+        meta = dict(dims=self._dims, rng_mode=self.rng.mode, py_random=None, mt=None, bytes=0)
+        if self.rng.mode == "python":
+            st = _pyrandom.getstate()
+            meta["py_random"] = [st[0], list(st[1]), st[2]]
+        elif self.rng.mode == "engine":
+            _ffi.check(lib.gcrl_mt_get_state(self.rng.handle, self.rng._buf))
+            meta["mt"] = list(self.rng._buf)
+        if self._h is not None:
+            n = int(lib.gcrl_her_state_size(self._h))
+            blob = np.empty(n, np.uint8)
+            _ffi.check(lib.gcrl_her_save_state(self._h, blob.ctypes.data, n))
+            blob.tofile(path)
+            meta["bytes"] = n
+        if hasattr(self, "priorities"):
+            meta["priorities"] = [float(p) for p in self.priorities]
+        return meta
+
+    def load_state(self, path: str, meta: dict):
+        if meta["bytes"]:
+            self._ensure(*meta["dims"])
+            blob = np.fromfile(path, dtype=np.uint8)
+            _ffi.check(lib.gcrl_her_load_state(self._h, blob.ctypes.data, blob.size))
+        if meta.get("py_random") is not None and self.rng.mode == "python":
+            v, words, gauss = meta["py_random"]
+            _pyrandom.setstate((v, tuple(words), gauss))
+        if meta.get("mt") is not None and self.rng.mode == "engine":
+            self.rng._buf[:] = meta["mt"]
+            _ffi.check(lib.gcrl_mt_set_state(self.rng.handle, self.rng._buf))
+        if hasattr(self, "priorities") and "priorities" in meta:
+            self.priorities.clear()
+            self.priorities.extend(np.float32(p) for p in meta["priorities"])
+
+
+class HERBuffer(_RingState):
     def __init__(self, max_mem_len: int, max_eps_len: int, nenvs: int, threshold: float = 0.05,
                  k_future: int = 4, *, rng: str = "python", seed: int | None = None,
                  device_index: int = 0):
@@ -287,37 +326,6 @@ class HERBuffer:
         out = (states, actions, rewards, next_states, dones)
         return out + (drawn,) if return_indices else out
 
-    # ------------------------------------------------------------------ full resume state
-    def save_state(self, path: str) -> dict:
-        """Ring rows (logical order), staged partial episodes and the MT19937 stream -> `path`; returns the metadata
-        load_state needs.  An untouched buffer (no transition pushed yet) saves as empty."""
-        meta = dict(dims=self._dims, rng_mode=self.rng.mode, py_random=None, mt=None, bytes=0)
-        if self.rng.mode == "python":
-            st = _pyrandom.getstate()
-            meta["py_random"] = [st[0], list(st[1]), st[2]]
-        elif self.rng.mode == "engine":
-            _ffi.check(lib.gcrl_mt_get_state(self.rng.handle, self.rng._buf))
-            meta["mt"] = list(self.rng._buf)
-        if self._h is not None:
-            n = int(lib.gcrl_her_state_size(self._h))
-            blob = np.empty(n, np.uint8)
-            _ffi.check(lib.gcrl_her_save_state(self._h, blob.ctypes.data, n))
-            blob.tofile(path)
-            meta["bytes"] = n
-        return meta
-
-    def load_state(self, path: str, meta: dict):
-        if meta["bytes"]:
-            self._ensure(*meta["dims"])
-            blob = np.fromfile(path, dtype=np.uint8)
-            _ffi.check(lib.gcrl_her_load_state(self._h, blob.ctypes.data, blob.size))
-        if meta.get("py_random") is not None and self.rng.mode == "python":
-            v, words, gauss = meta["py_random"]
-            _pyrandom.setstate((v, tuple(words), gauss))
-        if meta.get("mt") is not None and self.rng.mode == "engine":
-            self.rng._buf[:] = meta["mt"]
-            _ffi.check(lib.gcrl_mt_set_state(self.rng.handle, self.rng._buf))
-
     def rows(self, first: int = 0, count: int | None = None):
         """Test helper: ring rows in logical (oldest-first) order as numpy arrays."""
         n = len(self) - first if count is None else count
@@ -330,3 +338,123 @@ class HERBuffer:
 
     def compute_termination(self, dg, ag):
         return np.linalg.norm(dg - ag, axis=-1) < self.threshold
+
+
+class ReplayBuffer(_RingState):
+    """Drop-in for the reference's ReplayBuffer (src/buffer.py:8-35): FIFO rows in the HBM ring (same packed record as
+    HERBuffer, no staging, no relabelling), `sample` = `random.sample` over the stored rows (CPython-exact index stream)
+    + the gather kernel.  `push(state, action, reward, next_state, done)` appends ONE row at once."""
+
+    def __init__(self, max_len: int, *, rng: str = "python", seed: int | None = None, device_index: int = 0):
+        if not torch.cuda.is_available() or lib.gcrl_device_count() <= 0:
+            raise _ffi.GcrlError(f"{type(self).__name__} needs a HIP device: the replay ring lives in HBM and there is no CPU fallback")
+        self.max_len = int(max_len)
+        self.device = "cuda"
+        self.device_index = device_index
+        self.rng = MTStream(rng, seed)
+        self._h = None
+        self._dims = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.gcrl_her_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __len__(self):
+        return 0 if self._h is None else int(lib.gcrl_her_len(self._h))
+
+    def _ensure(self, S: int, A: int):
+        if self._h is not None:
+            if self._dims != (S, A):
+                raise ValueError(f"transition dims {(S, A)} differ from the ring's {self._dims}")
+            return
+        cfg = _ffi.HerConfig(state_dim=S, action_dim=A, goal_dim=1, capacity=self.max_len, nenvs=1, k_future=0,
+                             flush_len=FLUSH_LEN, reward_kind=0, reward_threshold=0.0, device=self.device_index,
+                             rng_mode=1 if self.rng.mode == "device" else 0, seed=self.rng.seed_value)
+        self._h = _ffi.check_ptr(lib.gcrl_her_create(C.byref(cfg), self.rng.handle), "gcrl_her_create")
+        self._dims = (S, A)
+
+    def push(self, state, action, reward, next_state, done):
+        act = np.ascontiguousarray(action, dtype=np.float32).reshape(-1)
+        ks, ps, ds = HERBuffer._state_arg(state)
+        kn, pn, dn = HERBuffer._state_arg(next_state)
+        S = int(ks.numel() if isinstance(ks, torch.Tensor) else ks.size)
+        self._ensure(S, act.size)
+        _ffi.check(int(lib.gcrl_her_append(self._h, ps, ds, act.ctypes.data, float(reward), pn, dn, 1 if done else 0,
+                                           _ffi.stream_handle())))
+
+    def _gather(self, batch_size: int, indices=None):
+        S, A = self._dims
+        dev = torch.device("cuda", self.device_index)
+        out = (torch.empty((batch_size, S), dtype=torch.float32, device=dev), torch.empty((batch_size, A), dtype=torch.float32, device=dev),
+               torch.empty((batch_size, 1), dtype=torch.float32, device=dev), torch.empty((batch_size, S), dtype=torch.float32, device=dev),
+               torch.empty((batch_size, 1), dtype=torch.float32, device=dev))
+        idx = None if indices is None else np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        if idx is None:
+            self.rng.pull()
+        _ffi.check(lib.gcrl_her_sample(self._h, batch_size, 1, idx.ctypes.data if idx is not None else None, out[0].data_ptr(), S,
+                                       out[1].data_ptr(), A, out[2].data_ptr(), out[3].data_ptr(), S, out[4].data_ptr(), None,
+                                       _ffi.stream_handle()))
+        if idx is None:
+            self.rng.push_back()
+        return out
+
+    def sample(self, batch_size: int):
+        assert len(self) >= batch_size, "Not enough in buffer to sample"
+        return self._gather(batch_size)
+
+    def rows(self, first: int = 0, count: int | None = None):
+        n = len(self) - first if count is None else count
+        S, A = self._dims
+        s = np.empty((n, S), np.float32); a = np.empty((n, A), np.float32)
+        ns = np.empty((n, S), np.float32); r = np.empty(n, np.float32); d = np.empty(n, np.float32)
+        _ffi.check(lib.gcrl_her_read_rows(self._h, first, n, s.ctypes.data, a.ctypes.data, ns.ctypes.data, r.ctypes.data, d.ctypes.data))
+        return s, a, ns, r, d
+
+
+class PERBuffer(ReplayBuffer):
+    """Drop-in for the reference's proportional PERBuffer (src/buffer.py:38-89).  Rows live in the HBM ring; the
+    priorities and the draw stay on the host in numpy, operation for operation as the reference writes them
+    (`np.random.choice(N, B, p=P)` consumes numpy's global stream; float32 priorities / weights), because the
+    priority update needs the per-sample |td| on the host anyway (one read-back per step, as in the reference)."""
+
+    def __init__(self, max_len: int, alpha: float, **kw):
+        super().__init__(max_len, **kw)
+        from collections import deque
+        self.priorities = deque(maxlen=int(max_len))
+        self.alpha = alpha
+        self.epsilon = 1e-6
+
+    def push(self, state, action, reward, next_state, done):
+        super().push(state, action, reward, next_state, done)
+        self.priorities.append(1.0)
+
+    def draw(self, batch_size: int, beta: float):
+        """-> (indices, weights float32 [B]) exactly as src/buffer.py:50-65."""
+        assert len(self) >= batch_size, "Not enough in buffer to sample"
+        N = len(self)
+        P = np.array(self.priorities, dtype=np.float32)
+        P_sum = P.sum()
+        if P_sum > 0:
+            P /= P_sum
+        else:
+            P[:] = 1.0 / N
+        indices = np.random.choice(N, batch_size, p=P)
+        weights = (N * P[indices]) ** (-beta)
+        weights /= weights.max()
+        return indices, weights
+
+    def sample(self, batch_size: int, beta: float):
+        indices, weights = self.draw(batch_size, beta)
+        batch = self._gather(batch_size, indices)
+        w = torch.as_tensor(weights, dtype=torch.float32).unsqueeze(-1).to(batch[0].device)
+        return batch + (w, indices)
+
+    def update_priorities(self, indices, priorities):
+        priorities = np.asarray(priorities).squeeze(-1)
+        for index, priority in zip(indices, priorities):
+            self.priorities[index] = (abs(priority) + self.epsilon) ** self.alpha

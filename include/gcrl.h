@@ -132,6 +132,11 @@ int64_t gcrl_her_push(gcrl_her* h, int env, const float* state, int state_on_dev
                       const float* desired_goal_host, const float* achieved_goal_host,
                       void* stream);
 
+/* ReplayBuffer.push / PERBuffer.push (src/buffer.py:13-14, :46-48): ONE row appended at once (no staging, no relabel,
+ * visible to the next sample), deque(maxlen) eviction.  state / next_state: S floats on the device or the host. */
+int64_t gcrl_her_append(gcrl_her* h, const float* state, int state_on_device, const float* action_host, float reward,
+                        const float* next_state, int next_state_on_device, int done, void* stream);
+
 /* One step of a vector env (the loop of src/env.py:192-201 as ONE call): transition i belongs to
  * env env0+i.  states / next_states: device matrices [n][ld] (what _process_step builds,
  * src/env.py:189-190); actions [n][A], rewards [n], dones [n] (0/1 bytes), achieved goals [n][G]:
@@ -287,6 +292,12 @@ typedef struct gcrl_update_inputs {
   const float* noise_dev;      /* TD3: randn_like(action) [B, A]   (src/agent.py:175) */
   const float* eps_next_dev;   /* SAC/TQC: rsample eps for actor.sample(next_state) [B, A] */
   const float* eps_cur_dev;    /* SAC/TQC: rsample eps for actor.sample(states)     [B, A] */
+  /* prioritised replay (PERBuffer, src/buffer.py:38-89): the caller draws the batch (np.random.choice over the priorities,
+   * host) and passes the logical row indices and the importance-sampling weights; the critic losses become
+   * (weights * loss).mean() (src/agent.py:193-197, :577-581, :993-997, :1320-1325).  Layer-per-launch schedule only
+   * (pipeline_steps = 0).  The per-sample |td| of the step is the named vector "td_abs" (gcrl_agent_get). */
+  const uint32_t* idx_host;    /* [B] logical ring indices instead of a random.sample draw (needs `her`) */
+  const float* weights_host;   /* [B] */
 } gcrl_update_inputs;
 
 /* One agent.update(step).  Batch: sampled from `her` (HERBuffer.sample semantics) unless

@@ -193,7 +193,7 @@ class OracleAgent:
         return srt[: -self.top_drop].mean(dim=0) if self.top_drop > 0 else qs.mean(dim=0)
 
     # ------------------------------------------------------------------ critic update
-    def critic_update(self, s, a, r, ns, d, noise=None, eps_next=None):
+    def critic_update(self, s, a, r, ns, d, noise=None, eps_next=None, weights=None):
         cfg, kind = self.cfg, self.kind
         with torch.no_grad():
             if kind == "DDPG":                                # :1311-1317
@@ -219,7 +219,10 @@ class OracleAgent:
         for i, (c, opt) in enumerate(zip(self.critics, self.critic_opts)):
             q = cur[i] if kind != "TQC" else c(x)             # TQC: forward inside the loop (:990)
             opt.zero_grad()
-            loss = loss_fn(q, y)
+            if weights is not None and weights.numel() > 0:       # PER: (weights * loss).mean()  (:193-197, :577-581, :993-997, :1320-1325)
+                loss = (weights * loss_fn(q, y, reduction="none")).mean()
+            else:
+                loss = loss_fn(q, y)
             loss.backward()
             if self.grad_sync is not None:
                 self.grad_sync(f"critic_{i}", list(c.parameters()))
@@ -238,7 +241,8 @@ class OracleAgent:
         if kind in ("TD3", "SAC"):
             for sc in self.critic_scheds:                     # :218-219 / :606-607
                 sc.step()
-        self.last.update(critic_grads_pre=pre, critic_grads_post=post, target=y.detach().numpy().copy())
+        self.last.update(critic_grads_pre=pre, critic_grads_post=post, target=y.detach().numpy().copy(),
+                         td_per_sample=torch.stack(tds).max(dim=0)[0].numpy().copy())
         if kind == "DDPG":                                    # :1336-1343
             return losses[0], torch.mean(tds[0]).cpu().numpy(), qs[0].mean().cpu().item(), gnorms[0]
         if kind == "TQC":                                     # :1013-1042
@@ -298,14 +302,14 @@ class OracleAgent:
         return loss.item()
 
     # ------------------------------------------------------------------ update
-    def update(self, step, batch=None, noise=None, eps_next=None, eps_cur=None):
+    def update(self, step, batch=None, noise=None, eps_next=None, eps_cur=None, weights=None):
         """DDPG :1378-1404, TD3 :281-317, SAC :659-699, TQC :1062-1100."""
         self._train_mode()
         if batch is None:
             batch = tuple(torch.from_numpy(x) for x in self.buffer.sample(self.cfg.batch_size))
         s, a, r, ns, d = batch
         cfg, kind = self.cfg, self.kind
-        cinfo = self.critic_update(s, a, r, ns, d, noise=noise, eps_next=eps_next)
+        cinfo = self.critic_update(s, a, r, ns, d, noise=noise, eps_next=eps_next, weights=weights)
         do_actor = step % cfg.ac_update_freq == 0
         if kind == "DDPG":
             if step % 40 == 0:                                # literal 40 (:1397)

@@ -312,7 +312,76 @@ def gen_normalizer():
     print("normalizer ok")
 
 
+# --------------------------------------------------------------------------- G10: PER / Replay buffers (src/buffer.py:8-89)
+def gen_per(kind, tag, yaml_name):
+    """The reference agent with buffer_type="PER": transitions pushed through agent.push, three update() steps drawing
+    through np.random.choice over the priorities (global numpy stream, seeded), importance-sampling weights in the critic
+    loss, priorities updated from the per-sample td_error.  Captured: the pushed rows, drawn indices, weights, returned
+    tuples (td_error is a [B,1] array on this path), pre-clip gradients, priorities after every step."""
+    S, A, B, N = 10, 3, 32, 200
+    cfg = load_her_config(os.path.join(CFG_DIR, kind, yaml_name), kind)
+    acfg = cfg.agent.model_copy(update=dict(batch_size=B, hidden_dim=32, layer_count=2, buffer_type="PER", max_len=150, alpha=0.6,
+                                            beta=0.4, beta_end=1000, ac_update_freq=1))
+    torch.manual_seed(1898); np.random.seed(1898); random.seed(1898)
+    cls = dict(DDPG=DDPG, TD3=TD3Agent)[kind]
+    agent = cls(obs_dim=S, ac_dim=A, config=acfg, weights=None, nenvs=1, gradient_step=40)
+    agent.buffer.device = "cpu"
+    if kind == "DDPG":
+        nets = dict(actor=agent.actor, critic_0=agent.critic)
+        opts = dict(actor=agent.actor_opt, critic_0=agent.critic_opt)
+    else:
+        nets = dict(actor=agent.actor, critic_0=agent.critic_1, critic_1=agent.critic_2)
+        opts = dict(actor=agent.actor_opt, critic_0=agent.critic_1_opt, critic_1=agent.critic_2_opt)
+    gen = np.random.default_rng(55)
+    with torch.no_grad():
+        for net in nets.values():
+            for p in net.parameters():
+                p.add_(torch.from_numpy((0.02 * gen.standard_normal(tuple(p.shape))).astype(np.float32)))
+    agent.update_target_network()
+    out = dict(kind=np.array([kind]), dims=np.array([S, A, B, N]))
+    hp = acfg.model_dump()
+    out["hparams_keys"] = np.array(list(hp.keys()))
+    out["hparams_vals"] = np.array([str(v) for v in hp.values()])
+    for name, net in nets.items():
+        out[f"init_{name}"] = flat(net.parameters())
+    rows = synthetic_batch(gen, N, S, A)            # (s, a, r, ns, d); 200 pushes into a 150-row deque: evicts
+    for key, v in zip(("s", "a", "r", "ns", "d"), rows):
+        out[f"rows_{key}"] = v
+    for i in range(N):
+        agent.push(torch.from_numpy(rows[0][i]), rows[1][i], float(rows[2][i, 0]), torch.from_numpy(rows[3][i]), bool(rows[4][i, 0]))
+    rec = Recorder()
+    for name, opt in opts.items():
+        rec.register(name, nets[name], opt)
+    orig_clip, orig_choice, orig_rl = torch.nn.utils.clip_grad_norm_, np.random.choice, torch.randn_like
+    torch.nn.utils.clip_grad_norm_ = rec.clip_hook(orig_clip)
+    drawn = []
+    np.random.choice = lambda *a, **k: drawn.append(orig_choice(*a, **k)) or drawn[-1]
+    torch.randn_like = lambda t, *a, **k: torch.zeros_like(t)       # TD3 smoothing noise off (policy_noise scales it anyway)
+    np.random.seed(4242)
+    try:
+        for i, step in enumerate((1, 2, 3)):
+            rec.reset()
+            info = agent.update(step=step)
+            out[f"step{i}_indices"] = np.asarray(drawn[-1], dtype=np.int64)
+            td_pos = {6: 2, 8: 3}[len(info)]
+            out[f"step{i}_td"] = np.asarray(info[td_pos], dtype=np.float32)
+            out[f"step{i}_tuple"] = np.array([float(np.asarray(x)) if j != td_pos else float(np.mean(info[td_pos])) for j, x in enumerate(info)])
+            out[f"step{i}_priorities"] = np.array(agent.buffer.priorities, dtype=np.float64)
+            out[f"step{i}_beta"] = np.array([agent.beta])
+            for name in opts:
+                if name in rec.pre:
+                    out[f"step{i}_gradpre_{name}"] = rec.pre[name]
+            for name, net in nets.items():
+                out[f"step{i}_param_{name}"] = flat(net.parameters())
+    finally:
+        torch.nn.utils.clip_grad_norm_, np.random.choice, torch.randn_like = orig_clip, orig_choice, orig_rl
+    np.savez_compressed(os.path.join(HERE, f"per_{tag}.npz"), **out)
+    print("per", tag, "ok", out["step0_tuple"])
+
+
 def main():
+    gen_per("DDPG", "ddpg", "config_ddpg_reach.yaml")
+    gen_per("TD3", "td3", "config_td3_reach.yaml")
     gen_normalizer()
     gen_index_streams()
     gen_her_rows()

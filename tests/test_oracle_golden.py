@@ -215,3 +215,39 @@ def test_normalizer_oracle_matches_reference_bitwise():
         assert np.array_equal(nz.mean, g[f"mean{i}"]) and np.array_equal(nz.var, g[f"var{i}"]) and nz.count == g[f"count{i}"][0], i
         z = nz.normalize(g["probe"])
         assert np.array_equal(z, g[f"norm64_{i}"]) and np.array_equal(z.astype(np.float32), g[f"norm32_{i}"]), i
+
+
+# ---------------------------------------------------------------- G10: PER buffer + weighted critic losses
+@pytest.mark.parametrize("tag", ["ddpg", "td3"])
+def test_per_oracle_matches_reference(tag):
+    from oracle.replay_oracle import PERBufferOracle, per_update
+    g = load_golden(f"per_{tag}.npz")
+    kind = str(g["kind"][0])
+    S, A, B, N = (int(x) for x in g["dims"])
+    cfg = hparams_from_golden(g)
+    torch.set_num_threads(1)
+    orc = OracleAgent(kind, S, A, cfg, nenvs=1)
+    nets = {"actor": orc.actor, **{f"critic_{i}": c for i, c in enumerate(orc.critics)}}
+    for n, net in nets.items():
+        orc.set_flat_params(net, g[f"init_{n}"])
+    orc.hard_update()
+    buf = PERBufferOracle(cfg.max_len, cfg.alpha)
+    for i in range(N):
+        buf.push(g["rows_s"][i], g["rows_a"][i], float(g["rows_r"][i, 0]), g["rows_ns"][i], bool(g["rows_d"][i, 0]))
+    np.random.seed(4242)
+    beta = dict(beta=cfg.beta, beta0=cfg.beta)
+    for i, step in enumerate((1, 2, 3)):
+        info, td, idx, w = per_update(orc, buf, step, beta)
+        assert np.array_equal(idx, g[f"step{i}_indices"])
+        assert np.array_equal(td, g[f"step{i}_td"])
+        assert np.array_equal(np.array(buf.priorities, np.float64), g[f"step{i}_priorities"])
+        want = g[f"step{i}_tuple"]
+        got = np.array([float(np.asarray(x)) for x in info])
+        td_pos = {6: 2, 8: 3}[len(want)]
+        got[td_pos] = float(np.mean(td))        # on this path the reference returns the per-sample array there
+        assert close(got, want), (i, got, want)
+        for n in nets:
+            k = f"step{i}_gradpre_{n}"
+            if k in g.files:
+                pre = orc.last["actor_grads_pre"] if n == "actor" else orc.last["critic_grads_pre"][int(n[-1])]
+                assert close(pre, g[k]), (i, n)
