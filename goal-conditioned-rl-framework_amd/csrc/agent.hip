@@ -1533,6 +1533,31 @@ int gcrl_agent_observe_act(gcrl_agent* a, gcrl_normalizer* nz_obs, gcrl_normaliz
   // layout: doubles first (alignment): noise [B*A], out [B*A]; then floats: obs, dg, eps
   double* p_noise = (double*)a->oa_pinned; double* p_out = p_noise + d_cnt; float* p_f = (float*)(p_out + d_cnt);
   double* d_noise = (double*)a->oa_dev; double* d_out = d_noise + d_cnt; float* d_f = (float*)(d_out + d_cnt);
+  if (a->rowchain && !a->sac) {
+    // ONE launch: raw [observation | goal] rows up, normalisation in the row-chain act kernel's prologue, select_action's
+    // tanh / noise / clip in its epilogue
+    if (a->wt_dirty) TRY(rc_rebuild_wt(a, st));
+    for (int i = 0; i < n; ++i) {
+      std::memcpy(p_f + (size_t)i * a->S, obs_host + (size_t)i * D, sizeof(float) * D);
+      std::memcpy(p_f + (size_t)i * a->S + D, dg_host + (size_t)i * G, sizeof(float) * G);
+    }
+    const bool with_noise = noise_host && mode == 1;
+    if (with_noise) std::memcpy(p_noise, noise_host, sizeof(double) * n * A);
+    // noise [B*A doubles], out [B*A doubles] and the rows are contiguous in the staging block: one copy covers what is used
+    if (with_noise) GCRL_HIP(hipMemcpyAsync(d_noise, p_noise, sizeof(double) * n * A, hipMemcpyHostToDevice, st));
+    GCRL_HIP(hipMemcpyAsync(d_f, p_f, sizeof(float) * (size_t)n * a->S, hipMemcpyHostToDevice, st));
+    RowActArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.actor = make_rownet(a, a->actor, a->P_actor(), 0);
+    ra.obs = d_f; ra.ld_obs = a->S; ra.out = a->dact; ra.ld_out = a->Apad;
+    ra.n = n; ra.S = a->S; ra.A = A; ra.ldl = a->row_ldl;
+    ra.D = D;
+    gcrl::normalizer_view(nz_obs, &ra.nz_mean, &ra.nz_var, nullptr, &ra.nz_clip);
+    gcrl::normalizer_view(nz_dg, &ra.nzg_mean, &ra.nzg_var, nullptr, &ra.nzg_clip);
+    ra.post = mode == 1 ? 1 : (mode == 0 ? 2 : 3);
+    ra.noise = with_noise ? d_noise : nullptr; ra.out64 = d_out;
+    TRY(launch_rowchain_act(st, ra));
+  } else {
   std::memcpy(p_f, obs_host, sizeof(float) * n * D);
   std::memcpy(p_f + (size_t)n * D, dg_host, sizeof(float) * n * G);
   const bool eps_act = a->sac && noise_host;
@@ -1549,6 +1574,7 @@ int gcrl_agent_observe_act(gcrl_agent* a, gcrl_normalizer* nz_obs, gcrl_normaliz
   hipLaunchKernelGGL(act_post_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, a->dact, a->Apad, n, A,
                      (noise_host && !eps_act) ? d_noise : nullptr, pm, d_out);
   GCRL_HIP(hipGetLastError());
+  }
   GCRL_HIP(hipMemcpyAsync(p_out, d_out, sizeof(double) * n * A, hipMemcpyDeviceToHost, st));
   GCRL_HIP(hipStreamSynchronize(st));
   std::memcpy(out_host, p_out, sizeof(double) * n * A);

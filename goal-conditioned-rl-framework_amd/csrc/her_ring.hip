@@ -17,6 +17,7 @@ constexpr int kMaxInline = 128;    // S limit for host-pointer pushes (values tr
 constexpr int kMaxFut = 2048;      // k_future*(T-1) limit for inline future indices
 constexpr int kMaxEp = 8;          // episodes per flush launch
 constexpr int kStepsPerBlock = 4;
+constexpr int kPayW = 32;          // floats per env of a vector-env step's payload [t | r | d | a(A) | ag(G)]
 
 // ---------------------------------------------------------------- stage one transition
 struct StageArgs {
@@ -47,7 +48,6 @@ __global__ __launch_bounds__(64) void her_stage_kernel(StageArgs p) {
 
 // one transition per block for a whole vector-env step; the small per-env payload
 // [t | r | d | a(A) | ag(G)] was uploaded in one copy
-constexpr int kPayW = 32;
 __global__ __launch_bounds__(64) void her_stage_batch_kernel(float* stage, const float* pay, const float* s_dev, int ld_s,
                                                              const float* ns_dev, int ld_ns, int env0, int flush_len, int S,
                                                              int A, int G, int SA4, int S4, int RG) {
@@ -65,6 +65,68 @@ __global__ __launch_bounds__(64) void her_stage_batch_kernel(float* stage, const
     else if (c == o_r + 1) v = pw[2];
     else if (c >= RW) v = pw[3 + A + (c - RW)];
     dst[c] = v;
+  }
+}
+
+// One vector-env step of the trainer's _process_step (src/env.py:163-201) in ONE single-block launch: the observation
+// normaliser's update from [obs ; next_obs] (RunningNormalizer.update, src/utils.py:75-93 — float32 batch moments in
+// numpy's order, float64 merge), then every env's transition written to its staging record with the observation columns
+// normalised by the UPDATED statistics (normalize, :95-97) and the goal columns raw.
+struct ProcArgs {
+  float* stage; const float* raw; const float* pay;   // raw = [obs n*D | next_obs n*D | dg n*G | next_dg n*G]
+  double* mean; double* var; double* count; double clip;   // null mean: no normaliser
+  int update, n, env0, flush_len, D, S, A, G, SA4, S4, RG;
+};
+__global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
+  __shared__ double s_mean[128], s_den[128];
+  const int n = p.n, D = p.D, G = p.G;
+  const float* obs = p.raw; const float* nobs = obs + (size_t)n * D;
+  const float* dg = nobs + (size_t)n * D; const float* ndg = dg + (size_t)n * G;
+  if (p.mean) {
+    for (int j = threadIdx.x; j < D; j += 256) {
+      double m = p.mean[j], v = p.var[j];
+      if (p.update) {
+        const int rows = 2 * n;                 // np.concatenate([obs, next_obs]) is how the two blocks lie
+        float s = 0.f;
+        for (int i = 0; i < rows; ++i) s = __fadd_rn(s, obs[(size_t)i * D + j]);
+        const float bm = __fdiv_rn(s, (float)rows);
+        float q = 0.f;
+        for (int i = 0; i < rows; ++i) { const float d = __fsub_rn(obs[(size_t)i * D + j], bm); q = __fadd_rn(q, __fmul_rn(d, d)); }
+        const float bv = __fdiv_rn(q, (float)rows);
+        const double c0 = *p.count, cb = (double)rows, total = c0 + cb;
+        const double delta = (double)bm - m;
+        const double nm = m + delta * cb / total;
+        const double M2 = v * c0 + (double)__fmul_rn(bv, (float)rows) + delta * delta * c0 * cb / total;
+        m = nm; v = M2 / total;
+        p.mean[j] = m; p.var[j] = v;
+      }
+      s_mean[j] = m; s_den[j] = sqrt(v) + 1e-8;
+    }
+  }
+  __syncthreads();
+  if (p.mean && p.update && threadIdx.x == 0) *p.count = *p.count + (double)(2 * n);   // every column has read the old count
+  const int o_ns = p.SA4, o_r = p.SA4 + p.S4, RW = o_r + 2, W = RW + G;
+  for (int e = threadIdx.x; e < n * W; e += 256) {
+    const int i = e / W, c = e - i * W;
+    const float* pw = p.pay + (long long)i * kPayW;
+    const int t = __float_as_int(pw[0]);
+    float v = 0.f;
+    auto state_col = [&](const float* o, const float* g, int cc) -> float {
+      if (cc < D) {
+        const float x = o[(size_t)i * D + cc];
+        if (!p.mean) return x;
+        const double z = ((double)x - s_mean[cc]) / s_den[cc];
+        return (float)fmin(fmax(z, -p.clip), p.clip);
+      }
+      return g[(size_t)i * G + (cc - D)];
+    };
+    if (c < p.S) v = state_col(obs, dg, c);
+    else if (c < p.S + p.A) v = pw[3 + (c - p.S)];
+    else if (c >= o_ns && c < o_ns + p.S) v = state_col(nobs, ndg, c - o_ns);
+    else if (c == o_r) v = pw[1];
+    else if (c == o_r + 1) v = pw[2];
+    else if (c >= RW) v = pw[3 + p.A + (c - RW)];
+    p.stage[((long long)(p.env0 + i) * p.flush_len + t) * p.RG + c] = v;
   }
 }
 
@@ -648,6 +710,32 @@ int64_t gcrl_her_push(gcrl_her* h, int env, const float* state, int state_on_dev
   return 0;
 }
 
+// after a vector-env step's transitions are staged: envs that finish this step flush together, in env order (the
+// reference's loop order, src/env.py:192-201), up to kMaxEp episodes per launch.  Returns ring rows appended.
+static int64_t finish_vector_step(gcrl_her* h, int env0, int n, const uint8_t* dones_host, hipStream_t st) {
+  int envs[kMaxEp], Ts[kMaxEp], cnt = 0;
+  int64_t total = 0;
+  auto flush_pending = [&]() -> int {
+    if (cnt == 0) return GCRL_OK;
+    int64_t rows = 0;
+    if (int rc = launch_flush(h, cnt, envs, Ts, nullptr, st, &rows)) return rc;
+    for (int q = 0; q < cnt; ++q) h->staged[envs[q]] = 0;
+    total += rows;
+    cnt = 0;
+    return GCRL_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const int env = env0 + i;
+    h->staged[env] += 1;
+    if (dones_host[i] || h->staged[env] >= h->cfg.flush_len) {
+      if (cnt == kMaxEp) if (int rc = flush_pending()) return rc;
+      envs[cnt] = env; Ts[cnt] = h->staged[env]; ++cnt;
+    }
+  }
+  if (int rc = flush_pending()) return rc;
+  return total;
+}
+
 int64_t gcrl_her_append(gcrl_her* h, const float* state, int state_on_device, const float* action_host, float reward,
                         const float* next_state, int next_on_device, int done, void* stream) {
   GCRL_CHECK_ARG(h && state && action_host && next_state, "gcrl_her_append: null argument");
@@ -707,55 +795,26 @@ int64_t gcrl_her_push_batch(gcrl_her* h, int env0, int n, const float* states_de
   hipLaunchKernelGGL(her_stage_batch_kernel, dim3(n), dim3(64), 0, st, h->stage, h->pay_dev, states_dev, ld_s, next_states_dev,
                      ld_ns, env0, h->cfg.flush_len, h->S, h->A, h->G, h->SA4, h->S4, h->RG);
   GCRL_HIP(hipGetLastError());
-  // envs that finish this step flush together, in env order (the reference's loop order,
-  // src/env.py:192-201), up to kMaxEp episodes per launch
-  int envs[kMaxEp], Ts[kMaxEp], cnt = 0, fut_acc = 0;
-  int64_t total = 0;
-  auto flush_pending = [&]() -> int {
-    if (cnt == 0) return GCRL_OK;
-    int64_t rows = 0;
-    if (int rc = launch_flush(h, cnt, envs, Ts, nullptr, st, &rows)) return rc;
-    for (int q = 0; q < cnt; ++q) h->staged[envs[q]] = 0;
-    total += rows;
-    cnt = 0;
-    fut_acc = 0;
-    return GCRL_OK;
-  };
-  for (int i = 0; i < n; ++i) {
-    const int env = env0 + i;
-    h->staged[env] += 1;
-    if (dones_host[i] || h->staged[env] >= h->cfg.flush_len) {
-      const int need = h->cfg.k_future * (h->staged[env] - 1);  // inline future indices of this episode
-      if (cnt == kMaxEp) if (int rc = flush_pending()) return rc;
-      envs[cnt] = env; Ts[cnt] = h->staged[env]; ++cnt;
-      fut_acc += need;
-    }
-  }
-  if (int rc = flush_pending()) return rc;
-  return total;
+  return finish_vector_step(h, env0, n, dones_host, st);
 }
 
-// _process_step of the reference's trainer (src/env.py:163-201) for one vector-env step as ONE call: the observation
-// normaliser takes [obs ; next_obs] (src/agent.py:1425-1433 via :165-175), both state matrices are rebuilt from the
-// UPDATED statistics ([normalize(obs) | goal], src/env.py:177-188), and all n transitions are pushed (gcrl_her_push_batch).
-// Raw rows come from the host; nothing returns to it.  Goals stay raw (g_normalize is false in every shipped config;
-// a goal normaliser is refused here rather than half-applied — use the unfused calls for it).
 int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_stats, const float* obs_host,
                               const float* next_obs_host, int obs_dim, const float* dg_host, const float* next_dg_host,
                               const float* next_ag_host, const float* actions_host, const float* rewards_host,
                               const uint8_t* dones_host, int env0, int n, void* stream) {
   GCRL_CHECK_ARG(h && obs_host && next_obs_host && dg_host && next_dg_host && next_ag_host && actions_host && rewards_host && dones_host,
                  "gcrl_her_process_step: null argument");
-  GCRL_CHECK_ARG(obs_dim >= 1 && obs_dim + h->G == h->S, "gcrl_her_process_step: obs_dim %d + goal_dim %d != state_dim %d", obs_dim, h->G, h->S);
+  GCRL_CHECK_ARG(obs_dim >= 1 && obs_dim <= 128 && obs_dim + h->G == h->S, "gcrl_her_process_step: obs_dim %d + goal_dim %d != state_dim %d (obs_dim <= 128)", obs_dim, h->G, h->S);
   GCRL_CHECK_ARG(n >= 1 && env0 >= 0 && env0 + n <= h->cfg.nenvs, "gcrl_her_process_step: envs [%d, %d) outside [0, %d)", env0, env0 + n, h->cfg.nenvs);
+  GCRL_CHECK_ARG(3 + h->A + h->G <= kPayW, "gcrl_her_process_step: action_dim + goal_dim too large for the payload");
   hipStream_t st = h->pick(stream);
-  const int D = obs_dim, G = h->G, S = h->S;
-  // staging layout (floats): raw [obs(n*D) | next_obs(n*D) | dg(n*G) | next_dg(n*G)], then s [n*S], ns [n*S]
-  const size_t raw = (size_t)n * (2 * D + 2 * G), need = raw + 2 * (size_t)n * S;
+  const int D = obs_dim, G = h->G;
+  // ONE upload: raw rows [obs(n*D) | next_obs(n*D) | dg(n*G) | next_dg(n*G)], then the per-env payload [t | r | d | a | ag]
+  const size_t raw = (size_t)n * (2 * D + 2 * G), need = raw + (size_t)n * kPayW;
   if (need > h->ps_floats) {
     GCRL_HIP(hipDeviceSynchronize());
     if (h->ps_dev) GCRL_HIP(hipFree(h->ps_dev));
-    const size_t want = std::max<size_t>(need, (size_t)h->cfg.nenvs * (2 * D + 2 * G + 2 * S));
+    const size_t want = std::max<size_t>(need, (size_t)h->cfg.nenvs * (2 * D + 2 * G + kPayW));
     GCRL_HIP(hipMalloc((void**)&h->ps_dev, want * sizeof(float)));
     for (int i = 0; i < gcrl_her::kSlots; ++i) {
       if (h->ps_pinned[i]) GCRL_HIP(hipHostFree(h->ps_pinned[i]));
@@ -763,23 +822,38 @@ int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_s
     }
     h->ps_floats = want;
   }
-  const int slot = h->next_epi_slot;   // shares the slot counter / events of the payload uploads of the same step
+  const int slot = h->next_epi_slot;
+  h->next_epi_slot = (slot + 1) % gcrl_her::kSlots;
   GCRL_HIP(hipEventSynchronize(h->epi_ev[slot]));
   float* pin = h->ps_pinned[slot];
   std::memcpy(pin, obs_host, sizeof(float) * n * D);
   std::memcpy(pin + (size_t)n * D, next_obs_host, sizeof(float) * n * D);
   std::memcpy(pin + (size_t)2 * n * D, dg_host, sizeof(float) * n * G);
   std::memcpy(pin + (size_t)2 * n * D + (size_t)n * G, next_dg_host, sizeof(float) * n * G);
-  GCRL_HIP(hipMemcpyAsync(h->ps_dev, pin, raw * sizeof(float), hipMemcpyHostToDevice, st));
-  float* d_obs = h->ps_dev; float* d_nobs = d_obs + (size_t)n * D; float* d_dg = d_nobs + (size_t)n * D; float* d_ndg = d_dg + (size_t)n * G;
-  float* d_s = h->ps_dev + raw; float* d_ns = d_s + (size_t)n * S;
-  if (nz_obs && update_stats)
-    if (int rc = gcrl::normalizer_update_dev(nz_obs, d_obs, 2 * n, D, st)) return rc;   // np.concatenate([obs, next_obs]) is how they lie
-  if (int rc = gcrl::normalizer_apply_dev(nz_obs, d_obs, n, D, D, d_s, S, 0, st)) return rc;
-  if (int rc = gcrl::normalizer_apply_dev(nullptr, d_dg, n, G, G, d_s, S, D, st)) return rc;
-  if (int rc = gcrl::normalizer_apply_dev(nz_obs, d_nobs, n, D, D, d_ns, S, 0, st)) return rc;
-  if (int rc = gcrl::normalizer_apply_dev(nullptr, d_ndg, n, G, G, d_ns, S, D, st)) return rc;
-  return gcrl_her_push_batch(h, env0, n, d_s, S, actions_host, d_ns, S, rewards_host, dones_host, next_ag_host, stream);
+  float* pay = pin + raw;
+  for (int i = 0; i < n; ++i) {
+    float* pw = pay + (size_t)i * kPayW;
+    const int t = h->staged[env0 + i];
+    std::memcpy(&pw[0], &t, sizeof(int));
+    pw[1] = rewards_host[i];
+    pw[2] = dones_host[i] ? 1.0f : 0.0f;
+    std::memcpy(pw + 3, actions_host + (size_t)i * h->A, sizeof(float) * h->A);
+    std::memcpy(pw + 3 + h->A, next_ag_host + (size_t)i * G, sizeof(float) * G);
+  }
+  GCRL_HIP(hipMemcpyAsync(h->ps_dev, pin, need * sizeof(float), hipMemcpyHostToDevice, st));
+  GCRL_HIP(hipEventRecord(h->epi_ev[slot], st));
+  ProcArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.stage = h->stage; pa.raw = h->ps_dev; pa.pay = h->ps_dev + raw;
+  const double *mean = nullptr, *var = nullptr;
+  gcrl::normalizer_view(nz_obs, &mean, &var, &pa.count, &pa.clip);
+  pa.mean = const_cast<double*>(mean); pa.var = const_cast<double*>(var);
+  pa.update = (nz_obs && update_stats) ? 1 : 0;
+  pa.n = n; pa.env0 = env0; pa.flush_len = h->cfg.flush_len; pa.D = D; pa.S = h->S; pa.A = h->A; pa.G = G;
+  pa.SA4 = h->SA4; pa.S4 = h->S4; pa.RG = h->RG;
+  hipLaunchKernelGGL(her_process_step_kernel, dim3(1), dim3(256), 0, st, pa);
+  GCRL_HIP(hipGetLastError());
+  return finish_vector_step(h, env0, n, dones_host, st);
 }
 
 int64_t gcrl_her_push_episode(gcrl_her* h, int env, int T, const float* s, const float* a,

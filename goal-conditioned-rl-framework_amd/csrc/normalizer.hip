@@ -89,6 +89,9 @@ hipStream_t pick_stream(void* s) { return s == GCRL_STREAM_LEGACY ? (hipStream_t
 }  // namespace
 
 namespace gcrl {
+void normalizer_view(const gcrl_normalizer* z, const double** mean, const double** var, double** count, double* clip) {
+  *mean = z ? z->mean : nullptr; *var = z ? z->var : nullptr; if (count) *count = z ? z->count : nullptr; *clip = z ? z->clip : 0.0;
+}
 // device rows in, statistics updated (used by the fused entry points)
 int normalizer_update_dev(gcrl_normalizer* z, const float* x_dev, int n, int ld, hipStream_t st) {
   hipLaunchKernelGGL(norm_update_kernel, dim3((z->size + 63) / 64), dim3(64), 0, st, x_dev, n, ld, z->size, z->mean, z->var, z->count);

@@ -279,6 +279,13 @@ struct RowActArgs {
   const float* obs; int ld_obs;   // [n, >= S]
   float* out; int ld_out;         // [n, >= A]
   int n, S, A, ldl;
+  // fused acting entry (gcrl_agent_observe_act): `obs` then holds RAW rows [n][S] = [observation (D) | goal (S - D)]; the
+  // first D columns go through (x - mean) / (sqrt(var) + 1e-8), clipped to +-clip (float64, rounded to float32), when
+  // nz_mean is set, the goal columns when nzg_mean is; post != 0: out64[n][A] = mode 1: clip(tanh(y) + noise, -1, 1),
+  // mode 2 (post == 2): clip(tanh(y), -1, 1), mode 3: y   (select_action's arithmetic, src/agent.py:1345-1366, :253-270)
+  const double* nz_mean; const double* nz_var; double nz_clip; int D;
+  const double* nzg_mean; const double* nzg_var; double nzg_clip;
+  int post; const double* noise; double* out64;
 };
 int launch_rowchain_act(hipStream_t st, const RowActArgs& a);
 

@@ -565,6 +565,24 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a)
   rows_load<1>(s_x, rows, a.ld_obs, a.S, a.actor.jpad0, rv);
   seg_load(s_h, src_h, A * H);
   const float v_hb = tid < A ? a.actor.P[a.actor.b[a.actor.L] + tid] : 0.f;
+  // fused acting entry: the rows are raw; normalise this thread's elements on their way into LDS
+  if (a.nz_mean || a.nzg_mean) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = tid + u * kRowThreads, jp = a.actor.jpad0, r = i / jp, c = i - r * jp;
+      if (i < R * jp && r < rv && c < a.S) {
+        const bool ob = c < a.D;
+        const double* m = ob ? a.nz_mean : a.nzg_mean;
+        if (m) {
+          const int j = ob ? c : c - a.D;
+          const double* v = ob ? a.nz_var : a.nzg_var;
+          const double clip = ob ? a.nz_clip : a.nzg_clip;
+          double z = ((double)s_x.v[u] - m[j]) / (sqrt(v[j]) + 1e-8);
+          s_x.v[u] = (float)fmin(fmax(z, -clip), clip);
+        }
+      }
+    }
+  }
   rows_store<1>(s_x, X0, ldl, rows, a.ld_obs, a.S, a.actor.jpad0, rv);
   seg_store(s_h, hw, src_h, A * H);
   if (tid < A) hb[tid] = v_hb;
@@ -574,7 +592,20 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a)
   __syncthreads();
   if (tid < R * A) {
     const int r = tid / A, o = tid - r * A;
-    if (r < rv) a.out[(row0 + r) * a.ld_out + o] = sm[r * 16 + o];
+    if (r < rv) {
+      const float y = sm[r * 16 + o];
+      if (!a.post) a.out[(row0 + r) * a.ld_out + o] = y;
+      else {
+        const long long t = (row0 + r) * A + o;
+        double v = (double)y;
+        if (a.post != 3) {
+          v = (double)tanhf(y);
+          if (a.post == 1 && a.noise) v += a.noise[t];
+          v = fmin(fmax(v, -1.0), 1.0);
+        }
+        a.out64[t] = v;
+      }
+    }
   }
 }
 
@@ -645,6 +676,7 @@ int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int pha
 
 int launch_rowchain_act(hipStream_t st, const RowActArgs& a) {
   GCRL_CHECK_ARG(a.actor.H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16 && a.n >= 1, "rowchain act: unsupported shape");
+  GCRL_CHECK_ARG(!(a.nz_mean || a.nzg_mean) || 4 * a.actor.jpad0 <= 2 * kRowThreads, "rowchain act: fused normalisation supports state_dim <= 128");
   const size_t lds = (size_t)(3 * 4 * a.ldl + 2 * 4 * 4 * kRowChunk + 4 * 16 + a.A * a.actor.H + 32) * sizeof(float);
   GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain act: %zu bytes of LDS needed", lds);
   static thread_local size_t raised = 0;
