@@ -109,6 +109,7 @@ struct gcrl_agent {
   float *hC2 = nullptr, *gC2 = nullptr, *bn_part = nullptr;
   float *q = nullptr, *qt = nullptr, *q2 = nullptr, *dq = nullptr, *dq2 = nullptr, *dact = nullptr;
   float *zA = nullptr, *xhatA = nullptr, *invstdA = nullptr, *headA = nullptr, *ghead = nullptr, *dh2 = nullptr;
+  float *zN = nullptr, *hN = nullptr, *headN = nullptr, *bn_partN = nullptr;   // scratch of the co-scheduled actor.sample(next_state) forward
   float *logp = nullptr, *logp_next = nullptr, *epsbuf = nullptr, *stdbuf = nullptr;
   float *noise_in = nullptr, *eps_next_in = nullptr, *eps_cur_in = nullptr, *norm_partial = nullptr;
   float *w_in = nullptr, *td_abs = nullptr;   // prioritised replay: IS weights of the batch [B], per-sample |td| [B]
@@ -313,55 +314,94 @@ void chain_mlp(gcrl_agent* a, Launches& ls, size_t at, const NetSpec& net, const
   }
 }
 
-// SACActorModel forward (src/model.py:118-141): [Linear -> BatchNorm1d(train) -> ReLU] x L, two
-// heads, tanh-Gaussian sample.  save: keep what the backward needs.  extra: critic-chain
-// launches co-scheduled with the actor's GEMM launches (may be null).
-int sac_actor_forward(gcrl_agent* a, hipStream_t st, const float* X0, long long x_slot, bool save, float* act_dst,
-                      long long act_slot, float* logp_dst, const float* eps_in, int rng_stream, Launches* extra, int ld_act = 0) {
+// SACActorModel forward (src/model.py:118-141): [Linear -> BatchNorm1d(train) -> ReLU] x L, two heads, tanh-Gaussian
+// sample — for ONE input or for TWO inputs co-scheduled layer by layer in the same launches.  The reference calls
+// actor.sample(next_state) in the critic phase (src/agent.py:558, no_grad) and actor.sample(states) in the actor phase
+// (:514) with the SAME actor parameters (the actor steps only afterwards), so on actor steps the two forwards are
+// independent: one GEMM launch carries both layers-l problems, one BatchNorm launch pair both batches (running
+// statistics: next_state's batch first, then the state's, as in the reference's call order).  11 launches instead of 22.
+struct ActorFwd {
+  const float* X0; long long x_slot;   // input rows (+ batch_slot * x_slot)
+  bool save;                           // keep xhat / invstd / eps / std for the backward
+  float* act_dst; long long act_slot; int ld_act;
+  float* logp; const float* eps; int rng_stream;
+  float *z, *h, *head, *bn_part;       // z [B,H] scratch, h [L][B][H] (save) or [2][B][H] ping-pong, head [B][2*Apad]
+};
+
+int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, int nf, Launches* extra) {
   const NetSpec& net = a->actor;
   const float* P = a->P_actor();
   const int B = a->B, H = a->H;
+  const long long BH = (long long)B * H;
+  auto hbuf = [&](const ActorFwd& q, int l) { return q.save ? q.h + (long long)l * BH : q.h + (long long)(l & 1) * BH; };
   for (int l = 0; l < net.L; ++l) {
-    const float* X = l == 0 ? X0 : a->hA_at(l - 1);
-    GemmDesc d = fwd(X, l == 0 ? a->ldx : H, P, net.lin[l], a->zA, H, B, EPI_NONE);
-    if (l == 0 && x_slot) { d.slot = a->slot_ptr(); d.a_slot = x_slot; }
-    std::vector<GemmDesc> v{d};
+    std::vector<GemmDesc> v;
+    for (int i = 0; i < nf; ++i) {
+      const float* X = l == 0 ? f[i].X0 : hbuf(f[i], l - 1);
+      GemmDesc d = fwd(X, l == 0 ? a->ldx : H, P, net.lin[l], f[i].z, H, B, EPI_NONE);
+      if (l == 0 && f[i].x_slot) { d.slot = a->slot_ptr(); d.a_slot = f[i].x_slot; }
+      v.push_back(d);
+    }
     if (extra && (size_t)l < extra->steps.size()) v.insert(v.end(), extra->steps[l].begin(), extra->steps[l].end());
-    TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
-    TRY(launch_bn_relu_fwd(st, a->zA, B, H, P + net.bn_g[l], P + net.bn_b[l], a->hA_at(l),
-                           save ? a->xhatA + (long long)l * B * H : nullptr,
-                           save ? a->invstdA + (long long)l * H : nullptr, a->bn_rmean + (long long)l * H,
-                           a->bn_rvar + (long long)l * H, a->bn_part));
+    for (size_t o = 0; o < v.size(); o += kMaxProb) TRY(launch_gemm_batch(st, v.data() + o, (int)std::min<size_t>(kMaxProb, v.size() - o)));
+    BnFwdProb pb[2];
+    for (int i = 0; i < nf; ++i)
+      pb[i] = BnFwdProb{f[i].z, hbuf(f[i], l), f[i].save ? a->xhatA + (long long)l * BH : nullptr,
+                        f[i].save ? a->invstdA + (long long)l * H : nullptr, f[i].bn_part};
+    TRY(launch_bn_relu_fwd_multi(st, pb, nf, B, H, P + net.bn_g[l], P + net.bn_b[l], a->bn_rmean + (long long)l * H,
+                                 a->bn_rvar + (long long)l * H));
   }
   {
     const int ldh = 2 * a->Apad;
     std::vector<GemmDesc> v;
-    v.push_back(fwd(a->hA_at(net.L - 1), H, P, net.lin[net.L], a->headA, ldh, B, EPI_NONE));                // mean
-    v.push_back(fwd(a->hA_at(net.L - 1), H, P, net.lin[net.L + 1], a->headA + a->Apad, ldh, B, EPI_NONE));  // log_std
-    if (extra && (size_t)net.L < extra->steps.size())
-      v.insert(v.end(), extra->steps[net.L].begin(), extra->steps[net.L].end());
-    TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
+    for (int i = 0; i < nf; ++i) {
+      v.push_back(fwd(hbuf(f[i], net.L - 1), H, P, net.lin[net.L], f[i].head, ldh, B, EPI_NONE));                // mean
+      v.push_back(fwd(hbuf(f[i], net.L - 1), H, P, net.lin[net.L + 1], f[i].head + a->Apad, ldh, B, EPI_NONE));  // log_std
+    }
+    if (extra && (size_t)net.L < extra->steps.size()) v.insert(v.end(), extra->steps[net.L].begin(), extra->steps[net.L].end());
+    for (size_t o = 0; o < v.size(); o += kMaxProb) TRY(launch_gemm_batch(st, v.data() + o, (int)std::min<size_t>(kMaxProb, v.size() - o)));
   }
-  TanhGaussArgs tg;
-  std::memset(&tg, 0, sizeof(tg));
-  tg.cur = a->cur();
-  tg.mu = a->headA; tg.ls_raw = a->headA + a->Apad; tg.ld_head = 2 * a->Apad;
-  tg.eps = eps_in;
-  tg.act = act_dst; tg.act_slot_stride = act_slot; tg.ld_act = ld_act ? ld_act : a->ldx;
-  tg.logp = logp_dst;
-  tg.save_eps = save ? a->epsbuf : nullptr;
-  tg.save_std = save ? a->stdbuf : nullptr;
-  tg.B = B; tg.A = a->A;
-  tg.seed = a->cfg.seed; tg.rng_stream = rng_stream;
-  TRY(launch_tanh_gauss_fwd(st, tg));
+  TanhGaussArgs tg[2];
+  for (int i = 0; i < nf; ++i) {
+    std::memset(&tg[i], 0, sizeof(tg[i]));
+    tg[i].cur = a->cur();
+    tg[i].mu = f[i].head; tg[i].ls_raw = f[i].head + a->Apad; tg[i].ld_head = 2 * a->Apad;
+    tg[i].eps = f[i].eps;
+    tg[i].act = f[i].act_dst; tg[i].act_slot_stride = f[i].act_slot; tg[i].ld_act = f[i].ld_act ? f[i].ld_act : a->ldx;
+    tg[i].logp = f[i].logp;
+    tg[i].save_eps = f[i].save ? a->epsbuf : nullptr;
+    tg[i].save_std = f[i].save ? a->stdbuf : nullptr;
+    tg[i].B = B; tg[i].A = a->A;
+    tg[i].seed = a->cfg.seed; tg[i].rng_stream = f[i].rng_stream;
+  }
+  if (nf == 2) TRY(launch_tanh_gauss_fwd2(st, tg[0], tg[1]));
+  else TRY(launch_tanh_gauss_fwd(st, tg[0]));
   return GCRL_OK;
 }
+
+// the two forwards of a step: actor.sample(next_state) -> action columns of nsa + logp_next (scratch buffers), and —
+// with_cur — actor.sample(states) -> pi(s) + logp, activations saved for the actor's backward
+int sac_actor_forwards(gcrl_agent* a, hipStream_t st, int variant, bool with_cur, Launches* extra);
 
 // V_FUSED_NORM: gradient sum-of-squares partials come out of the dW GEMM epilogues (whole step in
 // one graph); off in data-parallel runs, where the norm is of the all-reduced gradients
 enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32, V_FUSED_NORM = 64, V_WEIGHTS = 128 };
 
 int adam_common(gcrl_agent* a, AdamArgs& ad);
+
+int sac_actor_forwards(gcrl_agent* a, hipStream_t st, int variant, bool with_cur, Launches* extra) {
+  const int S = a->S;
+  ActorFwd f[2];
+  f[0] = ActorFwd{a->nsa, a->slot_x, false, a->nsa + S, a->slot_x, 0, a->logp_next, (variant & V_EPSN) ? a->eps_next_in : nullptr, 1,
+                  a->zN, a->hN, a->headN, a->bn_partN};
+  if (a->rowchain)   // s is read from sa's rows, pi(s) goes to its own [B][Apad] matrix (no spa on this path)
+    f[1] = ActorFwd{a->sa, a->slot_x, true, a->pi_buf, 0, a->Apad, a->logp, (variant & V_EPSC) ? a->eps_cur_in : nullptr, 2,
+                    a->zA, a->hA, a->headA, a->bn_part};
+  else
+    f[1] = ActorFwd{a->spa, a->slot_x, true, a->spa + S, a->slot_x, 0, a->logp, (variant & V_EPSC) ? a->eps_cur_in : nullptr, 2,
+                    a->zA, a->hA, a->headA, a->bn_part};
+  return sac_actor_forward_multi(a, st, f, with_cur ? 2 : 1, extra);
+}
 
 // hipGraph replay pays when a step is many launches (31 per DDPG step launch-per-layer: 1.8 us per
 // dependent kernel in a graph vs ~5 us issued one by one); the row-block step is 3-7 launches issued
@@ -379,9 +419,7 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
   if (a->rowchain) {
     // row-block form: the whole critic phase up to the input gradients in one launch, then every dW|db
     // (SAC: the BatchNorm actor samples the next action first, into the action columns of nsa)
-    if (a->sac)
-      TRY(sac_actor_forward(a, st, a->nsa, a->slot_x, false, a->nsa + S, a->slot_x, a->logp_next,
-                            (variant & V_EPSN) ? a->eps_next_in : nullptr, 1, nullptr));
+    if (a->sac) TRY(sac_actor_forwards(a, st, variant, (variant & V_ACTOR) != 0, nullptr));
     const PipeCtx kc{a->cur(), a->slot_ptr()};
     TRY(rc_launch_chain(a, st, kc, kc, 1, (variant & V_NOISE) ? a->noise_in : nullptr));
     Launches dw;
@@ -403,8 +441,7 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
                             (float)a->cfg.noise_clamp, a->cfg.seed));
   } else {
     // actor.sample(next_state) under no_grad, BatchNorm in training mode (src/agent.py:558, :961)
-    TRY(sac_actor_forward(a, st, a->nsa, a->slot_x, false, a->nsa + S, a->slot_x, a->logp_next,
-                          (variant & V_EPSN) ? a->eps_next_in : nullptr, 1, &crit));
+    TRY(sac_actor_forwards(a, st, variant, (variant & V_ACTOR) != 0, &crit));
   }
   Launches tc;
   for (int c = 0; c < C; ++c)
@@ -531,12 +568,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     chain_mlp(a, af, 0, a->actor, a->P_actor(), a->spa, a->ldx, a->slot_x, hid_A, 0, a->spa + S, a->ldx, a->slot_x, EPI_TANH, B);
     TRY(af.run(st));
   } else {
-    if (a->rowchain)   // s is read from sa's rows, pi(s) goes to its own [B][Apad] matrix (no spa on this path)
-      TRY(sac_actor_forward(a, st, a->sa, a->slot_x, true, a->pi_buf, 0, a->logp, (variant & V_EPSC) ? a->eps_cur_in : nullptr, 2,
-                            nullptr, a->Apad));
-    else
-      TRY(sac_actor_forward(a, st, a->spa, a->slot_x, true, a->spa + S, a->slot_x, a->logp,
-                            (variant & V_EPSC) ? a->eps_cur_in : nullptr, 2, nullptr));
+    // (actor.sample(states) already ran, co-scheduled with actor.sample(next_state), in phase 0: sac_actor_forwards)
   }
   if (a->rowchain) {   // SAC: both stepped critics, the min-selection gradient and their action gradients, one launch
     const PipeCtx pc{a->cur(), a->slot_ptr()};
@@ -912,7 +944,8 @@ int build(gcrl_agent* a) {
       {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
       {&a->hC2, (long long)C * L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H},
       {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}, {&a->pi_buf, (long long)B * a->Apad},
-      {&a->w_in, B}, {&a->td_abs, B}};
+      {&a->w_in, B}, {&a->td_abs, B},
+      {&a->zN, BH}, {&a->hN, 2 * BH}, {&a->headN, (long long)B * 2 * a->Apad}, {&a->bn_partN, 2LL * ((B + 63) / 64) * H}};
   // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
   {
     const long long per_a = (long long)round_up(S, 4) * H + (long long)(L - 1) * H * H;

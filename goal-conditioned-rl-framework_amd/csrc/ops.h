@@ -161,6 +161,13 @@ int launch_polyak(hipStream_t st, const float* p, float* target, long long n, do
 int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
                        const float* beta, float* h, float* xhat, float* invstd,
                        float* running_mean, float* running_var, float* scratch);
+// The same for up to two independent inputs of the SAME layer in one pair of launches (SAC / TQC: actor.sample(next_state)
+// of the critic phase and actor.sample(states) of the actor phase use the same actor parameters, src/agent.py:558 and
+// :514, so the two forwards run layer by layer in the same launches).  The running statistics take problem 0's batch
+// first, then problem 1's — the order of the reference's two forward calls.
+struct BnFwdProb { const float* z; float* h; float* xhat; float* invstd; float* scratch; };
+int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, int B, int H, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var);
 // eval mode (running statistics): select_action path
 int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const float* gamma,
                         const float* beta, const float* running_mean, const float* running_var,
@@ -183,6 +190,7 @@ struct TanhGaussArgs {
   unsigned long long seed; int rng_stream;
 };
 int launch_tanh_gauss_fwd(hipStream_t st, const TanhGaussArgs& a);
+int launch_tanh_gauss_fwd2(hipStream_t st, const TanhGaussArgs& a0, const TanhGaussArgs& a1);   // two heads, one launch
 
 // actor loss of SAC/TQC: L = mean(alpha*logp - sel(q_c)) with sel = min (C=2) or mean of the
 // lowest C-drop of the sorted ensemble (src/agent.py:516-521, :916-925).  Writes

@@ -6,6 +6,7 @@
 //   wavefront bitonic sort + truncated mean         generalisation of src/agent.py:919-921
 #include "ops.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace gcrl {
@@ -64,9 +65,14 @@ __device__ inline float col_sum4(float v, float (*red)[64], int cl, int rg) {
 // inside the accumulation loops they were 16-32 DEPENDENT round trips long (6-10 us per launch, profiles/r02e).
 constexpr int kBnPer = kBnRows / 4;
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int B, int H,
-                                                       float* __restrict__ part_mean, float* __restrict__ part_m2) {
+struct BnFwdPair { BnFwdProb p[2]; int n; };
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(BnFwdPair pr, int B, int H) {
   __shared__ float red[4][64];
+  const float* __restrict__ z = pr.p[blockIdx.z].z;
+  const int nrb_ = (B + kBnRows - 1) / kBnRows;
+  float* __restrict__ part_mean = pr.p[blockIdx.z].scratch;
+  float* __restrict__ part_m2 = part_mean + (long long)nrb_ * H;
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
   const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
@@ -93,16 +99,34 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 
 constexpr int kBnMaxPart = 32;   // row-block partials held in registers (B <= 2048); more fall back to a loop
 
-__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, int B, int H,
-                                                            const float* gamma, const float* beta,
-                                                            const float* __restrict__ part_mean,
-                                                            const float* __restrict__ part_m2,
-                                                            float* __restrict__ h, float* xhat, float* invstd_out,
+// Chan merge of a problem's row-block partials for one column (same order in every block) -> (mean, biased var)
+__device__ inline void bn_merge(const float* part_mean, const float* part_m2, int nrb, int B, int H, int col, float* mean_out,
+                                float* var_out) {
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int rb = 0; rb < nrb; ++rb) {
+    const float nb = (float)(min(B, (rb + 1) * kBnRows) - rb * kBnRows);
+    const float mb = part_mean[(long long)rb * H + col], qb = part_m2[(long long)rb * H + col];
+    const float delta = mb - mean, tot = n + nb;
+    mean += delta * (nb / tot);
+    m2 += qb + delta * delta * (n * nb / tot);
+    n = tot;
+  }
+  *mean_out = mean; *var_out = m2 / (float)B;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B, int H, const float* gamma, const float* beta,
                                                             float* rmean, float* rvar) {
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
   if (col >= H) return;
   const int nrb = (B + kBnRows - 1) / kBnRows;
+  const BnFwdProb me = pr.p[blockIdx.z];
+  const float* __restrict__ z = me.z;
+  const float* __restrict__ part_mean = me.scratch;
+  const float* __restrict__ part_m2 = me.scratch + (long long)nrb * H;
+  float* __restrict__ h = me.h;
+  float* xhat = me.xhat;
+  float* invstd_out = me.invstd;
   const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
   // request everything first: the partials, the affine pair, this thread's rows
   float pm[kBnMaxPart], pq[kBnMaxPart], v[kBnPer];
@@ -143,9 +167,19 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
   }
   if (blockIdx.y == 0 && rg == 0) {
     if (invstd_out) invstd_out[col] = invstd;
-    const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
-    rmean[col] = (1.0f - kBnMomentum) * rmean[col] + kBnMomentum * mean;
-    rvar[col] = (1.0f - kBnMomentum) * rvar[col] + kBnMomentum * unbiased;
+    if (blockIdx.z == 0) {   // running statistics: problem 0's batch, then problem 1's (two forward calls, in that order)
+      const float ub = B > 1 ? (float)B / (float)(B - 1) : 1.0f;
+      float rm = (1.0f - kBnMomentum) * rmean[col] + kBnMomentum * mean;
+      float rv = (1.0f - kBnMomentum) * rvar[col] + kBnMomentum * (var * ub);
+      if (pr.n > 1) {
+        float m1, v1;
+        bn_merge(pr.p[1].scratch, pr.p[1].scratch + (long long)nrb * H, nrb, B, H, col, &m1, &v1);
+        rm = (1.0f - kBnMomentum) * rm + kBnMomentum * m1;
+        rv = (1.0f - kBnMomentum) * rv + kBnMomentum * (v1 * ub);
+      }
+      rmean[col] = rm;
+      rvar[col] = rv;
+    }
   }
 }
 
@@ -240,7 +274,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
   if (blockIdx.y == 0 && rg == 0) { dgamma[col] = sum_dyx; dbeta[col] = sum_dy; }
 }
 
-__global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) {
+__device__ inline void tanh_gauss_fwd_body(const TanhGaussArgs& a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   const StepCtrl c = *a.cur;
@@ -271,6 +305,12 @@ __global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) {
     if (a.save_eps) { a.save_eps[i] = e; a.save_std[i] = sd; }
   }
   if (!a.deterministic && a.logp) a.logp[b] = lp;
+}
+
+__global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) { tanh_gauss_fwd_body(a); }
+__global__ void tanh_gauss_fwd2_kernel(TanhGaussArgs a0, TanhGaussArgs a1) {
+  if (blockIdx.y == 0) tanh_gauss_fwd_body(a0);
+  else tanh_gauss_fwd_body(a1);
 }
 
 __device__ inline void actor_select_body(const ActorSelArgs& a, float* scratch) {
@@ -539,14 +579,22 @@ int launch_quantile_actor(hipStream_t st, const QuantileActorArgs& a) {
 int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
                        const float* beta, float* h, float* xhat, float* invstd, float* rmean,
                        float* rvar, float* scratch) {
+  const BnFwdProb one{z, h, xhat, invstd, scratch};
+  return launch_bn_relu_fwd_multi(st, &one, 1, B, H, gamma, beta, rmean, rvar);
+}
+
+int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, int B, int H, const float* gamma,
+                             const float* beta, float* rmean, float* rvar) {
+  GCRL_CHECK_ARG(nprob == 1 || nprob == 2, "bn_relu_fwd_multi: 1 or 2 problems");
   const int nrb = (B + kBnRows - 1) / kBnRows;
-  const dim3 grid((H + 63) / 64, nrb);
-  float* part_mean = scratch;
-  float* part_m2 = scratch + (long long)nrb * H;
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, st, z, B, H, part_mean, part_m2);
+  const dim3 grid((H + 63) / 64, nrb, nprob);
+  BnFwdPair pr;
+  pr.n = nprob;
+  pr.p[0] = probs[0];
+  pr.p[1] = nprob > 1 ? probs[1] : probs[0];
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, st, pr, B, H);
   GCRL_HIP(hipGetLastError());
-  hipLaunchKernelGGL(bn_relu_apply_kernel, grid, dim3(256), 0, st, z, B, H, gamma, beta, part_mean, part_m2, h,
-                     xhat, invstd, rmean, rvar);
+  hipLaunchKernelGGL(bn_relu_apply_kernel, grid, dim3(256), 0, st, pr, B, H, gamma, beta, rmean, rvar);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
@@ -577,6 +625,12 @@ int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const 
 
 int launch_tanh_gauss_fwd(hipStream_t st, const TanhGaussArgs& a) {
   hipLaunchKernelGGL(tanh_gauss_fwd_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_tanh_gauss_fwd2(hipStream_t st, const TanhGaussArgs& a0, const TanhGaussArgs& a1) {
+  hipLaunchKernelGGL(tanh_gauss_fwd2_kernel, dim3((std::max(a0.B, a1.B) + 255) / 256, 2), dim3(256), 0, st, a0, a1);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
