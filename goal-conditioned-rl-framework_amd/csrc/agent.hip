@@ -123,6 +123,7 @@ struct gcrl_agent {
   // target critic 0, per-layer gradient buffers, TD targets
   bool rowchain = false, wt_dirty = true;
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
+  int split_rg[4] = {1, 1, 1, 1};
   int row_rg = 1, row_ldl = 0;
   float *wt = nullptr, *rc_gC = nullptr, *rc_gA = nullptr, *ybuf = nullptr;
   long long wt_net[4] = {};   // offsets of actor | target actor | critic 0 | target critic 0 inside wt
@@ -966,6 +967,9 @@ int build(gcrl_agent* a) {
     // fused form leaves CUs idle, i.e. up to ~one workgroup per CU per role pair
     a->split_roles = a->rowchain && c.kind == GCRL_AGENT_SAC && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) <= 256 &&
                      !std::getenv("GCRL_NO_SPLIT_ROLES");
+    for (int i = 0; i < 4; ++i) a->split_rg[i] = a->row_rg;
+    if (const char* e = std::getenv("GCRL_SPLIT_RG"))   // experiment knob: four digits, rows/4 per workgroup of the four launches
+      for (int i = 0; i < 4 && e[i]; ++i) a->split_rg[i] = e[i] - '0';
   }
   long long total = 0;
   for (auto& w : wants) total += align_up(w.second, 64);

@@ -26,14 +26,15 @@ pass write WRITE_SIZE
 pass l2 TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum
 pass l1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_GATE_EN1_sum
 cd $GRAFT_REPO_ROOT
-python3 - "$out" <<'PY'
+wl=$(echo "$BENCH_ARGS" | sed -n 's/.*--workload \([a-z0-9_]*\).*/\1/p'); wl=${wl:-ddpg_pickplace_b256}
+python3 - "$out" "$wl" <<'PY'
 import collections, csv, glob, json, sys
-out = sys.argv[1]
+out, BENCH_WORKLOAD = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(collections.Counter)
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-56:]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").replace("gcrl::", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
 res = {}
@@ -46,6 +47,11 @@ for k in acc:
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:   # KB per launch
         d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
     res[k] = d
+for k, d in res.items():
+    if "her_gather_update" in k:   # bench.py scales the per-row figure to its own launch size: one launch gathers 40 batches
+        import re
+        m = re.search(r"--workload (\w+)", open(glob.glob(out + "/fetch.log")[0]).read()) if glob.glob(out + "/fetch.log") else None
+        d["rows_per_launch"] = 40 * {"ddpg_pickplace_b256": 256, "td3_pickplace_b2048": 2048, "ddpg_reach_b1024": 1024, "sac_slide_b512": 512, "tqc_push_b2048": 2048}.get(BENCH_WORKLOAD, 256)
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch_corrected", 0)):
     print(k, {c: round(v, 1) for c, v in d.items()})
