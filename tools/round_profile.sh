@@ -20,8 +20,10 @@ for w in ddpg_pickplace_b256 td3_pickplace_b2048 sac_slide_b512 tqc_push_b2048; 
   rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_$w -o p -- python3 $root/bench.py --no-cpu-baseline --workload $w --steps 2000 --warmup 200 > $root/$out/prof_$w.log 2>&1
 done
 cd $root
+find $out -name "*kernel_trace.csv" -delete      # tens of MB each; the stats summaries are what is kept
 for w in ddpg_pickplace_b256 td3_pickplace_b2048; do
   GRAFT_REPO_ROOT=$root bash tools/pmc_traffic.sh $tag/pmc_$w --workload $w > $out/pmc_$w.log 2>&1
 done
+find $out -name "*counter_collection.csv" -delete; find $out -name "*kernel_trace.csv" -delete
 cut -c1-260 $out/bench_driver_cmd.json
 cut -c1-260 $out/bench_default.json
