@@ -960,6 +960,7 @@ int build(gcrl_agent* a) {
     const int phases = c.kind == GCRL_AGENT_DDPG ? 2 : 1;
     a->row_rg = 1;
     while (a->row_rg < 4 && phases * ((B + 4 * a->row_rg - 1) / (4 * a->row_rg)) > 256) a->row_rg *= 2;
+    if (const char* e = std::getenv("GCRL_ROW_RG")) a->row_rg = std::max(1, std::min(4, std::atoi(e)));   // experiment knob
     a->rowchain = (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3 || c.kind == GCRL_AGENT_SAC) && H % 4 == 0 &&
                   c.pipeline_steps >= 2 &&
                   rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H, C) <= 160 * 1024;

@@ -34,7 +34,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(collections.Counter)
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").replace("gcrl::", "")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("gcrl::", "").split("(")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
 res = {}
@@ -56,3 +56,4 @@ json.dump(res, open(out + "/summary.json", "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch_corrected", 0)):
     print(k, {c: round(v, 1) for c, v in d.items()})
 PY
+find $out -name "*counter_collection.csv" -delete; find $out -name "*kernel_trace.csv" -delete
