@@ -416,8 +416,9 @@ def main():
                                 "timing": "device wall clock inside the kernel (last block end - first block start = rocprofv3's "
                                           "kernel duration), separate untimed leg of 10 trainer cycles",
                                 "hip_event_us": avg_us, "achieved_hip_event": achieved,
-                                "note": "one launch per trainer cycle gathers gradient_step x B rows; below ~1e5 rows the launch is "
-                                        "latency-bound (DESIGN.md §4)"},
+                                "note": "a trainer cycle's main gather (gradient_step - 1 batches; batch 0 travels in a small head launch so "
+                                        "that step 0 starts while the host draws the rest); below ~1e5 rows the launch is latency-bound "
+                                        "(DESIGN.md §4)"},
             "update_flops": {"gflop_per_step": flops_per_step(w) / 1e9,
                              "achieved_tflops": flops_per_step(w) * args.steps / elapsed / 1e12,
                              "peak_tflops": FP32_MFMA_PEAK_TF},

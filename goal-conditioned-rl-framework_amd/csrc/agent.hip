@@ -157,6 +157,9 @@ struct gcrl_agent {
   double lr_actor = 0, lr_critic = 0;
   uint64_t rng_ctr = 0;
   int pending_variant = 0;  // variant of the step whose phases are being issued one by one
+  // update_n: batches 1..n-1 are drawn / uploaded / gathered AFTER the first step's launches have been issued (the host
+  // draws ~2 us per batch from the MT stream: with all n batches up front the GPU idled ~40 us at the start of a cycle)
+  struct { gcrl_her* her = nullptr; int n = 0; int slot = 0; } deferred;
   std::vector<StepPlan> dp_plans;  // steps of the data-parallel cycle begun by gcrl_agent_dp_begin
   std::vector<DpSeg> dp_segs;      // ... as segments separated by gradient exchanges
   size_t dp_pos = 0;
@@ -389,6 +392,7 @@ int sac_actor_forwards(gcrl_agent* a, hipStream_t st, int variant, bool with_cur
 enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32, V_FUSED_NORM = 64, V_WEIGHTS = 128 };
 
 int adam_common(gcrl_agent* a, AdamArgs& ad);
+int finish_deferred_draw(gcrl_agent* a, hipStream_t st);
 
 int sac_actor_forwards(gcrl_agent* a, hipStream_t st, int variant, bool with_cur, Launches* extra) {
   const int S = a->S;
@@ -818,8 +822,22 @@ int stage_injected(gcrl_agent* a, const gcrl_update_inputs* in, hipStream_t st, 
 }
 
 // phase-0 entry of `n` steps: control table + indices upload, batch gather / pack
+int finish_deferred_draw(gcrl_agent* a, hipStream_t st) {
+  gcrl_her* her = a->deferred.her;
+  if (!her) return GCRL_OK;
+  a->deferred.her = nullptr;
+  const int n = a->deferred.n, B = a->B;
+  uint32_t* idx = (uint32_t*)(a->upload_pinned[a->deferred.slot] + sizeof(UploadBlock));
+  for (int i = 1; i < n; ++i) TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)B, idx + (size_t)i * B));
+  GCRL_HIP(hipMemcpyAsync(a->idx_dev() + B, idx + B, (size_t)(n - 1) * B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  GCRL_HIP(hipEventRecord(a->upload_ev[a->deferred.slot], st));
+  return her_gather_update(her, a->idx_dev() + B, (int64_t)(n - 1) * B, a->sa + a->slot_x, a->nsa + a->slot_x,
+                           a->rowchain ? nullptr : a->spa + a->slot_x, a->ldx, a->rbuf + a->slot_rd, a->dbuf + a->slot_rd, st);
+}
+
 int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_update_inputs* in, float grad_scale,
-               hipStream_t st, std::vector<StepPlan>& plans, int64_t* tickets, int32_t* lens) {
+               hipStream_t st, std::vector<StepPlan>& plans, int64_t* tickets, int32_t* lens, bool defer_rest = false) {
+  TRY(finish_deferred_draw(a, st));   // (never pending here; cheap safety)
   GCRL_CHECK_ARG(n >= 1 && n <= kMaxStepsPerCall && n <= a->Mmax, "update: n=%d steps per call (max %d)", n, std::min(kMaxStepsPerCall, a->Mmax));
   const bool injected = in && in->s_dev;
   GCRL_CHECK_ARG(injected || her, "update: neither a replay ring nor an injected batch was given");
@@ -854,10 +872,13 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
     }
     bytes += (size_t)a->B * sizeof(uint32_t);
   } else if (!injected && !device_rng) {
-    for (int i = 0; i < n; ++i)
+    defer_rest = defer_rest && n > 1;
+    const int now = defer_rest ? 1 : n;      // same MT stream order either way: batch 0 first, then 1..n-1
+    for (int i = 0; i < now; ++i)
       TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)a->B, idx + (size_t)i * a->B));
-    bytes += (size_t)n * a->B * sizeof(uint32_t);
-  }
+    bytes += (size_t)now * a->B * sizeof(uint32_t);
+    if (defer_rest) { a->deferred.her = her; a->deferred.n = n; a->deferred.slot = slot; }
+  } else defer_rest = false;
   if (device_rng && !explicit_idx) {   // the gather kernel computes the indices itself: nothing to draw or upload here
     her->last_gen = IdxGen{her->cfg.seed, her->draws_done, (uint32_t)her->len, a->B, feistel_half_bits((uint32_t)her->len)};
     her->draws_done += n;
@@ -865,7 +886,8 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
   GCRL_HIP(hipMemcpyAsync(a->upload_dev, ub, bytes, hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(a->upload_ev[slot], st));
   if (!injected)
-    TRY(her_gather_update(her, (device_rng && !explicit_idx) ? nullptr : a->idx_dev(), (int64_t)n * a->B, a->sa, a->nsa, a->rowchain ? nullptr : a->spa, a->ldx, a->rbuf, a->dbuf, st));
+    TRY(her_gather_update(her, (device_rng && !explicit_idx) ? nullptr : a->idx_dev(), (int64_t)(a->deferred.her ? 1 : n) * a->B, a->sa, a->nsa,
+                          a->rowchain ? nullptr : a->spa, a->ldx, a->rbuf, a->dbuf, st));
   return GCRL_OK;
 }
 
@@ -1331,15 +1353,19 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
     const int m = std::min(chunk, n - done);
     std::vector<StepPlan> plans;
     TRY(begin_call(a, her, step0 + done, m, nullptr, 1.0f, st, plans, tickets_out ? tickets_out + done : nullptr,
-                   lens_out ? lens_out + done : nullptr));
+                   lens_out ? lens_out + done : nullptr, /*defer_rest=*/true));
     if (a->cfg.kind == GCRL_AGENT_DDPG && a->cfg.pipeline_steps != 0) {
       // plain actor steps overlap pairwise: P(i) shares its launches with K(i+1)
       std::vector<int> variants(m);
       for (int i = 0; i < m; ++i) variants[i] = plans[i].variant;
       TRY(run_steps_ddpg(a, st, variants.data(), m));
     } else {
-      for (int i = 0; i < m; ++i) TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM, 7));
+      for (int i = 0; i < m; ++i) {
+        TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM, 7));
+        if (i == 0) TRY(finish_deferred_draw(a, st));   // step 0 is in flight: now draw and gather batches 1..m-1
+      }
     }
+    TRY(finish_deferred_draw(a, st));
     TRY(end_call(a, st));
   }
   return GCRL_OK;

@@ -124,6 +124,8 @@ struct gcrl_her {
   // gather-launch timing (gcrl_her_profile_*)
   bool prof = false;
   std::vector<hipEvent_t> prof_a, prof_b;
+  std::vector<int64_t> prof_pair_rows;   // rows of each pending bracketed launch
+  int64_t prof_class_rows = 0;           // statistics are kept for the LARGEST launch size seen (a cycle's main gather)
   size_t prof_used = 0;
   int64_t prof_launches = 0, prof_rows = 0;
   double prof_ms = 0.0, prof_clk_ticks = 0.0;

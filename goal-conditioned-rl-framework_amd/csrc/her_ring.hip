@@ -411,17 +411,23 @@ constexpr size_t kProfPairs = 256;
 
 int prof_drain(gcrl_her* h) {
   if (h->prof_used == 0) return GCRL_OK;
+  // device-clock view of the same launches: max block end - min block start
+  std::vector<unsigned long long> clk(2 * h->prof_used);
+  GCRL_HIP(hipMemcpy(clk.data(), h->prof_clk, clk.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < h->prof_used; ++i) {
     float ms = 0.f;
     GCRL_HIP(hipEventSynchronize(h->prof_b[i]));
     GCRL_HIP(hipEventElapsedTime(&ms, h->prof_a[i], h->prof_b[i]));
+    const int64_t rows = h->prof_pair_rows[i];
+    // a trainer cycle issues a 1-batch head launch (so that step 0 starts early) and the main gather of the other
+    // batches: the statistics describe the largest launch size seen
+    if (rows > h->prof_class_rows) { h->prof_class_rows = rows; h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0; h->prof_clk_ticks = 0.0; }
+    if (rows != h->prof_class_rows) continue;
+    h->prof_launches++;
+    h->prof_rows += rows;
     h->prof_ms += ms;
-  }
-  // device-clock view of the same launches: max block end - min block start
-  std::vector<unsigned long long> clk(2 * h->prof_used);
-  GCRL_HIP(hipMemcpy(clk.data(), h->prof_clk, clk.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < h->prof_used; ++i)
     if (clk[2 * i + 1] > clk[2 * i]) h->prof_clk_ticks += (double)(clk[2 * i + 1] - clk[2 * i]);
+  }
   h->prof_used = 0;
   return GCRL_OK;
 }
@@ -438,9 +444,8 @@ unsigned long long* prof_slot(gcrl_her* h) { return h->prof ? h->prof_clk + 2 * 
 int prof_end(gcrl_her* h, hipStream_t st, int64_t rows) {
   if (!h->prof) return GCRL_OK;
   GCRL_HIP(hipEventRecord(h->prof_b[h->prof_used], st));
+  h->prof_pair_rows[h->prof_used] = rows;
   h->prof_used++;
-  h->prof_launches++;
-  h->prof_rows += rows;
   return GCRL_OK;
 }
 
@@ -919,6 +924,7 @@ int gcrl_her_profile_enable(gcrl_her* h, int on) {
   if (on && h->prof_a.empty()) {
     h->prof_a.resize(kProfPairs);
     h->prof_b.resize(kProfPairs);
+    h->prof_pair_rows.assign(kProfPairs, 0);
     for (size_t i = 0; i < kProfPairs; ++i) {
       GCRL_HIP(hipEventCreate(&h->prof_a[i]));
       GCRL_HIP(hipEventCreate(&h->prof_b[i]));
@@ -930,7 +936,7 @@ int gcrl_her_profile_enable(gcrl_her* h, int on) {
   }
   if (int rc = prof_drain(h)) return rc;
   h->prof = on != 0;
-  h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0; h->prof_clk_ticks = 0.0;
+  h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0; h->prof_clk_ticks = 0.0; h->prof_class_rows = 0;
   return GCRL_OK;
 }
 

@@ -171,7 +171,8 @@ int gcrl_her_sample(gcrl_her* h, int B, int M, const uint32_t* idx_host,
 
 /* Measurement: when enabled, every gather launch of this ring (gcrl_her_sample and the update
  * engine's batch gather) is bracketed by two hipEvents on the stream it is launched on.
- * gcrl_her_profile_read waits for the pending events and returns, since enabling, the number
+ * gcrl_her_profile_read waits for the pending events and returns, since enabling, for the LARGEST launch size seen (a
+ * trainer cycle's main gather; the one-batch head launch that lets step 0 start early is not counted), the number
  * of gather launches, their summed hipEvent time (ms, includes the event/dispatch overhead of a
  * bracketed launch), the rows they gathered, and the summed in-kernel time by the device
  * wall clock (last block end - first block start; what rocprofv3's kernel duration measures). */
