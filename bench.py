@@ -356,27 +356,39 @@ def main():
 
         legs = {}
         if world > 1 and not args.no_extra_legs:
-            # strong scaling: the metric's batch of B rows split over the ranks (B/N rows each), same ring size
-            if w["B"] % world == 0:
+            # the extra legs must never cost the headline line: a failure is recorded, not raised (all ranks run the same
+            # code, so they fail or succeed together)
+            def leg(name, fn):
+                try:
+                    legs[name] = fn()
+                except Exception as e:   # noqa: BLE001
+                    legs[name] = dict(error=f"{type(e).__name__}: {e}"[:400])
+
+            def strong():
+                # strong scaling: the metric's batch of B rows split over the ranks (B/N rows each), same ring size
                 ag_s, _, _ = build_agent(w, args, rank, local_rank, batch=w["B"] // world)
                 dp_s = DataParallelUpdater(ag_s)
-                el_s, _, _, _ = timed_region(ag_s, dp_s, w, max(gstep, min(args.steps, 10 * gstep)), min(args.warmup, 2 * gstep))
                 n_s = max(gstep, min(args.steps, 10 * gstep))
-                legs["strong_scaling"] = dict(global_batch=w["B"], batch_per_gpu=w["B"] // world, steps=n_s,
-                                              value=n_s / el_s, unit="gradient-steps/s", ms_per_step=1e3 * el_s / n_s,
-                                              note="fixed global batch: a latency-bound chain of 256-wide layers does not get "
-                                                   "shorter with fewer rows per GPU, and gains two exchanges (DESIGN.md §6)")
-                del dp_s, ag_s
-            # BASELINE cfg 5: SAC Slide, B=512 per GPU, 64 env streams over the ranks
-            w5 = WORKLOADS["sac_slide_b512"]
-            ag5, _, _ = build_agent(w5, args, rank, local_rank)
-            dp5 = DataParallelUpdater(ag5)
-            n5 = max(w5["gstep"], min(args.steps, 5 * w5["gstep"]))
-            el5, _, _, _ = timed_region(ag5, dp5, w5, n5, min(args.warmup, 2 * w5["gstep"]))
-            legs["cfg5_sac_slide_b512"] = dict(batch_per_gpu=w5["B"], steps=n5, sync_optimizer_steps_per_s=n5 / el5,
-                                               value=world * n5 / el5, unit="gradient-steps/s (batch-512 equivalents)",
-                                               ms_per_step=1e3 * el5 / n5, batchnorm="local statistics per rank (DESIGN.md §6)")
-            del dp5, ag5
+                el_s, _, _, _ = timed_region(ag_s, dp_s, w, n_s, min(args.warmup, 2 * gstep))
+                return dict(global_batch=w["B"], batch_per_gpu=w["B"] // world, steps=n_s, value=n_s / el_s, unit="gradient-steps/s",
+                            ms_per_step=1e3 * el_s / n_s,
+                            note="fixed global batch: a latency-bound chain of 256-wide layers does not get shorter with fewer rows "
+                                 "per GPU, and gains two exchanges (DESIGN.md §7)")
+
+            def cfg5():
+                # BASELINE cfg 5: SAC Slide, B=512 per GPU, 64 env streams over the ranks
+                w5 = WORKLOADS["sac_slide_b512"]
+                ag5, _, _ = build_agent(w5, args, rank, local_rank)
+                dp5 = DataParallelUpdater(ag5)
+                n5 = max(w5["gstep"], min(args.steps, 5 * w5["gstep"]))
+                el5, _, _, _ = timed_region(ag5, dp5, w5, n5, min(args.warmup, 2 * w5["gstep"]))
+                return dict(batch_per_gpu=w5["B"], steps=n5, sync_optimizer_steps_per_s=n5 / el5, value=world * n5 / el5,
+                            unit="gradient-steps/s (batch-512 equivalents)", ms_per_step=1e3 * el5 / n5,
+                            batchnorm="local statistics per rank (DESIGN.md §7)")
+
+            if w["B"] % world == 0:
+                leg("strong_scaling", strong)
+            leg("cfg5_sac_slide_b512", cfg5)
 
     if rank == 0:
         R = (2 * w["S"] + w["A"] + 2) * 4

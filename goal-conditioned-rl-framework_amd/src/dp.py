@@ -92,12 +92,23 @@ class DataParallelUpdater:
             # the librccl PyTorch itself uses (two RCCL / HIP runtime copies in one process do not mix)
             path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
             uid = (C.c_uint8 * 128)()
+            ok = 1
             if dist.get_rank(group) == 0:
-                _ffi.check(lib.gcrl_dp_unique_id(uid, path))
-            box = [bytes(uid)]
+                ok = 1 if lib.gcrl_dp_unique_id(uid, path) == 0 else 0
+            box = [bytes(uid), ok]
             dist.broadcast_object_list(box, src=0, group=group)
-            self._native = _ffi.check_ptr(lib.gcrl_dp_create(dist.get_rank(group), self.world, box[0], agent.device_index, path),
-                                          "gcrl_dp_create")
+            h = lib.gcrl_dp_create(dist.get_rank(group), self.world, box[0], agent.device_index, path) if box[1] else None
+            # every rank must take the same path: the in-engine exchange only if ALL ranks got their communicator
+            good = torch.tensor([1 if h else 0], device="cuda")
+            dist.all_reduce(good, op=dist.ReduceOp.MIN, group=group)
+            if int(good.item()):
+                self._native = h
+            else:
+                import warnings
+                warnings.warn("gcrl_amd.dp: in-engine RCCL communicator unavailable (" + _ffi.last_error() +
+                              "); exchanging gradients through torch.distributed instead")
+                if h:
+                    lib.gcrl_dp_destroy(h)
         for phase in (0, 1):
             p, n = C.c_void_p(), C.c_int64()
             _ffi.check(lib.gcrl_agent_grad_ptr(agent._h, phase, C.byref(p), C.byref(n)))
