@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgcrl_hip.so")
+# GCRL_HIP_LIB: development knob (A/B builds of the same library); the default is the in-tree build
+LIB_PATH = os.environ.get("GCRL_HIP_LIB") or os.path.join(_HERE, "libgcrl_hip.so")
 
 STREAM_LEGACY = 1  # GCRL_STREAM_LEGACY
 
