@@ -661,9 +661,9 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     for (int l = L - 1; l >= 0; --l) {
       const float* dh = l == L - 1 ? a->gA[0] : a->gA[(l + 1) & 1];
       // (dh for layer l<L-1 was written by the dX of layer l+1 into gA[(l+1)&1])
-      TRY(launch_bn_relu_bwd(st, dh, l == L - 1 ? a->dh2 : nullptr, a->hA_at(l), a->xhatA + (long long)l * B * H,
-                             a->invstdA + (long long)l * H, Pa + a->actor.bn_g[l], B, H, a->zA, Ga + a->actor.bn_g[l],
-                             Ga + a->actor.bn_b[l], a->bn_part));
+      TRY(launch_bn_relu_bwd(st, dh, l == L - 1 ? a->dh2 : nullptr, a->xhatA + (long long)l * B * H,
+                             a->invstdA + (long long)l * H, Pa + a->actor.bn_g[l], Pa + a->actor.bn_b[l], B, H, a->zA,
+                             Ga + a->actor.bn_g[l], Ga + a->actor.bn_b[l], a->bn_part));
       std::vector<GemmDesc> v;
       GemmDesc dw = bwd_dw(a->zA, H, l == 0 ? (a->rowchain ? a->sa : a->spa) : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }

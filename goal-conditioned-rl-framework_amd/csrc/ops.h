@@ -173,9 +173,9 @@ int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const floa
                         const float* beta, const float* running_mean, const float* running_var,
                         float* h);
 // backward of BN(train)+ReLU: dh -> dz, dgamma, dbeta
-int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* h, const float* xhat,
-                       const float* invstd, const float* gamma, int B, int H, float* dz,
-                       float* dgamma, float* dbeta, float* scratch);
+int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* xhat, const float* invstd,
+                       const float* gamma, const float* beta, int B, int H, float* dz, float* dgamma, float* dbeta,
+                       float* scratch);
 
 // SACActorModel.sample (src/model.py:125-141): mean/log_std head outputs -> action + log-prob.
 struct TanhGaussArgs {

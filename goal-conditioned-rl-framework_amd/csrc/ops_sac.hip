@@ -5,6 +5,7 @@
 //   log-alpha AdamW step                            src/agent.py:532-546, :936-949
 //   wavefront bitonic sort + truncated mean         generalisation of src/agent.py:919-921
 #include "ops.h"
+#include "gemm_mfma.h"   // v4f
 
 #include <algorithm>
 #include <cmath>
@@ -45,68 +46,100 @@ __device__ inline float hash_normal(unsigned long long seed, unsigned long long 
 // per 64 features left 252 of 256 CUs idle and serialised over the batch):
 //   stage 1  grid (H/64, B/64): block (cb, rb) reduces its 64 rows x 64 columns to a per-column
 //            partial — forward: (mean_b, M2_b) by a local two-pass; backward: (sum dy, sum dy*xhat)
-//   stage 2  grid (H/64, B/64): every block merges the <= B/64 partials of its columns in the same
-//            fixed order (Chan's parallel-variance merge / plain sums), then transforms its rows.
-// A block = 64 columns x 4 row groups of 16 rows; every wave-load is one coalesced 256-B row segment.
+//   stage 2  grid (H/64, B/16): every block merges the <= B/64 partials of its columns in the same
+//            fixed order (Chan's parallel-variance merge / plain sums), then transforms its 16 rows.
+// Thread layout: 16 column quads (one float4 = 4 columns per lane) x 16 row slots, so a wave-load moves four
+// 256-B row segments.  These kernels move 0.5-2 MB and are nothing but memory round trips; what a launch costs
+// is the number of vector-memory instructions a CU has to issue (64 in flight, ~1 us per batch of 64): with
+// one column per lane the apply kernels issued 80 loads per thread — 16 rows + 64 row-block partials that all
+// 64 blocks re-read lane by lane — and took 11.5 us (profiles/r02_kernel_stats_sac_slide_b512.csv).  Now a
+// thread issues 4-6 float4 loads: its row(s), the affine pair, and ONE slice of the partials, which the block
+// gathers cooperatively into LDS before every thread merges them.
 // (Measured alternatives, both slower at B = 512 / H = 256: one launch with a block owning 16 columns and all
 // rows — 16 blocks, 2 695 vs 2 773 SAC steps/s; one launch on this grid with every block re-reducing its
 // columns over all rows — 128 dependent-latency loads per thread, 2 176 steps/s.)
-constexpr int kBnRows = 64;
+constexpr int kBnRows = 64;      // rows per partial
+constexpr int kBnSlots = 16;     // row slots of a block (256 threads / 16 column quads)
+constexpr int kBnMaxPart = 32;   // row-block partials gathered through LDS (B <= 2048); more are read from memory in the merge loop
 
-__device__ inline float col_sum4(float v, float (*red)[64], int cl, int rg) {
+__device__ inline v4f ld4(const float* p) { return *(const v4f*)p; }
+__device__ inline v4f zero4() { return (v4f){0.f, 0.f, 0.f, 0.f}; }
+
+// sum over the block's 16 row slots for every column quad (all threads get the result; same order everywhere)
+__device__ inline v4f slot_sum(v4f v, v4f (*red)[16], int cq, int slot) {
   __syncthreads();
-  red[rg][cl] = v;
+  red[slot][cq] = v;
   __syncthreads();
-  return red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+  v4f s = red[0][cq];
+#pragma unroll
+  for (int i = 1; i < kBnSlots; ++i) s += red[i][cq];
+  return s;
 }
 
-// Every thread owns kBnPer = 16 rows of one column (rows r0 + rg + 4 i).  All of a thread's operands are requested
-// before the first one is used: these kernels move 0.5 MB and are nothing but memory round trips — with the loads
-// inside the accumulation loops they were 16-32 DEPENDENT round trips long (6-10 us per launch, profiles/r02e).
-constexpr int kBnPer = kBnRows / 4;
+// the block's slice of two partial arrays [nrb][H] (its 64 columns) -> LDS sp[2][kBnMaxPart][16]; two phases so that
+// the caller's other loads are requested between `gather_request` and `gather_store`
+struct PartRegs { v4f a[2], b[2]; };
+__device__ inline void gather_request(PartRegs& r, const float* pa, const float* pb, int nrb, int H, int col0) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int it = threadIdx.x + 256 * u, rb = it >> 4, c = col0 + 4 * (it & 15);
+    const bool in = rb < nrb && rb < kBnMaxPart && c < H;
+    r.a[u] = in ? ld4(pa + (long long)rb * H + c) : zero4();
+    r.b[u] = in ? ld4(pb + (long long)rb * H + c) : zero4();
+  }
+}
+__device__ inline void gather_store(const PartRegs& r, v4f (*sp)[kBnMaxPart][16]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int it = threadIdx.x + 256 * u, rb = it >> 4;
+    if (rb < kBnMaxPart) { sp[0][rb][it & 15] = r.a[u]; sp[1][rb][it & 15] = r.b[u]; }
+  }
+  __syncthreads();
+}
 
 struct BnFwdPair { BnFwdProb p[2]; int n; };
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(BnFwdPair pr, int B, int H) {
-  __shared__ float red[4][64];
+  __shared__ v4f red[kBnSlots][16];
   const float* __restrict__ z = pr.p[blockIdx.z].z;
   const int nrb_ = (B + kBnRows - 1) / kBnRows;
   float* __restrict__ part_mean = pr.p[blockIdx.z].scratch;
   float* __restrict__ part_m2 = part_mean + (long long)nrb_ * H;
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
+  const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cq;
   const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
   const bool ok = col < H;
-  float v[kBnPer];
+  constexpr int NR = kBnRows / kBnSlots;
+  v4f v[NR];
 #pragma unroll
-  for (int i = 0; i < kBnPer; ++i) {
-    const int b = r0 + rg + 4 * i;
-    v[i] = (ok && b < r1) ? z[(long long)b * H + col] : 0.f;
+  for (int i = 0; i < NR; ++i) {
+    const int b = r0 + slot + kBnSlots * i;
+    v[i] = (ok && b < r1) ? ld4(z + (long long)b * H + col) : zero4();
   }
-  float s = 0.f;
+  v4f s = zero4();
 #pragma unroll
-  for (int i = 0; i < kBnPer; ++i) if (r0 + rg + 4 * i < r1) s += v[i];
-  const float mean = col_sum4(s, red, cl, rg) / (float)(r1 - r0);
-  float q = 0.f;
+  for (int i = 0; i < NR; ++i) if (r0 + slot + kBnSlots * i < r1) s += v[i];
+  const v4f mean = slot_sum(s, red, cq, slot) / (float)(r1 - r0);
+  v4f q = zero4();
 #pragma unroll
-  for (int i = 0; i < kBnPer; ++i) if (r0 + rg + 4 * i < r1) { const float df = v[i] - mean; q += df * df; }
-  const float m2 = col_sum4(q, red, cl, rg);
-  if (ok && rg == 0) {
-    part_mean[(long long)blockIdx.y * H + col] = mean;
-    part_m2[(long long)blockIdx.y * H + col] = m2;
+  for (int i = 0; i < NR; ++i) if (r0 + slot + kBnSlots * i < r1) { const v4f df = v[i] - mean; q += df * df; }
+  const v4f m2 = slot_sum(q, red, cq, slot);
+  if (ok && slot == 0) {
+    *(v4f*)(part_mean + (long long)blockIdx.y * H + col) = mean;
+    *(v4f*)(part_m2 + (long long)blockIdx.y * H + col) = m2;
   }
 }
 
-constexpr int kBnMaxPart = 32;   // row-block partials held in registers (B <= 2048); more fall back to a loop
-
-// Chan merge of a problem's row-block partials for one column (same order in every block) -> (mean, biased var)
-__device__ inline void bn_merge(const float* part_mean, const float* part_m2, int nrb, int B, int H, int col, float* mean_out,
-                                float* var_out) {
-  float n = 0.f, mean = 0.f, m2 = 0.f;
+// Chan merge of a problem's row-block partials for one column quad (same order in every block) -> (mean, biased var)
+template <typename PM, typename PQ>
+__device__ inline void bn_merge4(PM pm, PQ pq, int nrb, int B, v4f* mean_out, v4f* var_out) {
+  float n = 0.f;
+  v4f mean = zero4(), m2 = zero4();
   for (int rb = 0; rb < nrb; ++rb) {
     const float nb = (float)(min(B, (rb + 1) * kBnRows) - rb * kBnRows);
-    const float mb = part_mean[(long long)rb * H + col], qb = part_m2[(long long)rb * H + col];
-    const float delta = mb - mean, tot = n + nb;
+    const v4f mb = pm(rb), qb = pq(rb);
+    const v4f delta = mb - mean;
+    const float tot = n + nb;
     mean += delta * (nb / tot);
     m2 += qb + delta * delta * (n * nb / tot);
     n = tot;
@@ -116,69 +149,56 @@ __device__ inline void bn_merge(const float* part_mean, const float* part_m2, in
 
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B, int H, const float* gamma, const float* beta,
                                                             float* rmean, float* rvar) {
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
-  if (col >= H) return;
+  __shared__ v4f sp[2][kBnMaxPart][16];
+  const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cq;
+  const bool ok = col < H;
   const int nrb = (B + kBnRows - 1) / kBnRows;
   const BnFwdProb me = pr.p[blockIdx.z];
   const float* __restrict__ z = me.z;
   const float* __restrict__ part_mean = me.scratch;
   const float* __restrict__ part_m2 = me.scratch + (long long)nrb * H;
-  float* __restrict__ h = me.h;
-  float* xhat = me.xhat;
-  float* invstd_out = me.invstd;
-  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
-  // request everything first: the partials, the affine pair, this thread's rows
-  float pm[kBnMaxPart], pq[kBnMaxPart], v[kBnPer];
+  const int b = blockIdx.y * kBnSlots + slot;
+  // request everything first: the partials' slice, the affine pair, this thread's row
+  PartRegs prg;
+  gather_request(prg, part_mean, part_m2, nrb, H, blockIdx.x * 64);
+  const v4f g = ok ? ld4(gamma + col) : zero4(), bt = ok ? ld4(beta + col) : zero4();
+  const v4f v = (ok && b < B) ? ld4(z + (long long)b * H + col) : zero4();
+  gather_store(prg, sp);
+  v4f mean, var;
+  bn_merge4([&](int rb) { return rb < kBnMaxPart ? sp[0][rb][cq] : (ok ? ld4(part_mean + (long long)rb * H + col) : zero4()); },
+            [&](int rb) { return rb < kBnMaxPart ? sp[1][rb][cq] : (ok ? ld4(part_m2 + (long long)rb * H + col) : zero4()); },
+            nrb, B, &mean, &var);   // biased variance: what normalises the batch
+  v4f invstd;
 #pragma unroll
-  for (int rb = 0; rb < kBnMaxPart; ++rb) {
-    pm[rb] = rb < nrb ? part_mean[(long long)rb * H + col] : 0.f;
-    pq[rb] = rb < nrb ? part_m2[(long long)rb * H + col] : 0.f;
-  }
-  const float g = gamma[col], bt = beta[col];
+  for (int q = 0; q < 4; ++q) invstd[q] = 1.0f / sqrtf(var[q] + kBnEps);
+  if (ok && b < B) {
+    const long long idx = (long long)b * H + col;
+    const v4f xh = (v - mean) * invstd;
+    const v4f y = xh * g + bt;
+    v4f hv;
 #pragma unroll
-  for (int i = 0; i < kBnPer; ++i) {
-    const int b = r0 + rg + 4 * i;
-    v[i] = b < r1 ? z[(long long)b * H + col] : 0.f;
+    for (int q = 0; q < 4; ++q) hv[q] = y[q] > 0.f ? y[q] : 0.f;
+    *(v4f*)(me.h + idx) = hv;
+    if (me.xhat) *(v4f*)(me.xhat + idx) = xh;
   }
-  // merge the row-block partials (Chan et al.), same order in every block
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int rb = 0; rb < nrb; ++rb) {
-    const float nb = (float)(min(B, (rb + 1) * kBnRows) - rb * kBnRows);
-    const float mb = rb < kBnMaxPart ? pm[rb] : part_mean[(long long)rb * H + col];
-    const float qb = rb < kBnMaxPart ? pq[rb] : part_m2[(long long)rb * H + col];
-    const float delta = mb - mean, tot = n + nb;
-    mean += delta * (nb / tot);
-    m2 += qb + delta * delta * (n * nb / tot);
-    n = tot;
-  }
-  const float var = m2 / (float)B;  // biased: what normalises the batch
-  const float invstd = 1.0f / sqrtf(var + kBnEps);
-#pragma unroll
-  for (int i = 0; i < kBnPer; ++i) {
-    const int b = r0 + rg + 4 * i;
-    if (b < r1) {
-      const long long idx = (long long)b * H + col;
-      const float xh = (v[i] - mean) * invstd;
-      const float y = xh * g + bt;
-      h[idx] = y > 0.f ? y : 0.f;
-      if (xhat) xhat[idx] = xh;
-    }
-  }
-  if (blockIdx.y == 0 && rg == 0) {
-    if (invstd_out) invstd_out[col] = invstd;
+  if (ok && blockIdx.y == 0 && slot == 0) {
+    if (me.invstd) *(v4f*)(me.invstd + col) = invstd;
     if (blockIdx.z == 0) {   // running statistics: problem 0's batch, then problem 1's (two forward calls, in that order)
       const float ub = B > 1 ? (float)B / (float)(B - 1) : 1.0f;
-      float rm = (1.0f - kBnMomentum) * rmean[col] + kBnMomentum * mean;
-      float rv = (1.0f - kBnMomentum) * rvar[col] + kBnMomentum * (var * ub);
+      v4f rm = (1.0f - kBnMomentum) * ld4(rmean + col) + kBnMomentum * mean;
+      v4f rv = (1.0f - kBnMomentum) * ld4(rvar + col) + kBnMomentum * (var * ub);
       if (pr.n > 1) {
-        float m1, v1;
-        bn_merge(pr.p[1].scratch, pr.p[1].scratch + (long long)nrb * H, nrb, B, H, col, &m1, &v1);
+        const float* pm1 = pr.p[1].scratch;
+        const float* pq1 = pm1 + (long long)nrb * H;
+        v4f m1, v1;
+        bn_merge4([&](int rb) { return ld4(pm1 + (long long)rb * H + col); }, [&](int rb) { return ld4(pq1 + (long long)rb * H + col); },
+                  nrb, B, &m1, &v1);
         rm = (1.0f - kBnMomentum) * rm + kBnMomentum * m1;
         rv = (1.0f - kBnMomentum) * rv + kBnMomentum * (v1 * ub);
       }
-      rmean[col] = rm;
-      rvar[col] = rv;
+      *(v4f*)(rmean + col) = rm;
+      *(v4f*)(rvar + col) = rv;
     }
   }
 }
@@ -192,86 +212,87 @@ __global__ void bn_relu_eval_kernel(const float* z, int B, int H, const float* g
   h[i] = y > 0.f ? y : 0.f;
 }
 
+// backward: dy = dh (+ dh2) where the forward's output was positive.  The mask is recomputed from xhat exactly as the
+// forward computed it (y = xhat*gamma + beta, the same two fp32 operations), so the saved h is not read again.
+__device__ inline v4f bn_dy(v4f dh, v4f xh, v4f g, v4f bt) {
+  const v4f y = xh * g + bt;
+  v4f dy;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dy[q] = y[q] > 0.f ? dh[q] : 0.f;
+  return dy;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dh, const float* __restrict__ dh2,
-                                                           const float* __restrict__ h, const float* __restrict__ xhat,
+                                                           const float* __restrict__ xhat, const float* gamma, const float* beta,
                                                            int B, int H, float* __restrict__ part_dy,
                                                            float* __restrict__ part_dyx) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
+  __shared__ v4f red[kBnSlots][16];
+  const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cq;
   const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
   const bool ok = col < H;
-  float vd[kBnPer], vd2[kBnPer], vh[kBnPer], vx[kBnPer];
+  constexpr int NR = kBnRows / kBnSlots;
+  v4f vd[NR], vd2[NR], vx[NR];
+  const v4f g = ok ? ld4(gamma + col) : zero4(), bt = ok ? ld4(beta + col) : zero4();
 #pragma unroll
-  for (int i = 0; i < kBnPer; ++i) {
-    const int b = r0 + rg + 4 * i;
+  for (int i = 0; i < NR; ++i) {
+    const int b = r0 + slot + kBnSlots * i;
     const bool in = ok && b < r1;
     const long long idx = (long long)b * H + col;
-    vd[i] = in ? dh[idx] : 0.f;
-    vd2[i] = (in && dh2) ? dh2[idx] : 0.f;
-    vh[i] = in ? h[idx] : 0.f;
-    vx[i] = in ? xhat[idx] : 0.f;
+    vd[i] = in ? ld4(dh + idx) : zero4();
+    vd2[i] = (in && dh2) ? ld4(dh2 + idx) : zero4();
+    vx[i] = in ? ld4(xhat + idx) : zero4();
   }
-  float s1 = 0.f, s2 = 0.f;
+  v4f s1 = zero4(), s2 = zero4();
 #pragma unroll
-  for (int i = 0; i < kBnPer; ++i) {
-    if (ok && r0 + rg + 4 * i < r1) {
-      const float dy = vh[i] > 0.f ? (dh2 ? vd[i] + vd2[i] : vd[i]) : 0.f;
+  for (int i = 0; i < NR; ++i) {
+    if (ok && r0 + slot + kBnSlots * i < r1) {
+      const v4f dy = bn_dy(dh2 ? vd[i] + vd2[i] : vd[i], vx[i], g, bt);
       s1 += dy;
       s2 += dy * vx[i];
     }
   }
-  const float sum_dy = col_sum4(s1, red, cl, rg);
-  const float sum_dyx = col_sum4(s2, red, cl, rg);
-  if (ok && rg == 0) {
-    part_dy[(long long)blockIdx.y * H + col] = sum_dy;
-    part_dyx[(long long)blockIdx.y * H + col] = sum_dyx;
+  const v4f sum_dy = slot_sum(s1, red, cq, slot);
+  const v4f sum_dyx = slot_sum(s2, red, cq, slot);
+  if (ok && slot == 0) {
+    *(v4f*)(part_dy + (long long)blockIdx.y * H + col) = sum_dy;
+    *(v4f*)(part_dyx + (long long)blockIdx.y * H + col) = sum_dyx;
   }
 }
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __restrict__ dh, const float* __restrict__ dh2,
-                                                                const float* __restrict__ h, const float* __restrict__ xhat,
-                                                                const float* invstd, const float* gamma,
+                                                                const float* __restrict__ xhat, const float* invstd,
+                                                                const float* gamma, const float* beta,
                                                                 const float* __restrict__ part_dy,
                                                                 const float* __restrict__ part_dyx, int B, int H,
                                                                 float* __restrict__ dz, float* dgamma, float* dbeta) {
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
-  if (col >= H) return;
+  __shared__ v4f sp[2][kBnMaxPart][16];
+  const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cq;
+  const bool ok = col < H;
   const int nrb = (B + kBnRows - 1) / kBnRows;
-  const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
-  float p1[kBnMaxPart], p2[kBnMaxPart], vd[kBnPer], vd2[kBnPer], vh[kBnPer], vx[kBnPer];
-#pragma unroll
-  for (int rb = 0; rb < kBnMaxPart; ++rb) {
-    p1[rb] = rb < nrb ? part_dy[(long long)rb * H + col] : 0.f;
-    p2[rb] = rb < nrb ? part_dyx[(long long)rb * H + col] : 0.f;
-  }
-  const float k = gamma[col] * invstd[col];
-#pragma unroll
-  for (int i = 0; i < kBnPer; ++i) {
-    const int b = r0 + rg + 4 * i;
-    const bool in = b < r1;
-    const long long idx = (long long)b * H + col;
-    vd[i] = in ? dh[idx] : 0.f;
-    vd2[i] = (in && dh2) ? dh2[idx] : 0.f;
-    vh[i] = in ? h[idx] : 0.f;
-    vx[i] = in ? xhat[idx] : 0.f;
-  }
-  float sum_dy = 0.f, sum_dyx = 0.f;
+  const int b = blockIdx.y * kBnSlots + slot;
+  const bool in = ok && b < B;
+  const long long idx = (long long)b * H + col;
+  PartRegs prg;
+  gather_request(prg, part_dy, part_dyx, nrb, H, blockIdx.x * 64);
+  const v4f g = ok ? ld4(gamma + col) : zero4(), bt = ok ? ld4(beta + col) : zero4(), is = ok ? ld4(invstd + col) : zero4();
+  const v4f vd = in ? ld4(dh + idx) : zero4();
+  const v4f vd2 = (in && dh2) ? ld4(dh2 + idx) : zero4();
+  const v4f vx = in ? ld4(xhat + idx) : zero4();
+  gather_store(prg, sp);
+  v4f sum_dy = zero4(), sum_dyx = zero4();
   for (int rb = 0; rb < nrb; ++rb) {
-    sum_dy += rb < kBnMaxPart ? p1[rb] : part_dy[(long long)rb * H + col];
-    sum_dyx += rb < kBnMaxPart ? p2[rb] : part_dyx[(long long)rb * H + col];
+    sum_dy += rb < kBnMaxPart ? sp[0][rb][cq] : (ok ? ld4(part_dy + (long long)rb * H + col) : zero4());
+    sum_dyx += rb < kBnMaxPart ? sp[1][rb][cq] : (ok ? ld4(part_dyx + (long long)rb * H + col) : zero4());
   }
-  const float m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B;
-#pragma unroll
-  for (int i = 0; i < kBnPer; ++i) {
-    const int b = r0 + rg + 4 * i;
-    if (b < r1) {
-      const float dy = vh[i] > 0.f ? (dh2 ? vd[i] + vd2[i] : vd[i]) : 0.f;
-      dz[(long long)b * H + col] = (dy - m1 - vx[i] * m2) * k;
-    }
+  const v4f k = g * is;
+  const v4f m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B;
+  if (in) {
+    const v4f dy = bn_dy(dh2 ? vd + vd2 : vd, vx, g, bt);
+    *(v4f*)(dz + idx) = (dy - m1 - vx * m2) * k;
   }
-  if (blockIdx.y == 0 && rg == 0) { dgamma[col] = sum_dyx; dbeta[col] = sum_dy; }
+  if (ok && blockIdx.y == 0 && slot == 0) { *(v4f*)(dgamma + col) = sum_dyx; *(v4f*)(dbeta + col) = sum_dy; }
 }
 
 __device__ inline void tanh_gauss_fwd_body(const TanhGaussArgs& a) {
@@ -576,6 +597,8 @@ int launch_quantile_actor(hipStream_t st, const QuantileActorArgs& a) {
   return GCRL_OK;
 }
 
+static inline bool bn_aligned(const void* p) { return ((unsigned long long)p & 15ull) == 0; }
+
 int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
                        const float* beta, float* h, float* xhat, float* invstd, float* rmean,
                        float* rvar, float* scratch) {
@@ -586,15 +609,18 @@ int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float
 int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, int B, int H, const float* gamma,
                              const float* beta, float* rmean, float* rvar) {
   GCRL_CHECK_ARG(nprob == 1 || nprob == 2, "bn_relu_fwd_multi: 1 or 2 problems");
+  GCRL_CHECK_ARG(H % 4 == 0 && bn_aligned(gamma) && bn_aligned(beta) && bn_aligned(rmean) && bn_aligned(rvar) &&
+                     bn_aligned(probs[0].z) && bn_aligned(probs[0].h) && bn_aligned(probs[0].scratch),
+                 "bn_relu_fwd: H must be a multiple of 4 and every operand 16-byte aligned (H=%d)", H);
   const int nrb = (B + kBnRows - 1) / kBnRows;
-  const dim3 grid((H + 63) / 64, nrb, nprob);
   BnFwdPair pr;
   pr.n = nprob;
   pr.p[0] = probs[0];
   pr.p[1] = nprob > 1 ? probs[1] : probs[0];
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, st, pr, B, H);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((H + 63) / 64, nrb, nprob), dim3(256), 0, st, pr, B, H);
   GCRL_HIP(hipGetLastError());
-  hipLaunchKernelGGL(bn_relu_apply_kernel, grid, dim3(256), 0, st, pr, B, H, gamma, beta, rmean, rvar);
+  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots - 1) / kBnSlots, nprob), dim3(256), 0, st, pr, B, H, gamma,
+                     beta, rmean, rvar);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
@@ -608,17 +634,20 @@ int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const floa
   return GCRL_OK;
 }
 
-int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* h, const float* xhat,
-                       const float* invstd, const float* gamma, int B, int H, float* dz,
-                       float* dgamma, float* dbeta, float* scratch) {
+int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* xhat, const float* invstd,
+                       const float* gamma, const float* beta, int B, int H, float* dz, float* dgamma, float* dbeta,
+                       float* scratch) {
+  GCRL_CHECK_ARG(H % 4 == 0 && bn_aligned(dh) && bn_aligned(dh2) && bn_aligned(xhat) && bn_aligned(invstd) && bn_aligned(gamma) &&
+                     bn_aligned(beta) && bn_aligned(dz) && bn_aligned(dgamma) && bn_aligned(dbeta) && bn_aligned(scratch),
+                 "bn_relu_bwd: H must be a multiple of 4 and every operand 16-byte aligned (H=%d)", H);
   const int nrb = (B + kBnRows - 1) / kBnRows;
-  const dim3 grid((H + 63) / 64, nrb);
   float* part_dy = scratch;
   float* part_dyx = scratch + (long long)nrb * H;
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, grid, dim3(256), 0, st, dh, dh2, h, xhat, B, H, part_dy, part_dyx);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((H + 63) / 64, nrb), dim3(256), 0, st, dh, dh2, xhat, gamma, beta, B, H, part_dy,
+                     part_dyx);
   GCRL_HIP(hipGetLastError());
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, grid, dim3(256), 0, st, dh, dh2, h, xhat, invstd, gamma, part_dy,
-                     part_dyx, B, H, dz, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots - 1) / kBnSlots), dim3(256), 0, st, dh, dh2, xhat,
+                     invstd, gamma, beta, part_dy, part_dyx, B, H, dz, dgamma, dbeta);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
