@@ -122,6 +122,7 @@ struct gcrl_agent {
   // row-block DDPG path (rowchain.h): [in][out] weight copies of actor | target actor | critic 0 |
   // target critic 0, per-layer gradient buffers, TD targets
   bool rowchain = false, wt_dirty = true;
+  bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
   int split_rg[4] = {1, 1, 1, 1};
   int row_rg = 1, row_ldl = 0;
@@ -340,10 +341,14 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
   auto hbuf = [&](const ActorFwd& q, int l) { return q.save ? q.h + (long long)l * BH : q.h + (long long)(l & 1) * BH; };
   for (int l = 0; l < net.L; ++l) {
     std::vector<GemmDesc> v;
+    bool fused_stats = false;
     for (int i = 0; i < nf; ++i) {
       const float* X = l == 0 ? f[i].X0 : hbuf(f[i], l - 1);
       GemmDesc d = fwd(X, l == 0 ? a->ldx : H, P, net.lin[l], f[i].z, H, B, EPI_NONE);
       if (l == 0 && f[i].x_slot) { d.slot = a->slot_ptr(); d.a_slot = f[i].x_slot; }
+      // BatchNorm statistics out of this GEMM's epilogue when its form allows (16-row partials, at most 32 of them)
+      if (i == 0) fused_stats = a->bn_fused && gemm_shape_of(d) == 1 && (B + kBnFusedRows - 1) / kBnFusedRows <= kBnFusedMaxParts;
+      if (fused_stats) d.bn_part = f[i].bn_part;
       v.push_back(d);
     }
     if (extra && (size_t)l < extra->steps.size()) v.insert(v.end(), extra->steps[l].begin(), extra->steps[l].end());
@@ -353,7 +358,7 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
       pb[i] = BnFwdProb{f[i].z, hbuf(f[i], l), f[i].save ? a->xhatA + (long long)l * BH : nullptr,
                         f[i].save ? a->invstdA + (long long)l * H : nullptr, f[i].bn_part};
     TRY(launch_bn_relu_fwd_multi(st, pb, nf, B, H, P + net.bn_g[l], P + net.bn_b[l], a->bn_rmean + (long long)l * H,
-                                 a->bn_rvar + (long long)l * H));
+                                 a->bn_rvar + (long long)l * H, fused_stats ? kBnFusedRows : 64));
   }
   {
     const int ldh = 2 * a->Apad;
@@ -389,7 +394,11 @@ int sac_actor_forwards(gcrl_agent* a, hipStream_t st, int variant, bool with_cur
 
 // V_FUSED_NORM: gradient sum-of-squares partials come out of the dW GEMM epilogues (whole step in
 // one graph); off in data-parallel runs, where the norm is of the all-reduced gradients
-enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32, V_FUSED_NORM = 64, V_WEIGHTS = 128 };
+// V_PRE / V_ADV (SAC on the row-block path, update_n): the step's LAST optimiser launch also advances the control block
+// for the next step (V_ADV; it reads the cur_b copy the first row-block launch refreshed), so that step starts without
+// a begin_step launch (V_PRE)
+enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32, V_FUSED_NORM = 64, V_WEIGHTS = 128,
+       V_PRE = 256, V_ADV = 512 };
 
 int adam_common(gcrl_agent* a, AdamArgs& ad);
 int finish_deferred_draw(gcrl_agent* a, hipStream_t st);
@@ -420,7 +429,7 @@ bool graph_on(const gcrl_agent* a) { return a->cfg.use_graph >= 2 || (a->cfg.use
 // ---------------------------------------------------------------- phase 0
 int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
   const int kind = a->cfg.kind, B = a->B, C = a->C, S = a->S, L = a->L, H = a->H;
-  TRY(launch_begin_step(st, a->ctrl()));
+  if (!(variant & V_PRE)) TRY(launch_begin_step(st, a->ctrl()));
   if (a->rowchain) {
     // row-block form: the whole critic phase up to the input gradients in one launch, then every dW|db
     // (SAC: the BatchNorm actor samples the next action first, into the action columns of nsa)
@@ -539,6 +548,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     ad.polyak = (variant & V_POLYAK_C) ? 1 : 0;
     ad.metric_index = MET_CRITIC_GRAD;
     if (a->rowchain) rc_adam_extras(a, ad, true);
+    if ((variant & V_ADV) && !(variant & V_ACTOR)) { ad.cur = &a->ctrl()->cur_b; ad.advance = a->ctrl(); }   // last launch of this step
     TRY(launch_adam(st, ad));
   }
   if (kind == GCRL_AGENT_TQC) {
@@ -696,8 +706,14 @@ int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
     ad.mean_x = a->q2; ad.mean_n = a->B; ad.mean_scale = -1.0f; ad.mean_index = MET_ACTOR_LOSS;
   }
   if (a->rowchain && !a->sac) rc_adam_extras(a, ad, false);
+  const bool alpha_rider = a->sac && a->rowchain;   // the log-alpha step rides on the actor's optimiser launch
+  if (alpha_rider) {
+    ad.alpha = AlphaStep{a->P_logalpha(), a->adam_m + a->goff_alpha, a->adam_v + a->goff_alpha, a->alpha_dev, a->grads + a->goff_alpha,
+                         (float)kBeta2, (float)(1.0 - kBeta1), (float)(1.0 - kBeta2), (float)kAdamEps, a->metrics_dev};
+    if (variant & V_ADV) { ad.cur = &a->ctrl()->cur_b; ad.advance = a->ctrl(); }
+  }
   TRY(launch_adam(st, ad));
-  if (a->sac) {
+  if (a->sac && !alpha_rider) {
     AlphaArgs al;
     std::memset(&al, 0, sizeof(al));
     al.cur = a->cur(); al.logp = a->logp; al.B = a->B;
@@ -720,7 +736,7 @@ int enqueue_phases(gcrl_agent* a, hipStream_t st, int variant, int mask) {
 int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask) {
   if (a->rowchain && a->wt_dirty) TRY(rc_rebuild_wt(a, st));
   if (!graph_on(a)) return enqueue_phases(a, st, variant, mask);
-  const int key = variant | (mask << 8);
+  const int key = variant | (mask << 12);
   auto it = a->graphs.find(key);
   if (it == a->graphs.end()) {
     hipGraph_t g = nullptr;
@@ -965,10 +981,10 @@ int build(gcrl_agent* a) {
       {&a->norm_partial, (long long)kMaxCritics * kNormBlocks}, {&a->act_in, (long long)B * a->ldx},
       {&a->act_tmp[0], BH}, {&a->act_tmp[1], BH},
       {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
-      {&a->hC2, (long long)C * L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 63) / 64) * H},
+      {&a->hC2, (long long)C * L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 15) / 16) * H},
       {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}, {&a->pi_buf, (long long)B * a->Apad},
       {&a->w_in, B}, {&a->td_abs, B},
-      {&a->zN, BH}, {&a->hN, 2 * BH}, {&a->headN, (long long)B * 2 * a->Apad}, {&a->bn_partN, 2LL * ((B + 63) / 64) * H}};
+      {&a->zN, BH}, {&a->hN, 2 * BH}, {&a->headN, (long long)B * 2 * a->Apad}, {&a->bn_partN, 2LL * ((B + 15) / 16) * H}};
   // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
   {
     const long long per_a = (long long)round_up(S, 4) * H + (long long)(L - 1) * H * H;
@@ -991,6 +1007,7 @@ int build(gcrl_agent* a) {
     a->split_roles = a->rowchain && c.kind == GCRL_AGENT_SAC && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) <= 256 &&
                      !std::getenv("GCRL_NO_SPLIT_ROLES");
     for (int i = 0; i < 4; ++i) a->split_rg[i] = a->row_rg;
+    a->bn_fused = std::getenv("GCRL_BN_FUSED") != nullptr;   // measured equal at cfg 5 (204.6 vs 203.6 us/step): off by default
     if (const char* e = std::getenv("GCRL_SPLIT_RG"))   // experiment knob: four digits, rows/4 per workgroup of the four launches
       for (int i = 0; i < 4 && e[i]; ++i) a->split_rg[i] = e[i] - '0';
   }
@@ -1360,8 +1377,9 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
       for (int i = 0; i < m; ++i) variants[i] = plans[i].variant;
       TRY(run_steps_ddpg(a, st, variants.data(), m));
     } else {
+      const int adv = (a->sac && a->rowchain) ? V_ADV : 0;   // (the call's last step advances into table[m]: never read)
       for (int i = 0; i < m; ++i) {
-        TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM, 7));
+        TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM | adv | (adv && i > 0 ? V_PRE : 0), 7));
         if (i == 0) TRY(finish_deferred_draw(a, st));   // step 0 is in flight: now draw and gather batches 1..m-1
       }
     }

@@ -48,6 +48,10 @@ struct GemmDesc {
   // sumsq_out[(tile * KSPLIT) + wave]: the global-norm clip needs ||g||, and producing the
   // partials here (fixed slots, fixed order -> deterministic) removes a reduction launch
   float* sumsq_out;
+  // BatchNorm statistics of the result (KSPLIT = 4 form only, launcher-checked): per-column (mean, M2) of each 16-row tile
+  // by a local two-pass, at bn_part[tm*N + n] and bn_part[(tiles_m + tm)*N + n] — the row-block partials bn_relu_apply
+  // merges (ops_sac.hip), so the producing GEMM replaces the bn_stats launch
+  float* bn_part;
   int a_vec, b_vec;  // 16-byte loads legal along k (filled by the launcher)
   int a_rvec, b_rvec;  // 16-byte loads legal along the row index (operand stored k-major)
   int tile0, tiles_n, ntiles;  // filled by the launcher
@@ -275,14 +279,15 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
   const int epi = d.epi;
   float ss = 0.f;
 
-  auto finish = [&](float v, int m, int n, float b, float h) {
-    if (m >= M || n >= N) return;
+  auto finish = [&](float v, int m, int n, float b, float h) -> float {
+    if (m >= M || n >= N) return 0.f;
     v += b;
     v = act_apply(v, epi);
     if (mul != MUL_NONE) v *= act_deriv(h, mul);
     ss += v * v;
     if (ones_col && n == N - 1) d.col_out[m] = v;
     else C[(long long)m * d.c_rs + n] = v;
+    return v;
   };
 
   if (KSPLIT == 4) {
@@ -296,7 +301,28 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += red[w][wave][lane];
-    finish(v, m0 + 4 * lg + wave, n0 + li, pre_b[0], pre_h[0][0][0]);
+    const float x = finish(v, m0 + 4 * lg + wave, n0 + li, pre_b[0], pre_h[0][0][0]);
+    if (d.bn_part) {   // (uniform per workgroup: one problem, one tile)
+      __shared__ float cs[2][4][16];
+      const int rows = min(16, M - m0), n = n0 + li;
+      float s = x;
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lg == 0) cs[0][wave][li] = s;
+      __syncthreads();
+      const float mean = (cs[0][0][li] + cs[0][1][li] + cs[0][2][li] + cs[0][3][li]) / (float)rows;
+      const float df = (m0 + 4 * lg + wave < M) ? x - mean : 0.f;
+      float q = df * df;
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lg == 0) cs[1][wave][li] = q;
+      __syncthreads();
+      if (wave == 0 && lg == 0 && n < N) {
+        const int tiles_m = (M + 15) >> 4;
+        d.bn_part[(long long)tm * N + n] = mean;
+        d.bn_part[(long long)(tiles_m + tm) * N + n] = cs[1][0][li] + cs[1][1][li] + cs[1][2][li] + cs[1][3][li];
+      }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -312,6 +338,9 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
     if (lane == 0) d.sumsq_out[(long long)t * KSPLIT + (KSPLIT == 4 ? wave : 0)] = ss;
   }
 }
+
+// 1: one 16x16 tile per workgroup with K split over its waves (the form that can produce bn_part), 2-4: larger forms
+int gemm_shape_of(const GemmDesc& d);
 
 // Launch `n` problems in one grid.  shape: 0 = auto.
 int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape = 0);

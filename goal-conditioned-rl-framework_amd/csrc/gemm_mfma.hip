@@ -68,6 +68,8 @@ int launch_tiled(hipStream_t st, GemmBatch& gb) {
 }
 }  // namespace
 
+int gemm_shape_of(const GemmDesc& d) { return shape_of(d); }
+
 int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape) {
   GCRL_CHECK_ARG(n >= 1 && n <= kMaxProb, "launch_gemm_batch: %d problems (max %d)", n, kMaxProb);
   int shapes[kMaxProb];
@@ -80,6 +82,7 @@ int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape) {
     d.a_rvec = (d.a_rs == 1 && d.a_cs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
     d.b_rvec = (d.b_cs == 1 && d.b_rs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
     shapes[i] = shape ? shape : shape_of(d);
+    GCRL_CHECK_ARG(!d.bn_part || (shapes[i] == 1 && !d.ones_col && d.c_rs >= d.N), "launch_gemm_batch: bn_part needs the k-split 16x16 form");
   }
   for (int s = 1; s <= 4; ++s) {  // one launch per shape present (almost always exactly one)
     GemmBatch gb;

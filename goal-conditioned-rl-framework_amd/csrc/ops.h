@@ -115,6 +115,29 @@ int launch_sumsq(hipStream_t st, const float* g, long long n, long long net_stri
 int launch_sumsq2(hipStream_t st, const float* g0, long long n0, float* partial0, const float* g1, long long n1,
                   float* partial1);
 
+// log-alpha AdamW step (src/agent.py:532-546) as a scalar rider on another launch: thread 0 of block (0,0) of the
+// actor's optimiser launch performs it (alpha_update_kernel's phase 1), saving that launch.  log_alpha == null: off
+struct AlphaStep {
+  float* log_alpha; float* m; float* v; float* alpha; const float* grad;
+  float beta2, w1, w2, eps;
+  float* metrics;
+};
+
+__device__ inline void alpha_step(const AlphaStep& a, const StepCtrl& c) {
+  if (!c.do_alpha) return;
+  const float g = *a.grad * c.grad_scale;
+  float p = *a.log_alpha;
+  if (c.decay_alpha != 1.0f) p = __fmul_rn(p, c.decay_alpha);
+  float m = *a.m, v = *a.v;
+  m = __fadd_rn(m, __fmul_rn(a.w1, __fsub_rn(g, m)));
+  v = __fadd_rn(__fmul_rn(v, a.beta2), __fmul_rn(__fmul_rn(a.w2, g), g));
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), c.bc2s_alpha), a.eps);
+  p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-c.step_size_alpha, m), denom));
+  *a.log_alpha = p; *a.m = m; *a.v = v;
+  *a.alpha = expf(p);
+  a.metrics[(long long)c.metrics_slot * kMetricFloats + MET_ALPHA] = expf(p);
+}
+
 struct AdamArgs {
   const StepCtrl* cur;
   int which;            // 0 actor, 1 critic, 2 alpha : selects the StepCtrl triple
@@ -144,6 +167,7 @@ struct AdamArgs {
   // would do for the next step (prev <- cur, cur <- table[cursor++]), saving that launch.  Legal
   // only when this launch reads the copies cur_b / prev_b (CtrlBlock)
   CtrlBlock* advance;
+  AlphaStep alpha;
   // net i's copies live at wt + i*wt_net_stride; wt_target: the same for the Polyak destination
   float* wt; float* wt_target; long long wt_net_stride;
   int n_seg, seg_blocks;
@@ -166,8 +190,12 @@ int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float
 // :514, so the two forwards run layer by layer in the same launches).  The running statistics take problem 0's batch
 // first, then problem 1's — the order of the reference's two forward calls.
 struct BnFwdProb { const float* z; float* h; float* xhat; float* invstd; float* scratch; };
+// rows_per_part: 64 = this launch computes the row-block partials itself (bn_stats launch); 16 = the GEMM that produced z
+// already left them in `scratch` (GemmDesc::bn_part), only the apply launch runs.  scratch: 2 * ceil(B/rows_per_part) * H floats
 int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, int B, int H, const float* gamma,
-                             const float* beta, float* running_mean, float* running_var);
+                             const float* beta, float* running_mean, float* running_var, int rows_per_part = 64);
+constexpr int kBnFusedRows = 16;      // GEMM tile height
+constexpr int kBnFusedMaxParts = 32;  // what bn_relu_apply gathers through LDS
 // eval mode (running statistics): select_action path
 int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const float* gamma,
                         const float* beta, const float* running_mean, const float* running_var,

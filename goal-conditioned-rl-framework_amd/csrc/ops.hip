@@ -355,6 +355,7 @@ __device__ inline void advance_ctrl(const AdamArgs& a) {
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   adam_body(a, blockIdx.y);
+  if (a.alpha.log_alpha && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) alpha_step(a.alpha, *a.cur);
   advance_ctrl(a);
 }
 

@@ -97,7 +97,7 @@ __device__ inline void gather_store(const PartRegs& r, v4f (*sp)[kBnMaxPart][16]
   __syncthreads();
 }
 
-struct BnFwdPair { BnFwdProb p[2]; int n; };
+struct BnFwdPair { BnFwdProb p[2]; int n; int rpp; };   // rpp: rows per partial (64: bn_stats_kernel, 16: GEMM epilogue)
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(BnFwdPair pr, int B, int H) {
   __shared__ v4f red[kBnSlots][16];
@@ -130,19 +130,31 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnFwdPair pr, int B, int 
   }
 }
 
-// Chan merge of a problem's row-block partials for one column quad (same order in every block) -> (mean, biased var)
-template <typename PM, typename PQ>
-__device__ inline void bn_merge4(PM pm, PQ pq, int nrb, int B, v4f* mean_out, v4f* var_out) {
-  float n = 0.f;
-  v4f mean = zero4(), m2 = zero4();
-  for (int rb = 0; rb < nrb; ++rb) {
-    const float nb = (float)(min(B, (rb + 1) * kBnRows) - rb * kBnRows);
-    const v4f mb = pm(rb), qb = pq(rb);
-    const v4f delta = mb - mean;
-    const float tot = n + nb;
-    mean += delta * (nb / tot);
-    m2 += qb + delta * delta * (n * nb / tot);
-    n = tot;
+// Merge of a problem's row-block partials (mean_b, M2_b over n_b rows) for one column quad, the same in every block:
+//   mean = sum n_b mean_b / B,   M2 = sum (M2_b + n_b (mean_b - mean)^2)      -> (mean, biased variance)
+// — two short passes over the partials without a division in the loop (Chan's sequential merge, used before, is a
+// serial chain of divisions: ~1 us for 32 partials in every block).
+// sp: the block's LDS copy of the first min(nrb, kBnMaxPart) partials; gm / gq: the arrays in memory for the rest
+// (column quad `col`; only B > 2048).  The LDS loops are unrolled so that their reads are in flight together — as a
+// plain loop every iteration waited out its own LDS latency (17.5 us per launch with 32 partials, measured).
+__device__ inline void bn_merge4(v4f (*sp)[kBnMaxPart][16], int cq, const float* gm, const float* gq, int H, int col, bool ok,
+                                 int nrb, int B, int rpp, v4f* mean_out, v4f* var_out) {
+  const int nl = min(nrb, kBnMaxPart);
+  auto rows = [&](int rb) { return (float)(min(B, (rb + 1) * rpp) - rb * rpp); };
+  v4f s = zero4();
+#pragma unroll 8
+  for (int rb = 0; rb < nl; ++rb) s += sp[0][rb][cq] * rows(rb);
+  for (int rb = nl; rb < nrb; ++rb) s += (ok ? ld4(gm + (long long)rb * H + col) : zero4()) * rows(rb);
+  const v4f mean = s / (float)B;
+  v4f m2 = zero4();
+#pragma unroll 8
+  for (int rb = 0; rb < nl; ++rb) {
+    const v4f dm = sp[0][rb][cq] - mean;
+    m2 += sp[1][rb][cq] + dm * dm * rows(rb);
+  }
+  for (int rb = nl; rb < nrb; ++rb) {
+    const v4f dm = (ok ? ld4(gm + (long long)rb * H + col) : zero4()) - mean;
+    m2 += (ok ? ld4(gq + (long long)rb * H + col) : zero4()) + dm * dm * rows(rb);
   }
   *mean_out = mean; *var_out = m2 / (float)B;
 }
@@ -153,22 +165,25 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
   const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cq;
   const bool ok = col < H;
-  const int nrb = (B + kBnRows - 1) / kBnRows;
+  const int rpp = pr.rpp, nrb = (B + rpp - 1) / rpp;
   const BnFwdProb me = pr.p[blockIdx.z];
   const float* __restrict__ z = me.z;
   const float* __restrict__ part_mean = me.scratch;
   const float* __restrict__ part_m2 = me.scratch + (long long)nrb * H;
   const int b = blockIdx.y * kBnSlots + slot;
   // request everything first: the partials' slice, the affine pair, this thread's row
-  PartRegs prg;
+  // the block that updates the running statistics of a two-problem launch also needs problem 1's merged statistics
+  const bool second = blockIdx.y == 0 && blockIdx.z == 0 && pr.n > 1;   // (uniform per block)
+  PartRegs prg, prg1;
   gather_request(prg, part_mean, part_m2, nrb, H, blockIdx.x * 64);
+  if (second) gather_request(prg1, pr.p[1].scratch, pr.p[1].scratch + (long long)nrb * H, nrb, H, blockIdx.x * 64);
   const v4f g = ok ? ld4(gamma + col) : zero4(), bt = ok ? ld4(beta + col) : zero4();
   const v4f v = (ok && b < B) ? ld4(z + (long long)b * H + col) : zero4();
+  v4f rm0 = zero4(), rv0 = zero4();
+  if (blockIdx.y == 0 && blockIdx.z == 0 && slot == 0 && ok) { rm0 = ld4(rmean + col); rv0 = ld4(rvar + col); }
   gather_store(prg, sp);
   v4f mean, var;
-  bn_merge4([&](int rb) { return rb < kBnMaxPart ? sp[0][rb][cq] : (ok ? ld4(part_mean + (long long)rb * H + col) : zero4()); },
-            [&](int rb) { return rb < kBnMaxPart ? sp[1][rb][cq] : (ok ? ld4(part_m2 + (long long)rb * H + col) : zero4()); },
-            nrb, B, &mean, &var);   // biased variance: what normalises the batch
+  bn_merge4(sp, cq, part_mean, part_m2, H, col, ok, nrb, B, rpp, &mean, &var);   // biased variance: what normalises the batch
   v4f invstd;
 #pragma unroll
   for (int q = 0; q < 4; ++q) invstd[q] = 1.0f / sqrtf(var[q] + kBnEps);
@@ -182,21 +197,23 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
     *(v4f*)(me.h + idx) = hv;
     if (me.xhat) *(v4f*)(me.xhat + idx) = xh;
   }
-  if (ok && blockIdx.y == 0 && slot == 0) {
-    if (me.invstd) *(v4f*)(me.invstd + col) = invstd;
-    if (blockIdx.z == 0) {   // running statistics: problem 0's batch, then problem 1's (two forward calls, in that order)
-      const float ub = B > 1 ? (float)B / (float)(B - 1) : 1.0f;
-      v4f rm = (1.0f - kBnMomentum) * ld4(rmean + col) + kBnMomentum * mean;
-      v4f rv = (1.0f - kBnMomentum) * ld4(rvar + col) + kBnMomentum * (var * ub);
-      if (pr.n > 1) {
-        const float* pm1 = pr.p[1].scratch;
-        const float* pq1 = pm1 + (long long)nrb * H;
-        v4f m1, v1;
-        bn_merge4([&](int rb) { return ld4(pm1 + (long long)rb * H + col); }, [&](int rb) { return ld4(pq1 + (long long)rb * H + col); },
-                  nrb, B, &m1, &v1);
-        rm = (1.0f - kBnMomentum) * rm + kBnMomentum * m1;
-        rv = (1.0f - kBnMomentum) * rv + kBnMomentum * (v1 * ub);
-      }
+  if (ok && blockIdx.y == 0 && slot == 0 && me.invstd) *(v4f*)(me.invstd + col) = invstd;
+  // running statistics: problem 0's batch, then problem 1's (two forward calls, in that order)
+  if (blockIdx.y == 0 && blockIdx.z == 0) {
+    const float ub = B > 1 ? (float)B / (float)(B - 1) : 1.0f;
+    v4f rm = (1.0f - kBnMomentum) * rm0 + kBnMomentum * mean;
+    v4f rv = (1.0f - kBnMomentum) * rv0 + kBnMomentum * (var * ub);
+    if (second) {
+      __syncthreads();   // every thread is done with problem 0's partials
+      gather_store(prg1, sp);
+      const float* pm1 = pr.p[1].scratch;
+      const float* pq1 = pm1 + (long long)nrb * H;
+      v4f m1, v1;
+      bn_merge4(sp, cq, pm1, pq1, H, col, ok, nrb, B, rpp, &m1, &v1);
+      rm = (1.0f - kBnMomentum) * rm + kBnMomentum * m1;
+      rv = (1.0f - kBnMomentum) * rv + kBnMomentum * (v1 * ub);
+    }
+    if (ok && slot == 0) {
       *(v4f*)(rmean + col) = rm;
       *(v4f*)(rvar + col) = rv;
     }
@@ -282,9 +299,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
   const v4f vx = in ? ld4(xhat + idx) : zero4();
   gather_store(prg, sp);
   v4f sum_dy = zero4(), sum_dyx = zero4();
-  for (int rb = 0; rb < nrb; ++rb) {
-    sum_dy += rb < kBnMaxPart ? sp[0][rb][cq] : (ok ? ld4(part_dy + (long long)rb * H + col) : zero4());
-    sum_dyx += rb < kBnMaxPart ? sp[1][rb][cq] : (ok ? ld4(part_dyx + (long long)rb * H + col) : zero4());
+  const int nl = min(nrb, kBnMaxPart);
+#pragma unroll 8
+  for (int rb = 0; rb < nl; ++rb) { sum_dy += sp[0][rb][cq]; sum_dyx += sp[1][rb][cq]; }
+  for (int rb = nl; rb < nrb; ++rb) {
+    sum_dy += ok ? ld4(part_dy + (long long)rb * H + col) : zero4();
+    sum_dyx += ok ? ld4(part_dyx + (long long)rb * H + col) : zero4();
   }
   const v4f k = g * is;
   const v4f m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B;
@@ -425,17 +445,8 @@ __device__ inline void alpha_body(const AlphaArgs& a, float* scratch) {
     }
   }
   if (a.phase != 0 && threadIdx.x == 0) {
-    const float g = *a.grad_out * c.grad_scale;
-    float p = *a.log_alpha;
-    if (c.decay_alpha != 1.0f) p = __fmul_rn(p, c.decay_alpha);
-    float m = *a.m, v = *a.v;
-    m = __fadd_rn(m, __fmul_rn(a.w1, __fsub_rn(g, m)));
-    v = __fadd_rn(__fmul_rn(v, a.beta2), __fmul_rn(__fmul_rn(a.w2, g), g));
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), c.bc2s_alpha), a.eps);
-    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-c.step_size_alpha, m), denom));
-    *a.log_alpha = p; *a.m = m; *a.v = v;
-    *a.alpha = expf(p);
-    met[MET_ALPHA] = expf(p);
+    const AlphaStep st{a.log_alpha, a.m, a.v, a.alpha, a.grad_out, a.beta2, a.w1, a.w2, a.eps, a.metrics};
+    alpha_step(st, c);
   }
 }
 
@@ -607,8 +618,10 @@ int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float
 }
 
 int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, int B, int H, const float* gamma,
-                             const float* beta, float* rmean, float* rvar) {
+                             const float* beta, float* rmean, float* rvar, int rows_per_part) {
   GCRL_CHECK_ARG(nprob == 1 || nprob == 2, "bn_relu_fwd_multi: 1 or 2 problems");
+  GCRL_CHECK_ARG(rows_per_part == kBnRows || (rows_per_part == kBnFusedRows && (B + kBnFusedRows - 1) / kBnFusedRows <= kBnMaxPart),
+                 "bn_relu_fwd_multi: %d rows per partial at B=%d", rows_per_part, B);
   GCRL_CHECK_ARG(H % 4 == 0 && bn_aligned(gamma) && bn_aligned(beta) && bn_aligned(rmean) && bn_aligned(rvar) &&
                      bn_aligned(probs[0].z) && bn_aligned(probs[0].h) && bn_aligned(probs[0].scratch),
                  "bn_relu_fwd: H must be a multiple of 4 and every operand 16-byte aligned (H=%d)", H);
@@ -617,8 +630,11 @@ int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, 
   pr.n = nprob;
   pr.p[0] = probs[0];
   pr.p[1] = nprob > 1 ? probs[1] : probs[0];
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((H + 63) / 64, nrb, nprob), dim3(256), 0, st, pr, B, H);
-  GCRL_HIP(hipGetLastError());
+  pr.rpp = rows_per_part;
+  if (rows_per_part == kBnRows) {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((H + 63) / 64, nrb, nprob), dim3(256), 0, st, pr, B, H);
+    GCRL_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots - 1) / kBnSlots, nprob), dim3(256), 0, st, pr, B, H, gamma,
                      beta, rmean, rvar);
   GCRL_HIP(hipGetLastError());
