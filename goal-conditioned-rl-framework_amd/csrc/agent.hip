@@ -138,7 +138,7 @@ struct gcrl_agent {
   int64_t prof_launches = 0;
   double prof_ms = 0, prof_ticks = 0;
   float *parts_c = nullptr, *parts_a = nullptr;   // fused-norm partials: [C][nparts_c], [nparts_a]
-  int nparts_c = 0, nparts_a = 0;
+  int nparts_c = 0, nparts_a = 0, part_off_bn = 0;   // part_off_bn: first BatchNorm slot of parts_a (L x ceil(H/64))
   std::vector<int> part_off_c, part_off_a;        // per-layer offsets inside a net's partials
 
   char* upload_dev = nullptr;
@@ -594,6 +594,9 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
   for (int c = 0; c < (a->rowchain ? 0 : nac); ++c)
     chain_mlp(a, c2, 0, a->critic, a->P_critic(c), a->spa, a->ldx, a->slot_x, hid_C, c, a->q2 + (long long)c * B * a->Q, a->Q, 0, EPI_NONE, B);
   TRY(c2.run(st));
+  bool sel_deferred = false;
+  ActorSelArgs as_d;
+  AlphaArgs al_d;
   if (a->sac) {
     ActorSelArgs as;
     std::memset(&as, 0, sizeof(as));
@@ -613,6 +616,9 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
       QuantileActorArgs qa{a->cur(), a->q2, a->logp, a->alpha_dev, a->dq2, a->metrics_dev, B, nac, a->Q};
       TRY(launch_quantile_actor(st, qa));
       TRY(launch_alpha_update(st, al));
+    } else if (a->rowchain) {
+      sel_deferred = true;   // metrics + log-alpha gradient only on this path: rides on the tanh-Gaussian backward launch below
+      as_d = as; al_d = al;
     } else {
       TRY(launch_actor_select_alpha(st, as, al));
     }
@@ -658,12 +664,14 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     if (kind == GCRL_AGENT_SAC) tb.alpha_const = 0.2f; else tb.alpha_dev = a->alpha_dev;
     tb.gmu = a->ghead; tb.gls = a->ghead + a->Apad; tb.ld_g = 2 * a->Apad;
     tb.B = B; tb.A = A;
-    TRY(launch_tanh_gauss_bwd(st, tb));
+    if (sel_deferred) TRY(launch_tanh_gauss_bwd_select(st, tb, as_d, al_d));
+    else TRY(launch_tanh_gauss_bwd(st, tb));
     {
       const int ldg = 2 * a->Apad;
       std::vector<GemmDesc> v;
       v.push_back(bwd_dw(a->ghead, ldg, a->hA_at(L - 1), H, Ga, a->actor.lin[L], B));
       v.push_back(bwd_dw(a->ghead + a->Apad, ldg, a->hA_at(L - 1), H, Ga, a->actor.lin[L + 1], B));
+      if (variant & V_FUSED_NORM) { v[0].sumsq_out = a->parts_a + a->part_off_a[L]; v[1].sumsq_out = a->parts_a + a->part_off_a[L + 1]; }
       v.push_back(bwd_dx(a->ghead, ldg, Pa, a->actor.lin[L], 0, H, a->gA[0], H, B, MUL_NONE, nullptr, 0));
       v.push_back(bwd_dx(a->ghead + a->Apad, ldg, Pa, a->actor.lin[L + 1], 0, H, a->dh2, H, B, MUL_NONE, nullptr, 0));
       TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
@@ -673,10 +681,12 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
       // (dh for layer l<L-1 was written by the dX of layer l+1 into gA[(l+1)&1])
       TRY(launch_bn_relu_bwd(st, dh, l == L - 1 ? a->dh2 : nullptr, a->xhatA + (long long)l * B * H,
                              a->invstdA + (long long)l * H, Pa + a->actor.bn_g[l], Pa + a->actor.bn_b[l], B, H, a->zA,
-                             Ga + a->actor.bn_g[l], Ga + a->actor.bn_b[l], a->bn_part));
+                             Ga + a->actor.bn_g[l], Ga + a->actor.bn_b[l], a->bn_part,
+                             (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * ((H + 63) / 64) : nullptr));
       std::vector<GemmDesc> v;
       GemmDesc dw = bwd_dw(a->zA, H, l == 0 ? (a->rowchain ? a->sa : a->spa) : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
+      if (variant & V_FUSED_NORM) dw.sumsq_out = a->parts_a + a->part_off_a[l];
       v.push_back(dw);
       if (l > 0) v.push_back(bwd_dx(a->zA, H, Pa, a->actor.lin[l], 0, H, a->gA[l & 1], H, B, MUL_NONE, nullptr, 0));
       TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
@@ -689,7 +699,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
 int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   if (!(variant & V_ACTOR)) return GCRL_OK;
   const int kind = a->cfg.kind;
-  const bool fused = (variant & V_FUSED_NORM) && !a->sac;   // BN gradients do not come from a GEMM
+  const bool fused = (variant & V_FUSED_NORM) != 0;   // (BatchNorm gradients: their launches leave partials too)
   if (!fused) TRY(launch_sumsq(st, a->G_actor(), a->actor.numel, 0, 1, a->norm_partial));
   AdamArgs ad;
   std::memset(&ad, 0, sizeof(ad));
@@ -966,6 +976,7 @@ int build(gcrl_agent* a) {
   };
   a->nparts_c = part_layout(a->critic, a->part_off_c);
   a->nparts_a = part_layout(a->actor, a->part_off_a);
+  if (a->sac) { a->part_off_bn = a->nparts_a; a->nparts_a += L * ((H + 63) / 64); }   // dgamma | dbeta of every BatchNorm layer
   // work buffers
   const long long BH = (long long)B * H;
   std::vector<std::pair<float**, long long>> wants = {

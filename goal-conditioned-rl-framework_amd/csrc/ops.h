@@ -203,7 +203,7 @@ int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const floa
 // backward of BN(train)+ReLU: dh -> dz, dgamma, dbeta
 int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* xhat, const float* invstd,
                        const float* gamma, const float* beta, int B, int H, float* dz, float* dgamma, float* dbeta,
-                       float* scratch);
+                       float* scratch, float* sumsq_out = nullptr);   // sumsq_out[ceil(H/64)]: sum of squares of dgamma | dbeta per column block
 
 // SACActorModel.sample (src/model.py:125-141): mean/log_std head outputs -> action + log-prob.
 struct TanhGaussArgs {
@@ -260,6 +260,8 @@ struct AlphaArgs {
 int launch_alpha_update(hipStream_t st, const AlphaArgs& a);
 // actor_select + the gradient / loss-metric half of alpha_update (phase 0) as one launch
 int launch_actor_select_alpha(hipStream_t st, const ActorSelArgs& a, const AlphaArgs& al);
+// tanh_gauss_bwd + (as one extra block) actor_select + the gradient half of alpha_update
+int launch_tanh_gauss_bwd_select(hipStream_t st, const TanhGaussBwdArgs& a, const ActorSelArgs& s, const AlphaArgs& al);
 
 // ---- distributional TQC (BASELINE.json configs[3]: "25 quantiles x 2 critics, top-2 truncate"; Kuznetsov et al. 2020).
 // NOT the reference's TQC (an ensemble of scalar critics, SURVEY.md headline facts): no reference parity, pinned to

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                                                                 const float* gamma, const float* beta,
                                                                 const float* __restrict__ part_dy,
                                                                 const float* __restrict__ part_dyx, int B, int H,
-                                                                float* __restrict__ dz, float* dgamma, float* dbeta) {
+                                                                float* __restrict__ dz, float* dgamma, float* dbeta,
+                                                                float* sumsq_out) {
   __shared__ v4f sp[2][kBnMaxPart][16];
   const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cq;
@@ -313,6 +314,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
     *(v4f*)(dz + idx) = (dy - m1 - vx * m2) * k;
   }
   if (ok && blockIdx.y == 0 && slot == 0) { *(v4f*)(dgamma + col) = sum_dyx; *(v4f*)(dbeta + col) = sum_dy; }
+  if (sumsq_out && blockIdx.y == 0) {   // sum of squares of this column block's dgamma | dbeta (global-norm clip, fixed slot)
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q += sum_dyx[k] * sum_dyx[k] + sum_dy[k] * sum_dy[k];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);   // over the 16 column quads
+    if (threadIdx.x == 0) sumsq_out[blockIdx.x] = q;
+  }
 }
 
 __device__ inline void tanh_gauss_fwd_body(const TanhGaussArgs& a) {
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(256) void actor_select_kernel(ActorSelArgs a) {
   actor_select_body(a, scratch);
 }
 
-__global__ void tanh_gauss_bwd_kernel(TanhGaussBwdArgs a) {
+__device__ inline void tanh_gauss_bwd_body(const TanhGaussBwdArgs& a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.B * a.A) return;
   const int b = i / a.A, j = i - b * a.A;
@@ -426,6 +435,8 @@ __global__ void tanh_gauss_bwd_kernel(TanhGaussBwdArgs a) {
   a.gmu[(long long)b * a.ld_g + j] = dx;
   a.gls[(long long)b * a.ld_g + j] = in_range ? (dx * a.eps[i] * a.std[i] - wlp) : 0.f;
 }
+
+__global__ __launch_bounds__(256) void tanh_gauss_bwd_kernel(TanhGaussBwdArgs a) { tanh_gauss_bwd_body(a); }
 
 __device__ inline void alpha_body(const AlphaArgs& a, float* scratch) {
   const StepCtrl c = *a.cur;
@@ -457,6 +468,16 @@ __global__ __launch_bounds__(256) void alpha_update_kernel(AlphaArgs a) {
 
 // actor-loss selection and the log-alpha gradient (both single-block passes over logp) in one launch
 __global__ __launch_bounds__(256) void actor_select_alpha_kernel(ActorSelArgs s, AlphaArgs al) {
+  __shared__ float scratch[4];
+  actor_select_body(s, scratch);
+  __syncthreads();
+  alpha_body(al, scratch);
+}
+
+// row-block SAC: the selection kernel's outputs are metrics and the log-alpha gradient only (the row-block launch forms
+// its own min-selection), so its single block rides on the tanh-Gaussian backward launch as one extra block
+__global__ __launch_bounds__(256) void tanh_gauss_bwd_select_kernel(TanhGaussBwdArgs a, ActorSelArgs s, AlphaArgs al) {
+  if (blockIdx.x + 1 < gridDim.x) { tanh_gauss_bwd_body(a); return; }
   __shared__ float scratch[4];
   actor_select_body(s, scratch);
   __syncthreads();
@@ -652,7 +673,7 @@ int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const floa
 
 int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* xhat, const float* invstd,
                        const float* gamma, const float* beta, int B, int H, float* dz, float* dgamma, float* dbeta,
-                       float* scratch) {
+                       float* scratch, float* sumsq_out) {
   GCRL_CHECK_ARG(H % 4 == 0 && bn_aligned(dh) && bn_aligned(dh2) && bn_aligned(xhat) && bn_aligned(invstd) && bn_aligned(gamma) &&
                      bn_aligned(beta) && bn_aligned(dz) && bn_aligned(dgamma) && bn_aligned(dbeta) && bn_aligned(scratch),
                  "bn_relu_bwd: H must be a multiple of 4 and every operand 16-byte aligned (H=%d)", H);
@@ -663,7 +684,7 @@ int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const 
                      part_dyx);
   GCRL_HIP(hipGetLastError());
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots - 1) / kBnSlots), dim3(256), 0, st, dh, dh2, xhat,
-                     invstd, gamma, beta, part_dy, part_dyx, B, H, dz, dgamma, dbeta);
+                     invstd, gamma, beta, part_dy, part_dyx, B, H, dz, dgamma, dbeta, sumsq_out);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
@@ -696,6 +717,13 @@ int launch_actor_select_alpha(hipStream_t st, const ActorSelArgs& a, const Alpha
 
 int launch_tanh_gauss_bwd(hipStream_t st, const TanhGaussBwdArgs& a) {
   hipLaunchKernelGGL(tanh_gauss_bwd_kernel, dim3((a.B * a.A + 255) / 256), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_tanh_gauss_bwd_select(hipStream_t st, const TanhGaussBwdArgs& a, const ActorSelArgs& s, const AlphaArgs& al) {
+  GCRL_CHECK_ARG(s.C >= 1 && s.C <= kMaxCritics && s.drop >= 0 && s.drop < s.C, "actor_select: bad C=%d drop=%d", s.C, s.drop);
+  hipLaunchKernelGGL(tanh_gauss_bwd_select_kernel, dim3((a.B * a.A + 255) / 256 + 1), dim3(256), 0, st, a, s, al);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
