@@ -76,6 +76,17 @@ __device__ inline __amdgpu_buffer_rsrc_t wave_uniform_rsrc(const float* p) {
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0x7fffffff, 0x00020000);
 }
 
+// the same with an extent in floats: loads at or past it return 0
+__device__ inline __amdgpu_buffer_rsrc_t wave_uniform_rsrc_n(const float* p, long long nfloats) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  void* q = (void*)(((unsigned long long)hi << 32) | lo);
+  const long long bytes = nfloats * 4;
+  const int nb = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffe0LL ? 0x7fffffe0LL : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, nb, 0x00020000);
+}
+
 __device__ inline float act_apply(float v, int epi) {
   switch (epi) {
     case EPI_LEAKY: return v > 0.f ? v : 0.01f * v;  // nn.LeakyReLU() default slope

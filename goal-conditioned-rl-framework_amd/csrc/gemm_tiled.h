@@ -23,50 +23,78 @@ constexpr int kLDT = kBK + 4;  // LDS row stride (floats): 144 B keeps b128 alig
 
 enum { FETCH_KC = 0, FETCH_RC = 1, FETCH_GEN = 2 };
 
-// Fetch a 64 x 32 operand tile (rows r0.., k k0..) into 8 registers per thread.
+// Fetch a 64 x 64 operand tile (rows r0.., k k0..) into 16 registers per thread.
 // element(row, k) = base[row*rs + k*cs]; rows >= R or k >= K read as 0; `ones_row`: that row := 1.
+//
+// The two vector modes are free of control flow and of per-step address arithmetic: a thread's four fragment offsets
+// (bytes, at k-step 0) are computed ONCE (`FetchPlan`; rows outside the operand get an offset past the descriptor's
+// extent, for which the hardware returns 0) and a k-step only adds a scalar offset to the buffer load.  Before, every
+// step re-derived rows, clamps and 64-bit products and branched around each load: ~1 300 instructions per k-step for
+// 64 MFMAs, issue-bound on bookkeeping (64 TFLOP/s at M=10240, N=K=512 against 94 for the library's plain fp32 GEMM;
+// a lone workgroup spent 3.1 us per k-step, 0.85 us of it in MFMAs).  The launcher grants FETCH_KC / FETCH_RC only
+// when whole 16-byte fragments are legal and K is a multiple of the k-step (no k tail); everything else is FETCH_GEN.
+constexpr int kOob = 0x7ffffff0;   // byte offset past any descriptor extent
+
+struct FetchPlan { int voff[kNV]; int step; bool ones[kNV][4]; bool any_one; };
+
+// R: rows of the operand that exist in memory (for B with a synthesised ones row: N - 1)
 template <int MODE>
-__device__ inline void tile_fetch(float (&reg)[kNR], const float* __restrict__ base, long long rs, long long cs, int r0,
-                                  int R, int k0, int K, int ones_row) {
+__device__ inline FetchPlan fetch_plan(long long rs, long long cs, int r0, int R, int ones_row) {
+  FetchPlan pl;
   const int tid = threadIdx.x;
-  if (MODE == FETCH_KC) {
+  pl.any_one = false;
 #pragma unroll
-    for (int p = 0; p < kNV; ++p) {
-      const int f = tid + 256 * p, r = r0 + f / (kBK / 4), k = k0 + ((f % (kBK / 4)) << 2);
-      const float* src = base + (long long)min(r, R - 1) * rs + k;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < R) {
-        if (k + 3 < K) v = *reinterpret_cast<const float4*>(src);
-        else { if (k < K) v.x = src[0]; if (k + 1 < K) v.y = src[1]; if (k + 2 < K) v.z = src[2]; }
-      }
-      if (r == ones_row) { v.x = k < K ? 1.f : 0.f; v.y = k + 1 < K ? 1.f : 0.f; v.z = k + 2 < K ? 1.f : 0.f; v.w = k + 3 < K ? 1.f : 0.f; }
-      reg[4 * p] = v.x; reg[4 * p + 1] = v.y; reg[4 * p + 2] = v.z; reg[4 * p + 3] = v.w;
+  for (int p = 0; p < kNV; ++p) {
+    const int f = tid + 256 * p;
+    if (MODE == FETCH_KC) {
+      const int r = r0 + f / (kBK / 4), k = (f % (kBK / 4)) << 2;
+      pl.voff[p] = r < R ? (int)(((long long)r * rs + k) * 4) : kOob;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { pl.ones[p][q] = r == ones_row; pl.any_one |= pl.ones[p][q]; }
+    } else {
+      const int k = f >> 4, r = r0 + ((f & 15) << 2);
+      pl.voff[p] = r < R ? (int)(((long long)k * cs + r) * 4) : kOob;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { pl.ones[p][q] = r + q == ones_row; pl.any_one |= pl.ones[p][q]; }
     }
-  } else if (MODE == FETCH_RC) {
+  }
+  pl.step = MODE == FETCH_KC ? kBK * 4 : (int)(cs * kBK * 4);
+  return pl;
+}
+
+// `in` false (a k-step past the end, issued to keep the pipeline free of branches): zeros
+template <int MODE>
+__device__ inline void tile_fetch(float (&reg)[kNR], const float* __restrict__ base, __amdgpu_buffer_rsrc_t rsrc, const FetchPlan& pl,
+                                  long long rs, long long cs, int r0, int R, int ks, int K, int ones_row, bool in) {
+  if (MODE != FETCH_GEN) {
+    const int soff = in ? ks * pl.step : 0;
 #pragma unroll
     for (int p = 0; p < kNV; ++p) {
-      const int f = tid + 256 * p, k = k0 + (f >> 4), r = r0 + ((f & 15) << 2);
-      const float* src = base + (long long)min(k, K - 1) * cs + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < K) {
-        if (r + 3 < R) v = *reinterpret_cast<const float4*>(src);
-        else { if (r < R) v.x = src[0]; if (r + 1 < R) v.y = src[1]; if (r + 2 < R) v.z = src[2]; }
-        if (r == ones_row) v.x = 1.f;
-        if (r + 1 == ones_row) v.y = 1.f;
-        if (r + 2 == ones_row) v.z = 1.f;
-        if (r + 3 == ones_row) v.w = 1.f;
-      }
-      reg[4 * p] = v.x; reg[4 * p + 1] = v.y; reg[4 * p + 2] = v.z; reg[4 * p + 3] = v.w;
+      const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, in ? pl.voff[p] : kOob, soff, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) reg[4 * p + q] = __uint_as_float(v[q]);
     }
   } else {
+    const int tid = threadIdx.x, k0 = ks * kBK;
 #pragma unroll
     for (int p = 0; p < kNR; ++p) {
       const int e = tid + 256 * p, r = r0 + (e & 63), k = k0 + (e >> 6);
       float v = 0.f;
-      if (r < R && k < K) v = (r == ones_row) ? 1.f : base[(long long)r * rs + (long long)k * cs];
+      if (in && r < R && k < K) v = (r == ones_row) ? 1.f : base[(long long)r * rs + (long long)k * cs];
       reg[p] = v;
     }
   }
+}
+
+// the synthesised ones row of a dW problem's B operand, applied when the registers go to LDS (not when they are
+// requested: the select would wait for the loads one k-step early).  `in`: the tile lies inside K
+template <int MODE>
+__device__ inline void tile_ones(float (&reg)[kNR], const FetchPlan& pl, bool in) {
+  if (MODE == FETCH_GEN || !pl.any_one) return;
+#pragma unroll
+  for (int p = 0; p < kNV; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) reg[4 * p + q] = (pl.ones[p][q] && in) ? 1.f : reg[4 * p + q];
 }
 
 template <int MODE>
@@ -115,26 +143,38 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-  float ra[kNR], rb[kNR];
-  tile_fetch<MA>(ra, A, d.a_rs, d.a_cs, m0, M, 0, K, -1);
-  tile_fetch<MB>(rb, Bm, d.b_cs, d.b_rs, n0, N, 0, K, ones_row);
+  // extents for the vector modes: whole rows of the operand (KC: R rows of rs floats; RC: K rows of cs floats)
+  const int n_mem = N - (d.ones_col ? 1 : 0);   // B's rows that exist in memory (the ones column is synthesised)
+  const __amdgpu_buffer_rsrc_t rsa = wave_uniform_rsrc_n(A, MA == FETCH_KC ? (long long)(M - 1) * d.a_rs + K : (long long)(K - 1) * d.a_cs + M);
+  const __amdgpu_buffer_rsrc_t rsb = wave_uniform_rsrc_n(Bm, MB == FETCH_KC ? (long long)(n_mem - 1) * d.b_cs + K : (long long)(K - 1) * d.b_rs + n_mem);
+  // Software pipeline.  Operand tiles come from HBM / the infinity cache the first time they are touched (2-3 us
+  // under load), longer than one k-step's MFMAs (64 per wave, ~1.4 us): with a single register stage every step
+  // waited out the rest of that latency (a lone workgroup spent 3.1 us per k-step, 1.4 us of it computing).  Two
+  // register stages keep the fetch of tile ks+3 in flight across the MFMAs of steps ks+1 and ks+2, and two LDS
+  // buffers leave ONE barrier per step: while the waves read buffer ks&1, the tile of step ks+1 is written to the other.
   const int ksteps = (K + kBK - 1) / kBK;
-  for (int ks = 0; ks < ksteps; ++ks) {
-    __syncthreads();  // the previous step's fragment reads are done
-    tile_store<MA>(ra, ldsA);
-    tile_store<MB>(rb, ldsB);
-    __syncthreads();
-    if (ks + 1 < ksteps) {  // next tiles travel while this step's MFMAs run
-      tile_fetch<MA>(ra, A, d.a_rs, d.a_cs, m0, M, (ks + 1) * kBK, K, -1);
-      tile_fetch<MB>(rb, Bm, d.b_cs, d.b_rs, n0, N, (ks + 1) * kBK, K, ones_row);
-    }
+  float ra[2][kNR], rb[2][kNR];
+  const FetchPlan pla = fetch_plan<MA>(d.a_rs, d.a_cs, m0, M, -1);
+  const FetchPlan plb = fetch_plan<MB>(d.b_cs, d.b_rs, n0, n_mem, ones_row);
+  auto fetch = [&](float (&xa)[kNR], float (&xb)[kNR], int ks) {
+    tile_fetch<MA>(xa, A, rsa, pla, d.a_rs, d.a_cs, m0, M, ks, K, -1, ks < ksteps);
+    tile_fetch<MB>(xb, Bm, rsb, plb, d.b_cs, d.b_rs, n0, N, ks, K, ones_row, ks < ksteps);
+  };
+  auto store = [&](const float (&xa)[kNR], float (&xb)[kNR], int buf, int ks) {
+    tile_ones<MB>(xb, plb, ks < ksteps);
+    tile_store<MA>(xa, ldsA + buf * (kTB * kLDT));
+    tile_store<MB>(xb, ldsB + buf * (kTB * kLDT));
+  };
+  auto compute = [&](int buf) {
+    const float* la = ldsA + buf * (kTB * kLDT);
+    const float* lb = ldsB + buf * (kTB * kLDT);
 #pragma unroll
     for (int kc = 0; kc < kBK / 16; ++kc) {
       float4 a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(ldsA + (32 * wm + 16 * i + li) * kLDT + kc * 16 + 4 * lg);
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(la + (32 * wm + 16 * i + li) * kLDT + kc * 16 + 4 * lg);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(ldsB + (32 * wn + 16 * j + li) * kLDT + kc * 16 + 4 * lg);
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(lb + (32 * wn + 16 * j + li) * kLDT + kc * 16 + 4 * lg);
       // q outer: consecutive MFMAs go to the four different accumulators (an accumulator is
       // reused every 128 cycles, above the 40-cycle dependent latency of 16x16x4 f32)
       const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
@@ -147,6 +187,28 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
     }
+  };
+  // one step: LDS[ks&1] holds tile ks; `nx` (registers) holds tile ks+1, requested two steps ago; the other register
+  // stage (tile ks+2) stays in flight.  After the MFMAs: tile ks+1 -> the other LDS buffer, then request tile ks+3
+  // into the registers just freed.  NOTHING here is conditional: with `if (ks + 3 < ksteps)` around the request the
+  // compiler could no longer count the loads in flight and waited for the newest stage before every LDS store
+  // (s_waitcnt vmcnt(0): the pipeline was one step deep again).  Steps past the end fetch zeros (tile_fetch `in`),
+  // so the step count is simply rounded up to even and the tail costs at most one k-step of MFMAs on zeros.
+  auto step = [&](float (&nxa)[kNR], float (&nxb)[kNR], int ks) {
+    compute(ks & 1);
+    store(nxa, nxb, (ks + 1) & 1, ks + 1);
+    fetch(nxa, nxb, ks + 3);
+    __syncthreads();
+  };
+  fetch(ra[0], rb[0], 0);
+  fetch(ra[1], rb[1], 1);
+  store(ra[0], rb[0], 0, 0);
+  fetch(ra[0], rb[0], 2);
+  __syncthreads();
+  const int kp = (ksteps + 1) & ~1;
+  for (int ks = 0; ks < kp; ks += 2) {
+    step(ra[1], rb[1], ks);
+    step(ra[0], rb[0], ks + 1);
   }
 
   const float* __restrict__ bias = d.bias;
@@ -178,8 +240,8 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
 }
 
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmBatch gb) {
-  __shared__ __attribute__((aligned(16))) float ldsA[kTB * kLDT];
-  __shared__ __attribute__((aligned(16))) float ldsB[kTB * kLDT];
+  __shared__ __attribute__((aligned(16))) float ldsA[2 * kTB * kLDT];   // two buffers each (gemm_tiled_body)
+  __shared__ __attribute__((aligned(16))) float ldsB[2 * kTB * kLDT];
   const int tile = blockIdx.x;
   int pi = 0;
 #pragma unroll
@@ -189,8 +251,11 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmBatch gb) {
   const int t = tile - d.tile0;
   if (t >= d.ntiles) return;
   // fetch modes are per problem and wave-uniform: 3 x 3 straight-line instances
-  const int ma = d.a_vec ? FETCH_KC : (d.a_rvec ? FETCH_RC : FETCH_GEN);
-  const int mb = d.b_vec ? FETCH_KC : (d.b_rvec ? FETCH_RC : FETCH_GEN);
+  // (vector modes need whole 16-byte fragments: extents in multiples of 4 along the vector direction)
+  const int n_mem = d.N - (d.ones_col ? 1 : 0);
+  const bool kfull = d.K % kBK == 0;
+  const int ma = (d.a_vec && kfull) ? FETCH_KC : ((d.a_rvec && kfull && d.M % 4 == 0) ? FETCH_RC : FETCH_GEN);
+  const int mb = (d.b_vec && kfull) ? FETCH_KC : ((d.b_rvec && kfull && n_mem % 4 == 0) ? FETCH_RC : FETCH_GEN);
   switch (ma * 3 + mb) {
     case 0: gemm_tiled_body<FETCH_KC, FETCH_KC>(d, t, ldsA, ldsB); break;
     case 1: gemm_tiled_body<FETCH_KC, FETCH_RC>(d, t, ldsA, ldsB); break;
