@@ -1,5 +1,7 @@
 // gemm_mfma.hip — launcher of the batched fp32-MFMA GEMM (kernel: gemm_mfma.h).
 #include "gemm_mfma.h"
+#include <cstdio>
+#include <cstdlib>
 #include "gemm_tiled.h"
 
 namespace gcrl {
@@ -53,6 +55,15 @@ int shape_of(const GemmDesc& d) {
 }
 
 int launch_tiled(hipStream_t st, GemmBatch& gb) {
+  static const bool trace = std::getenv("GCRL_GEMM_TRACE") != nullptr;
+  if (trace) {
+    std::fprintf(stderr, "[tiled] %d problems:", gb.n);
+    for (int i = 0; i < gb.n; ++i) {
+      const GemmDesc& d = gb.d[i];
+      std::fprintf(stderr, " (M=%d N=%d K=%d a:%d%d b:%d%d ones=%d)", d.M, d.N, d.K, d.a_vec, d.a_rvec, d.b_vec, d.b_rvec, d.ones_col);
+    }
+    std::fprintf(stderr, "\n");
+  }
   int tiles = 0;
   for (int i = 0; i < gb.n; ++i) {
     GemmDesc& d = gb.d[i];

@@ -75,13 +75,22 @@ __device__ inline void tile_fetch(float (&reg)[kNR], const float* __restrict__ b
       for (int q = 0; q < 4; ++q) reg[4 * p + q] = __uint_as_float(v[q]);
     }
   } else {
+    // element-wise mode (first layers with K = 25, heads with K = 1..4, unaligned operands): still one buffer load per
+    // element and no branch — with `if (r < R && k < K) v = base[...]` each of a thread's 16 loads sat behind its own
+    // branch and a SINGLE k-step took 50 us (TQC's first-layer and head launches cost as much as the K = 512 ones)
+    if (!in) {   // (uniform)
+#pragma unroll
+      for (int p = 0; p < kNR; ++p) reg[p] = 0.f;
+      return;
+    }
     const int tid = threadIdx.x, k0 = ks * kBK;
 #pragma unroll
     for (int p = 0; p < kNR; ++p) {
       const int e = tid + 256 * p, r = r0 + (e & 63), k = k0 + (e >> 6);
-      float v = 0.f;
-      if (in && r < R && k < K) v = (r == ones_row) ? 1.f : base[(long long)r * rs + (long long)k * cs];
-      reg[p] = v;
+      const bool ok = r < R && k < K && r != ones_row;
+      const int off = ok ? (int)(((long long)r * rs + (long long)k * cs) * 4) : kOob;
+      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+      reg[p] = (r == ones_row && k < K) ? 1.f : v;
     }
   }
 }
@@ -145,8 +154,9 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
 
   // extents for the vector modes: whole rows of the operand (KC: R rows of rs floats; RC: K rows of cs floats)
   const int n_mem = N - (d.ones_col ? 1 : 0);   // B's rows that exist in memory (the ones column is synthesised)
-  const __amdgpu_buffer_rsrc_t rsa = wave_uniform_rsrc_n(A, MA == FETCH_KC ? (long long)(M - 1) * d.a_rs + K : (long long)(K - 1) * d.a_cs + M);
-  const __amdgpu_buffer_rsrc_t rsb = wave_uniform_rsrc_n(Bm, MB == FETCH_KC ? (long long)(n_mem - 1) * d.b_cs + K : (long long)(K - 1) * d.b_rs + n_mem);
+  // (the last element's index + 1: exact for all three modes)
+  const __amdgpu_buffer_rsrc_t rsa = wave_uniform_rsrc_n(A, (long long)(M - 1) * d.a_rs + (long long)(K - 1) * d.a_cs + 1);
+  const __amdgpu_buffer_rsrc_t rsb = wave_uniform_rsrc_n(Bm, (long long)(n_mem - 1) * d.b_cs + (long long)(K - 1) * d.b_rs + 1);
   // Software pipeline.  Operand tiles come from HBM / the infinity cache the first time they are touched (2-3 us
   // under load), longer than one k-step's MFMAs (64 per wave, ~1.4 us): with a single register stage every step
   // waited out the rest of that latency (a lone workgroup spent 3.1 us per k-step, 1.4 us of it computing).  Two
@@ -165,11 +175,13 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
     tile_store<MA>(xa, ldsA + buf * (kTB * kLDT));
     tile_store<MB>(xb, ldsB + buf * (kTB * kLDT));
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int ks) {
     const float* la = ldsA + buf * (kTB * kLDT);
     const float* lb = ldsB + buf * (kTB * kLDT);
+    const int nk = K - ks * kBK;   // k left from this step on: whole 16-k chunks of zeros are skipped (small-K problems)
 #pragma unroll
     for (int kc = 0; kc < kBK / 16; ++kc) {
+      if (kc * 16 >= nk) break;
       float4 a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(la + (32 * wm + 16 * i + li) * kLDT + kc * 16 + 4 * lg);
@@ -195,7 +207,7 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   // (s_waitcnt vmcnt(0): the pipeline was one step deep again).  Steps past the end fetch zeros (tile_fetch `in`),
   // so the step count is simply rounded up to even and the tail costs at most one k-step of MFMAs on zeros.
   auto step = [&](float (&nxa)[kNR], float (&nxb)[kNR], int ks) {
-    compute(ks & 1);
+    compute(ks & 1, ks);
     store(nxa, nxb, (ks + 1) & 1, ks + 1);
     fetch(nxa, nxb, ks + 3);
     __syncthreads();
