@@ -197,7 +197,7 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j][q], av[i][q], acc[i][j], 0, 0, 0);   // roles swapped: see the epilogue
     }
   };
   // one step: LDS[ks&1] holds tile ks; `nx` (registers) holds tile ks+1, requested two steps ago; the other register
@@ -227,23 +227,47 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   const float* __restrict__ H = d.H + sl * d.h_slot;
   float* __restrict__ C = d.C + sl * d.c_slot;
   const int epi = d.epi, mul = d.mul;
+  // The MFMAs ran with the operand roles swapped (B fragment as the instruction's A): the accumulator tile is the
+  // transpose, i.e. register r of lane (li, lg) is C[m = li][n = 4*lg + r] — four CONSECUTIVE columns of one row per
+  // lane, so bias / saved activations / results move as one 16-byte access per lane and 16x16 tile (16 rows x 64 B
+  // per wave instruction) instead of four dwords each.
   float ss = 0.f;
+  const bool vec_ok = (d.c_rs % 4 == 0) && (((unsigned long long)C & 15) == 0) && !d.ones_col &&
+                      (mul == MUL_NONE || (d.h_rs % 4 == 0 && (((unsigned long long)H & 15) == 0))) &&
+                      (!bias || (((unsigned long long)bias & 15) == 0));
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + 32 * wm + 16 * i + li, nq = n0 + 32 * wn + 16 * j + 4 * lg;
+      if (m >= M || nq >= N) continue;
+      if (vec_ok && nq + 3 < N) {
+        v4f v = acc[i][j];
+        if (bias) v += *(const v4f*)(bias + nq);
+        v4f h = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (mul != MUL_NONE) h = *(const v4f*)(H + (long long)m * d.h_rs + nq);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 32 * wm + 16 * i + 4 * lg + r, n = n0 + 32 * wn + 16 * j + li;
-        if (m >= M || n >= N) continue;
-        float v = acc[i][j][r];
-        if (bias) v += bias[n];
-        v = act_apply(v, epi);
-        if (mul != MUL_NONE) v *= act_deriv(H[(long long)m * d.h_rs + n], mul);
-        ss += v * v;
-        if (d.ones_col && n == N - 1) d.col_out[m] = v;
-        else C[(long long)m * d.c_rs + n] = v;
+        for (int r = 0; r < 4; ++r) {
+          v[r] = act_apply(v[r], epi);
+          if (mul != MUL_NONE) v[r] *= act_deriv(h[r], mul);
+          ss += v[r] * v[r];
+        }
+        *(v4f*)(C + (long long)m * d.c_rs + nq) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nq + r;
+          if (n >= N) continue;
+          float v = acc[i][j][r];
+          if (bias) v += bias[n];
+          v = act_apply(v, epi);
+          if (mul != MUL_NONE) v *= act_deriv(H[(long long)m * d.h_rs + n], mul);
+          ss += v * v;
+          if (d.ones_col && n == N - 1) d.col_out[m] = v;
+          else C[(long long)m * d.c_rs + n] = v;
+        }
       }
+    }
   if (d.sumsq_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
