@@ -108,6 +108,11 @@ template <int TM, int TN, int KSPLIT>
 __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
   static_assert(KSPLIT == 1 || (TM == 1 && TN == 1), "k-split only for single 16x16 tiles");
   constexpr int NACC = (TM * TN >= 4) ? 1 : (TM * TN == 2 ? 2 : 4);
+  // wave-tile forms: the MFMAs run with the operand roles swapped, so the accumulator holds the TRANSPOSED tile —
+  // register r of lane (li, lg) is C[m = li][n = 4*lg + r], four consecutive columns of one row: bias, saved
+  // activations and results move as 16 bytes per lane (gemm_tiled.h does the same).  The k-split form keeps the
+  // plain layout (its waves exchange partial tiles through LDS and finish one element per lane).
+  constexpr bool TR = KSPLIT == 1;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wtile = (KSPLIT == 4) ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j][q % NACC] =
-              __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j][q % NACC], 0, 0, 0);
+          acc[i][j][q % NACC] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][q], a[i][q], acc[i][j][q % NACC], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j][q % NACC], 0, 0, 0);
   };
 
   // byte offsets of the fragment rows for the 16-byte path (operands are < 2 GiB)
@@ -188,18 +193,44 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
   const float* __restrict__ H = d.H + sl * d.h_slot;
   const int mul = d.mul;
   constexpr int NE = (KSPLIT == 4) ? 1 : 4;
-  float pre_b[TN], pre_h[TM][TN][NE];
+  float pre_b[TN][NE], pre_h[TM][TN][NE];
+  const bool epi_vec = TR && (d.c_rs % 4 == 0) && (((unsigned long long)(d.C + sl * d.c_slot)) & 15) == 0 && !ones_col &&
+                       (mul == MUL_NONE || (d.h_rs % 4 == 0 && (((unsigned long long)H) & 15) == 0)) &&
+                       (!bias || (((unsigned long long)bias) & 15) == 0) && (N % 4 == 0);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + 16 * j + li;
-    pre_b[j] = (bias && active && n < N) ? bias[n] : 0.f;
+    if constexpr (TR) {
+      const int nq = n0 + 16 * j + 4 * lg;
+      if (epi_vec) {
+        const v4f bv = (bias && active && nq < N) ? *(const v4f*)(bias + nq) : (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int r = 0; r < 4; ++r) pre_b[j][r] = bv[r];
+      } else {
 #pragma unroll
-      for (int r = 0; r < NE; ++r) {
-        const int m = (KSPLIT == 4) ? m0 + 4 * lg + wave : m0 + 16 * i + 4 * lg + r;
-        pre_h[i][j][r] = (mul != MUL_NONE && active && m < M && n < N) ? H[(long long)m * d.h_rs + n] : 0.f;
+        for (int r = 0; r < 4; ++r) pre_b[j][r] = (bias && active && nq + r < N) ? bias[nq + r] : 0.f;
       }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + 16 * i + li;
+        if (epi_vec) {
+          const v4f hv = (mul != MUL_NONE && active && m < M && nq < N) ? *(const v4f*)(H + (long long)m * d.h_rs + nq) : (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pre_h[i][j][r] = hv[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pre_h[i][j][r] = (mul != MUL_NONE && active && m < M && nq + r < N) ? H[(long long)m * d.h_rs + nq + r] : 0.f;
+        }
+      }
+    } else {
+      const int n = n0 + 16 * j + li;
+      pre_b[j][0] = (bias && active && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + 4 * lg + wave;
+        pre_h[i][j][0] = (mul != MUL_NONE && active && m < M && n < N) ? H[(long long)m * d.h_rs + n] : 0.f;
+      }
+    }
   }
 
   if (active) {
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += red[w][wave][lane];
-    const float x = finish(v, m0 + 4 * lg + wave, n0 + li, pre_b[0], pre_h[0][0][0]);
+    const float x = finish(v, m0 + 4 * lg + wave, n0 + li, pre_b[0][0], pre_h[0][0][0]);
     if (d.bn_part) {   // (uniform per workgroup: one problem, one tile)
       __shared__ float cs[2][4][16];
       const int rows = min(16, M - m0), n = n0 + li;
@@ -338,10 +369,26 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j) {
+        const int m = m0 + 16 * i + li, nq = n0 + 16 * j + 4 * lg;
+        if (epi_vec) {
+          if (m < M && nq < N) {   // (N % 4 == 0: the whole quad is inside)
+            v4f v = acc[i][j][0];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          finish(acc[i][j][0][r], m0 + 16 * i + 4 * lg + r, n0 + 16 * j + li, pre_b[j], pre_h[i][j][r % NE]);
+            for (int r = 0; r < 4; ++r) {
+              float x = v[r] + pre_b[j][r];
+              x = act_apply(x, epi);
+              if (mul != MUL_NONE) x *= act_deriv(pre_h[i][j][r], mul);
+              ss += x * x;
+              v[r] = x;
+            }
+            *(v4f*)(C + (long long)m * d.c_rs + nq) = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) finish(acc[i][j][0][r], m, nq + r, pre_b[j][r], pre_h[i][j][r]);
+        }
+      }
   }
   if (d.sumsq_out) {
 #pragma unroll
