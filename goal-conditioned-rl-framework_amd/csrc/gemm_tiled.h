@@ -4,19 +4,26 @@
 // A 256-thread workgroup owns a 64x64 output tile; its 4 waves own 32x32 each (2x2 MFMA tiles of
 // 16x16x4).  Per 32-wide k-step the two 64x32 operand tiles are fetched from global memory with
 // fully coalesced 16-byte loads (along k when the operand is k-contiguous, along the row index
-// otherwise — then transposed on the LDS write), kept in registers while the previous step's
-// MFMAs run, and stored to LDS as [row][k] with a 4-float pad.  Fragments come back as one
-// ds_read_b128 per 16x16x16 chunk (same k-permutation as gemm_mfma.h: element q of the read feeds
-// MFMA q).  Compared with per-wave fragment loads straight from global memory (16 rows x 64 B per
-// instruction, each operand re-read by every wave that needs it) this cuts global/L2 traffic 2x
-// per wave and turns every global access into whole lines.
+// otherwise — then transposed on the LDS write), held in registers for two k-steps while earlier
+// steps' MFMAs run, and stored to one of two LDS buffers as [row][k] with a 4-float pad (one barrier
+// per step).  Fragments come back as one ds_read_b128 per 16x16x16 chunk (same k-permutation as
+// gemm_mfma.h: element q of the read feeds MFMA q); the MFMAs accumulate the TRANSPOSED tile so the
+// epilogue moves 16 bytes per lane.
+//
+// Round-2 measurements (M=10240, N=K=512 = the 1280 tiles of TQC's 5-critic launches; the library's plain
+// fp32 GEMM on the same operands: 94-97 TFLOP/s; results bitwise equal to it):
+//   round 1 (k-step 64, per-step address arithmetic, branch per load, 2 barriers, 4-byte epilogue)   63 / 57 TFLOP/s (fwd / dX)
+//   branch-free fetch, offsets planned once, 2 register stages + 2 LDS buffers                      73 / 71
+//   + transposed accumulators, 16-byte epilogue                                                      78 / 72
+//   + k-step 32 (80 VGPRs, 36 KB LDS: 4 workgroups per CU instead of 2, all 5 tiles of a CU resident)  88 / 80
+//   (k-step 16: 86 / 89, TQC step equal, the quantile variant 3 % slower)
 #pragma once
 #include "gemm_mfma.h"
 
 namespace gcrl {
 
 constexpr int kTB = 64;        // block tile
-constexpr int kBK = 64;        // k-step: 64 MFMAs (0.85 us) per wave per fetched tile pair, ~ the L2 latency
+constexpr int kBK = 32;        // k-step: 32 MFMAs per wave between barriers; small enough for 4 workgroups per CU (see above)
 constexpr int kNV = kTB * kBK / 4 / 256;  // float4 per thread per operand tile
 constexpr int kNR = 4 * kNV;              // staging registers per operand
 constexpr int kLDT = kBK + 4;  // LDS row stride (floats): 144 B keeps b128 alignment, spreads banks
