@@ -123,6 +123,7 @@ struct gcrl_agent {
   // target critic 0, per-layer gradient buffers, TD targets
   bool rowchain = false, wt_dirty = true;
   bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
+  bool split_k = false;       // TD3: critic phase as role-parallel launches (agent_rowchain.inc)
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
   int split_rg[4] = {1, 1, 1, 1};
   int row_rg = 1, row_ldl = 0;
@@ -1018,6 +1019,9 @@ int build(gcrl_agent* a) {
     a->split_roles = a->rowchain && c.kind == GCRL_AGENT_SAC && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) <= 256 &&
                      !std::getenv("GCRL_NO_SPLIT_ROLES");
     for (int i = 0; i < 4; ++i) a->split_rg[i] = a->row_rg;
+    // TD3 once the batch fills the chip (cfg 3: 183.5 -> 178.4 us/step; below that the fused launch is the shorter chain)
+    a->split_k = a->rowchain && c.kind == GCRL_AGENT_TD3 && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) >= 256 &&
+                 !std::getenv("GCRL_NO_SPLIT_TD3");
     a->bn_fused = std::getenv("GCRL_BN_FUSED") != nullptr;   // measured equal at cfg 5 (204.6 vs 203.6 us/step): off by default
     if (const char* e = std::getenv("GCRL_SPLIT_RG"))   // experiment knob: four digits, rows/4 per workgroup of the four launches
       for (int i = 0; i < 4 && e[i]; ++i) a->split_rg[i] = e[i] - '0';
