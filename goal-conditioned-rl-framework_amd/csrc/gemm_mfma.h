@@ -288,24 +288,31 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
     if (a_vec) { if (b_vec) interior(T1{}, T1{}); else interior(T1{}, T0{}); }
     else       { if (b_vec) interior(T0{}, T1{}); else interior(T0{}, T0{}); }
     if (kc_beg <= kfull && kfull < kc_end) {
-      // the one partial chunk at the end of K: guarded scalar loads
+      // the one partial chunk at the end of K (first layers: K = obs + ac dims): element loads through descriptors
+      // with the operands' extents, k >= K pushed past them (the hardware returns 0) — no branch per element.  With
+      // `(kb + q < K) ? p[..] : 0` each load sat in its own predicated block and a K = 25 problem spent most of
+      // its time here.
+      constexpr int kPast = 0x7ffffff0;
+      const __amdgpu_buffer_rsrc_t ta = wave_uniform_rsrc_n(A, (long long)(M - 1) * a_rs + (long long)(K - 1) * a_cs + 1);
+      const int n_mem = ones_col ? N - 1 : N;
+      const __amdgpu_buffer_rsrc_t tb = wave_uniform_rsrc_n(Bm, (long long)(n_mem - 1) * b_cs + (long long)(K - 1) * b_rs + 1);
       const int kb = (kfull << 4) + (lg << 2);
       float a[TM][4], b[TN][4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const float* p = ap[i] + (long long)kb * a_cs;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[i][q] = (kb + q < K) ? p[q * a_cs] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const float* p = bp[j] + (long long)kb * b_rs;
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float v = (kb + q < K) ? p[q * b_rs] : 0.f;
+          const int off = (kb + q < K) ? aoff[i] + (int)((long long)(kb + q) * a_cs * 4) : kPast;
+          a[i][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ta, off, 0, 0));
+        }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int off = (kb + q < K) ? boff[j] + (int)((long long)(kb + q) * b_rs * 4) : kPast;
+          const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tb, off, 0, 0));
           b[j][q] = bone[j] ? ((kb + q < K) ? 1.f : 0.f) : v;
         }
-      }
       mfma_chunk(a, b);
     }
   }

@@ -51,9 +51,10 @@ int shape_of(const GemmDesc& d) {
   // (TD3 at B=2048, H=256: 128 tiles of 64x64 was 16% slower than 2048 wave tiles)
   // ... or when the reduction is long (dW at batch 2048: a wave walking 128 k-chunks alone took
   // 89 us; 64x64 tiles with LDS reuse are MFMA-bound there too)
-  // one k-step or less (first layers with K = obs + ac, head dX with K = 1..4): nothing to stage — the LDS-tiled form
-  // spends its time in prologue and barriers (29-31 us vs 15-25 us for 32x32 wave tiles at M=10240, N=512; measured)
-  if (d.K <= 64) return 3;
+  // a single 16-k chunk (head dX with K = 1..4: outer products): nothing to stage, 32x32 wave tiles (12 us vs 17 us
+  // LDS-tiled at M=10240, N=512).  K = 25 first layers: the LDS-tiled form again (19 us vs 24 us) since its element-wise
+  // fetch went branch-free.
+  if (d.K <= 16) return 3;
   const long long tiles64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64);
   return (tiles64 >= 192 || d.K >= 1024) ? 4 : 2;
 }
