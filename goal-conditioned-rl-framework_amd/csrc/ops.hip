@@ -25,6 +25,18 @@ __device__ inline double wave_sum_d(double v) {
   return v;
 }
 // sum over a 256-thread block; result valid in thread 0.  `scratch` holds 4 floats.
+// sum over a block of up to 1024 threads (whole waves); result valid in every thread.  `scratch` holds 16 floats.
+// Waves beyond the data contribute exact zeros, so the result does not depend on the block size chosen for small B.
+__device__ inline float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  float s = scratch[0];
+  for (int w = 1; w < nw; ++w) s += scratch[w];
+  return s;
+}
 __device__ inline float block_sum_256(float v, float* scratch) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -44,8 +56,10 @@ __global__ void begin_step_kernel(CtrlBlock* cb, int shift) {
 }
 
 // ------------------------------------------------------------------ TD target + loss
-__global__ __launch_bounds__(256) void td_loss_kernel(TdLossArgs a) {
-  __shared__ float scratch[4];
+// one block of 256..1024 threads (launch_td_loss): at B = 2048 a 256-thread block walked 8 dependent rounds of ~13 loads
+// each (31 us in TQC's step)
+__global__ __launch_bounds__(1024) void td_loss_kernel(TdLossArgs a) {
+  __shared__ float scratch[16];
   const StepCtrl c = *a.cur;
   const float* __restrict__ r = a.r + (long long)c.batch_slot * a.slot_stride;
   const float* __restrict__ d = a.d + (long long)c.batch_slot * a.slot_stride;
@@ -58,7 +72,7 @@ __global__ __launch_bounds__(256) void td_loss_kernel(TdLossArgs a) {
   float td = 0.f, qsum = 0.f;
   const float mse_norm = 2.0f / (float)B, l1_norm = 1.0f / (float)B;
 
-  for (int b = threadIdx.x; b < B; b += 256) {
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
     float qt[kMaxCritics];
 #pragma unroll
     for (int k = 0; k < kMaxCritics; ++k) qt[k] = (k < C) ? a.qt[(long long)k * B + b] : INFINITY;
@@ -116,24 +130,25 @@ __global__ __launch_bounds__(256) void td_loss_kernel(TdLossArgs a) {
 #pragma unroll
   for (int k = 0; k < kMaxCritics; ++k) {
     if (k < C) {
-      const float s = block_sum_256(loss[k], scratch);
+      const float s = block_sum(loss[k], scratch);
       if (threadIdx.x == 0) met[MET_CRITIC_LOSS + k] = s / (float)B;
     }
   }
-  const float tds = block_sum_256(td, scratch);
-  const float qs = block_sum_256(qsum, scratch);
+  const float tds = block_sum(td, scratch);
+  const float qs = block_sum(qsum, scratch);
   if (threadIdx.x == 0) {
     met[MET_TD] = tds / (float)B;
     met[MET_Q] = qs / (float)(B * C);
   }
 }
 
-__global__ __launch_bounds__(256) void mean_metric_kernel(const StepCtrl* cur, const float* x, int n,
-                                                          float scale, float* metrics, int idx) {
-  __shared__ float scratch[4];
+__global__ __launch_bounds__(1024) void mean_metric_kernel(const StepCtrl* cur, const float* x, int n,
+                                                           float scale, float* metrics, int idx) {
+  __shared__ float scratch[16];
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
-  s = block_sum_256(s, scratch);
+#pragma unroll 8
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+  s = block_sum(s, scratch);
   if (threadIdx.x == 0) metrics[(long long)cur->metrics_slot * kMetricFloats + idx] = scale * (s / (float)n);
 }
 
@@ -374,6 +389,9 @@ __global__ void polyak_kernel(const float* p, float* tp, long long n, float tau,
 
 }  // namespace
 
+// threads of a single-block reduction over n items: whole waves, 256..1024
+static inline unsigned reduce_threads(long long n) { return (unsigned)std::min<long long>(1024, std::max<long long>(256, (n + 63) / 64 * 64)); }
+
 int launch_begin_step(hipStream_t st, CtrlBlock* cb, int shift) {
   hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(64), 0, st, cb, shift);
   GCRL_HIP(hipGetLastError());
@@ -382,14 +400,14 @@ int launch_begin_step(hipStream_t st, CtrlBlock* cb, int shift) {
 
 int launch_td_loss(hipStream_t st, const TdLossArgs& a) {
   GCRL_CHECK_ARG(a.C >= 1 && a.C <= kMaxCritics && a.B >= 1, "td_loss: bad C=%d B=%d", a.C, a.B);
-  hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(reduce_threads(a.B)), 0, st, a);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
 
 int launch_mean_metric(hipStream_t st, const StepCtrl* cur, const float* x, int n, float scale,
                        float* metrics, int idx) {
-  hipLaunchKernelGGL(mean_metric_kernel, dim3(1), dim3(256), 0, st, cur, x, n, scale, metrics, idx);
+  hipLaunchKernelGGL(mean_metric_kernel, dim3(1), dim3(reduce_threads(n)), 0, st, cur, x, n, scale, metrics, idx);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

@@ -21,6 +21,18 @@ __device__ inline float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
+// sum over a block of up to 1024 threads (whole waves); result valid in every thread.  `scratch` holds 16 floats.
+// Waves beyond the data contribute exact zeros, so the result does not depend on the block size chosen for small B.
+__device__ inline float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  float s = scratch[0];
+  for (int w = 1; w < nw; ++w) s += scratch[w];
+  return s;
+}
 __device__ inline float block_sum_256(float v, float* scratch) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -369,7 +381,7 @@ __device__ inline void actor_select_body(const ActorSelArgs& a, float* scratch) 
   const int B = a.B, C = a.C, keep = a.C - a.drop;
   const float gb = -1.0f / (float)B;
   float acc = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) {
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
     float q[kMaxCritics];
 #pragma unroll
     for (int k = 0; k < kMaxCritics; ++k) q[k] = (k < C) ? a.q[(long long)k * B + b] : INFINITY;
@@ -407,12 +419,12 @@ __device__ inline void actor_select_body(const ActorSelArgs& a, float* scratch) 
     }
     acc += __fsub_rn(__fmul_rn(alpha, a.logp[b]), sel);
   }
-  acc = block_sum_256(acc, scratch);
+  acc = block_sum(acc, scratch);
   if (threadIdx.x == 0) a.metrics[(long long)c.metrics_slot * kMetricFloats + MET_ACTOR_LOSS] = acc / (float)B;
 }
 
-__global__ __launch_bounds__(256) void actor_select_kernel(ActorSelArgs a) {
-  __shared__ float scratch[4];
+__global__ __launch_bounds__(1024) void actor_select_kernel(ActorSelArgs a) {
+  __shared__ float scratch[16];
   actor_select_body(a, scratch);
 }
 
@@ -447,8 +459,8 @@ __device__ inline void alpha_body(const AlphaArgs& a, float* scratch) {
   }
   if (a.phase != 1) {
     float s = 0.f;
-    for (int b = threadIdx.x; b < a.B; b += 256) s += a.logp[b] + a.target_entropy;
-    s = block_sum_256(s, scratch);
+    for (int b = threadIdx.x; b < a.B; b += blockDim.x) s += a.logp[b] + a.target_entropy;
+    s = block_sum(s, scratch);
     if (threadIdx.x == 0) {
       const float mean_x = s / (float)a.B;
       met[MET_ALPHA_LOSS] = -(*a.log_alpha * mean_x);
@@ -461,14 +473,14 @@ __device__ inline void alpha_body(const AlphaArgs& a, float* scratch) {
   }
 }
 
-__global__ __launch_bounds__(256) void alpha_update_kernel(AlphaArgs a) {
-  __shared__ float scratch[4];
+__global__ __launch_bounds__(1024) void alpha_update_kernel(AlphaArgs a) {
+  __shared__ float scratch[16];
   alpha_body(a, scratch);
 }
 
 // actor-loss selection and the log-alpha gradient (both single-block passes over logp) in one launch
-__global__ __launch_bounds__(256) void actor_select_alpha_kernel(ActorSelArgs s, AlphaArgs al) {
-  __shared__ float scratch[4];
+__global__ __launch_bounds__(1024) void actor_select_alpha_kernel(ActorSelArgs s, AlphaArgs al) {
+  __shared__ float scratch[16];
   actor_select_body(s, scratch);
   __syncthreads();
   alpha_body(al, scratch);
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(256) void actor_select_alpha_kernel(ActorSelArgs s,
 // its own min-selection), so its single block rides on the tanh-Gaussian backward launch as one extra block
 __global__ __launch_bounds__(256) void tanh_gauss_bwd_select_kernel(TanhGaussBwdArgs a, ActorSelArgs s, AlphaArgs al) {
   if (blockIdx.x + 1 < gridDim.x) { tanh_gauss_bwd_body(a); return; }
-  __shared__ float scratch[4];
+  __shared__ float scratch[16];
   actor_select_body(s, scratch);
   __syncthreads();
   alpha_body(al, scratch);
@@ -629,6 +641,7 @@ int launch_quantile_actor(hipStream_t st, const QuantileActorArgs& a) {
   return GCRL_OK;
 }
 
+static inline unsigned reduce_threads(long long n) { return (unsigned)std::min<long long>(1024, std::max<long long>(256, (n + 63) / 64 * 64)); }
 static inline bool bn_aligned(const void* p) { return ((unsigned long long)p & 15ull) == 0; }
 
 int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
@@ -703,14 +716,14 @@ int launch_tanh_gauss_fwd2(hipStream_t st, const TanhGaussArgs& a0, const TanhGa
 
 int launch_actor_select(hipStream_t st, const ActorSelArgs& a) {
   GCRL_CHECK_ARG(a.C >= 1 && a.C <= kMaxCritics && a.drop >= 0 && a.drop < a.C, "actor_select: bad C=%d drop=%d", a.C, a.drop);
-  hipLaunchKernelGGL(actor_select_kernel, dim3(1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(actor_select_kernel, dim3(1), dim3(reduce_threads(a.B)), 0, st, a);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
 
 int launch_actor_select_alpha(hipStream_t st, const ActorSelArgs& a, const AlphaArgs& al) {
   GCRL_CHECK_ARG(a.C >= 1 && a.C <= kMaxCritics && a.drop >= 0 && a.drop < a.C, "actor_select: bad C=%d drop=%d", a.C, a.drop);
-  hipLaunchKernelGGL(actor_select_alpha_kernel, dim3(1), dim3(256), 0, st, a, al);
+  hipLaunchKernelGGL(actor_select_alpha_kernel, dim3(1), dim3(reduce_threads(a.B)), 0, st, a, al);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
