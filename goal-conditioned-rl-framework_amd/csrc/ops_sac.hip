@@ -109,7 +109,8 @@ __device__ inline void gather_store(const PartRegs& r, v4f (*sp)[kBnMaxPart][16]
   __syncthreads();
 }
 
-struct BnFwdPair { BnFwdProb p[2]; int n; int rpp; };   // rpp: rows per partial (64: bn_stats_kernel, 16: GEMM epilogue)
+constexpr int kBnSlabMax = 4;
+struct BnFwdPair { BnFwdProb p[2]; int n; int rpp; int slabs; };   // rpp: rows per partial (64: bn_stats_kernel, 16: GEMM epilogue)
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(BnFwdPair pr, int B, int H) {
   __shared__ v4f red[kBnSlots][16];
@@ -182,15 +183,22 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
   const float* __restrict__ z = me.z;
   const float* __restrict__ part_mean = me.scratch;
   const float* __restrict__ part_m2 = me.scratch + (long long)nrb * H;
-  const int b = blockIdx.y * kBnSlots + slot;
-  // request everything first: the partials' slice, the affine pair, this thread's row
+  // a block transforms `slabs` slabs of 16 rows (launcher: 1 up to B = 1024, then B/1024): the gather + merge of the
+  // partials is paid once per block, and at B = 2048 it was most of a 19.6 us launch
+  const int slabs = pr.slabs;
+  // request everything first: the partials' slice, the affine pair, this thread's rows
   // the block that updates the running statistics of a two-problem launch also needs problem 1's merged statistics
   const bool second = blockIdx.y == 0 && blockIdx.z == 0 && pr.n > 1;   // (uniform per block)
   PartRegs prg, prg1;
   gather_request(prg, part_mean, part_m2, nrb, H, blockIdx.x * 64);
   if (second) gather_request(prg1, pr.p[1].scratch, pr.p[1].scratch + (long long)nrb * H, nrb, H, blockIdx.x * 64);
   const v4f g = ok ? ld4(gamma + col) : zero4(), bt = ok ? ld4(beta + col) : zero4();
-  const v4f v = (ok && b < B) ? ld4(z + (long long)b * H + col) : zero4();
+  v4f v[kBnSlabMax];
+#pragma unroll
+  for (int sl = 0; sl < kBnSlabMax; ++sl) {
+    const int b = (blockIdx.y * slabs + sl) * kBnSlots + slot;
+    v[sl] = (ok && sl < slabs && b < B) ? ld4(z + (long long)b * H + col) : zero4();
+  }
   v4f rm0 = zero4(), rv0 = zero4();
   if (blockIdx.y == 0 && blockIdx.z == 0 && slot == 0 && ok) { rm0 = ld4(rmean + col); rv0 = ld4(rvar + col); }
   gather_store(prg, sp);
@@ -199,15 +207,19 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
   v4f invstd;
 #pragma unroll
   for (int q = 0; q < 4; ++q) invstd[q] = 1.0f / sqrtf(var[q] + kBnEps);
-  if (ok && b < B) {
-    const long long idx = (long long)b * H + col;
-    const v4f xh = (v - mean) * invstd;
-    const v4f y = xh * g + bt;
-    v4f hv;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) hv[q] = y[q] > 0.f ? y[q] : 0.f;
-    *(v4f*)(me.h + idx) = hv;
-    if (me.xhat) *(v4f*)(me.xhat + idx) = xh;
+  for (int sl = 0; sl < kBnSlabMax; ++sl) {
+    const int b = (blockIdx.y * slabs + sl) * kBnSlots + slot;
+    if (ok && sl < slabs && b < B) {
+      const long long idx = (long long)b * H + col;
+      const v4f xh = (v[sl] - mean) * invstd;
+      const v4f y = xh * g + bt;
+      v4f hv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hv[q] = y[q] > 0.f ? y[q] : 0.f;
+      *(v4f*)(me.h + idx) = hv;
+      if (me.xhat) *(v4f*)(me.xhat + idx) = xh;
+    }
   }
   if (ok && blockIdx.y == 0 && slot == 0 && me.invstd) *(v4f*)(me.invstd + col) = invstd;
   // running statistics: problem 0's batch, then problem 1's (two forward calls, in that order)
@@ -295,21 +307,25 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ part_dy,
                                                                 const float* __restrict__ part_dyx, int B, int H,
                                                                 float* __restrict__ dz, float* dgamma, float* dbeta,
-                                                                float* sumsq_out) {
+                                                                float* sumsq_out, int slabs) {
   __shared__ v4f sp[2][kBnMaxPart][16];
   const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cq;
   const bool ok = col < H;
   const int nrb = (B + kBnRows - 1) / kBnRows;
-  const int b = blockIdx.y * kBnSlots + slot;
-  const bool in = ok && b < B;
-  const long long idx = (long long)b * H + col;
   PartRegs prg;
   gather_request(prg, part_dy, part_dyx, nrb, H, blockIdx.x * 64);
   const v4f g = ok ? ld4(gamma + col) : zero4(), bt = ok ? ld4(beta + col) : zero4(), is = ok ? ld4(invstd + col) : zero4();
-  const v4f vd = in ? ld4(dh + idx) : zero4();
-  const v4f vd2 = (in && dh2) ? ld4(dh2 + idx) : zero4();
-  const v4f vx = in ? ld4(xhat + idx) : zero4();
+  v4f vd[kBnSlabMax], vd2[kBnSlabMax], vx[kBnSlabMax];
+#pragma unroll
+  for (int sl = 0; sl < kBnSlabMax; ++sl) {
+    const int b = (blockIdx.y * slabs + sl) * kBnSlots + slot;
+    const bool in = ok && sl < slabs && b < B;
+    const long long idx = (long long)b * H + col;
+    vd[sl] = in ? ld4(dh + idx) : zero4();
+    vd2[sl] = (in && dh2) ? ld4(dh2 + idx) : zero4();
+    vx[sl] = in ? ld4(xhat + idx) : zero4();
+  }
   gather_store(prg, sp);
   v4f sum_dy = zero4(), sum_dyx = zero4();
   const int nl = min(nrb, kBnMaxPart);
@@ -321,9 +337,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
   }
   const v4f k = g * is;
   const v4f m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B;
-  if (in) {
-    const v4f dy = bn_dy(dh2 ? vd + vd2 : vd, vx, g, bt);
-    *(v4f*)(dz + idx) = (dy - m1 - vx * m2) * k;
+#pragma unroll
+  for (int sl = 0; sl < kBnSlabMax; ++sl) {
+    const int b = (blockIdx.y * slabs + sl) * kBnSlots + slot;
+    if (ok && sl < slabs && b < B) {
+      const v4f dy = bn_dy(dh2 ? vd[sl] + vd2[sl] : vd[sl], vx[sl], g, bt);
+      *(v4f*)(dz + (long long)b * H + col) = (dy - m1 - vx[sl] * m2) * k;
+    }
   }
   if (ok && blockIdx.y == 0 && slot == 0) { *(v4f*)(dgamma + col) = sum_dyx; *(v4f*)(dbeta + col) = sum_dy; }
   if (sumsq_out && blockIdx.y == 0) {   // sum of squares of this column block's dgamma | dbeta (global-norm clip, fixed slot)
@@ -642,6 +662,7 @@ int launch_quantile_actor(hipStream_t st, const QuantileActorArgs& a) {
 }
 
 static inline unsigned reduce_threads(long long n) { return (unsigned)std::min<long long>(1024, std::max<long long>(256, (n + 63) / 64 * 64)); }
+static inline int bn_slabs(int B) { return std::min(kBnSlabMax, std::max(1, B / 1024)); }
 static inline bool bn_aligned(const void* p) { return ((unsigned long long)p & 15ull) == 0; }
 
 int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
@@ -669,8 +690,9 @@ int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, 
     hipLaunchKernelGGL(bn_stats_kernel, dim3((H + 63) / 64, nrb, nprob), dim3(256), 0, st, pr, B, H);
     GCRL_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots - 1) / kBnSlots, nprob), dim3(256), 0, st, pr, B, H, gamma,
-                     beta, rmean, rvar);
+  pr.slabs = bn_slabs(B);
+  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots * pr.slabs - 1) / (kBnSlots * pr.slabs), nprob), dim3(256), 0,
+                     st, pr, B, H, gamma, beta, rmean, rvar);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
@@ -696,8 +718,9 @@ int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const 
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((H + 63) / 64, nrb), dim3(256), 0, st, dh, dh2, xhat, gamma, beta, B, H, part_dy,
                      part_dyx);
   GCRL_HIP(hipGetLastError());
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots - 1) / kBnSlots), dim3(256), 0, st, dh, dh2, xhat,
-                     invstd, gamma, beta, part_dy, part_dyx, B, H, dz, dgamma, dbeta, sumsq_out);
+  const int slabs = bn_slabs(B);
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots * slabs - 1) / (kBnSlots * slabs)), dim3(256), 0, st, dh,
+                     dh2, xhat, invstd, gamma, beta, part_dy, part_dyx, B, H, dz, dgamma, dbeta, sumsq_out, slabs);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
