@@ -162,6 +162,8 @@ struct gcrl_agent {
   // update_n: batches 1..n-1 are drawn / uploaded / gathered AFTER the first step's launches have been issued (the host
   // draws ~2 us per batch from the MT stream: with all n batches up front the GPU idled ~40 us at the start of a cycle)
   struct { gcrl_her* her = nullptr; int n = 0; int slot = 0; } deferred;
+  hipStream_t aux_stream = nullptr;   // the deferred gather of batches 1..n-1 runs here, next to step 0
+  hipEvent_t pre_ev = nullptr, defer_ev = nullptr;
   std::vector<StepPlan> dp_plans;  // steps of the data-parallel cycle begun by gcrl_agent_dp_begin
   std::vector<DpSeg> dp_segs;      // ... as segments separated by gradient exchanges
   size_t dp_pos = 0;
@@ -856,14 +858,24 @@ int finish_deferred_draw(gcrl_agent* a, hipStream_t st) {
   const int n = a->deferred.n, B = a->B;
   uint32_t* idx = (uint32_t*)(a->upload_pinned[a->deferred.slot] + sizeof(UploadBlock));
   for (int i = 1; i < n; ++i) TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)B, idx + (size_t)i * B));
-  GCRL_HIP(hipMemcpyAsync(a->idx_dev() + B, idx + B, (size_t)(n - 1) * B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  GCRL_HIP(hipEventRecord(a->upload_ev[a->deferred.slot], st));
-  return her_gather_update(her, a->idx_dev() + B, (int64_t)(n - 1) * B, a->sa + a->slot_x, a->nsa + a->slot_x,
-                           a->rowchain ? nullptr : a->spa + a->slot_x, a->ldx, a->rbuf + a->slot_rd, a->dbuf + a->slot_rd, st);
+  // The index upload and the gather go to a second stream: on `st` they queued BEHIND step 0 (in-order) and step 1
+  // waited for draw + copy + gather after it (43 us of idle GPU per call in the 20-step trace); here they run next
+  // to step 0's launches (which occupy half the chip).  aux waits for everything earlier on `st` (pre_ev: the previous
+  // call's steps still read batches 1.., ring flushes), `st` waits for the gather before step 1.
+  hipStream_t ax = a->aux_stream;
+  GCRL_HIP(hipStreamWaitEvent(ax, a->pre_ev, 0));
+  GCRL_HIP(hipMemcpyAsync(a->idx_dev() + B, idx + B, (size_t)(n - 1) * B * sizeof(uint32_t), hipMemcpyHostToDevice, ax));
+  GCRL_HIP(hipEventRecord(a->upload_ev[a->deferred.slot], ax));
+  TRY(her_gather_update(her, a->idx_dev() + B, (int64_t)(n - 1) * B, a->sa + a->slot_x, a->nsa + a->slot_x,
+                        a->rowchain ? nullptr : a->spa + a->slot_x, a->ldx, a->rbuf + a->slot_rd, a->dbuf + a->slot_rd, ax));
+  GCRL_HIP(hipEventRecord(a->defer_ev, ax));
+  GCRL_HIP(hipStreamWaitEvent(st, a->defer_ev, 0));
+  return GCRL_OK;
 }
 
 int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_update_inputs* in, float grad_scale,
-               hipStream_t st, std::vector<StepPlan>& plans, int64_t* tickets, int32_t* lens, bool defer_rest = false) {
+               hipStream_t st, std::vector<StepPlan>& plans, int64_t* tickets, int32_t* lens, bool defer_rest = false,
+               bool pre_advanced = false) {
   TRY(finish_deferred_draw(a, st));   // (never pending here; cheap safety)
   GCRL_CHECK_ARG(n >= 1 && n <= kMaxStepsPerCall && n <= a->Mmax, "update: n=%d steps per call (max %d)", n, std::min(kMaxStepsPerCall, a->Mmax));
   const bool injected = in && in->s_dev;
@@ -878,7 +890,7 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
   GCRL_HIP(hipEventSynchronize(a->upload_ev[slot]));
   UploadBlock* ub = (UploadBlock*)a->upload_pinned[slot];
   uint32_t* idx = (uint32_t*)(a->upload_pinned[slot] + sizeof(UploadBlock));
-  ub->cb.cursor = 0;
+  ub->cb.cursor = pre_advanced ? 1 : 0;   // pre_advanced: cur = table[0] travels in the block itself, the first step launches no begin_step
   plans.resize(n);
   StepCtrl* table = ub->cb.table;
   for (int i = 0; i < n; ++i) {
@@ -910,11 +922,24 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
     her->last_gen = IdxGen{her->cfg.seed, her->draws_done, (uint32_t)her->len, a->B, feistel_half_bits((uint32_t)her->len)};
     her->draws_done += n;
   }
-  GCRL_HIP(hipMemcpyAsync(a->upload_dev, ub, bytes, hipMemcpyHostToDevice, st));
-  GCRL_HIP(hipEventRecord(a->upload_ev[slot], st));
-  if (!injected)
-    TRY(her_gather_update(her, (device_rng && !explicit_idx) ? nullptr : a->idx_dev(), (int64_t)(a->deferred.her ? 1 : n) * a->B, a->sa, a->nsa,
-                          a->rowchain ? nullptr : a->spa, a->ldx, a->rbuf, a->dbuf, st));
+  const bool host_idx = !injected && !(device_rng && !explicit_idx);
+  const int64_t rows_now = (int64_t)(a->deferred.her ? 1 : n) * a->B;
+  if (!injected && (!host_idx || rows_now == a->B)) {
+    // One launch starts the call: the gather reads its (<= B) indices straight from the pinned block and carries the
+    // control block to the device (header + the n table entries in use) — before, two staged copies and their launch
+    // gaps (19 us) preceded the first gather.
+    const size_t cb_bytes = (offsetof(UploadBlock, cb) + offsetof(CtrlBlock, table) + (size_t)n * sizeof(StepCtrl) + 15) & ~(size_t)15;
+    TRY(her_gather_update(her, host_idx ? idx : nullptr, rows_now, a->sa, a->nsa, a->rowchain ? nullptr : a->spa, a->ldx, a->rbuf,
+                          a->dbuf, st, ub, a->upload_dev, cb_bytes));
+    GCRL_HIP(hipEventRecord(a->upload_ev[slot], st));
+  } else {
+    GCRL_HIP(hipMemcpyAsync(a->upload_dev, ub, bytes, hipMemcpyHostToDevice, st));
+    GCRL_HIP(hipEventRecord(a->upload_ev[slot], st));
+    if (!injected)
+      TRY(her_gather_update(her, host_idx ? a->idx_dev() : nullptr, rows_now, a->sa, a->nsa, a->rowchain ? nullptr : a->spa, a->ldx,
+                            a->rbuf, a->dbuf, st));
+  }
+  if (a->deferred.her) GCRL_HIP(hipEventRecord(a->pre_ev, st));
   return GCRL_OK;
 }
 
@@ -937,6 +962,9 @@ int build(gcrl_agent* a) {
   GCRL_HIP(hipSetDevice(c.device));
   GCRL_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
   GCRL_HIP(hipStreamCreateWithFlags(&a->cap_stream, hipStreamNonBlocking));
+  GCRL_HIP(hipStreamCreateWithFlags(&a->aux_stream, hipStreamNonBlocking));
+  GCRL_HIP(hipEventCreateWithFlags(&a->pre_ev, hipEventDisableTiming));
+  GCRL_HIP(hipEventCreateWithFlags(&a->defer_ev, hipEventDisableTiming));
   const int S = a->S, A = a->A, H = a->H, L = a->L, B = a->B, C = a->C;
   a->actor = make_net(S, H, L, A, a->sac);
   a->critic = make_net(S + A, H, L, a->Q, false);
@@ -1150,6 +1178,9 @@ void gcrl_agent_destroy(gcrl_agent* a) {
   for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
   float* bufs[] = {a->params, a->grads, a->adam_m, a->adam_v, a->bn_rmean, a->bn_rvar, a->alpha_dev, a->work};
   for (float* p : bufs) if (p) (void)hipFree(p);
+  if (a->aux_stream) (void)hipStreamDestroy(a->aux_stream);
+  if (a->pre_ev) (void)hipEventDestroy(a->pre_ev);
+  if (a->defer_ev) (void)hipEventDestroy(a->defer_ev);
   if (a->upload_dev) (void)hipFree(a->upload_dev);
   for (int i = 0; i < kCtrlSlots; ++i) {
     if (a->upload_pinned[i]) (void)hipHostFree(a->upload_pinned[i]);
@@ -1384,17 +1415,19 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
   for (int done = 0; done < n; done += chunk) {
     const int m = std::min(chunk, n - done);
     std::vector<StepPlan> plans;
+    const bool ddpg_pipe = a->cfg.kind == GCRL_AGENT_DDPG && a->cfg.pipeline_steps != 0;
+    const int adv = (a->sac && a->rowchain) ? V_ADV : 0;   // (the call's last step advances into table[m]: never read)
+    const bool pre = ddpg_pipe || adv != 0;                 // these paths start from the uploaded cur: no begin_step launch at all
     TRY(begin_call(a, her, step0 + done, m, nullptr, 1.0f, st, plans, tickets_out ? tickets_out + done : nullptr,
-                   lens_out ? lens_out + done : nullptr, /*defer_rest=*/true));
-    if (a->cfg.kind == GCRL_AGENT_DDPG && a->cfg.pipeline_steps != 0) {
+                   lens_out ? lens_out + done : nullptr, /*defer_rest=*/true, pre));
+    if (ddpg_pipe) {
       // plain actor steps overlap pairwise: P(i) shares its launches with K(i+1)
       std::vector<int> variants(m);
       for (int i = 0; i < m; ++i) variants[i] = plans[i].variant;
-      TRY(run_steps_ddpg(a, st, variants.data(), m));
+      TRY(run_steps_ddpg(a, st, variants.data(), m, /*first_pre=*/true));
     } else {
-      const int adv = (a->sac && a->rowchain) ? V_ADV : 0;   // (the call's last step advances into table[m]: never read)
       for (int i = 0; i < m; ++i) {
-        TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM | adv | (adv && i > 0 ? V_PRE : 0), 7));
+        TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM | adv | (adv ? V_PRE : 0), 7));
         if (i == 0) TRY(finish_deferred_draw(a, st));   // step 0 is in flight: now draw and gather batches 1..m-1
       }
     }

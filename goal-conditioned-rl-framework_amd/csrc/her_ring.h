@@ -159,7 +159,11 @@ int her_upload_indices(gcrl_her* h, int B, int M, const uint32_t* idx_host, hipS
 
 // Gather for the update engine: rows idx_dev[0..n) -> three GEMM-ready matrices with row
 // stride ldx = roundup(S+A,4): sa = [s|a], nsa = [ns|0..], spa = [s|0..] (may be null: not written); r[n], d[n].
+// `idx_dev` may point into pinned (device-mapped) host memory: the update engine's head launch of a call reads its 256
+// indices straight from the upload block.  cp_*: the same launch also copies cp_bytes (a multiple of 16) from cp_src
+// (pinned host) to cp_dst (device) — the call's control block travels with its first gather instead of as copies before it.
 int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa, float* nsa,
-                      float* spa, int ldx, float* r, float* d, hipStream_t st);
+                      float* spa, int ldx, float* r, float* d, hipStream_t st, const void* cp_src = nullptr,
+                      void* cp_dst = nullptr, size_t cp_bytes = 0);
 
 }  // namespace gcrl

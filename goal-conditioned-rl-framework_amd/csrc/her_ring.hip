@@ -349,6 +349,7 @@ struct GatherUpdArgs {
   int SA4, S4, RS, ldx;   // ldx == SA4
   float *sa, *nsa, *spa, *r, *d;
   unsigned long long* clk;
+  const uint4* cp_src; uint4* cp_dst; int cp_n16;   // optional side copy (her_ring.h), all blocks share it
 };
 
 // 16 lanes x 16 B cover one record; every batch matrix is a 16-byte-aligned slice of it, so each
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p)
   const long long nwaves = (long long)gridDim.x * 4;
   const int o_r = p.SA4 + p.S4;
   clk_begin(p.clk);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < p.cp_n16; i += gridDim.x * 256) p.cp_dst[i] = p.cp_src[i];
   // records wider than 64 floats (state dims above ~28) take further 64-float column passes
   for (int cc = 0; cc < p.RS; cc += 64) {
     const int c0 = cc + v4 * 4;
@@ -577,10 +579,12 @@ int her_upload_indices(gcrl_her* h, int B, int M, const uint32_t* idx_host, hipS
 }
 
 int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa, float* nsa,
-                      float* spa, int ldx, float* r, float* d, hipStream_t st) {
+                      float* spa, int ldx, float* r, float* d, hipStream_t st, const void* cp_src, void* cp_dst, size_t cp_bytes) {
+  if (cp_bytes % 16 != 0 || (cp_bytes && (!cp_src || !cp_dst))) return fail(GCRL_ERR_ARG, "her_gather_update: bad side copy (%zu bytes)", cp_bytes);
   if (ldx != h->SA4) return fail(GCRL_ERR_ARG, "her_gather_update: batch row stride %d != roundup(S+A,4) = %d", ldx, h->SA4);
   if (int rc = prof_begin(h, st)) return rc;
-  GatherUpdArgs ga{h->ring, idx_dev, h->last_gen, n, h->head, h->cfg.capacity, h->SA4, h->S4, h->RS, ldx, sa, nsa, spa, r, d, prof_slot(h)};
+  GatherUpdArgs ga{h->ring, idx_dev, h->last_gen, n, h->head, h->cfg.capacity, h->SA4, h->S4, h->RS, ldx, sa, nsa, spa, r, d, prof_slot(h),
+                   (const uint4*)cp_src, (uint4*)cp_dst, (int)(cp_bytes / 16)};
   constexpr int kUnroll = 4;
   int blocks = (int)std::min<int64_t>((n + 16 * kUnroll - 1) / (16 * kUnroll), 8192);
   hipLaunchKernelGGL(her_gather_update_kernel<kUnroll>, dim3(blocks), dim3(256), 0, st, ga);
