@@ -723,8 +723,8 @@ int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   if (alpha_rider) {
     ad.alpha = AlphaStep{a->P_logalpha(), a->adam_m + a->goff_alpha, a->adam_v + a->goff_alpha, a->alpha_dev, a->grads + a->goff_alpha,
                          (float)kBeta2, (float)(1.0 - kBeta1), (float)(1.0 - kBeta2), (float)kAdamEps, a->metrics_dev};
-    if (variant & V_ADV) { ad.cur = &a->ctrl()->cur_b; ad.advance = a->ctrl(); }
   }
+  if (variant & V_ADV) { ad.cur = &a->ctrl()->cur_b; ad.advance = a->ctrl(); }   // the step's last launch (row-block paths only)
   TRY(launch_adam(st, ad));
   if (a->sac && !alpha_rider) {
     AlphaArgs al;
@@ -1416,7 +1416,7 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
     const int m = std::min(chunk, n - done);
     std::vector<StepPlan> plans;
     const bool ddpg_pipe = a->cfg.kind == GCRL_AGENT_DDPG && a->cfg.pipeline_steps != 0;
-    const int adv = (a->sac && a->rowchain) ? V_ADV : 0;   // (the call's last step advances into table[m]: never read)
+    const int adv = (a->rowchain && !ddpg_pipe) ? V_ADV : 0;   // SAC / TD3 on the row-block path (the call's last step advances into table[m]: never read)
     const bool pre = ddpg_pipe || adv != 0;                 // these paths start from the uploaded cur: no begin_step launch at all
     TRY(begin_call(a, her, step0 + done, m, nullptr, 1.0f, st, plans, tickets_out ? tickets_out + done : nullptr,
                    lens_out ? lens_out + done : nullptr, /*defer_rest=*/true, pre));
