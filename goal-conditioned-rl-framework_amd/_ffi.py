@@ -144,6 +144,8 @@ PROTOTYPES = {
     "gcrl_her_process_step": (_i64, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "gcrl_sort_truncate_mean": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp]),
     "gcrl_gemm_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "gcrl_bn_relu_fwd_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gcrl_bn_relu_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_event_create": (_vp, []),
     "gcrl_event_destroy": (None, [_vp]),
     "gcrl_event_record": (C.c_int, [_vp, _vp]),

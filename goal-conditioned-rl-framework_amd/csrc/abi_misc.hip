@@ -34,6 +34,19 @@ int gcrl_gemm_f32(const float* a, int64_t a_rs, int64_t a_cs, const float* b, in
   return gcrl::launch_gemm_batch(as_stream(stream), &d, 1, shape);
 }
 
+int gcrl_bn_relu_fwd_f32(const float* z, int B, int H, const float* gamma, const float* beta, float* h, float* xhat, float* invstd,
+                         float* running_mean, float* running_var, float* scratch, void* stream) {
+  GCRL_CHECK_ARG(z && gamma && beta && h && running_mean && running_var && scratch && B >= 1 && H >= 4, "gcrl_bn_relu_fwd_f32: bad arguments");
+  return gcrl::launch_bn_relu_fwd(as_stream(stream), z, B, H, gamma, beta, h, xhat, invstd, running_mean, running_var, scratch);
+}
+
+int gcrl_bn_relu_bwd_f32(const float* dh, const float* xhat, const float* invstd, const float* gamma, const float* beta, int B, int H,
+                         float* dz, float* dgamma, float* dbeta, float* scratch, void* stream) {
+  GCRL_CHECK_ARG(dh && xhat && invstd && gamma && beta && dz && dgamma && dbeta && scratch && B >= 1 && H >= 4,
+                 "gcrl_bn_relu_bwd_f32: bad arguments");
+  return gcrl::launch_bn_relu_bwd(as_stream(stream), dh, nullptr, xhat, invstd, gamma, beta, B, H, dz, dgamma, dbeta, scratch);
+}
+
 void* gcrl_event_create(void) {
   hipEvent_t ev = nullptr;
   if (hipEventCreate(&ev) != hipSuccess) { gcrl::fail(GCRL_ERR_HIP, "hipEventCreate failed"); return nullptr; }

@@ -423,6 +423,19 @@ int gcrl_gemm_f32(const float* a_dev, int64_t a_rs, int64_t a_cs, const float* b
                   int64_t b_cs, float* c_dev, int64_t c_rs, const float* bias_dev, int M, int N,
                   int K, int act, int shape, void* stream);
 
+/* nn.BatchNorm1d in training mode followed by ReLU, as the SAC / TQC actors run it per hidden layer
+ * (src/model.py:106-108: Linear -> BatchNorm1d -> ReLU; eps 1e-5, momentum 0.1, running variance unbiased), forward and
+ * backward as single problems.  All pointers are device memory, row-major [B, H]; H must be a multiple of 4 and every
+ * pointer 16-byte aligned.  `scratch_dev`: 2 * ceil(B/64) * H floats.
+ *   fwd: z -> h = relu(gamma * xhat + beta); saves xhat [B,H] and invstd [H]; updates running_mean / running_var in place.
+ *   bwd: dh (gradient w.r.t. h), xhat / invstd from the forward -> dz [B,H], dgamma [H], dbeta [H]. */
+int gcrl_bn_relu_fwd_f32(const float* z_dev, int B, int H, const float* gamma_dev, const float* beta_dev, float* h_dev,
+                         float* xhat_dev, float* invstd_dev, float* running_mean_dev, float* running_var_dev,
+                         float* scratch_dev, void* stream);
+int gcrl_bn_relu_bwd_f32(const float* dh_dev, const float* xhat_dev, const float* invstd_dev, const float* gamma_dev,
+                         const float* beta_dev, int B, int H, float* dz_dev, float* dgamma_dev, float* dbeta_dev,
+                         float* scratch_dev, void* stream);
+
 /* hipEvent helpers so a Python caller can time the engine's own stream (torch.cuda.Event only
  * sees torch's current stream). */
 void* gcrl_event_create(void);

@@ -66,6 +66,61 @@ def test_gemm_asymmetric_identity(lib):
         assert torch.equal(Cc, B)
 
 
+# ------------------------------------------------------------------ BatchNorm1d(train) + ReLU kernels vs torch (fp32 op, fp64 yardstick)
+@pytest.mark.parametrize("B,H", [(512, 256), (64, 64), (100, 48), (33, 4), (2048, 512), (2100, 68), (1, 8)])
+def test_batchnorm_relu_forward_backward_against_torch(lib, B, H):
+    """nn.BatchNorm1d in training mode followed by ReLU (src/model.py:106-108), forward and backward, at shapes that hit
+    every partial block: B not a multiple of 16 / 64, H not a multiple of 64, several 16-row slabs per block (B >= 2048)."""
+    gen = torch.Generator().manual_seed(B * 131 + H)
+    z = torch.randn(B, H, generator=gen) * 1.7 + 0.3
+    gamma = torch.rand(H, generator=gen) + 0.5
+    beta = torch.randn(H, generator=gen) * 0.2
+    dh = torch.randn(B, H, generator=gen)
+    rm0, rv0 = torch.randn(H, generator=gen) * 0.1, torch.rand(H, generator=gen) + 0.5
+
+    def reference(dtype):
+        zz = z.detach().clone().to(dtype).requires_grad_(True)
+        g, b = gamma.detach().clone().to(dtype).requires_grad_(True), beta.detach().clone().to(dtype).requires_grad_(True)
+        rm, rv = rm0.to(dtype).clone(), rv0.to(dtype).clone()
+        if B > 1:
+            y = torch.nn.functional.batch_norm(zz, rm, rv, g, b, training=True, momentum=0.1, eps=1e-5)
+        else:   # torch refuses one row in training mode; the formula still holds (variance 0)
+            y = (zz - zz.mean(0)) / torch.sqrt(zz.var(0, unbiased=False) + 1e-5) * g + b
+        h = torch.relu(y)
+        h.backward(dh.to(dtype))
+        return h.detach(), zz.grad, g.grad, b.grad, rm, rv
+
+    h32, dz32, dg32, db32, rm32, rv32 = reference(torch.float32)
+    h64, dz64, dg64, db64, rm64, rv64 = reference(torch.float64)
+    dev = dict(device="cuda", dtype=torch.float32)
+    zd, gd, bd, dhd = z.cuda(), gamma.cuda(), beta.cuda(), dh.cuda()
+    rmd, rvd = rm0.cuda().clone(), rv0.cuda().clone()
+    h, xhat, dz = torch.empty(B, H, **dev), torch.empty(B, H, **dev), torch.empty(B, H, **dev)
+    invstd, dgamma, dbeta = torch.empty(H, **dev), torch.empty(H, **dev), torch.empty(H, **dev)
+    scratch = torch.zeros(2 * ((B + 63) // 64) * H, **dev)
+    assert lib.gcrl_bn_relu_fwd_f32(zd.data_ptr(), B, H, gd.data_ptr(), bd.data_ptr(), h.data_ptr(), xhat.data_ptr(), invstd.data_ptr(),
+                                    rmd.data_ptr(), rvd.data_ptr(), scratch.data_ptr(), 1) == 0
+    assert lib.gcrl_bn_relu_bwd_f32(dhd.data_ptr(), xhat.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), B, H, dz.data_ptr(),
+                                    dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(), 1) == 0
+    torch.cuda.synchronize()
+
+    def check(name, got, r32, r64):
+        got, r32, r64 = got.cpu().double(), r32.double(), r64
+        scale = float(r64.abs().max()) + 1e-30
+        e_got, e_ref = float((got - r64).abs().max()) / scale, float((r32 - r64).abs().max()) / scale
+        # no worse than 3x torch's own fp32 error against fp64, or 1e-5 relative (the north star's tolerance)
+        assert e_got <= max(3.0 * e_ref, 1e-5), (name, B, H, e_got, e_ref)
+
+    check("h", h, h32, h64)
+    if B > 1:   # (with one row every gradient w.r.t. z is exactly 0 up to rounding noise of size eps)
+        check("dz", dz, dz32, dz64)
+    check("dgamma", dgamma, dg32, dg64)
+    check("dbeta", dbeta, db32, db64)
+    if B > 1:
+        check("running_mean", rmd, rm32, rm64)
+        check("running_var", rvd, rv32, rv64)
+
+
 # ------------------------------------------------------------------ HER rows / batches vs the reference's goldens
 CASES = ["full50", "done12", "single", "wrap300", "k8_two_envs", "tiny_cap100"]
 
