@@ -192,6 +192,47 @@ def test_her_engine_rng_equals_python_rng_and_oracle(gcrl):
             assert np.array_equal(bits(gt.cpu().numpy()), bits(w))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_her_randomized_differential_vs_oracle(gcrl, seed):
+    """Property-style sweep: random state / action / goal widths (records of 1 and 2 column passes), ring
+    capacities small enough to wrap several times, 1-4 env streams pushed interleaved, k_future 0-8, ragged episodes
+    (1, 2, ... 50 steps; ended by `done` or by the 50-step flush) — stored rows, sampled batches and the index stream
+    must equal the oracle's (itself pinned to the reference's goldens) bit for bit."""
+    cfg = random.Random(1000 + seed)
+    G = cfg.choice([1, 2, 3, 3, 4])
+    S = cfg.randint(G + 2, 44)
+    A = cfg.randint(1, 8)
+    nenvs = cfg.randint(1, 4)
+    k = cfg.choice([0, 1, 4, 4, 8])
+    cap = cfg.choice([60, 130, 500, 1700, 4000])
+    n_eps = cfg.randint(6, 16)
+    gen = np.random.default_rng(seed)
+    eng = gcrl.HERBuffer(cap, 50, nenvs, k_future=k, rng="engine", seed=500 + seed)
+    orc = her_oracle.HERBufferOracle(cap, 50, nenvs, k_future=k, rng=random.Random(500 + seed))
+    # one episode queue per env stream, pushed round-robin one transition at a time (the vector-env order, env.py:343-375)
+    queues = [[] for _ in range(nenvs)]
+    for e in range(n_eps):
+        T = cfg.choice([1, 2, 3, 7, 13, 31, 49, 50, 50, 50])
+        steps = her_oracle.synthetic_episode(gen, T, S, A, G)
+        for t, st in enumerate(steps):
+            queues[e % nenvs].append(st[:4] + ((t == T - 1) and T < 50,) + st[5:])
+    while any(queues):
+        for env in range(nenvs):
+            if queues[env]:
+                st = queues[env].pop(0)
+                eng.push(env, torch.from_numpy(st[0]).cuda(), st[1], torch.from_numpy(st[2]).cuda(), st[3], st[4], st[5], st[6])
+                orc.push(env, *st)
+    assert len(eng) == len(orc), (len(eng), len(orc))
+    if len(orc) == 0:
+        return
+    for key, got, want in zip("s a ns r d".split(), eng.rows(), orc.as_arrays()):
+        assert np.array_equal(bits(got), bits(want)), (seed, key, S, A, G, nenvs, k, cap)
+    B = min(len(orc), cfg.choice([1, 7, 32, 64]))
+    for _ in range(2):
+        for got, want in zip(eng.sample(B), orc.sample(B)):
+            assert np.array_equal(bits(got.cpu().numpy()), bits(np.asarray(want, dtype=np.float32).reshape(got.shape))), (seed, B)
+
+
 def test_device_rng_mode_equals_its_restatement(gcrl):
     """rng="device": future picks by a counter hash inside the flush kernel, batch draws by the same hash
     with duplicates rejected.  Not the reference's stream — pinned against oracle/her_oracle.py HashRng:
