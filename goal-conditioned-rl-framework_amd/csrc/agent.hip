@@ -161,9 +161,7 @@ struct gcrl_agent {
   int pending_variant = 0;  // variant of the step whose phases are being issued one by one
   // update_n: batches 1..n-1 are drawn / uploaded / gathered AFTER the first step's launches have been issued (the host
   // draws ~2 us per batch from the MT stream: with all n batches up front the GPU idled ~40 us at the start of a cycle)
-  struct { gcrl_her* her = nullptr; int n = 0; int slot = 0; } deferred;
-  hipStream_t aux_stream = nullptr;   // the deferred gather of batches 1..n-1 runs here, next to step 0
-  hipEvent_t pre_ev = nullptr, defer_ev = nullptr;
+  struct { gcrl_her* her = nullptr; int n = 0; int slot = 0; int next = 0; } deferred;   // batches [next, n) not yet drawn
   std::vector<StepPlan> dp_plans;  // steps of the data-parallel cycle begun by gcrl_agent_dp_begin
   std::vector<DpSeg> dp_segs;      // ... as segments separated by gradient exchanges
   size_t dp_pos = 0;
@@ -851,26 +849,25 @@ int stage_injected(gcrl_agent* a, const gcrl_update_inputs* in, hipStream_t st, 
 }
 
 // phase-0 entry of `n` steps: control table + indices upload, batch gather / pack
+// Draw and gather the batches a call left for later ([deferred.next, n); same MT stream order as drawing them all up
+// front).  Called once steps 0 and 1 have been issued: the GPU then has two steps (~110 us) queued, more than the host
+// needs for the draw, and the upload + gather run in order behind step 1.  (Round-2 history: gathering everything up
+// front delayed step 0 by the whole draw; deferring batches 1.. behind step 0 left the GPU idle for 21 us per call while
+// the host was still drawing; a second stream for the deferred part removed the wait on the driver's 20-step line but
+// cost 1-3 % in steady state and depended on how HIP maps streams to hardware queues.)
 int finish_deferred_draw(gcrl_agent* a, hipStream_t st) {
   gcrl_her* her = a->deferred.her;
   if (!her) return GCRL_OK;
   a->deferred.her = nullptr;
-  const int n = a->deferred.n, B = a->B;
+  const int n = a->deferred.n, B = a->B, first = a->deferred.next;
   uint32_t* idx = (uint32_t*)(a->upload_pinned[a->deferred.slot] + sizeof(UploadBlock));
-  for (int i = 1; i < n; ++i) TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)B, idx + (size_t)i * B));
-  // The index upload and the gather go to a second stream: on `st` they queued BEHIND step 0 (in-order) and step 1
-  // waited for draw + copy + gather after it (43 us of idle GPU per call in the 20-step trace); here they run next
-  // to step 0's launches (which occupy half the chip).  aux waits for everything earlier on `st` (pre_ev: the previous
-  // call's steps still read batches 1.., ring flushes), `st` waits for the gather before step 1.
-  hipStream_t ax = a->aux_stream;
-  GCRL_HIP(hipStreamWaitEvent(ax, a->pre_ev, 0));
-  GCRL_HIP(hipMemcpyAsync(a->idx_dev() + B, idx + B, (size_t)(n - 1) * B * sizeof(uint32_t), hipMemcpyHostToDevice, ax));
-  GCRL_HIP(hipEventRecord(a->upload_ev[a->deferred.slot], ax));
-  TRY(her_gather_update(her, a->idx_dev() + B, (int64_t)(n - 1) * B, a->sa + a->slot_x, a->nsa + a->slot_x,
-                        a->rowchain ? nullptr : a->spa + a->slot_x, a->ldx, a->rbuf + a->slot_rd, a->dbuf + a->slot_rd, ax));
-  GCRL_HIP(hipEventRecord(a->defer_ev, ax));
-  GCRL_HIP(hipStreamWaitEvent(st, a->defer_ev, 0));
-  return GCRL_OK;
+  for (int i = first; i < n; ++i) TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)B, idx + (size_t)i * B));
+  GCRL_HIP(hipMemcpyAsync(a->idx_dev() + (size_t)first * B, idx + (size_t)first * B, (size_t)(n - first) * B * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, st));
+  GCRL_HIP(hipEventRecord(a->upload_ev[a->deferred.slot], st));
+  return her_gather_update(her, a->idx_dev() + (size_t)first * B, (int64_t)(n - first) * B, a->sa + first * a->slot_x,
+                           a->nsa + first * a->slot_x, a->rowchain ? nullptr : a->spa + first * a->slot_x, a->ldx,
+                           a->rbuf + first * a->slot_rd, a->dbuf + first * a->slot_rd, st);
 }
 
 int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_update_inputs* in, float grad_scale,
@@ -911,21 +908,21 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
     }
     bytes += (size_t)a->B * sizeof(uint32_t);
   } else if (!injected && !device_rng) {
-    defer_rest = defer_rest && n > 1;
-    const int now = defer_rest ? 1 : n;      // same MT stream order either way: batch 0 first, then 1..n-1
+    defer_rest = defer_rest && n > 2;
+    const int now = defer_rest ? 2 : n;      // same MT stream order either way: batches 0 and 1 now, 2..n-1 once steps 0 and 1 are issued
     for (int i = 0; i < now; ++i)
       TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)a->B, idx + (size_t)i * a->B));
     bytes += (size_t)now * a->B * sizeof(uint32_t);
-    if (defer_rest) { a->deferred.her = her; a->deferred.n = n; a->deferred.slot = slot; }
+    if (defer_rest) { a->deferred.her = her; a->deferred.n = n; a->deferred.slot = slot; a->deferred.next = now; }
   } else defer_rest = false;
   if (device_rng && !explicit_idx) {   // the gather kernel computes the indices itself: nothing to draw or upload here
     her->last_gen = IdxGen{her->cfg.seed, her->draws_done, (uint32_t)her->len, a->B, feistel_half_bits((uint32_t)her->len)};
     her->draws_done += n;
   }
   const bool host_idx = !injected && !(device_rng && !explicit_idx);
-  const int64_t rows_now = (int64_t)(a->deferred.her ? 1 : n) * a->B;
-  if (!injected && (!host_idx || rows_now == a->B)) {
-    // One launch starts the call: the gather reads its (<= B) indices straight from the pinned block and carries the
+  const int64_t rows_now = (int64_t)(a->deferred.her ? a->deferred.next : n) * a->B;
+  if (!injected && (!host_idx || rows_now <= 2 * a->B)) {
+    // One launch starts the call: the gather reads its (<= 2 B) indices straight from the pinned block and carries the
     // control block to the device (header + the n table entries in use) — before, two staged copies and their launch
     // gaps (19 us) preceded the first gather.
     const size_t cb_bytes = (offsetof(UploadBlock, cb) + offsetof(CtrlBlock, table) + (size_t)n * sizeof(StepCtrl) + 15) & ~(size_t)15;
@@ -939,7 +936,6 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
       TRY(her_gather_update(her, host_idx ? a->idx_dev() : nullptr, rows_now, a->sa, a->nsa, a->rowchain ? nullptr : a->spa, a->ldx,
                             a->rbuf, a->dbuf, st));
   }
-  if (a->deferred.her) GCRL_HIP(hipEventRecord(a->pre_ev, st));
   return GCRL_OK;
 }
 
@@ -962,9 +958,6 @@ int build(gcrl_agent* a) {
   GCRL_HIP(hipSetDevice(c.device));
   GCRL_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
   GCRL_HIP(hipStreamCreateWithFlags(&a->cap_stream, hipStreamNonBlocking));
-  GCRL_HIP(hipStreamCreateWithFlags(&a->aux_stream, hipStreamNonBlocking));
-  GCRL_HIP(hipEventCreateWithFlags(&a->pre_ev, hipEventDisableTiming));
-  GCRL_HIP(hipEventCreateWithFlags(&a->defer_ev, hipEventDisableTiming));
   const int S = a->S, A = a->A, H = a->H, L = a->L, B = a->B, C = a->C;
   a->actor = make_net(S, H, L, A, a->sac);
   a->critic = make_net(S + A, H, L, a->Q, false);
@@ -1178,9 +1171,6 @@ void gcrl_agent_destroy(gcrl_agent* a) {
   for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
   float* bufs[] = {a->params, a->grads, a->adam_m, a->adam_v, a->bn_rmean, a->bn_rvar, a->alpha_dev, a->work};
   for (float* p : bufs) if (p) (void)hipFree(p);
-  if (a->aux_stream) (void)hipStreamDestroy(a->aux_stream);
-  if (a->pre_ev) (void)hipEventDestroy(a->pre_ev);
-  if (a->defer_ev) (void)hipEventDestroy(a->defer_ev);
   if (a->upload_dev) (void)hipFree(a->upload_dev);
   for (int i = 0; i < kCtrlSlots; ++i) {
     if (a->upload_pinned[i]) (void)hipHostFree(a->upload_pinned[i]);
@@ -1428,7 +1418,7 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
     } else {
       for (int i = 0; i < m; ++i) {
         TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM | adv | (adv ? V_PRE : 0), 7));
-        if (i == 0) TRY(finish_deferred_draw(a, st));   // step 0 is in flight: now draw and gather batches 1..m-1
+        if (i == 1) TRY(finish_deferred_draw(a, st));   // steps 0 and 1 are in flight: now draw and gather batches 2..m-1
       }
     }
     TRY(finish_deferred_draw(a, st));

@@ -76,10 +76,12 @@ class _AlphaView:
     """`agent.alpha.item()` (src/env.py:574,604)."""
 
     def __init__(self, agent):
-        self._agent = agent
+        self._agent_ref = weakref.ref(agent)   # (no reference cycle: the agent must die with its last user reference)
 
     def item(self):
-        a = self._agent
+        a = self._agent_ref()
+        if a is None:
+            raise ReferenceError("the agent of this alpha view is gone")
         if not a._sac:
             raise AttributeError("alpha")
         buf = np.empty(1, np.float32)
@@ -165,7 +167,15 @@ class _EngineAgent:
         self.alpha_min_steps = getattr(config, "alpha_min_steps", 10000)
         self.alpha = _AlphaView(self)
 
-        get = lambda: self._h
+        # The network views reach the native handle through a weak reference: a closure over `self` made every agent part
+        # of a reference cycle, so dropping one left its HBM ring, pinned blocks and streams alive until the cyclic
+        # collector happened to run — and a process building agents one after another (sweeps) ran the next one 60 %
+        # slower beside the undead (tools/rowchain_vs_batch.py found it).
+        wself = weakref.ref(self)
+
+        def get():
+            a = wself()
+            return a._h if a is not None else None
         H, L = config.hidden_dim, config.layer_count
         if self._sac:
             self.actor = SACActorModel(get, "actor", obs_dim, H, ac_dim, L)
