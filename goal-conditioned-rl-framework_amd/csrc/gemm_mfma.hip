@@ -44,7 +44,9 @@ int shape_of(const GemmDesc& d) {
   if (tiles16 <= 1024) return 1;
   // a long reduction into a mid-sized output (dW of a 512-wide layer at batch 2048: 72 tiles of 64x64): the
   // LDS-tiled form has too few workgroups, each walking K alone (128 us alone vs 37 us k-split; measured.  Round 2,
-  // with the faster tiled kernel and TQC's five critics batched: still 1604 vs 1578 us/step, the k-split form stays)
+  // with the faster tiled kernel and TQC's five critics batched: still 1604 vs 1578 us/step, the k-split form stays.
+  // Also tried in round 2: 2x2 tiles per workgroup with the same k-split (half the operand bytes per MFMA, a quarter of
+  // the workgroups): TD3 177 -> 199, TQC 1520 -> 1553 us/step.)
   if (d.K >= 1024 && (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) < 192) return 1;
   // LDS-tiled 64x64 workgroup tiles (gemm_tiled.h) once a problem alone fills most CUs with
   // them (>= 192 tiles of 64x64); in between, one 16x16 tile per wave keeps more CUs busy
