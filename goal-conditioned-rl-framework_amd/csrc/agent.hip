@@ -744,15 +744,22 @@ int enqueue_phases(gcrl_agent* a, hipStream_t st, int variant, int mask) {
   return GCRL_OK;
 }
 
-int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask) {
+// `count` consecutive steps of the same variant as ONE graph: a graph launch leaves the GPU idle for ~8.6 us (measured
+// between the steps of SAC's one-graph-per-step sequence: 4 % of its 200 us step), so a trainer cycle's run of
+// identical steps is replayed with a single launch
+int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask, int count = 1) {
   if (a->rowchain && a->wt_dirty) TRY(rc_rebuild_wt(a, st));
-  if (!graph_on(a)) return enqueue_phases(a, st, variant, mask);
-  const int key = variant | (mask << 12);
+  if (!graph_on(a)) {
+    for (int c = 0; c < count; ++c) TRY(enqueue_phases(a, st, variant, mask));
+    return GCRL_OK;
+  }
+  const int key = variant | (mask << 12) | (count > 1 ? (0x40000000 | (count << 16)) : 0);
   auto it = a->graphs.find(key);
   if (it == a->graphs.end()) {
     hipGraph_t g = nullptr;
     GCRL_HIP(hipStreamBeginCapture(a->cap_stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_phases(a, a->cap_stream, variant, mask);
+    int rc = GCRL_OK;
+    for (int c = 0; c < count && !rc; ++c) rc = enqueue_phases(a, a->cap_stream, variant, mask);
     hipError_t e = hipStreamEndCapture(a->cap_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     GCRL_HIP(e);
@@ -1416,9 +1423,18 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
       for (int i = 0; i < m; ++i) variants[i] = plans[i].variant;
       TRY(run_steps_ddpg(a, st, variants.data(), m, /*first_pre=*/true));
     } else {
-      for (int i = 0; i < m; ++i) {
-        TRY(run_step(a, st, plans[i].variant | V_FUSED_NORM | adv | (adv ? V_PRE : 0), 7));
-        if (i == 1) TRY(finish_deferred_draw(a, st));   // steps 0 and 1 are in flight: now draw and gather batches 2..m-1
+      auto var_of = [&](int i) { return plans[i].variant | V_FUSED_NORM | adv | (adv ? V_PRE : 0); };
+      int i = 0;
+      while (i < m) {
+        int j = i + 1;
+        // steps 0 and 1 go out one by one (the rest of the call's batches is drawn once both are queued); after that a
+        // run of identical steps is one graph launch
+        // (at most 8 steps per graph: replaying graphs of 1 600 kernel nodes showed occasional 25-120 us stalls between nodes)
+        if (!a->deferred.her)
+          while (j < m && j - i < 8 && var_of(j) == var_of(i)) ++j;
+        TRY(run_step(a, st, var_of(i), 7, j - i));
+        if (i == 1 || j > 1) TRY(finish_deferred_draw(a, st));   // steps 0 and 1 are in flight: now draw and gather batches 2..m-1
+        i = j;
       }
     }
     TRY(finish_deferred_draw(a, st));
