@@ -1,6 +1,8 @@
 // abi_misc.hip — small C-ABI helpers: stand-alone sort op, hipEvent timing, raw device memory.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "gemm_mfma.h"
 #include "ops.h"
@@ -9,6 +11,10 @@ namespace {
 hipStream_t as_stream(void* s) {
   if (!s || s == GCRL_STREAM_LEGACY) return (hipStream_t) nullptr;
   return (hipStream_t)s;
+}
+__global__ __launch_bounds__(256) void hash_normal_fill_kernel(unsigned long long seed, unsigned long long ctr0, long long n, float* out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = gcrl::hash_normal(seed, ctr0 + (unsigned long long)i);
 }
 }  // namespace
 
@@ -45,6 +51,15 @@ int gcrl_bn_relu_bwd_f32(const float* dh, const float* xhat, const float* invstd
   GCRL_CHECK_ARG(dh && xhat && invstd && gamma && beta && dz && dgamma && dbeta && scratch && B >= 1 && H >= 4,
                  "gcrl_bn_relu_bwd_f32: bad arguments");
   return gcrl::launch_bn_relu_bwd(as_stream(stream), dh, nullptr, xhat, invstd, gamma, beta, B, H, dz, dgamma, dbeta, scratch);
+}
+
+int gcrl_hash_normal_fill(uint64_t seed, uint64_t ctr0, int64_t n, float* out_dev, void* stream) {
+  GCRL_CHECK_ARG(out_dev && n >= 1, "gcrl_hash_normal_fill: bad arguments");
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(hash_normal_fill_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (unsigned long long)seed,
+                     (unsigned long long)ctr0, (long long)n, out_dev);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
 }
 
 void* gcrl_event_create(void) {

@@ -753,6 +753,7 @@ int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask, int count = 1
     for (int c = 0; c < count; ++c) TRY(enqueue_phases(a, st, variant, mask));
     return GCRL_OK;
   }
+  static_assert(2 * V_ADV <= (1 << 12), "graph key: the variant flags must stay below the phase-mask bits");
   const int key = variant | (mask << 12) | (count > 1 ? (0x40000000 | (count << 16)) : 0);
   auto it = a->graphs.find(key);
   if (it == a->graphs.end()) {
@@ -889,6 +890,9 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
     GCRL_CHECK_ARG(her->S == a->S && her->A == a->A, "update: ring dims (S=%d,A=%d) differ from the agent's (S=%d,A=%d)", her->S, her->A, a->S, a->A);
     if (her->len < a->B) return fail(GCRL_ERR_NOT_ENOUGH, "[ERROR] Not enough in buffer to sample");
   }
+  if (!injected && in && in->idx_host)     // every argument is checked before a ticket, slot or plan is consumed
+    for (int i = 0; i < a->B; ++i)
+      GCRL_CHECK_ARG((int64_t)in->idx_host[i] < her->len, "update: row index %u outside the ring (len %lld)", in->idx_host[i], (long long)her->len);
   const int slot = a->next_upload;
   a->next_upload = (slot + 1) % kCtrlSlots;
   GCRL_HIP(hipEventSynchronize(a->upload_ev[slot]));
@@ -909,10 +913,7 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
   const bool device_rng = !injected && her->cfg.rng_mode != GCRL_RNG_CPYTHON_MT;
   const bool explicit_idx = !injected && in && in->idx_host;
   if (explicit_idx) {   // prioritised replay: the caller drew the rows
-    for (int i = 0; i < a->B; ++i) {
-      GCRL_CHECK_ARG((int64_t)in->idx_host[i] < her->len, "update: row index %u outside the ring (len %lld)", in->idx_host[i], (long long)her->len);
-      idx[i] = in->idx_host[i];
-    }
+    for (int i = 0; i < a->B; ++i) idx[i] = in->idx_host[i];
     bytes += (size_t)a->B * sizeof(uint32_t);
   } else if (!injected && !device_rng) {
     defer_rest = defer_rest && n > 2;
@@ -1657,6 +1658,10 @@ int gcrl_agent_observe_act(gcrl_agent* a, gcrl_normalizer* nz_obs, gcrl_normaliz
   GCRL_CHECK_ARG(a && obs_host && dg_host && out_host && n >= 1 && n <= a->B, "gcrl_agent_observe_act: bad arguments (n must be 1..batch_size)");
   GCRL_CHECK_ARG(obs_dim >= 1 && goal_dim >= 0 && obs_dim + goal_dim == a->S, "gcrl_agent_observe_act: obs_dim %d + goal_dim %d != %d", obs_dim, goal_dim, a->S);
   GCRL_CHECK_ARG(mode >= 0 && mode <= 2, "gcrl_agent_observe_act: mode must be 0, 1 or 2");
+  // the kernels index mean[j] / var[j] for j < obs_dim (goal_dim): a normaliser of another size is an argument error
+  // (the reference raises numpy's broadcast error, src/utils.py:95-97), never an out-of-bounds device access
+  GCRL_CHECK_ARG(!nz_obs || gcrl_normalizer_size(nz_obs) == obs_dim, "gcrl_agent_observe_act: observation normaliser of size %d for obs_dim %d", gcrl_normalizer_size(nz_obs), obs_dim);
+  GCRL_CHECK_ARG(!nz_dg || gcrl_normalizer_size(nz_dg) == goal_dim, "gcrl_agent_observe_act: goal normaliser of size %d for goal_dim %d", gcrl_normalizer_size(nz_dg), goal_dim);
   hipStream_t st = a->pick(stream);
   const int D = obs_dim, G = goal_dim, A = a->A;
   const size_t f_raw = (size_t)a->B * (D + G + A), d_cnt = (size_t)a->B * A;

@@ -113,6 +113,15 @@ struct gcrl_her {
   uint8_t* fut_pinned[kSlots] = {};
   hipEvent_t fut_ev[kSlots] = {};
   int next_fut_slot = 0;
+  // GCRL_REWARD_HOST: the caller's compute_reward evaluates every relabel slot of a flush on the host (gcrl_her_set_reward_callback)
+  gcrl_reward_fn reward_cb = nullptr;
+  void* reward_cb_user = nullptr;
+  std::vector<float> ag_mirror;          // [nenvs][flush_len][G]: host copy of the staged achieved goals
+  std::vector<float> cb_ag, cb_goal;     // pair lists handed to the callback
+  float* rew_dev = nullptr;
+  float* rew_pinned[kSlots] = {};
+  hipEvent_t rew_ev[kSlots] = {};
+  int next_rew_slot = 0;
   // raw observation rows of a vector-env step and their normalised [obs | goal] state matrices (gcrl_her_process_step)
   float* ps_dev = nullptr;
   float* ps_pinned[kSlots] = {};

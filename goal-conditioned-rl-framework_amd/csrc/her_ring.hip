@@ -142,8 +142,9 @@ struct FlushArgs {
   const float* stage[kMaxEp];
   int T[kMaxEp];
   unsigned long long epi_id[kMaxEp];
-  int fut_off[kMaxEp];
+  int fut_off[kMaxEp];      // first relabel slot of episode e in this launch (k*(T-1) slots per episode, draw order)
   const uint8_t* fut_ext;   // more than kMaxFut future indices in this launch: they were uploaded instead (k_future >= 42)
+  const float* rew_ext;     // GCRL_REWARD_HOST: relabel rewards computed by the caller's compute_reward on the host, one per slot
   uint8_t fut[kMaxFut];
 };
 
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
       }
       float dist = __fsqrt_rn(acc);
       rew = (p.reward_kind == GCRL_REWARD_SPARSE) ? ((dist > p.thr) ? -1.0f : -0.0f) : -dist;
+      if (p.rew_ext) rew = p.rew_ext[p.fut_off[e] + i * p.k + (rep - 1)];
       done = 0.f;
     }
     float* out = p.ring + phys * p.RS;
@@ -509,8 +511,8 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
     if (c.rng_mode == GCRL_RNG_CPYTHON_MT) {
       if (futs && futs[e]) std::memcpy(fut_host + fut_used, futs[e], nf);
       else if (int rc = gcrl_mt_future_indices(h->rng, T, c.k_future, fut_host + fut_used)) return rc;
-      fut_used += nf;
     }
+    fut_used += nf;
     total += T + (int64_t)c.k_future * (T - 1);
     maxT = std::max(maxT, T);
   }
@@ -518,6 +520,43 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
     GCRL_HIP(hipMemcpyAsync(h->fut_dev, fut_host, (size_t)fut_used, hipMemcpyHostToDevice, st));
     GCRL_HIP(hipEventRecord(h->fut_ev[fslot], st));
     fa.fut_ext = h->fut_dev;
+  }
+  if (c.reward_kind == GCRL_REWARD_HOST && fut_used > 0) {
+    // compute_reward(ag_i, ag_f, {}) for every relabel slot (src/buffer.py:166) by the caller's function, in the
+    // reference's call order; the achieved goals are the host mirror of the staging area, the picks the ones the
+    // kernel will use (MT: drawn above; device RNG: the same counter hash, restated on the host)
+    if (!h->reward_cb) return gcrl::fail(GCRL_ERR_STATE, "flush: reward_kind is GCRL_REWARD_HOST but no callback is set (gcrl_her_set_reward_callback)");
+    const size_t cap = (size_t)kMaxEp * c.k_future * c.flush_len;
+    if (!h->rew_dev) {
+      GCRL_HIP(hipMalloc((void**)&h->rew_dev, cap * sizeof(float)));
+      for (int i = 0; i < gcrl_her::kSlots; ++i) {
+        GCRL_HIP(hipHostMalloc((void**)&h->rew_pinned[i], cap * sizeof(float), hipHostMallocDefault));
+        GCRL_HIP(hipEventCreateWithFlags(&h->rew_ev[i], hipEventDisableTiming));
+      }
+    }
+    const int rslot = h->next_rew_slot;
+    h->next_rew_slot = (rslot + 1) % gcrl_her::kSlots;
+    GCRL_HIP(hipEventSynchronize(h->rew_ev[rslot]));
+    const int G = h->G;
+    h->cb_ag.resize((size_t)fut_used * G);
+    h->cb_goal.resize((size_t)fut_used * G);
+    for (int e = 0; e < nep; ++e) {
+      const float* ag = h->ag_mirror.data() + (size_t)envs[e] * c.flush_len * G;
+      for (int i = 0; i + 1 < Ts[e]; ++i)
+        for (int r = 0; r < c.k_future; ++r) {
+          const int slot = fa.fut_off[e] + i * c.k_future + r;
+          const int f = c.rng_mode == GCRL_RNG_CPYTHON_MT
+                            ? fut_host[slot]
+                            : i + 1 + (int)gcrl::hash_below(c.seed, fa.epi_id[e], (unsigned long long)(i * c.k_future + r), (uint32_t)(Ts[e] - 1 - i));
+          std::memcpy(&h->cb_ag[(size_t)slot * G], ag + (size_t)i * G, sizeof(float) * G);
+          std::memcpy(&h->cb_goal[(size_t)slot * G], ag + (size_t)f * G, sizeof(float) * G);
+        }
+    }
+    if (h->reward_cb(h->cb_ag.data(), h->cb_goal.data(), fut_used, G, h->rew_pinned[rslot], h->reward_cb_user) != 0)
+      return gcrl::fail(GCRL_ERR_STATE, "flush: the compute_reward callback reported a failure");
+    GCRL_HIP(hipMemcpyAsync(h->rew_dev, h->rew_pinned[rslot], (size_t)fut_used * sizeof(float), hipMemcpyHostToDevice, st));
+    GCRL_HIP(hipEventRecord(h->rew_ev[rslot], st));
+    fa.rew_ext = h->rew_dev;
   }
   fa.skip = total > c.capacity ? total - c.capacity : 0;
   dim3 grid((maxT + kStepsPerBlock - 1) / kStepsPerBlock, nep);
@@ -625,6 +664,7 @@ gcrl_her* gcrl_her_create(const gcrl_her_config* cfg, gcrl_mt* rng) {
   h->RS = gcrl::round_up(h->RW, 16);
   h->RG = gcrl::round_up(h->RW + h->G, 16);
   h->staged.assign(cfg->nenvs, 0);
+  h->ag_mirror.assign((size_t)cfg->nenvs * cfg->flush_len * cfg->goal_dim, 0.f);
   if (rng) { h->rng = rng; h->own_rng = false; }
   else { h->rng = gcrl_mt_create(); h->own_rng = true; gcrl_mt_seed(h->rng, cfg->seed); }
   auto ok = [&](hipError_t e, const char* what) {
@@ -662,6 +702,11 @@ void gcrl_her_destroy(gcrl_her* h) {
   if (h->prof_clk) (void)hipFree(h->prof_clk);
   if (h->pay_dev) (void)hipFree(h->pay_dev);
   if (h->fut_dev) (void)hipFree(h->fut_dev);
+  if (h->rew_dev) (void)hipFree(h->rew_dev);
+  for (int i = 0; i < gcrl_her::kSlots; ++i) {
+    if (h->rew_pinned[i]) (void)hipHostFree(h->rew_pinned[i]);
+    if (h->rew_ev[i]) (void)hipEventDestroy(h->rew_ev[i]);
+  }
   if (h->ps_dev) (void)hipFree(h->ps_dev);
   for (int i = 0; i < gcrl_her::kSlots; ++i) if (h->ps_pinned[i]) (void)hipHostFree(h->ps_pinned[i]);
   for (int i = 0; i < gcrl_her::kSlots; ++i) {
@@ -675,6 +720,14 @@ void gcrl_her_destroy(gcrl_her* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->own_rng) gcrl_mt_destroy(h->rng);
   delete h;
+}
+
+int gcrl_her_set_reward_callback(gcrl_her* h, gcrl_reward_fn fn, void* user) {
+  GCRL_CHECK_ARG(h, "gcrl_her_set_reward_callback: null handle");
+  GCRL_CHECK_ARG(h->cfg.reward_kind == GCRL_REWARD_HOST || !fn, "gcrl_her_set_reward_callback: the ring was created with a built-in reward kind");
+  h->reward_cb = fn;
+  h->reward_cb_user = user;
+  return GCRL_OK;
 }
 
 int64_t gcrl_her_len(const gcrl_her* h) { return h ? h->len : 0; }
@@ -708,6 +761,7 @@ int64_t gcrl_her_push(gcrl_her* h, int env, const float* state, int state_on_dev
   if (!next_on_device) std::memcpy(sa.ns_inl, next_state, sizeof(float) * h->S);
   hipLaunchKernelGGL(her_stage_kernel, dim3(1), dim3(64), 0, st, sa);
   GCRL_HIP(hipGetLastError());
+  std::memcpy(&h->ag_mirror[((size_t)env * h->cfg.flush_len + t) * h->G], ag_host, sizeof(float) * h->G);
   h->staged[env] = t + 1;
   if (done || h->staged[env] >= h->cfg.flush_len) {  // src/buffer.py:117
     int64_t rows = 0;
@@ -798,6 +852,7 @@ int64_t gcrl_her_push_batch(gcrl_her* h, int env0, int n, const float* states_de
     pw[2] = dones_host[i] ? 1.0f : 0.0f;
     std::memcpy(pw + 3, actions_host + (size_t)i * h->A, sizeof(float) * h->A);
     std::memcpy(pw + 3 + h->A, achieved_goals_host + (size_t)i * h->G, sizeof(float) * h->G);
+    std::memcpy(&h->ag_mirror[((size_t)(env0 + i) * h->cfg.flush_len + t) * h->G], achieved_goals_host + (size_t)i * h->G, sizeof(float) * h->G);
   }
   GCRL_HIP(hipMemcpyAsync(h->pay_dev, pay, (size_t)n * kPayW * sizeof(float), hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(h->epi_ev[slot], st));
@@ -816,6 +871,7 @@ int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_s
   GCRL_CHECK_ARG(obs_dim >= 1 && obs_dim <= 128 && obs_dim + h->G == h->S, "gcrl_her_process_step: obs_dim %d + goal_dim %d != state_dim %d (obs_dim <= 128)", obs_dim, h->G, h->S);
   GCRL_CHECK_ARG(n >= 1 && env0 >= 0 && env0 + n <= h->cfg.nenvs, "gcrl_her_process_step: envs [%d, %d) outside [0, %d)", env0, env0 + n, h->cfg.nenvs);
   GCRL_CHECK_ARG(3 + h->A + h->G <= kPayW, "gcrl_her_process_step: action_dim + goal_dim too large for the payload");
+  GCRL_CHECK_ARG(!nz_obs || gcrl_normalizer_size(nz_obs) == obs_dim, "gcrl_her_process_step: observation normaliser of size %d for obs_dim %d", gcrl_normalizer_size(nz_obs), obs_dim);
   hipStream_t st = h->pick(stream);
   const int D = obs_dim, G = h->G;
   // ONE upload: raw rows [obs(n*D) | next_obs(n*D) | dg(n*G) | next_dg(n*G)], then the per-env payload [t | r | d | a | ag]
@@ -848,6 +904,7 @@ int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_s
     pw[2] = dones_host[i] ? 1.0f : 0.0f;
     std::memcpy(pw + 3, actions_host + (size_t)i * h->A, sizeof(float) * h->A);
     std::memcpy(pw + 3 + h->A, next_ag_host + (size_t)i * G, sizeof(float) * G);
+    std::memcpy(&h->ag_mirror[((size_t)(env0 + i) * h->cfg.flush_len + t) * G], next_ag_host + (size_t)i * G, sizeof(float) * G);
   }
   GCRL_HIP(hipMemcpyAsync(h->ps_dev, pin, need * sizeof(float), hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(h->epi_ev[slot], st));
@@ -887,6 +944,7 @@ int64_t gcrl_her_push_episode(gcrl_her* h, int env, int T, const float* s, const
     rec[h->SA4 + h->S4 + 1] = d[t];
     std::memcpy(rec + h->RW, ag + (size_t)t * h->G, sizeof(float) * h->G);
   }
+  std::memcpy(&h->ag_mirror[(size_t)env * h->cfg.flush_len * h->G], ag, sizeof(float) * (size_t)T * h->G);
   float* dst = h->stage + ((size_t)env * h->cfg.flush_len) * h->RG;
   GCRL_HIP(hipMemcpyAsync(dst, buf, (size_t)T * h->RG * sizeof(float), hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(h->epi_ev[slot], st));

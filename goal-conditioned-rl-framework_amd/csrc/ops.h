@@ -85,7 +85,10 @@ int launch_td3_smooth(hipStream_t st, const StepCtrl* cur, float* act, long long
                       int ld, int B, int A, const float* eps, float policy_noise,
                       float noise_clamp, unsigned long long seed);
 
-// counter-hash normals of the device-RNG mode (TD3 smoothing noise, SAC eps when not injected)
+// counter-hash normals of the device-RNG mode (TD3 smoothing noise, SAC eps when not injected): the ONE definition; stands
+// in for torch.randn_like (src/agent.py:175) and Normal.rsample's eps (src/model.py:134) when no noise is injected.
+// Box-Muller over two 24-bit uniforms cut from one 64-bit counter hash: u1 in (0,1] (so log is finite), u2 in [0,1).
+// Restated in oracle/device_rng_oracle.py; exposed for tests as gcrl_hash_normal_fill (abi_misc.hip).
 __device__ inline unsigned long long mix64d(unsigned long long z) {
   z += 0x9e3779b97f4a7c15ull;
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;

@@ -41,18 +41,7 @@ __device__ inline float block_sum_256(float v, float* scratch) {
   __syncthreads();
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
-__device__ inline unsigned long long mix64d(unsigned long long z) {
-  z += 0x9e3779b97f4a7c15ull;
-  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-  return z ^ (z >> 31);
-}
-__device__ inline float hash_normal(unsigned long long seed, unsigned long long ctr) {
-  const unsigned long long h = mix64d(mix64d(seed) + ctr);
-  const float u1 = ((float)((h >> 40) + 1)) * (1.0f / 16777217.0f);
-  const float u2 = (float)((h >> 8) & 0xffffff) * (1.0f / 16777216.0f);
-  return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
-}
+// (counter-hash normals: gcrl::hash_normal, ops.h — the one definition)
 
 // BatchNorm statistics in two fully parallel, deterministic stages (a single column-owning block
 // per 64 features left 252 of 256 CUs idle and serialised over the batch):

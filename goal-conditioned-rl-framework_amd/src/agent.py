@@ -406,7 +406,7 @@ class _EngineAgent:
         rows = lib.gcrl_her_process_step(buf.handle, nz[0], 1 if obs_normalize else 0, obs.ctypes.data, nobs.ctypes.data, obs.shape[1],
                                          dg.ctypes.data, ndg.ctypes.data, nag.ctypes.data, act.ctypes.data, rew.ctypes.data,
                                          dn.ctypes.data, 0, n, _ffi.stream_handle())
-        _ffi.check(int(rows))
+        buf._check_rows(rows)
         buf.rng.push_back()
         return int(rows)
 
@@ -482,12 +482,12 @@ class _EngineAgent:
 
     def load_state(self, path: str):
         import json
-        blob = np.fromfile(os.path.join(path, "agent.bin"), dtype=np.uint8)
-        _ffi.check(lib.gcrl_agent_load_state(self._h, blob.ctypes.data, blob.size))
         with open(os.path.join(path, "meta.json")) as f:
             meta = json.load(f)
-        if meta["kind"] != self.KIND_NAME:
+        if meta["kind"] != self.KIND_NAME:      # checked before anything of this agent is overwritten
             raise ValueError(f"state of a {meta['kind']} agent loaded into a {self.KIND_NAME}")
+        blob = np.fromfile(os.path.join(path, "agent.bin"), dtype=np.uint8)
+        _ffi.check(lib.gcrl_agent_load_state(self._h, blob.ctypes.data, blob.size))
         self.beta = meta["beta"]
         self.actor.num_batches_tracked = meta["num_batches_tracked"]
         self.buffer.load_state(os.path.join(path, "ring.bin"), meta["ring"])
@@ -495,8 +495,11 @@ class _EngineAgent:
             nz = getattr(self.buffer, name, None)
             if name in meta and nz is not None:
                 d = meta[name]
-                nz.mean, nz.var = np.array(d["mean"]), np.array(d["var"])
-                nz.count, nz.clip_range = d["count"], d["clip_range"]
+                if hasattr(nz, "set_state"):     # DeviceRunningNormalizer: its statistics live on the device
+                    nz.set_state(np.array(d["mean"]), np.array(d["var"]), d["count"], d["clip_range"])
+                else:
+                    nz.mean, nz.var = np.array(d["mean"]), np.array(d["var"])
+                    nz.count, nz.clip_range = d["count"], d["clip_range"]
         self._metric_cache.clear()
 
     def reset(self):

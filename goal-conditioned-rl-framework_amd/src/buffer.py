@@ -104,9 +104,10 @@ def _classify_reward(fn, goal_dim: int, default_threshold: float):
         return 0, thr
     if all(abs(v + p) <= 1e-6 * max(1.0, p) for v, p in zip(vals, probes)):
         return 1, float(default_threshold)
-    raise NotImplementedError(
-        "compute_reward is neither sparse -(||ag-g|| > thr) nor dense -||ag-g||; "
-        "only these two goal-distance rewards have a device implementation")
+    # anything else: the reference calls whatever was injected (src/env.py:105, src/buffer.py:166) — so does the ring,
+    # through the host-callback reward kind (include/gcrl.h GCRL_REWARD_HOST): picks and goal swap on the device, the
+    # relabel rewards of a flush computed by `fn` on the host
+    return 2, float(default_threshold)
 
 
 class _RingState:
@@ -200,6 +201,8 @@ class HERBuffer(_RingState):
         if self._h is None or self._reward_cfg is None:
             return
         now = _classify_reward(self._compute_reward, self._dims[2], self._threshold)
+        if now[0] == 2 and self._reward_cfg[0] == 2:
+            return      # host-callback ring: the callable in use is whatever is assigned now, as in the reference
         if now != self._reward_cfg:
             raise ValueError(f"compute_reward / threshold changed after the replay ring was created with reward config "
                              f"{self._reward_cfg} (now {now}): create a new buffer")
@@ -218,6 +221,41 @@ class HERBuffer(_RingState):
                              rng_mode=1 if self.rng.mode == "device" else 0, seed=self.rng.seed_value)
         self._h = _ffi.check_ptr(lib.gcrl_her_create(C.byref(cfg), self.rng.handle), "gcrl_her_create")
         self._dims = (S, A, G)
+        if kind == 2:
+            self._install_reward_callback()
+
+    def _install_reward_callback(self):
+        """GCRL_REWARD_HOST: compute_reward(ag_i, ag_f, {}) per relabelled row, one call per pair in the reference's order
+        (src/buffer.py:166), float32 like the stored rewards (src/buffer.py:129).  An exception raised by the callable is
+        kept and re-raised by the push that triggered the flush."""
+        import weakref
+        wself = weakref.ref(self)
+
+        def cb(ag_p, goal_p, n, G, out_p, _user):
+            me = wself()
+            try:
+                ag = np.ctypeslib.as_array(ag_p, shape=(n, G))
+                goal = np.ctypeslib.as_array(goal_p, shape=(n, G))
+                out = np.ctypeslib.as_array(out_p, shape=(n,))
+                fn = me._compute_reward
+                for i in range(n):
+                    out[i] = np.float32(np.asarray(fn(ag[i].copy(), goal[i].copy(), {})))
+                return 0
+            except BaseException as e:   # noqa: BLE001  (must not propagate through the C frames)
+                if me is not None:
+                    me._reward_exc = e
+                return 1
+
+        self._reward_exc = None
+        self._reward_cb = _ffi.REWARD_FN(cb)          # kept alive as long as the ring
+        _ffi.check(lib.gcrl_her_set_reward_callback(self._h, C.cast(self._reward_cb, C.c_void_p), None))
+
+    def _check_rows(self, rows: int) -> int:
+        """Status of a push-like native call; a failure caused by the compute_reward callable re-raises ITS exception."""
+        exc, self._reward_exc = getattr(self, "_reward_exc", None), None
+        if exc is not None:
+            raise exc
+        return _ffi.check(int(rows))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -257,7 +295,7 @@ class HERBuffer(_RingState):
         rows = lib.gcrl_her_push(self._h, int(idx), ps, ds, act.ctypes.data, pn, dn,
                                  float(reward), 1 if done else 0, dg.ctypes.data, ag.ctypes.data,
                                  _ffi.stream_handle())
-        _ffi.check(int(rows))
+        self._check_rows(rows)
         if flushing:
             self.rng.push_back()
 
@@ -278,7 +316,7 @@ class HERBuffer(_RingState):
         self.rng.pull()
         rows = lib.gcrl_her_push_batch(self._h, int(env0), n, s.data_ptr(), s.shape[1], a.ctypes.data, ns.data_ptr(),
                                        ns.shape[1], r.ctypes.data, d.ctypes.data, ag.ctypes.data, _ffi.stream_handle())
-        _ffi.check(int(rows))
+        self._check_rows(rows)
         self.rng.push_back()
         return int(rows)
 
@@ -296,7 +334,7 @@ class HERBuffer(_RingState):
         rows = lib.gcrl_her_push_episode(self._h, int(idx), T, s.ctypes.data, a.ctypes.data,
                                          ns.ctypes.data, r.ctypes.data, d.ctypes.data,
                                          ag.ctypes.data, None, _ffi.stream_handle())
-        _ffi.check(int(rows))
+        self._check_rows(rows)
         self.rng.push_back()
         return int(rows)
 

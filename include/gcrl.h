@@ -92,7 +92,11 @@ double gcrl_cosine_lr_next(double lr_now, double base_lr, double eta_min, int64_
  * ---------------------------------------------------------------------------------------- */
 typedef struct gcrl_her gcrl_her;
 
-enum { GCRL_REWARD_SPARSE = 0, GCRL_REWARD_DENSE = 1 };
+/* GCRL_REWARD_HOST: any other callable.  The reference calls whatever was injected (src/env.py:105) once per relabelled row
+ * (src/buffer.py:166); with this kind the flush does the same through gcrl_her_set_reward_callback: the picks and the goal
+ * swap stay on the device, the rewards of a flush launch's relabel slots are computed by the callback on the host (from a
+ * host mirror of the staged achieved goals) and uploaded with the launch. */
+enum { GCRL_REWARD_SPARSE = 0, GCRL_REWARD_DENSE = 1, GCRL_REWARD_HOST = 2 };
 enum { GCRL_RNG_CPYTHON_MT = 0, GCRL_RNG_DEVICE = 1 };
 
 typedef struct gcrl_her_config {
@@ -115,6 +119,11 @@ typedef struct gcrl_her_config {
  * cfg->seed).  The ring never frees a shared rng. */
 gcrl_her* gcrl_her_create(const gcrl_her_config* cfg, gcrl_mt* rng);
 void gcrl_her_destroy(gcrl_her* h);
+/* compute_reward for GCRL_REWARD_HOST rings: out[i] = compute_reward(achieved[i], goal[i], {}) for n pairs of goal_dim floats
+ * (row-major), in the reference's call order (src/buffer.py:151-166: step-major, relabel-minor).  Returns 0, or non-zero to
+ * abort the flush (the push call then fails with GCRL_ERR_STATE).  Called on the pushing thread, inside the push call. */
+typedef int (*gcrl_reward_fn)(const float* achieved, const float* goal, int n, int goal_dim, float* out, void* user);
+int gcrl_her_set_reward_callback(gcrl_her* h, gcrl_reward_fn fn, void* user);
 int64_t gcrl_her_len(const gcrl_her* h);       /* HERBuffer.__len__  src/buffer.py:137 */
 int64_t gcrl_her_head(const gcrl_her* h);      /* physical row of logical index 0 */
 int32_t gcrl_her_staged(const gcrl_her* h, int env);
@@ -435,6 +444,11 @@ int gcrl_bn_relu_fwd_f32(const float* z_dev, int B, int H, const float* gamma_de
 int gcrl_bn_relu_bwd_f32(const float* dh_dev, const float* xhat_dev, const float* invstd_dev, const float* gamma_dev,
                          const float* beta_dev, int B, int H, float* dz_dev, float* dgamma_dev, float* dbeta_dev,
                          float* scratch_dev, void* stream);
+
+/* The device-RNG mode's Gaussian: out[i] = hash_normal(seed, ctr0 + i), the counter-hash Box-Muller normal that stands in
+ * for torch.randn_like (src/agent.py:175, TD3 target smoothing) and Normal.rsample's eps (src/model.py:134) whenever an
+ * update is not given injected noise.  Not torch's stream; restated in oracle/device_rng_oracle.py and tested against it. */
+int gcrl_hash_normal_fill(uint64_t seed, uint64_t ctr0, int64_t n, float* out_dev, void* stream);
 
 /* hipEvent helpers so a Python caller can time the engine's own stream (torch.cuda.Event only
  * sees torch's current stream). */

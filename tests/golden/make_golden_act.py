@@ -1,0 +1,92 @@
+"""Generate tests/golden/select_action.npz from the REAL reference's select_action methods (run only in the build
+container, where /root/reference exists):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_act.py
+
+For DDPG, TD3Agent, SACAgent, TQCAgent (src/agent.py:1345-1366, :253-270, :641-647, :1044-1050): the three host generators
+(`random`, `np.random`, torch's) are seeded, then a sequence of calls with varying row counts is made — exploring and
+evaluating, DDPG's epsilon-random branch included (it draws `random.random()` from the stream HER shares).  Captured: the
+actor's parameters (and BatchNorm running statistics, moved away from 0 / 1), every call's input rows, flag and returned
+array (with its dtype), and the state of all three generators after the sequence — so a replacement is held to the
+reference's VALUES and to its CONSUMPTION of every stream.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (stubs gymnasium, imports the reference, pins torch to one thread)
+
+SEED = 777
+N_CALLS = 28
+
+
+def np_state_arrays():
+    name, keys, pos, has_gauss, cached = np.random.get_state()
+    assert name == "MT19937"
+    return np.asarray(keys, np.uint32), np.array([pos, has_gauss], np.int64), np.array([cached], np.float64)
+
+
+def gen_select_action():
+    out = dict(meta=np.array([str(mg.META)]), seed=np.array([SEED]), n_calls=np.array([N_CALLS]))
+    H, L = 32, 2
+    for kind, yaml_name, (S, A) in [("DDPG", "config_ddpg_reach.yaml", (10, 3)), ("TD3", "config_td3_pickplace.yaml", (23, 4)),
+                                    ("SAC", "config_sac_slide.yaml", (22, 3)), ("TQC", "config_tqc_push.yaml", (22, 3))]:
+        cfg = mg.load_her_config(os.path.join(mg.CFG_DIR, kind, yaml_name), kind)
+        acfg = cfg.agent.model_copy(update=dict(batch_size=64, hidden_dim=H, layer_count=L))
+        torch.manual_seed(1898); np.random.seed(1898); random.seed(1898)
+        cls = dict(DDPG=mg.DDPG, TD3=mg.TD3Agent, SAC=mg.SACAgent, TQC=mg.TQCAgent)[kind]
+        agent = cls(obs_dim=S, ac_dim=A, config=acfg, weights=None, nenvs=1, gradient_step=40)
+        gen = np.random.default_rng(31 + len(kind) + S)
+        with torch.no_grad():
+            for p in agent.actor.parameters():
+                p.add_(torch.from_numpy((0.05 * gen.standard_normal(tuple(p.shape))).astype(np.float32)))
+            if kind in ("SAC", "TQC"):
+                bns = [m for m in agent.actor.base_net if isinstance(m, torch.nn.BatchNorm1d)]
+                for m in bns:
+                    m.running_mean.copy_(torch.from_numpy((0.3 * gen.standard_normal(H)).astype(np.float32)))
+                    m.running_var.copy_(torch.from_numpy(gen.uniform(0.5, 2.0, H).astype(np.float32)))
+                out[f"{kind}_bn_mean"] = np.concatenate([m.running_mean.numpy() for m in bns])
+                out[f"{kind}_bn_var"] = np.concatenate([m.running_var.numpy() for m in bns])
+        out[f"{kind}_dims"] = np.array([S, A, H, L])
+        out[f"{kind}_noise_std"] = np.array([acfg.noise_std], np.float64)
+        out[f"{kind}_actor"] = mg.flat(agent.actor.parameters())
+        random.seed(SEED); np.random.seed(SEED); torch.manual_seed(SEED)
+        n_eps_branch = 0
+        for i in range(N_CALLS):
+            n = (1, 4, 8, 3)[i % 4]
+            ev = (i % 5 == 4)
+            obs = gen.standard_normal((n, S)).astype(np.float32)
+            before = random.getstate()[1]
+            act = agent.select_action(obs, eval_action=ev)
+            if kind == "DDPG" and not ev and random.getstate()[1] != before:
+                pass
+            assert isinstance(act, np.ndarray) and act.shape == (n, A)
+            out[f"{kind}_obs{i}"] = obs
+            out[f"{kind}_eval{i}"] = np.array([ev])
+            out[f"{kind}_act{i}"] = act
+            out[f"{kind}_dtype{i}"] = np.array([str(act.dtype)])
+        out[f"{kind}_py_state"] = mg.mt_words()
+        k, p, c = np_state_arrays()
+        out[f"{kind}_np_keys"], out[f"{kind}_np_pos"], out[f"{kind}_np_cached"] = k, p, c
+        out[f"{kind}_torch_state"] = torch.get_rng_state().numpy().copy()
+        # how many of DDPG's exploring calls took the epsilon branch (a replay of the stream: src/agent.py:1348)
+        if kind == "DDPG":
+            random.seed(SEED)
+            n_eps_branch = sum(1 for i in range(N_CALLS) if i % 5 != 4 and random.random() < 0.2)
+            out["DDPG_eps_branches"] = np.array([n_eps_branch])
+        print(kind, "ok", out[f"{kind}_act0"].dtype, out[f"{kind}_act4"].dtype, n_eps_branch)
+    # the property the engine's host-side eps draw leans on: rsample's eps on a CPU module == torch.randn of the same shape
+    torch.manual_seed(5)
+    a = torch.distributions.Normal(torch.zeros(7, 3), torch.ones(7, 3)).rsample()
+    torch.manual_seed(5)
+    assert torch.equal(a, torch.randn(7, 3))
+    np.savez_compressed(os.path.join(HERE, "select_action.npz"), **out)
+
+
+if __name__ == "__main__":
+    gen_select_action()

@@ -1,0 +1,132 @@
+"""GPU (-m gpu): the BENCHMARKED multi-step path of TD3 / SAC / TQC — `update_many` = the trainer's
+`for _ in range(gradient_step): agent.update(step)` loop (reference src/env.py:384-385; update bodies src/agent.py:281-317,
+:659-699, :1062-1100) — held to
+
+  (1) N x update(): one gather launch for all batches, runs of identical steps replayed as one hipGraph of up to 8 steps,
+      control-block advances riding on the optimiser launches — none of which may change a bit: tuples, parameters, targets,
+      BatchNorm statistics and log_alpha after `update_many` are BITWISE those of repeated `update()` (the device noise is
+      keyed by a per-step counter, so both sides draw the same values), across 8-step run boundaries, SAC's
+      `step % gradient_step` Polyak cadence and TD3's `ac_update_freq`;
+  (2) the oracle: sampled batches (same MT stream) and the noise the engine itself drew — restated by
+      oracle/device_rng_oracle.py from the documented counter scheme — fed to OracleAgent.update step by step.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import her_oracle
+from oracle.agent_oracle import OracleAgent, make_config
+from oracle.device_rng_oracle import hash_normal
+
+pytestmark = pytest.mark.gpu
+S, A = 10, 3
+
+
+def _cls(gcrl, kind):
+    return dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent, SAC=gcrl.SACAgent, TQC=gcrl.TQCAgent)[kind]
+
+
+def _cfg(kind, H, L, B, **over):
+    base = dict(hidden_dim=H, layer_count=L, batch_size=B, max_len=4000, grad_clip=1.0, policy_noise=0.2, noise_clamp=0.5,
+                ac_update_freq=2 if kind == "TD3" else 1, tau=0.05, actor_lr_min=2e-4, ac_scheduler_steps=30,
+                critic_lr_min=3e-4, cr_scheduler_steps=25)
+    if kind in ("SAC", "TQC"):
+        base.update(alpha_min_steps=6.0, alpha_lr=1e-2)       # the alpha branch switches on inside the run
+    base.update(over)
+    return make_config(kind, **base)
+
+
+def _build(gcrl, kind, cfg, gstep, seed=21, **kw):
+    ag = _cls(gcrl, kind)(S, A, cfg, None, nenvs=2, gradient_step=gstep, rng="engine", seed=seed, **kw)
+    gen = np.random.default_rng(3)
+    for ep in range(4):
+        for st in her_oracle.synthetic_episode(gen, 50, S, A):
+            ag.push_her(ep % 2, *st)
+    gen2 = np.random.default_rng(8)
+    for v in [ag.actor] + ag.critics:
+        v.set_flat((v.flat() + 0.05 * gen2.standard_normal(v.numel())).astype(np.float32))
+    ag.update_target_network()
+    return ag
+
+
+def _state(ag):
+    out = [ag.actor.flat()] + [c.flat() for c in ag.critics] + [t.flat() for t in ag.target_critics]
+    if hasattr(ag, "target_actor"):
+        out.append(ag.target_actor.flat())
+    if ag._sac:
+        out += [ag.actor._get("bn_running_mean"), ag.actor._get("bn_running_var"), np.array([ag.alpha.item()], np.float32)]
+    return out
+
+
+@pytest.mark.parametrize("use_graph", [True, 2])
+@pytest.mark.parametrize("kind,H,L,B", [("TD3", 32, 2, 32), ("SAC", 32, 2, 32), ("TQC", 32, 2, 32), ("TD3", 64, 3, 300), ("SAC", 64, 3, 130)])
+def test_update_many_is_bitwise_repeated_update(gcrl, kind, H, L, B, use_graph):
+    gstep = 5                      # SAC: Polyak on steps 5, 10, ... (src/agent.py:681); chunks below cross it and the 8-step graph runs
+    cfg = _cfg(kind, H, L, B)
+    one, many = _build(gcrl, kind, cfg, gstep, use_graph=use_graph), _build(gcrl, kind, cfg, gstep, use_graph=use_graph)
+    chunks = [(1, 19), (20, 1), (21, 8), (29, 11)]          # 19 = 8 + 8 + 3 steps of graph runs; 39 steps in all
+    t_many, t_one = [], []
+    for s0, n in chunks:
+        t_many += [tuple(float(x) for x in t) for t in many.update_many(s0, n)]
+    for step in range(1, 40):
+        t_one.append(tuple(float(x) for x in one.update(step)))
+    assert [len(t) for t in t_one] == [len(t) for t in t_many]
+    if kind == "TD3":
+        assert {len(t) for t in t_one} == {6, 8}            # critic-only and actor steps both occurred
+    for step, (a, b) in enumerate(zip(t_one, t_many), start=1):
+        assert a == b, (kind, step, a, b)
+    for x, y in zip(_state(one), _state(many)):
+        assert np.array_equal(x, y)
+    if kind in ("SAC", "TQC"):
+        assert any(t[-1] != 0.0 for t in t_one) and t_one[0][-1] == 0.0       # alpha_loss: off for step <= alpha_min_steps, live after
+
+
+def _engine_noise(seed, stream, step_index, B, n_cols):
+    """What the engine draws for the step planned `step_index`-th since the agent was created (csrc/agent.hip plan_step:
+    counter base += 16 * B per step; csrc/ops.h hash_normal(seed + stream, base + b * A + j)): TD3 smoothing noise is stream 0,
+    SAC / TQC eps of actor.sample(next_state) stream 1, of actor.sample(state) stream 2."""
+    base = np.uint64(step_index) * np.uint64(16 * B)
+    return hash_normal(seed + stream, base + np.arange(B * n_cols, dtype=np.uint64)).reshape(B, n_cols)
+
+
+@pytest.mark.parametrize("kind", ["TD3", "SAC", "TQC"])
+def test_sampled_noisy_updates_track_oracle(gcrl, kind):
+    """push -> flush -> sample -> update with DEVICE noise: 4 steps through update_many against OracleAgent.update fed the same
+    MT-sampled batches and the noise values the engine drew."""
+    B, H, L, seed = 64, 32, 2, 5
+    cfg = _cfg(kind, H, L, B, max_len=5000, grad_clip=5.0, alpha_min_steps=0.0, alpha_lr=3e-4)
+    ag = _cls(gcrl, kind)(S, A, cfg, None, nenvs=2, gradient_step=4, rng="engine", seed=seed)
+    orc = OracleAgent(kind, S, A, cfg, nenvs=2, gradient_step=4, rng=random.Random(seed))
+    gen = np.random.default_rng(1)
+    for ep in range(4):
+        for st in her_oracle.synthetic_episode(gen, 50, S, A):
+            ag.push_her(ep % 2, torch.from_numpy(st[0]).cuda(), *st[1:])
+            orc.push_her(ep % 2, *st)
+    if kind in ("SAC", "TQC"):
+        # trained-policy-like heads (std ~ 0.4, small means): with fresh Xavier heads |pre-tanh| runs past 4, where
+        # log(1 - tanh^2 + 1e-8) has no fp32 precision left in the reference itself
+        with torch.no_grad():
+            orc.actor.mean_head.weight.mul_(0.2); orc.actor.log_std_head.weight.mul_(0.1); orc.actor.log_std_head.bias.fill_(-0.9)
+    ag.actor.set_flat(orc.flat_params(orc.actor))
+    for i, c in enumerate(orc.critics):
+        ag.critics[i].set_flat(orc.flat_params(c))
+    ag.update_target_network()
+    orc.hard_update()
+    outs = ag.update_many(1, 4)
+    worst = 0.0
+    for k, (step, info) in enumerate(zip((1, 2, 3, 4), outs)):
+        kw = {}
+        if kind == "TD3":
+            kw["noise"] = torch.from_numpy(_engine_noise(seed, 0, k, B, A))
+        else:
+            kw["eps_next"] = torch.from_numpy(_engine_noise(seed, 1, k, B, A))
+            kw["eps_cur"] = torch.from_numpy(_engine_noise(seed, 2, k, B, A))
+        ref = orc.update(step, **kw)
+        got = np.array([float(x) for x in info])
+        want = np.array([float(np.asarray(x)) for x in ref])
+        assert got.shape == want.shape
+        worst = max(worst, float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-2))))
+        assert np.allclose(got, want, rtol=5e-5, atol=5e-6), (kind, step, got, want)
+    print(f"sampled noisy updates [{kind}]: worst relative tuple error {worst:.2e}")

@@ -87,6 +87,46 @@ def test_select_action_exploration_branches(gcrl):
     assert 0 < n_random < 20
 
 
+@pytest.mark.parametrize("path", ["select_action", "observe_act"])
+@pytest.mark.parametrize("kind", ["DDPG", "TD3", "SAC", "TQC"])
+def test_select_action_matches_reference_goldens(gcrl, golden, kind, path):
+    """tests/golden/select_action.npz: 28 calls of the REFERENCE's select_action per agent (src/agent.py:1345-1366, :253-270,
+    :641-647, :1044-1050) with all three host generators seeded — returned arrays (values and dtype) and the generators'
+    states afterwards.  `select_action` (gcrl_agent_act_host / gcrl_agent_act) and the fused `observe_act`
+    (gcrl_agent_observe_act) must return the same actions and leave `random`, `np.random` and torch's generator in the
+    reference's state: same draws, same order, DDPG's epsilon branch included."""
+    g = golden("select_action.npz")
+    S_, A_, H_, L_ = (int(x) for x in g[f"{kind}_dims"])
+    cfg = make_config(kind, hidden_dim=H_, layer_count=L_, batch_size=64, noise_std=float(g[f"{kind}_noise_std"][0]))
+    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent, SAC=gcrl.SACAgent, TQC=gcrl.TQCAgent)[kind]
+    ag = cls(S_, A_, cfg, None, nenvs=1, gradient_step=40, rng="python")
+    ag.actor.set_flat(g[f"{kind}_actor"])
+    if kind in ("SAC", "TQC"):
+        ag.actor._set("bn_running_mean", g[f"{kind}_bn_mean"])
+        ag.actor._set("bn_running_var", g[f"{kind}_bn_var"])
+    seed = int(g["seed"][0])
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    worst = 0.0
+    for i in range(int(g["n_calls"][0])):
+        obs, ev, want = g[f"{kind}_obs{i}"], bool(g[f"{kind}_eval{i}"][0]), g[f"{kind}_act{i}"]
+        if path == "select_action":
+            got = ag.select_action(obs, eval_action=ev)
+            assert str(got.dtype) == str(g[f"{kind}_dtype{i}"][0]), (i, got.dtype)
+        else:   # the env's dict observation: [observation | desired_goal] (src/env.py:348-355), no normalisation
+            got = ag.observe_act(obs[:, :S_ - 3], obs[:, S_ - 3:], eval_action=ev, obs_normalize=False, g_normalize=False)
+        assert got.shape == want.shape
+        worst = max(worst, float(np.max(np.abs(np.asarray(got, np.float64) - want))))
+        assert np.allclose(got, want, rtol=1e-5, atol=2e-6), (kind, i, ev, got, want)
+    assert np.array_equal(np.array(random.getstate()[1], np.uint32), g[f"{kind}_py_state"])
+    name, keys, pos, has_gauss, cached = np.random.get_state()
+    assert np.array_equal(np.asarray(keys, np.uint32), g[f"{kind}_np_keys"])
+    assert [pos, has_gauss] == [int(x) for x in g[f"{kind}_np_pos"]] and cached == float(g[f"{kind}_np_cached"][0])
+    assert np.array_equal(torch.get_rng_state().numpy(), g[f"{kind}_torch_state"])
+    if kind == "DDPG":
+        assert int(g["DDPG_eps_branches"][0]) > 0
+    print(f"select_action[{kind}/{path}] worst |diff| {worst:.2e}")
+
+
 def test_reset_and_alpha_view(gcrl):
     cfg = make_config("SAC", hidden_dim=H, layer_count=L, batch_size=16, alpha_min_steps=0.0, alpha_lr=1e-2)
     ag = gcrl.SACAgent(S, A, cfg, None, nenvs=1, gradient_step=2, rng="engine", seed=1)
@@ -122,10 +162,62 @@ def test_compute_reward_classification(gcrl):
         dense.push(0, *st)
     r = dense.rows()[3]
     assert np.all(r[1:5] <= 0) and len(np.unique(r)) > 10
-    weird = gcrl.HERBuffer(1000, 50, 1, rng="engine", seed=1)
-    weird.compute_reward = lambda ag, g, info: np.float32(3.0)
-    with pytest.raises(NotImplementedError):
-        weird.push(0, *steps[0])
+
+
+@pytest.mark.parametrize("rng", ["engine", "device"])
+def test_arbitrary_compute_reward_goes_through_the_host_callback(gcrl, rng):
+    """The reference calls whatever callable was injected (src/env.py:105, src/buffer.py:166).  One that is not a goal-distance
+    reward takes the host-callback path: same rows as the oracle (which calls it like the reference does), same number of calls
+    in the same order; changing the callable later is honoured; an exception inside it surfaces from the push."""
+    calls = []
+
+    def shaped(ag, g, info):          # not a function of the distance alone: classifies as neither sparse nor dense
+        assert info == {} and ag.dtype == np.float32 and ag.shape == g.shape == (3,)
+        calls.append((ag.copy(), g.copy()))
+        return np.float32(-np.abs(ag - g).sum() - 0.25 * float(ag[0] > g[1]))
+
+    gen = np.random.default_rng(0)
+    eps = [her_oracle.synthetic_episode(gen, T, S, A) for T in (50, 13, 50)]
+    buf = gcrl.HERBuffer(2000, 50, 2, k_future=4, rng=rng, seed=1)
+    buf.compute_reward = shaped
+    orc = her_oracle.HERBufferOracle(2000, 50, 2, k_future=4, rng=her_oracle.HashRng(1) if rng == "device" else random.Random(1))
+    orc.compute_reward = shaped
+    for e, ep in enumerate(eps[:2]):
+        for t, st in enumerate(ep):
+            done = (e == 1 and t == len(ep) - 1)
+            buf.push(e, st[0], st[1], st[2], st[3], done, st[5], st[6])
+    n_calls, calls_buf = len(calls), list(calls)
+    calls.clear()
+    for e, ep in enumerate(eps[:2]):
+        for t, st in enumerate(ep):
+            orc.push(e, st[0], st[1], st[2], st[3], (e == 1 and t == len(ep) - 1), st[5], st[6])
+    assert n_calls == len(calls) == 4 * 49 + 4 * 12
+    for (a0, g0), (a1, g1) in zip(calls_buf, calls):
+        assert np.array_equal(a0, a1) and np.array_equal(g0, g1)
+    for got, want in zip(buf.rows(), orc.as_arrays()):
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # a reassignment is honoured from the next flush on (the reference reads the attribute at every call)
+    buf.compute_reward = lambda ag, g, info: np.float32(3.0) if ag[0] > g[0] else np.float32(-7.5)
+    orc.compute_reward = buf.compute_reward
+    for st in eps[2]:
+        buf.push(0, *st)
+        orc.push(0, *st)
+    for got, want in zip(buf.rows(), orc.as_arrays()):
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert set(np.unique(buf.rows()[3][-246:])) >= {3.0, -7.5}
+
+    def broken(ag, g, info):
+        raise KeyError("reward exploded")
+    buf.compute_reward = broken
+    with pytest.raises(KeyError):
+        for st in eps[2]:
+            buf.push(1, *st)
+    # switching a built-in ring to another reward kind is still refused rather than ignored
+    sparse = gcrl.HERBuffer(1000, 50, 1, rng="engine", seed=1)
+    sparse.compute_reward = her_oracle.sparse_reward
+    sparse.push(0, *eps[0][0])
+    with pytest.raises(ValueError):
+        sparse.compute_reward = shaped
 
 
 def test_error_behaviour_matches_reference(gcrl):
@@ -352,6 +444,77 @@ def test_fused_acting_entries_equal_the_separate_calls(gcrl, kind):
     assert len(host.buffer) == len(dev.buffer) == min(1000, n * 246)      # 1000-row ring: wrapped
     for a, b in zip(host.buffer.rows(), dev.buffer.rows()):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_resume_with_device_normalizers(gcrl, tmp_path):
+    """save_state / load_state with DeviceRunningNormalizer on the buffer (the configuration observe_act / process_step and
+    examples/trainer_standin.py use): statistics restored on the device, the next fused step writes the same ring rows."""
+    from gcrl_amd.src.utils import DeviceRunningNormalizer
+    from oracle import her_oracle
+    D, G, n = 7, 3, 4
+    gen = np.random.default_rng(12)
+
+    def build():
+        ag = resume_agent(gcrl, "DDPG", nenvs=n)
+        ag.buffer.obs_normalizer, ag.buffer.dg_normalizer = DeviceRunningNormalizer(D), DeviceRunningNormalizer(G)
+        ag.buffer.compute_reward = her_oracle.sparse_reward
+        return ag
+
+    def obs_dict():
+        return dict(observation=gen.standard_normal((n, D)).astype(np.float32) * 2 - 1,
+                    desired_goal=gen.uniform(-0.2, 0.2, (n, G)).astype(np.float32),
+                    achieved_goal=gen.uniform(-0.2, 0.2, (n, G)).astype(np.float32))
+
+    a = build()
+    steps = [(obs_dict(), gen.uniform(-1, 1, (n, 3)).astype(np.float32), -(gen.uniform(size=n) > 0.3).astype(np.float32)) for _ in range(61)]
+    for i in range(55):                        # one flush per env at 50, five transitions staged afterwards
+        a.process_step(steps[i][0], steps[i][1], steps[i + 1][0], steps[i][2], np.zeros(n, bool))
+    a.buffer.dg_normalizer.update(steps[0][0]["desired_goal"])
+    a.save_state(str(tmp_path))
+    b = build()
+    b.load_state(str(tmp_path))
+    for name in ("obs_normalizer", "dg_normalizer"):
+        x, y = getattr(a.buffer, name), getattr(b.buffer, name)
+        assert np.array_equal(x.mean, y.mean) and np.array_equal(x.var, y.var) and x.count == y.count and x.clip_range == y.clip_range
+    assert a.buffer.obs_normalizer.count > 100
+    for i in range(55, 60):
+        for ag in (a, b):
+            ag.process_step(steps[i][0], steps[i][1], steps[i + 1][0], steps[i][2], np.array([i == 57] * n))
+    assert len(a.buffer) == len(b.buffer) > n * 246
+    for x, y in zip(a.buffer.rows(), b.buffer.rows()):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    # a state of another agent kind is refused before anything is overwritten
+    t = resume_agent(gcrl, "TD3", nenvs=n)
+    before = t.actor.flat().copy()
+    with pytest.raises(ValueError):
+        t.load_state(str(tmp_path))
+    assert np.array_equal(before, t.actor.flat())
+
+
+def test_fused_entries_refuse_a_normalizer_of_another_size(gcrl):
+    """A normaliser whose size is not the observation / goal width is an argument error (the reference raises numpy's
+    broadcast error there), never an out-of-bounds device access."""
+    from gcrl_amd.src.utils import DeviceRunningNormalizer
+    from oracle import her_oracle
+    GcrlError = ValueError        # GCRL_ERR_ARG surfaces as ValueError (_ffi.check)
+    D, G, n = 7, 3, 4
+    ag = resume_agent(gcrl, "DDPG", nenvs=n)
+    ag.buffer.compute_reward = her_oracle.sparse_reward
+    gen = np.random.default_rng(2)
+    st = dict(observation=gen.standard_normal((n, D)).astype(np.float32), desired_goal=gen.standard_normal((n, G)).astype(np.float32),
+              achieved_goal=gen.standard_normal((n, G)).astype(np.float32))
+    act, rew = gen.uniform(-1, 1, (n, 3)).astype(np.float32), np.zeros(n, np.float32)
+    ag.buffer.obs_normalizer, ag.buffer.dg_normalizer = DeviceRunningNormalizer(D + 2), DeviceRunningNormalizer(G)
+    with pytest.raises(GcrlError):
+        ag.process_step(st, act, st, rew, np.zeros(n, bool))
+    with pytest.raises(GcrlError):
+        ag.observe_act(st["observation"], st["desired_goal"], eval_action=True)
+    ag.buffer.obs_normalizer, ag.buffer.dg_normalizer = DeviceRunningNormalizer(D), DeviceRunningNormalizer(G + 1)
+    with pytest.raises(GcrlError):
+        ag.observe_act(st["observation"], st["desired_goal"], eval_action=True, g_normalize=True)
+    ag.buffer.dg_normalizer = DeviceRunningNormalizer(G)
+    assert ag.observe_act(st["observation"], st["desired_goal"], eval_action=True, g_normalize=True).shape == (n, 3)
+    assert len(ag.buffer) == 0
 
 
 # ------------------------------------------------------------------ ReplayBuffer / PERBuffer (SURVEY.md §8f-4)
