@@ -19,11 +19,18 @@ untimed-by-the-headline legs at N > 1: `strong_scaling` (the batch of B rows spl
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline         the dominant kernel.  DDPG (row-block path): rowchain_ddpg_kernel, the forward and
-                   input-gradient chains of a step's two phases in one launch — algorithmic flops /
-                   HIP-event kernel time vs the fp32 MFMA peak.  Other agents: the HER gather kernel
-                   (algorithmic bytes / HIP-event kernel time vs HBM peak).
-  roofline_gather  the HER gather kernel, always
-  cpu_baseline     the oracle (CPU restatement of the reference) timed on this host, same workload
+                   input-gradient chains of a step's two phases in one launch — algorithmic flops per launch /
+                   the kernel's average duration vs the fp32 MFMA peak.  Other agents: the whole step.
+  roofline_gather  the HER sample (gather) kernel against 8 TB/s, always: algorithmic bytes of a trainer cycle's MAIN gather
+                   launch / its average duration
+  roofline_flush   the HER relabel + flush kernel (bytes per episode / duration), and push-side rows/s
+  cpu_baseline     the oracle (CPU restatement of the reference) timed on this host, same workload; `cpu_baseline_n1e5`
+                   the same with a 1e5-row deque (BASELINE.md's sanity row: random.sample(deque) is O(N))
+Kernel durations are THE PROFILER'S: at N = 1 this script first runs itself once as a child under
+`rocprofv3 --kernel-trace --stats` (before this process touches the GPU; same workload, fewer steps) and reads the per-kernel
+average from the tool's own summary — `profiler.kernel_stats` in the line; `--keep-profile DIR` keeps the CSV.  The HIP-event
+pair around the same launches (on the launch stream, separate untimed leg) is reported next to it; it includes ~3-4 us of
+dispatch per bracketed launch.  If the tool cannot run, the line says so and the fractions come from the event time.
 """
 import argparse
 import ctypes as C
@@ -176,13 +183,35 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode("utf-8", "replace")
+    # rank 0's stdout is drained by a thread; the children are polled so that one failing rank ends the others (a rank that
+    # died leaves its peers blocked in a collective) instead of hanging this launcher
+    import threading
+    chunks = []
+    t = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    t.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+                break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    t.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode("utf-8", "replace"))
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        raise SystemExit(f"bench.py: rank(s) failed: {bad}")
+        raise SystemExit(f"bench.py: rank(s) failed: {bad} (first: {failed})")
 
 
 def host_info():
@@ -261,15 +290,99 @@ def timed_region(agent, dp, w, steps, warmup, step0=1):
 
 def pmc_traffic(workload, kernel_substr):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r02_pmc_traffic_<workload>.json, made by tools/pmc_traffic.sh: FETCH_SIZE x 2 + WRITE_SIZE per the
+    (profiles/r03_pmc_traffic_<workload>.json, made by tools/pmc_traffic.sh: FETCH_SIZE x 2 + WRITE_SIZE per the
     guide's gfx950 correction).  bench.py cannot run the counter tool on itself."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{workload}.json")
-    if not os.path.exists(path):
-        return None
-    for name, d in json.load(open(path)).items():
-        if kernel_substr in name and "hbm_bytes_per_launch_corrected" in d:
-            return d
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{workload}.json")
+        if not os.path.exists(path):
+            continue
+        for name, d in json.load(open(path)).items():
+            if kernel_substr in name and "hbm_bytes_per_launch_corrected" in d:
+                return dict(d, source=os.path.basename(path))
     return None
+
+
+KERNELS = {   # short name -> substring of the profiler's kernel name
+    "gather_main": "her_gather_update_kernel<false>", "gather_head": "her_gather_update_kernel<true>",
+    "flush_single": "her_flush_kernel<false>", "flush_multi": "her_flush_kernel<true>", "rowchain": "rowchain_ddpg_kernel",
+}
+
+
+def profiler_child(args, w):
+    """Run this same workload once as a child under `rocprofv3 --kernel-trace --stats` and return the tool's per-kernel
+    summary {short name: {calls, avg_us, min_us, max_us}} (+ the command).  Must be called BEFORE this process touches the
+    GPU.  The child is the program itself after `--` (never a shell or env hop).  Any failure -> (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return None, "rocprofv3 not found"
+    keep = args.keep_profile
+    out_dir = os.path.abspath(keep) if keep else tempfile.mkdtemp(prefix="gcrl_prof_", dir="/tmp")
+    os.makedirs(out_dir, exist_ok=True)
+    steps = 20 * w["gstep"]
+    cmd = [tool, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "-o", "p", "--", sys.executable,
+           os.path.abspath(__file__), "--workload", args.workload, "--steps", str(steps), "--warmup", str(2 * w["gstep"]),
+           "--no-cpu-baseline", "--no-profiler", "--rng", args.rng, "--pipeline", str(args.pipeline)] + (["--no-graph"] if args.no_graph else [])
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return None, f"{type(e).__name__}: {e}"[:300]
+    files = glob.glob(os.path.join(out_dir, "**", "*kernel_stats.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        return None, f"rocprofv3 rc={r.returncode}: " + r.stderr.decode("utf-8", "replace")[-300:]
+    stats = {}
+    for row in csv.DictReader(open(files[0])):
+        for short, sub in KERNELS.items():
+            if sub in row["Name"]:
+                stats[short] = dict(calls=int(row["Calls"]), avg_us=float(row["AverageNs"]) / 1e3, min_us=float(row["MinNs"]) / 1e3,
+                                    max_us=float(row["MaxNs"]) / 1e3)
+    for f in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True):
+        os.remove(f)                         # tens of MB; the statistics are what is read (and kept)
+    if not keep:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    return dict(kernel_stats=stats, command=" ".join(["rocprofv3 --kernel-trace --stats --"] + [os.path.basename(c) if c == sys.executable else c for c in cmd[cmd.index("--") + 1:]]).replace(ROOT + "/", ""),
+                steps=steps), None
+
+
+def push_leg(w):
+    """Push-side rates on a small ring of the workload's shape: (a) whole-episode pushes (one upload + one single-episode
+    flush launch each), (b) the trainer's vector-env step (`push_batch`, 8 envs in lock-step: every 50th step flushes 8
+    episodes in ONE launch).  Wall clock around enqueue + completion; rows = ring rows appended."""
+    import gcrl_amd
+    out = {}
+    pool = [episode_arrays(ep) for ep in episode_pool(w, 16, seed=7)]
+    rows_per_ep = 50 + w["k"] * 49
+    buf = gcrl_amd.HERBuffer(400_000, 50, 8, k_future=w["k"], rng="engine", seed=3)
+    for warm in (True, False):
+        n_eps = 64 if warm else 640
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for ep in range(n_eps):
+            s, a, ns, r, d, ag = pool[ep % len(pool)]
+            buf.push_episode(ep % 8, s, a, ns, r, d, ag)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    out["episode_push"] = dict(rows_per_s=n_eps * rows_per_ep / el, transitions_per_s=n_eps * 50 / el, us_per_episode=1e6 * el / n_eps)
+    buf2 = gcrl_amd.HERBuffer(400_000, 50, 8, k_future=w["k"], rng="engine", seed=3)
+    stk = [np.stack([pool[e][j] for e in range(8)]) for j in range(6)]     # [8][50][...]
+    dev_s = torch.from_numpy(stk[0]).cuda(); dev_ns = torch.from_numpy(stk[2]).cuda()
+    for warm in (True, False):
+        n_steps = 100 if warm else 1000
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            t = i % 50
+            buf2.push_batch(dev_s[:, t], stk[1][:, t], dev_ns[:, t], stk[3][:, t], np.zeros(8, bool), stk[5][:, t])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    out["vector_step_push"] = dict(envs=8, rows_per_s=(n_steps // 50) * 8 * rows_per_ep / el, transitions_per_s=n_steps * 8 / el,
+                                   us_per_vector_step=1e6 * el / n_steps)
+    return out
 
 
 def main():
@@ -284,6 +397,8 @@ def main():
     ap.add_argument("--rng", default="engine", choices=["engine", "device"], help="index streams: CPython-exact MT (default) or the counter hash")
     ap.add_argument("--pipeline", type=int, default=-1, help="schedule level (see gcrl_agent_config.pipeline_steps); -1: the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="N > 1: skip the strong-scaling and cfg-5 (SAC) legs")
+    ap.add_argument("--no-profiler", action="store_true", help="skip the rocprofv3 child run (kernel durations then come from HIP events)")
+    ap.add_argument("--keep-profile", default=None, help="directory that keeps the child's rocprofv3 summary (kernel_stats.csv)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -297,6 +412,9 @@ def main():
         if rank == 0:
             print(json.dumps(dict(rank=rank, world=world, master=os.environ.get("MASTER_ADDR"), port=os.environ.get("MASTER_PORT"))))
         raise SystemExit(int(os.environ["GCRL_BENCH_SPAWN_ECHO"]) if rank == world - 1 else 0)
+    prof, prof_why = None, "disabled (--no-profiler)" if args.no_profiler else "N > 1"
+    if world == 1 and not args.no_profiler and not int(os.environ.get("GCRL_FORCE_DP", "0")):
+        prof, prof_why = profiler_child(args, WORKLOADS[args.workload])      # nothing above has touched the GPU
     # one rank per GPU; GCRL_DIST_BACKEND=gloo lets several ranks rehearse the DP path on ONE GPU
     backend = os.environ.get("GCRL_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
@@ -325,11 +443,14 @@ def main():
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         agent, pool, t_fill = build_agent(w, args, rank, local_rank)
-        dp = DataParallelUpdater(agent) if (world > 1 or force_dp) else None
+        # over RCCL the gradient exchange must be the engine's own (a broken native path may not hide behind the slower
+        # per-exchange Python loop); the fallback is taken only when asked for (GCRL_DP_PYTHON_EXCHANGE, gloo rehearsals)
+        strict = backend == "nccl" and "GCRL_DIST_BACKEND" not in os.environ and not int(os.environ.get("GCRL_DP_PYTHON_EXCHANGE", "0"))
+        dp = DataParallelUpdater(agent, require_native=strict) if (world > 1 or force_dp) else None
         elapsed, next_step, extra_warm, run = timed_region(agent, dp, w, args.steps, args.warmup)
 
         # ---- untimed measurement legs -------------------------------------------------------
-        # HER gather kernel: hipEvent pairs + device clock around every gather launch of 10 trainer cycles
+        # HER gather kernel: a hipEvent pair around every gather launch of 10 trainer cycles (on the launch stream)
         her = agent.buffer.handle
         check(lib.gcrl_her_profile_enable(her, 1))
         run(next_step, 10 * gstep)
@@ -354,51 +475,26 @@ def main():
         next_step += 1
         assert all(np.isfinite(last)), last
 
-        legs = {}
-        if world > 1 and not args.no_extra_legs:
-            # the extra legs must never cost the headline line: a failure is recorded, not raised (all ranks run the same
-            # code, so they fail or succeed together)
-            def leg(name, fn):
-                try:
-                    legs[name] = fn()
-                except Exception as e:   # noqa: BLE001
-                    legs[name] = dict(error=f"{type(e).__name__}: {e}"[:400])
+        push = None
+        if rank == 0 and world == 1 and not force_dp:
+            try:
+                push = push_leg(w)
+            except Exception as e:   # noqa: BLE001  (a reporting leg never costs the headline line)
+                push = dict(error=f"{type(e).__name__}: {e}"[:300])
 
-            def strong():
-                # strong scaling: the metric's batch of B rows split over the ranks (B/N rows each), same ring size
-                ag_s, _, _ = build_agent(w, args, rank, local_rank, batch=w["B"] // world)
-                dp_s = DataParallelUpdater(ag_s)
-                n_s = max(gstep, min(args.steps, 10 * gstep))
-                el_s, _, _, _ = timed_region(ag_s, dp_s, w, n_s, min(args.warmup, 2 * gstep))
-                return dict(global_batch=w["B"], batch_per_gpu=w["B"] // world, steps=n_s, value=n_s / el_s, unit="gradient-steps/s",
-                            ms_per_step=1e3 * el_s / n_s,
-                            note="fixed global batch: a latency-bound chain of 256-wide layers does not get shorter with fewer rows "
-                                 "per GPU, and gains two exchanges (DESIGN.md §7)")
-
-            def cfg5():
-                # BASELINE cfg 5: SAC Slide, B=512 per GPU, 64 env streams over the ranks
-                w5 = WORKLOADS["sac_slide_b512"]
-                ag5, _, _ = build_agent(w5, args, rank, local_rank)
-                dp5 = DataParallelUpdater(ag5)
-                n5 = max(w5["gstep"], min(args.steps, 5 * w5["gstep"]))
-                el5, _, _, _ = timed_region(ag5, dp5, w5, n5, min(args.warmup, 2 * w5["gstep"]))
-                return dict(batch_per_gpu=w5["B"], steps=n5, sync_optimizer_steps_per_s=n5 / el5, value=world * n5 / el5,
-                            unit="gradient-steps/s (batch-512 equivalents)", ms_per_step=1e3 * el5 / n5,
-                            batchnorm="local statistics per rank (DESIGN.md §7)")
-
-            if w["B"] % world == 0:
-                leg("strong_scaling", strong)
-            leg("cfg5_sac_slide_b512", cfg5)
-
+    out = None
     if rank == 0:
         R = (2 * w["S"] + w["A"] + 2) * 4
         alg_bytes_per_row = 2 * R                      # read the record + write the batch row
         rows_per_launch = rows.value / max(1, launches.value)
-        avg_us = ms.value * 1e3 / max(1, launches.value)
-        dev_us = dev_ms.value * 1e3 / max(1, launches.value)
-        achieved = (alg_bytes_per_row * rows_per_launch) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-        achieved_dev = (alg_bytes_per_row * rows_per_launch) / (dev_us * 1e-6) / 1e9 if dev_us > 0 else 0.0
-        g_pmc = pmc_traffic(args.workload, "her_gather")
+        ev_us = ms.value * 1e3 / max(1, launches.value)
+        ks = (prof or {}).get("kernel_stats", {})
+        g_us = ks.get("gather_main", {}).get("avg_us")
+        clock = "rocprofv3 kernel duration (child run of this command, profiler.command)" if g_us else \
+                f"HIP-event pair (profiler unavailable: {prof_why}); includes dispatch overhead"
+        use_us = g_us or ev_us
+        achieved = (alg_bytes_per_row * rows_per_launch) / (use_us * 1e-6) / 1e9 if use_us > 0 else 0.0
+        g_pmc = pmc_traffic(args.workload, "her_gather_update_kernel<false>") or pmc_traffic(args.workload, "her_gather")
         traffic = None
         if g_pmc and g_pmc.get("rows_per_launch"):
             traffic = g_pmc["hbm_bytes_per_launch_corrected"] / g_pmc["rows_per_launch"] * rows_per_launch
@@ -421,35 +517,59 @@ def main():
                                 "sync_optimizer_steps_per_s (batch-%d-equivalent gradient steps)" % (w["B"], world, w["B"], w["B"], w["B"])),
             "sync_optimizer_steps_per_s": sync_rate,
             "warmup_extra_steps": extra_warm,
-            "roofline_gather": {"kernel": "her_gather_update_kernel", "bound": "hbm", "achieved": achieved_dev, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": achieved_dev / HBM_PEAK_GBS, "traffic": traffic,
-                                "launches": launches.value, "avg_launch_us": dev_us, "rows_per_launch": rows_per_launch,
-                                "algorithmic_bytes_per_row": alg_bytes_per_row,
-                                "timing": "device wall clock inside the kernel (last block end - first block start = rocprofv3's "
-                                          "kernel duration), separate untimed leg of 10 trainer cycles",
-                                "hip_event_us": avg_us, "achieved_hip_event": achieved,
-                                "note": "a trainer cycle's main gather (gradient_step - 1 batches; batch 0 travels in a small head launch so "
-                                        "that step 0 starts while the host draws the rest); below ~1e5 rows the launch is latency-bound "
-                                        "(DESIGN.md §4)"},
+            "roofline_gather": {"kernel": "her_gather_update_kernel<false> (a trainer cycle's main gather)", "bound": "hbm", "achieved": achieved,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                "avg_launch_us": use_us, "rows_per_launch": rows_per_launch,
+                                "algorithmic_bytes_per_row": alg_bytes_per_row, "timing": clock,
+                                "hip_event_us": ev_us, "hip_event_launches": launches.value,
+                                "achieved_hip_event": (alg_bytes_per_row * rows_per_launch) / (ev_us * 1e-6) / 1e9 if ev_us > 0 else None,
+                                "head_launch": ({"kernel": "her_gather_update_kernel<true>", "rows": 2 * w["B"], **ks["gather_head"]} if "gather_head" in ks else None),
+                                "profiler": ks.get("gather_main"),
+                                "note": "a call's first launch gathers batches 0-1 (indices read from the pinned upload block, carries the control "
+                                        "block) so that step 0 starts while the host draws the rest; the main launch gathers the other "
+                                        "gradient_step - 2 batches.  Below ~1e5 rows a launch is bounded by the ~1.3 us dispatch + two dependent "
+                                        "memory latencies, not by bandwidth (profiles/r03_gather_rows_curve.txt)"},
             "update_flops": {"gflop_per_step": flops_per_step(w) / 1e9,
                              "achieved_tflops": flops_per_step(w) * args.steps / elapsed / 1e12,
                              "peak_tflops": FP32_MFMA_PEAK_TF},
             "fill_s": t_fill, "last_metrics": last, "host": host_info(),
         }
-        out.update(legs)
+        if dp is not None:
+            out["dp_exchange"] = dp.exchange
+        # HER relabel + flush kernel: per episode read T*(2S+A+2+G)*4 B of staging, write (T + k(T-1)) rows of R bytes
+        T, G = 50, 3
+        ep_bytes = T * (2 * w["S"] + w["A"] + 2 + G) * 4 + (T + w["k"] * (T - 1)) * R
+        fl = {"kernel": "her_flush_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_episode": ep_bytes,
+              "fill_rows_per_s": len(agent.buffer) / t_fill if t_fill > 0 else None,
+              "note": "launch-bound by construction: an episode is %d KB (0.01 us at 8 TB/s) against a ~10 us launch; a vector-env "
+                      "step's episodes share one launch (up to 8)" % (ep_bytes // 1024)}
+        for key, eps in (("flush_single", 1), ("flush_multi", 8)):
+            if key in ks:
+                us = ks[key]["avg_us"]
+                fl[key] = dict(episodes_per_launch=eps, **ks[key], achieved=eps * ep_bytes / (us * 1e-6) / 1e9, frac=eps * ep_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+        if "flush_single" in fl:
+            fl["achieved"], fl["frac"] = fl["flush_single"]["achieved"], fl["flush_single"]["frac"]
+        if push is not None:
+            fl["push"] = push
+        out["roofline_flush"] = fl
+        if prof is not None:
+            out["profiler"] = {"tool": "rocprofv3 --kernel-trace --stats", "command": prof["command"], "steps": prof["steps"], "kernel_stats": ks}
+        else:
+            out["profiler"] = {"unavailable": prof_why}
         if rc is not None and w["kind"] == "DDPG":
-            fl = chain_flops_per_launch(w)
+            fl_ = chain_flops_per_launch(w)
             r_pmc = pmc_traffic(args.workload, "rowchain")
+            r_us = ks.get("rowchain", {}).get("avg_us") or rc[1]
             out["roofline"] = {
-                "kernel": "rowchain_ddpg_kernel", "bound": "mfma", "achieved": fl / (rc[2] * 1e-6) / 1e12,
-                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / (rc[2] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF,
+                "kernel": "rowchain_ddpg_kernel", "bound": "mfma", "achieved": fl_ / (r_us * 1e-6) / 1e12,
+                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl_ / (r_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF,
                 "traffic": r_pmc["hbm_bytes_per_launch_corrected"] if r_pmc else None,
                 "l2_to_cu_read_requests_per_launch": r_pmc.get("TCP_TCC_READ_REQ_sum") if r_pmc else None,
-                "launches": rc[0], "avg_launch_us": rc[2], "algorithmic_flops_per_launch": fl,
-                "timing": "device wall clock inside the kernel (= rocprofv3's kernel duration; profiles/), separate untimed leg of "
-                          "10 trainer cycles with every launch also bracketed by a hipEvent pair on its stream",
-                "hip_event_us": rc[1], "achieved_hip_event": fl / (rc[1] * 1e-6) / 1e12,
-                "share_of_step_time": rc[2] / (1e6 * elapsed / args.steps),
+                "avg_launch_us": r_us, "algorithmic_flops_per_launch": fl_,
+                "timing": "rocprofv3 kernel duration (child run of this command)" if "rowchain" in ks else "HIP-event pair (profiler unavailable)",
+                "profiler": ks.get("rowchain"),
+                "hip_event_us": rc[1], "hip_event_launches": rc[0], "device_clock_us": rc[2],
+                "share_of_step_time": r_us / (1e6 * elapsed / args.steps),
                 "note": "latency-bound chain (10 dependent 256-wide layer passes per phase, 128 of 256 CUs at B=256), see DESIGN.md §4"}
         else:
             # many-kernel steps (TD3 / SAC / TQC): the step as a whole against the MFMA roofline, not one kernel
@@ -460,8 +580,61 @@ def main():
         if not args.no_cpu_baseline and world == 1 and w.get("n_quantiles", 1) == 1:
             out["cpu_baseline"] = cpu_baseline(w, pool, args.cpu_seconds)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+            if w["cap"] > 100_000:
+                # BASELINE.md's sanity row is quoted with a 1e5-row deque: random.sample(deque) walks the deque, so the 1e6-row
+                # baseline above is slower for a reason that has nothing to do with the update arithmetic — report both
+                out["cpu_baseline_n1e5"] = cpu_baseline(dict(w, cap=100_000), pool, max(4.0, args.cpu_seconds / 2))
+                out["speedup_vs_cpu_port_n1e5"] = value / out["cpu_baseline_n1e5"]["value"]
         print(json.dumps(out))
         sys.stdout.flush()
+
+    if world > 1 and not args.no_extra_legs:
+        # Extra legs AFTER the headline line is out (a leg that fails or hangs can no longer cost it); their results go to
+        # stderr as one line.  After each leg every rank learns whether all ranks finished it (MIN over a flag): a rank-local
+        # failure ends the legs on every rank together instead of leaving the others inside a collective.
+        legs = {}
+        with torch.cuda.stream(stream):
+            def leg(name, fn):
+                ok = 1
+                try:
+                    res = fn()
+                except Exception as e:   # noqa: BLE001
+                    res, ok = dict(error=f"{type(e).__name__}: {e}"[:400]), 0
+                flag = torch.tensor([ok], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                legs[name] = res if int(flag.item()) or not ok else dict(error="another rank failed this leg")
+                return bool(int(flag.item()))
+
+            def strong():
+                # strong scaling: the metric's batch of B rows split over the ranks (B/N rows each), same ring size
+                ag_s, _, _ = build_agent(w, args, rank, local_rank, batch=w["B"] // world)
+                dp_s = DataParallelUpdater(ag_s, require_native=strict)
+                n_s = max(gstep, min(args.steps, 10 * gstep))
+                el_s, _, _, _ = timed_region(ag_s, dp_s, w, n_s, min(args.warmup, 2 * gstep))
+                return dict(global_batch=w["B"], batch_per_gpu=w["B"] // world, steps=n_s, value=n_s / el_s, unit="gradient-steps/s",
+                            ms_per_step=1e3 * el_s / n_s,
+                            note="fixed global batch: a latency-bound chain of 256-wide layers does not get shorter with fewer rows "
+                                 "per GPU, and gains two exchanges (DESIGN.md §7)")
+
+            def cfg5():
+                # BASELINE cfg 5: SAC Slide, B=512 per GPU, 64 env streams over the ranks
+                w5 = WORKLOADS["sac_slide_b512"]
+                ag5, _, _ = build_agent(w5, args, rank, local_rank)
+                dp5 = DataParallelUpdater(ag5, require_native=strict)
+                n5 = max(w5["gstep"], min(args.steps, 5 * w5["gstep"]))
+                el5, _, _, _ = timed_region(ag5, dp5, w5, n5, min(args.warmup, 2 * w5["gstep"]))
+                return dict(batch_per_gpu=w5["B"], steps=n5, sync_optimizer_steps_per_s=n5 / el5, value=world * n5 / el5,
+                            unit="gradient-steps/s (batch-512 equivalents)", ms_per_step=1e3 * el5 / n5,
+                            batchnorm="local statistics per rank (DESIGN.md §7)", dp_exchange=dp5.exchange)
+
+            alive = True
+            if w["B"] % world == 0:
+                alive = leg("strong_scaling", strong)
+            if alive:
+                leg("cfg5_sac_slide_b512", cfg5)
+        if rank == 0:
+            sys.stderr.write("bench-legs: " + json.dumps(legs) + "\n")
+            sys.stderr.flush()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -137,9 +137,7 @@ struct gcrl_her {
   int64_t prof_class_rows = 0;           // statistics are kept for the LARGEST launch size seen (a cycle's main gather)
   size_t prof_used = 0;
   int64_t prof_launches = 0, prof_rows = 0;
-  double prof_ms = 0.0, prof_clk_ticks = 0.0;
-  unsigned long long* prof_clk = nullptr;   // [pairs][2] device words
-  int prof_clk_khz = 100000;
+  double prof_ms = 0.0;
 
   // NULL -> the handle's own stream; GCRL_STREAM_LEGACY -> HIP's legacy default stream
   hipStream_t pick(void* s) const {

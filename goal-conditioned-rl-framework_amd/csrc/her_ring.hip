@@ -155,6 +155,8 @@ struct FlushArgs {
 //   (3) writes the original row and the k relabelled rows of each of its steps; relabel =
 //       goal slot of s and ns swapped for ag[f] from LDS, reward recomputed, done = 0
 //       (src/buffer.py:151-179).
+// (kMulti only separates the names in a profile: single-episode launches from a vector-env step's multi-episode ones)
+template <bool kMulti>
 __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
   __shared__ float ag_lds[kMaxT * kMaxG];
   __shared__ float rec_lds[kStepsPerBlock][160];
@@ -230,18 +232,6 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
   }
 }
 
-// Only the first 8 and the last <=64 blocks of the grid stamp (blocks are dispatched in order, so
-// the earliest start and the latest end are among them): one word hammered by every block costs
-// ~11 ns per atomic and doubled the kernel's time at 8K blocks.
-__device__ inline void clk_begin(unsigned long long* clk) {
-  if (clk && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(&clk[0], (unsigned long long)wall_clock64());
-}
-__device__ inline void clk_end(unsigned long long* clk) {
-  if (!clk || blockIdx.x + 64 < gridDim.x) return;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicMax(&clk[1], (unsigned long long)wall_clock64());
-}
-
 // ---------------------------------------------------------------- gather (public sample)
 struct GatherArgs {
   const float* ring;
@@ -251,7 +241,6 @@ struct GatherArgs {
   int S, A, SA4, S4, RS;
   float *out_s, *out_a, *out_r, *out_ns, *out_d;
   int ld_s, ld_a, ld_ns;
-  unsigned long long* clk;  // profiling: {min block start, max block end} in wall_clock64 ticks
 };
 
 // Records of <= 64 floats: a block owns 64 consecutive batch rows.  Load: 16 lanes x float4
@@ -265,7 +254,6 @@ __global__ __launch_bounds__(256) void her_gather_kernel(GatherArgs p) {
   const int sub = lane >> 4, v4 = lane & 15;
   const int o_ns = p.SA4, o_r = p.SA4 + p.S4;
   const int c0 = v4 * 4;
-  clk_begin(p.clk);
   for (long long r0 = (long long)blockIdx.x * 64; r0 < p.n; r0 += (long long)gridDim.x * 64) {
     float4 val[4];
 #pragma unroll
@@ -298,7 +286,6 @@ __global__ __launch_bounds__(256) void her_gather_kernel(GatherArgs p) {
     span(p.out_r, 1, 1, o_r);
     span(p.out_d, 1, 1, o_r + 1);
   }
-  clk_end(p.clk);
 }
 
 // records wider than 64 floats: per-lane routing, no LDS staging
@@ -350,55 +337,101 @@ struct GatherUpdArgs {
   long long n, head, cap;
   int SA4, S4, RS, ldx;   // ldx == SA4
   float *sa, *nsa, *spa, *r, *d;
-  unsigned long long* clk;
   const uint4* cp_src; uint4* cp_dst; int cp_n16;   // optional side copy (her_ring.h), all blocks share it
 };
 
-// 16 lanes x 16 B cover one record; every batch matrix is a 16-byte-aligned slice of it, so each
-// lane's float4 goes out as float4: sa <- [0,SA4), nsa <- [SA4,SA4+S4), (r,d); spa <- [0,S4) only for the
-// layer-per-launch schedules (null otherwise: the row-chain kernels read s from sa, 92 fewer bytes written per row).
-// kRows records per wave are fetched before any store (independent loads in flight).
-template <int kUnroll>
+typedef float gcrl_f4 __attribute__((ext_vector_type(4)));
+__device__ inline void store4_nt(float* p, float4 v) {
+  gcrl_f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<gcrl_f4*>(p));
+}
+
+// index -> record -> sa | nsa | r | d (src/buffer.py:121-135 as the update engine consumes it).  One wave owns 16
+// consecutive batch rows (exact grid, one pass):
+//   (1) its 16 indices arrive in ONE coalesced load (lane l <- idx[r0 + l]; device-RNG mode: lane l evaluates the keyed
+//       permutation) and reach the 16-lane groups by a cross-lane read; ring wrap by compare-and-subtract;
+//   (2) 16 lanes x 16 B cover a record, four records per wave-load, all of a wave's loads in flight before anything else
+//       (16 records per wave, ~78 K records per launch at once: the chip's random-row rate, not a latency chain);
+//       lanes that would fetch only the record's padding do not load;
+//   (3) the records pass through a WAVE-PRIVATE LDS tile laid out like the outputs — [16][SA4] rows of sa, [16][SA4] rows
+//       of nsa (columns >= S4: zeros; the actor writes a' there before any critic reads it), r[16], d[16] — so that
+//   (4) every store is a full-width 16-byte-per-lane instruction over CONTIGUOUS output bytes (sa rows r0..r0+15 are adjacent
+//       in memory, so are nsa's, r's, d's; lanes of one instruction may point into different matrices), non-temporal: the
+//       batch matrices are consumed once, by other kernels, much later.
+// Measured (tools/gather_micro.hip, rocprofv3 durations, 77 824 PickAndPlace rows from a 1e6-row ring): round-2 kernel (per-lane
+// index loads, 64-bit modulo, stores straight from the load lanes: 4 partly masked dwordx4 + 8 one-dword stores per wave)
+// 8.9 us; coalesced indices 8.1; + non-temporal stores 6.9; + LDS-staged contiguous stores 6.4 us = 0.63 of 8 TB/s
+// (an in-order copy of the same bytes: 6.4 / 5.2 us with plain / non-temporal stores).  Scalar (s_load) index fetches were
+// slower (8.9), so were 8 / 32 / 64 rows per wave and non-temporal record loads at this launch size.
+// kHead only separates the names in a profile: the call-start launch (2 batches, indices read from the pinned upload block,
+// control-block side copy) from a cycle's main gather.
+template <bool kHead>
 __global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p) {
-  const int lane = threadIdx.x & 63;
+  extern __shared__ float gather_lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int sub = lane >> 4, v4 = lane & 15;
-  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long nwaves = (long long)gridDim.x * 4;
-  const int o_r = p.SA4 + p.S4;
-  clk_begin(p.clk);
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < p.cp_n16; i += gridDim.x * 256) p.cp_dst[i] = p.cp_src[i];
+  if (kHead)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.cp_n16; i += gridDim.x * 256) p.cp_dst[i] = p.cp_src[i];
+  const int SA4 = p.SA4, S4 = p.S4, o_r = SA4 + S4;
+  const int nq = 4 * SA4;                                   // 16-byte quads of a [16][SA4] tile
+  float* tile = gather_lds + (size_t)w * (8 * nq + 32);     // [sa 16 x SA4 | nsa 16 x SA4 | r 16 | d 16]
+  float* t_ns = tile + 4 * nq;
+  float* t_rd = tile + 8 * nq;
+  const long long r0 = ((long long)blockIdx.x * 4 + w) * 16;
+  if (r0 >= p.n) return;
+  uint32_t ph32 = 0;
+  if (lane < 16 && r0 + lane < p.n) {
+    unsigned long long phys = (unsigned long long)p.head + (p.idx ? p.idx[r0 + lane] : gcrl::idxgen_at(p.gen, r0 + lane));
+    if (phys >= (unsigned long long)p.cap) phys -= (unsigned long long)p.cap;    // head, index < cap
+    ph32 = (uint32_t)phys;
+  }
+  const bool full = r0 + 16 <= p.n;
   // records wider than 64 floats (state dims above ~28) take further 64-float column passes
-  for (int cc = 0; cc < p.RS; cc += 64) {
+  for (int cc = 0; cc <= o_r; cc += 64) {
     const int c0 = cc + v4 * 4;
-    for (long long r0 = wave_id * (4 * kUnroll); r0 < p.n; r0 += nwaves * (4 * kUnroll)) {
-      float4 val[kUnroll];
-      long long row[kUnroll];
+    const bool useful = c0 <= o_r;
+    float4 val[4];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        row[u] = r0 + u * 4 + sub;
-        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row[u] < p.n && c0 < p.RS) {
-          const long long phys = (p.head + (long long)(p.idx ? p.idx[row[u]] : gcrl::idxgen_at(p.gen, row[u]))) % p.cap;
-          val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
-        }
-      }
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t ph = __shfl(ph32, u * 4 + sub, 64);
+      val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (useful && r0 + u * 4 + sub < p.n) val[u] = *reinterpret_cast<const float4*>(p.ring + (size_t)ph * p.RS + c0);
+    }
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        if (row[u] >= p.n) continue;
-        const long long ro = row[u] * p.ldx;
-        if (c0 < p.SA4) {
-          *reinterpret_cast<float4*>(p.sa + ro + c0) = val[u];
-          if (p.spa && c0 < p.S4) *reinterpret_cast<float4*>(p.spa + ro + c0) = val[u];
-        } else if (c0 < o_r) {
-          *reinterpret_cast<float4*>(p.nsa + ro + (c0 - p.SA4)) = val[u];
-        } else if (c0 == o_r) {
-          p.r[row[u]] = val[u].x;
-          p.d[row[u]] = val[u].y;
-        }
+    for (int u = 0; u < 4; ++u) {
+      const int rl = u * 4 + sub;
+      const long long row = r0 + rl;
+      if (!useful || row >= p.n) continue;
+      if (p.spa && c0 < S4) *reinterpret_cast<float4*>(p.spa + row * p.ldx + c0) = val[u];   // layer-per-launch schedules only
+      if (full) {
+        if (c0 < SA4) *reinterpret_cast<float4*>(tile + rl * SA4 + c0) = val[u];
+        else if (c0 < o_r) *reinterpret_cast<float4*>(t_ns + rl * SA4 + (c0 - SA4)) = val[u];
+        else { t_rd[rl] = val[u].x; t_rd[16 + rl] = val[u].y; }
+      } else {   // the launch's last, partial wave: straight from the load lanes
+        if (c0 < SA4) *reinterpret_cast<float4*>(p.sa + row * p.ldx + c0) = val[u];
+        else if (c0 < o_r) *reinterpret_cast<float4*>(p.nsa + row * p.ldx + (c0 - SA4)) = val[u];
+        else { p.r[row] = val[u].x; p.d[row] = val[u].y; }
       }
     }
   }
-  clk_end(p.clk);
+  if (!full) return;
+  const int zq = (SA4 - S4) >> 2;          // quads of an nsa row beyond the record's ns group (<= 5: action_dim <= 16)
+  if (v4 < zq) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(t_ns + (u * 4 + sub) * SA4 + S4 + v4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // the tile is private to this wave and a wave's LDS operations execute in order: no barrier, only the compiler is held back
+  __builtin_amdgcn_wave_barrier();
+  float* sa = p.sa + r0 * p.ldx;
+  float* nsa = p.nsa + r0 * p.ldx;
+  const bool rd_vec = ((reinterpret_cast<size_t>(p.r) | reinterpret_cast<size_t>(p.d)) & 15) == 0;
+  const int Q = 2 * nq + (rd_vec ? 8 : 0);
+  for (int q = lane; q < Q; q += 64) {
+    const float4 v = *reinterpret_cast<const float4*>(tile + q * 4);
+    float* dst = q < nq ? sa + q * 4 : q < 2 * nq ? nsa + (q - nq) * 4 : q < 2 * nq + 4 ? p.r + r0 + (q - 2 * nq) * 4 : p.d + r0 + (q - 2 * nq - 4) * 4;
+    store4_nt(dst, v);
+  }
+  if (!rd_vec && lane < 32) (lane < 16 ? p.r : p.d)[r0 + (lane & 15)] = t_rd[lane];
 }
 
 // rows [first, first+n) in logical order -> contiguous records (read_rows)
@@ -415,9 +448,6 @@ constexpr size_t kProfPairs = 256;
 
 int prof_drain(gcrl_her* h) {
   if (h->prof_used == 0) return GCRL_OK;
-  // device-clock view of the same launches: max block end - min block start
-  std::vector<unsigned long long> clk(2 * h->prof_used);
-  GCRL_HIP(hipMemcpy(clk.data(), h->prof_clk, clk.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < h->prof_used; ++i) {
     float ms = 0.f;
     GCRL_HIP(hipEventSynchronize(h->prof_b[i]));
@@ -425,12 +455,11 @@ int prof_drain(gcrl_her* h) {
     const int64_t rows = h->prof_pair_rows[i];
     // a trainer cycle issues a 1-batch head launch (so that step 0 starts early) and the main gather of the other
     // batches: the statistics describe the largest launch size seen
-    if (rows > h->prof_class_rows) { h->prof_class_rows = rows; h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0; h->prof_clk_ticks = 0.0; }
+    if (rows > h->prof_class_rows) { h->prof_class_rows = rows; h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0; }
     if (rows != h->prof_class_rows) continue;
     h->prof_launches++;
     h->prof_rows += rows;
     h->prof_ms += ms;
-    if (clk[2 * i + 1] > clk[2 * i]) h->prof_clk_ticks += (double)(clk[2 * i + 1] - clk[2 * i]);
   }
   h->prof_used = 0;
   return GCRL_OK;
@@ -439,12 +468,9 @@ int prof_begin(gcrl_her* h, hipStream_t st) {
   if (!h->prof) return GCRL_OK;
   if (h->prof_used == kProfPairs)
     if (int rc = prof_drain(h)) return rc;
-  const unsigned long long init[2] = {~0ull, 0ull};
-  GCRL_HIP(hipMemcpyAsync(h->prof_clk + 2 * h->prof_used, init, sizeof(init), hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(h->prof_a[h->prof_used], st));
   return GCRL_OK;
 }
-unsigned long long* prof_slot(gcrl_her* h) { return h->prof ? h->prof_clk + 2 * h->prof_used : nullptr; }
 int prof_end(gcrl_her* h, hipStream_t st, int64_t rows) {
   if (!h->prof) return GCRL_OK;
   GCRL_HIP(hipEventRecord(h->prof_b[h->prof_used], st));
@@ -560,7 +586,8 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
   }
   fa.skip = total > c.capacity ? total - c.capacity : 0;
   dim3 grid((maxT + kStepsPerBlock - 1) / kStepsPerBlock, nep);
-  hipLaunchKernelGGL(her_flush_kernel, grid, dim3(256), 0, st, fa);
+  if (nep > 1) hipLaunchKernelGGL(her_flush_kernel<true>, grid, dim3(256), 0, st, fa);
+  else hipLaunchKernelGGL(her_flush_kernel<false>, grid, dim3(256), 0, st, fa);
   GCRL_HIP(hipGetLastError());
   // deque(maxlen) bookkeeping: append `total` rows, the oldest fall off the front
   int64_t newlen = h->len + total;
@@ -622,11 +649,12 @@ int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa
   if (cp_bytes % 16 != 0 || (cp_bytes && (!cp_src || !cp_dst))) return fail(GCRL_ERR_ARG, "her_gather_update: bad side copy (%zu bytes)", cp_bytes);
   if (ldx != h->SA4) return fail(GCRL_ERR_ARG, "her_gather_update: batch row stride %d != roundup(S+A,4) = %d", ldx, h->SA4);
   if (int rc = prof_begin(h, st)) return rc;
-  GatherUpdArgs ga{h->ring, idx_dev, h->last_gen, n, h->head, h->cfg.capacity, h->SA4, h->S4, h->RS, ldx, sa, nsa, spa, r, d, prof_slot(h),
+  GatherUpdArgs ga{h->ring, idx_dev, h->last_gen, n, h->head, h->cfg.capacity, h->SA4, h->S4, h->RS, ldx, sa, nsa, spa, r, d,
                    (const uint4*)cp_src, (uint4*)cp_dst, (int)(cp_bytes / 16)};
-  constexpr int kUnroll = 4;
-  int blocks = (int)std::min<int64_t>((n + 16 * kUnroll - 1) / (16 * kUnroll), 8192);
-  hipLaunchKernelGGL(her_gather_update_kernel<kUnroll>, dim3(blocks), dim3(256), 0, st, ga);
+  const int blocks = (int)((n + 63) / 64);                                              // 16 rows per wave, 4 waves per block
+  const size_t lds = 4 * ((size_t)32 * h->SA4 + 32) * sizeof(float);                    // <= 54 KB (record <= 160 floats)
+  if (cp_bytes) hipLaunchKernelGGL(her_gather_update_kernel<true>, dim3(blocks), dim3(256), lds, st, ga);
+  else hipLaunchKernelGGL(her_gather_update_kernel<false>, dim3(blocks), dim3(256), lds, st, ga);
   GCRL_HIP(hipGetLastError());
   return prof_end(h, st, n);
 }
@@ -699,7 +727,6 @@ void gcrl_her_destroy(gcrl_her* h) {
   }
   for (hipEvent_t e : h->prof_a) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_b) (void)hipEventDestroy(e);
-  if (h->prof_clk) (void)hipFree(h->prof_clk);
   if (h->pay_dev) (void)hipFree(h->pay_dev);
   if (h->fut_dev) (void)hipFree(h->fut_dev);
   if (h->rew_dev) (void)hipFree(h->rew_dev);
@@ -966,9 +993,8 @@ int gcrl_her_sample(gcrl_her* h, int B, int M, const uint32_t* idx_host, float* 
   if (drawn_idx_host) std::memcpy(drawn_idx_host, host_copy, (size_t)B * M * sizeof(uint32_t));
   const long long n = (long long)B * M;
   GatherArgs ga{h->ring, h->idx_on_device ? h->idx_dev : nullptr, h->last_gen, n, h->head, h->cfg.capacity, h->S, h->A, h->SA4, h->S4, h->RS,
-                out_s, out_a, out_r, out_ns, out_d, ld_s, ld_a, ld_ns, nullptr};
+                out_s, out_a, out_r, out_ns, out_d, ld_s, ld_a, ld_ns};
   if (int rc = prof_begin(h, st)) return rc;
-  ga.clk = prof_slot(h);
   if (h->RS <= 64) {
     int blocks = (int)std::min<long long>((n + 63) / 64, 8192);
     hipLaunchKernelGGL(her_gather_kernel, dim3(blocks), dim3(256), 0, st, ga);
@@ -991,14 +1017,10 @@ int gcrl_her_profile_enable(gcrl_her* h, int on) {
       GCRL_HIP(hipEventCreate(&h->prof_a[i]));
       GCRL_HIP(hipEventCreate(&h->prof_b[i]));
     }
-    GCRL_HIP(hipMalloc((void**)&h->prof_clk, 2 * kProfPairs * sizeof(unsigned long long)));
-    int khz = 0;
-    GCRL_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device));
-    h->prof_clk_khz = khz > 0 ? khz : 100000;
   }
   if (int rc = prof_drain(h)) return rc;
   h->prof = on != 0;
-  h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0; h->prof_clk_ticks = 0.0; h->prof_class_rows = 0;
+  h->prof_launches = 0; h->prof_rows = 0; h->prof_ms = 0.0; h->prof_class_rows = 0;
   return GCRL_OK;
 }
 
@@ -1008,7 +1030,7 @@ int gcrl_her_profile_read(gcrl_her* h, int64_t* launches, double* total_ms, int6
   if (launches) *launches = h->prof_launches;
   if (total_ms) *total_ms = h->prof_ms;
   if (rows) *rows = h->prof_rows;
-  if (device_clock_ms) *device_clock_ms = h->prof_clk_ticks / (double)h->prof_clk_khz;
+  if (device_clock_ms) *device_clock_ms = 0.0;   // no longer measured (include/gcrl.h)
   return GCRL_OK;
 }
 

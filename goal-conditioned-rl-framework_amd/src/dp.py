@@ -76,7 +76,10 @@ def device_view(ptr: int, numel: int) -> torch.Tensor:
 class DataParallelUpdater:
     """Drives agent.update(step) across ranks.  `agent` is a gcrl_amd agent on this rank's GPU."""
 
-    def __init__(self, agent, group=None):
+    def __init__(self, agent, group=None, require_native: bool = False):
+        """`require_native`: over RCCL, raise on EVERY rank when the in-engine communicator cannot be created on any of them
+        instead of falling back to per-exchange torch.distributed calls (bench.py: a broken native path must not hide
+        behind a slower one).  `self.exchange` says which path moves the gradient bytes: "engine-rccl" or "python"."""
         from .. import _ffi
         self._ffi = _ffi
         self.agent = agent
@@ -104,11 +107,16 @@ class DataParallelUpdater:
             if int(good.item()):
                 self._native = h
             else:
-                import warnings
-                warnings.warn("gcrl_amd.dp: in-engine RCCL communicator unavailable (" + _ffi.last_error() +
-                              "); exchanging gradients through torch.distributed instead")
+                why = _ffi.last_error()
                 if h:
                     lib.gcrl_dp_destroy(h)
+                if require_native:
+                    raise _ffi.GcrlError("gcrl_amd.dp: the in-engine RCCL communicator could not be created on every rank (this rank: "
+                                         + (why or "ok") + "); refusing the torch.distributed fallback (require_native)")
+                import warnings
+                warnings.warn("gcrl_amd.dp: in-engine RCCL communicator unavailable (" + why +
+                              "); exchanging gradients through torch.distributed instead")
+        self.exchange = "engine-rccl" if self._native else "python"
         for phase in (0, 1):
             p, n = C.c_void_p(), C.c_int64()
             _ffi.check(lib.gcrl_agent_grad_ptr(agent._h, phase, C.byref(p), C.byref(n)))

@@ -183,8 +183,9 @@ int gcrl_her_sample(gcrl_her* h, int B, int M, const uint32_t* idx_host,
  * gcrl_her_profile_read waits for the pending events and returns, since enabling, for the LARGEST launch size seen (a
  * trainer cycle's main gather; the one-batch head launch that lets step 0 start early is not counted), the number
  * of gather launches, their summed hipEvent time (ms, includes the event/dispatch overhead of a
- * bracketed launch), the rows they gathered, and the summed in-kernel time by the device
- * wall clock (last block end - first block start; what rocprofv3's kernel duration measures). */
+ * bracketed launch: ~3-4 us more than rocprofv3's kernel duration) and the rows they gathered.  device_clock_ms_out is
+ * always 0 now: rounds 1-2 stamped the device wall clock in the first / last blocks, which excludes dispatch and drain and
+ * read ~half of the profiler's duration — bench.py takes the kernel's duration from rocprofv3 itself instead. */
 int gcrl_her_profile_enable(gcrl_her* h, int on);
 int gcrl_her_profile_read(gcrl_her* h, int64_t* launches_out, double* total_ms_out,
                           int64_t* rows_out, double* device_clock_ms_out);

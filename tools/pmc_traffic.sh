@@ -37,10 +37,13 @@ for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("gcrl::", "").split("(")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
+        if "her_gather_update" in k and r.get("Grid_Size"):   # 64 batch rows per 256-thread block: rows of THIS launch
+            acc[k]["_rows"] += float(r["Grid_Size"]) / 4.0
+            cnt[k]["_rows"] += 1
 res = {}
 for k in acc:
     n = max(cnt[k].values())
-    if n < 20:
+    if n < 5:
         continue
     d = {c: acc[k][c] / cnt[k][c] for c in acc[k]}
     d["launches_seen"] = n
@@ -48,10 +51,10 @@ for k in acc:
         d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
     res[k] = d
 for k, d in res.items():
-    if "her_gather_update" in k:   # bench.py scales the per-row figure to its own launch size: one launch gathers 40 batches
-        import re
-        m = re.search(r"--workload (\w+)", open(glob.glob(out + "/fetch.log")[0]).read()) if glob.glob(out + "/fetch.log") else None
-        d["rows_per_launch"] = 40 * {"ddpg_pickplace_b256": 256, "td3_pickplace_b2048": 2048, "ddpg_reach_b1024": 1024, "sac_slide_b512": 512, "tqc_push_b2048": 2048}.get(BENCH_WORKLOAD, 256)
+    if "_rows" in d:   # bench.py scales the per-row figure to its own launch size; rows come from the launches' own grids
+        d["rows_per_launch"] = d.pop("_rows")
+        if "hbm_bytes_per_launch_corrected" in d:
+            d["hbm_bytes_per_row"] = d["hbm_bytes_per_launch_corrected"] / d["rows_per_launch"]
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch_corrected", 0)):
     print(k, {c: round(v, 1) for c, v in d.items()})
