@@ -26,7 +26,17 @@ constexpr int kTB = 64;        // block tile
 constexpr int kBK = 32;        // k-step: 32 MFMAs per wave between barriers; small enough for 4 workgroups per CU (see above)
 constexpr int kNV = kTB * kBK / 4 / 256;  // float4 per thread per operand tile
 constexpr int kNR = 4 * kNV;              // staging registers per operand
-constexpr int kLDT = kBK + 4;  // LDS row stride (floats): 144 B keeps b128 alignment, spreads banks
+// LDS image of an operand tile: [64 rows][32 k], NO padding; the 16-byte chunk c (= k >> 2) of row r lives at chunk position
+// c ^ (r & 7) of its row (XOR swizzle).  Conflict-free for everything that touches it: the fragment reads (one ds_read_b128
+// per lane: a b128 lane group of 16 lanes {li = 0-3, 12-15 | li = 4-11 of the next k-quarter} lands on 16 distinct 16-byte
+// bank groups), the k-contiguous stores (8 lanes = one row's 8 chunks) and the transposing stores of the row-contiguous
+// mode (tile_store: 32 lanes = 4 k x 8 rows with 8 distinct r & 7 -> 32 banks).  Round 2 padded rows to 36 floats instead:
+// 36 KB per workgroup = FOUR workgroups per CU, so a launch of 1280 tiles (TQC's five critics at batch 2048: exactly five
+// tiles per CU) ran four tiles per CU and then the fifth alone, one wave per SIMD; the transposing stores were 4-way bank
+// conflicts (profiles/r02_gemm_tiled_sq_counters.txt).  32 KB = five resident workgroups per CU.
+constexpr int kLDT = kBK;
+constexpr int kRegStages = 1;   // register stages of the global -> LDS pipeline (2: round 2's form; see gemm_tiled_body)
+__device__ inline int lds_at(int row, int k) { return row * kLDT + ((((k >> 2) ^ (row & 7)) << 2) | (k & 3)); }
 
 enum { FETCH_KC = 0, FETCH_RC = 1, FETCH_GEN = 2 };
 
@@ -59,7 +69,10 @@ __device__ inline FetchPlan fetch_plan(long long rs, long long cs, int r0, int R
 #pragma unroll
       for (int q = 0; q < 4; ++q) { pl.ones[p][q] = r == ones_row; pl.any_one |= pl.ones[p][q]; }
     } else {
-      const int k = f >> 4, r = r0 + ((f & 15) << 2);
+      // row-contiguous operand: a wave-load covers 4 k (lane & 3) x 16 row quads (lane >> 2) — per k a 256-byte run —
+      // and the workgroup's 4 waves x kNV passes the 8 k-quads; tile_store transposes through bank-conflict-free dword stores
+      const int l = tid & 63, wv = tid >> 6;
+      const int k = 4 * (wv + 4 * p) + (l & 3), r = r0 + ((l >> 2) << 2);
       pl.voff[p] = r < R ? (int)(((long long)k * cs + r) * 4) : kOob;
 #pragma unroll
       for (int q = 0; q < 4; ++q) { pl.ones[p][q] = r + q == ones_row; pl.any_one |= pl.ones[p][q]; }
@@ -119,22 +132,33 @@ __device__ inline void tile_store(const float (&reg)[kNR], float* __restrict__ l
   if (MODE == FETCH_KC) {
 #pragma unroll
     for (int p = 0; p < kNV; ++p) {
-      const int f = tid + 256 * p;
-      *reinterpret_cast<float4*>(lds + (f / (kBK / 4)) * kLDT + ((f % (kBK / 4)) << 2)) =
+      const int f = tid + 256 * p, row = f / (kBK / 4), c = f % (kBK / 4);
+      *reinterpret_cast<float4*>(lds + row * kLDT + ((c ^ (row & 7)) << 2)) =
           make_float4(reg[4 * p], reg[4 * p + 1], reg[4 * p + 2], reg[4 * p + 3]);
     }
   } else if (MODE == FETCH_RC) {
+    // a thread holds rows r..r+3 at ONE k (fetch_plan).  Store instruction t writes row r + ((t + rot) & 3), rot = (lane >> 3) & 3:
+    // within 32 lanes (4 k x 8 row quads) the rows then show all 8 values of r & 7 -> 8 swizzled chunks x 4 k = 32 banks.
+    const int l = tid & 63, wv = tid >> 6, kq = l & 3, rq = l >> 2, rot = (rq >> 1) & 3;
 #pragma unroll
     for (int p = 0; p < kNV; ++p) {
-      const int f = tid + 256 * p, k = f >> 4, r = (f & 15) << 2;
+      // rotate the four row values left by rot (two conditional-swap stages) so that instruction t finds its value in slot t
+      float x0 = reg[4 * p], x1 = reg[4 * p + 1], x2 = reg[4 * p + 2], x3 = reg[4 * p + 3];
+      const bool b0 = rot & 1, b1 = rot & 2;
+      float y0 = b0 ? x1 : x0, y1 = b0 ? x2 : x1, y2 = b0 ? x3 : x2, y3 = b0 ? x0 : x3;
+      const float z[4] = {b1 ? y2 : y0, b1 ? y3 : y1, b1 ? y0 : y2, b1 ? y1 : y3};
+      const int c = wv + 4 * p;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) lds[(r + q) * kLDT + k] = reg[4 * p + q];
+      for (int t = 0; t < 4; ++t) {
+        const int row = (rq << 2) + ((t + rot) & 3);
+        lds[row * kLDT + (((c ^ (row & 7)) << 2) | kq)] = z[t];
+      }
     }
   } else {
 #pragma unroll
     for (int p = 0; p < kNR; ++p) {
       const int e = tid + 256 * p;
-      lds[(e & 63) * kLDT + (e >> 6)] = reg[p];
+      lds[lds_at(e & 63, e >> 6)] = reg[p];
     }
   }
 }
@@ -170,7 +194,7 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   // register stages keep the fetch of tile ks+3 in flight across the MFMAs of steps ks+1 and ks+2, and two LDS
   // buffers leave ONE barrier per step: while the waves read buffer ks&1, the tile of step ks+1 is written to the other.
   const int ksteps = (K + kBK - 1) / kBK;
-  float ra[2][kNR], rb[2][kNR];
+  float ra[kRegStages][kNR], rb[kRegStages][kNR];
   const FetchPlan pla = fetch_plan<MA>(d.a_rs, d.a_cs, m0, M, -1);
   const FetchPlan plb = fetch_plan<MB>(d.b_cs, d.b_rs, n0, n_mem, ones_row);
   auto fetch = [&](float (&xa)[kNR], float (&xb)[kNR], int ks) {
@@ -191,9 +215,9 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
       if (kc * 16 >= nk) break;
       float4 a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(la + (32 * wm + 16 * i + li) * kLDT + kc * 16 + 4 * lg);
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(la + (32 * wm + 16 * i + li) * kLDT + (((kc * 4 + lg) ^ (li & 7)) << 2));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(lb + (32 * wn + 16 * j + li) * kLDT + kc * 16 + 4 * lg);
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(lb + (32 * wn + 16 * j + li) * kLDT + (((kc * 4 + lg) ^ (li & 7)) << 2));
       // q outer: consecutive MFMAs go to the four different accumulators (an accumulator is
       // reused every 128 cycles, above the 40-cycle dependent latency of 16x16x4 f32)
       const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
@@ -219,15 +243,31 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
     fetch(nxa, nxb, ks + 3);
     __syncthreads();
   };
-  fetch(ra[0], rb[0], 0);
-  fetch(ra[1], rb[1], 1);
-  store(ra[0], rb[0], 0, 0);
-  fetch(ra[0], rb[0], 2);
-  __syncthreads();
-  const int kp = (ksteps + 1) & ~1;
-  for (int ks = 0; ks < kp; ks += 2) {
-    step(ra[1], rb[1], ks);
-    step(ra[0], rb[0], ks + 1);
+  if (kRegStages == 2) {
+    fetch(ra[0], rb[0], 0);
+    fetch(ra[kRegStages - 1], rb[kRegStages - 1], 1);
+    store(ra[0], rb[0], 0, 0);
+    fetch(ra[0], rb[0], 2);
+    __syncthreads();
+    const int kp = (ksteps + 1) & ~1;
+    for (int ks = 0; ks < kp; ks += 2) {
+      step(ra[kRegStages - 1], rb[kRegStages - 1], ks);
+      step(ra[0], rb[0], ks + 1);
+    }
+  } else {
+    // ONE register stage: tile ks+1 is requested a whole k-step before it goes to LDS.  With five workgroups resident per
+    // CU a k-step lasts ~5 x 1024 MFMA cycles of wall time (the SIMD's matrix pipe is shared by five waves), longer than
+    // an HBM round trip, and the 16 registers of the second stage are what kept the kernel at four waves per SIMD.
+    fetch(ra[0], rb[0], 0);
+    store(ra[0], rb[0], 0, 0);
+    fetch(ra[0], rb[0], 1);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+      compute(ks & 1, ks);
+      store(ra[0], rb[0], (ks + 1) & 1, ks + 1);
+      fetch(ra[0], rb[0], ks + 2);
+      __syncthreads();
+    }
   }
 
   const float* __restrict__ bias = d.bias;

@@ -8,6 +8,7 @@
 #include "her_ring.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -365,7 +366,7 @@ __device__ inline void store4_nt(float* p, float4 v) {
 // slower (8.9), so were 8 / 32 / 64 rows per wave and non-temporal record loads at this launch size.
 // kHead only separates the names in a profile: the call-start launch (2 batches, indices read from the pinned upload block,
 // control-block side copy) from a cycle's main gather.
-template <bool kHead>
+template <bool kHead, bool kNT = true>
 __global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p) {
   extern __shared__ float gather_lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -429,9 +430,53 @@ __global__ __launch_bounds__(256) void her_gather_update_kernel(GatherUpdArgs p)
   for (int q = lane; q < Q; q += 64) {
     const float4 v = *reinterpret_cast<const float4*>(tile + q * 4);
     float* dst = q < nq ? sa + q * 4 : q < 2 * nq ? nsa + (q - nq) * 4 : q < 2 * nq + 4 ? p.r + r0 + (q - 2 * nq) * 4 : p.d + r0 + (q - 2 * nq - 4) * 4;
-    store4_nt(dst, v);
+    if (kNT) store4_nt(dst, v);
+    else *reinterpret_cast<float4*>(dst) = v;
   }
   if (!rd_vec && lane < 32) (lane < 16 ? p.r : p.d)[r0 + (lane & 15)] = t_rd[lane];
+}
+
+// round 2's form of the same gather (per-lane index loads, stores straight from the load lanes), kept for same-box A/B runs:
+// GCRL_GATHER_R2=1
+template <int kUnroll>
+__global__ __launch_bounds__(256) void her_gather_update_r2_kernel(GatherUpdArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane >> 4, v4 = lane & 15;
+  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  const int o_r = p.SA4 + p.S4;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < p.cp_n16; i += gridDim.x * 256) p.cp_dst[i] = p.cp_src[i];
+  // records wider than 64 floats (state dims above ~28) take further 64-float column passes
+  for (int cc = 0; cc < p.RS; cc += 64) {
+    const int c0 = cc + v4 * 4;
+    for (long long r0 = wave_id * (4 * kUnroll); r0 < p.n; r0 += nwaves * (4 * kUnroll)) {
+      float4 val[kUnroll];
+      long long row[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        row[u] = r0 + u * 4 + sub;
+        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row[u] < p.n && c0 < p.RS) {
+          const long long phys = (p.head + (long long)(p.idx ? p.idx[row[u]] : gcrl::idxgen_at(p.gen, row[u]))) % p.cap;
+          val[u] = *reinterpret_cast<const float4*>(p.ring + phys * p.RS + c0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (row[u] >= p.n) continue;
+        const long long ro = row[u] * p.ldx;
+        if (c0 < p.SA4) {
+          *reinterpret_cast<float4*>(p.sa + ro + c0) = val[u];
+          if (p.spa && c0 < p.S4) *reinterpret_cast<float4*>(p.spa + ro + c0) = val[u];
+        } else if (c0 < o_r) {
+          *reinterpret_cast<float4*>(p.nsa + ro + (c0 - p.SA4)) = val[u];
+        } else if (c0 == o_r) {
+          p.r[row[u]] = val[u].x;
+          p.d[row[u]] = val[u].y;
+        }
+      }
+    }
+  }
 }
 
 // rows [first, first+n) in logical order -> contiguous records (read_rows)
@@ -653,7 +698,10 @@ int her_gather_update(gcrl_her* h, const uint32_t* idx_dev, int64_t n, float* sa
                    (const uint4*)cp_src, (uint4*)cp_dst, (int)(cp_bytes / 16)};
   const int blocks = (int)((n + 63) / 64);                                              // 16 rows per wave, 4 waves per block
   const size_t lds = 4 * ((size_t)32 * h->SA4 + 32) * sizeof(float);                    // <= 54 KB (record <= 160 floats)
-  if (cp_bytes) hipLaunchKernelGGL(her_gather_update_kernel<true>, dim3(blocks), dim3(256), lds, st, ga);
+  static const int dev_variant = std::getenv("GCRL_GATHER_R2") ? 2 : (std::getenv("GCRL_GATHER_PLAIN") ? 1 : 0);   // development A/B knobs
+  if (dev_variant == 2) hipLaunchKernelGGL(her_gather_update_r2_kernel<4>, dim3((int)std::min<int64_t>((n + 63) / 64, 8192)), dim3(256), 0, st, ga);
+  else if (cp_bytes) hipLaunchKernelGGL(her_gather_update_kernel<true>, dim3(blocks), dim3(256), lds, st, ga);
+  else if (dev_variant == 1) hipLaunchKernelGGL((her_gather_update_kernel<false, false>), dim3(blocks), dim3(256), lds, st, ga);
   else hipLaunchKernelGGL(her_gather_update_kernel<false>, dim3(blocks), dim3(256), lds, st, ga);
   GCRL_HIP(hipGetLastError());
   return prof_end(h, st, n);

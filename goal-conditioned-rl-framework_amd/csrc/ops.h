@@ -97,7 +97,7 @@ __device__ inline unsigned long long mix64d(unsigned long long z) {
 }
 __device__ inline float hash_normal(unsigned long long seed, unsigned long long ctr) {
   const unsigned long long h = mix64d(mix64d(seed) + ctr);
-  const float u1 = ((float)((h >> 40) + 1)) * (1.0f / 16777217.0f);  // (0,1]
+  const float u1 = ((float)((h >> 40) + 1)) * (1.0f / 16777217.0f);  // (0,1]  (the literal rounds to 2^24: scale 2^-24, u1 = 1 occurs)
   const float u2 = (float)((h >> 8) & 0xffffff) * (1.0f / 16777216.0f);
   return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
 }

@@ -87,6 +87,22 @@ def _classify_reward(fn, goal_dim: int, default_threshold: float):
         g[0] = dist
         return float(np.asarray(fn(zero, g, {})))
 
+    def agrees(kind, thr):
+        """The candidate built-in kind against the callable on random goal pairs in general position (the axis probes below
+        cannot tell a distance reward from, say, an L1 or a shaped one)."""
+        gen = np.random.default_rng(20240229)
+        for _ in range(24):
+            ag = gen.uniform(-0.3, 0.3, goal_dim).astype(np.float32)
+            g = (ag + gen.standard_normal(goal_dim) * gen.choice([0.01, 0.05, 0.3])).astype(np.float32)
+            d = float(np.linalg.norm(ag.astype(np.float64) - g.astype(np.float64)))
+            got = float(np.asarray(fn(ag, g, {})))
+            if kind == 0:
+                if abs(d - thr) > 1e-5 * max(1.0, thr) and got != (-1.0 if d > thr else 0.0):
+                    return False
+            elif abs(got + d) > 1e-5 * max(1.0, d):
+                return False
+        return True
+
     probes = [0.0, 1e-3, 0.3, 5.0]
     vals = [at(p) for p in probes]
     if all(v in (0.0, -1.0) for v in vals) and vals[0] == 0.0 and vals[-1] == -1.0:
@@ -101,8 +117,9 @@ def _classify_reward(fn, goal_dim: int, default_threshold: float):
         # snap to the advertised threshold when the probe agrees with it
         if abs(thr - default_threshold) < 1e-6:
             thr = float(default_threshold)
-        return 0, thr
-    if all(abs(v + p) <= 1e-6 * max(1.0, p) for v, p in zip(vals, probes)):
+        if agrees(0, thr):
+            return 0, thr
+    elif all(abs(v + p) <= 1e-6 * max(1.0, p) for v, p in zip(vals, probes)) and agrees(1, 0.0):
         return 1, float(default_threshold)
     # anything else: the reference calls whatever was injected (src/env.py:105, src/buffer.py:166) — so does the ring,
     # through the host-callback reward kind (include/gcrl.h GCRL_REWARD_HOST): picks and goal swap on the device, the

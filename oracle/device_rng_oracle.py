@@ -23,11 +23,12 @@ def mix64(z):
 
 
 def hash_uniforms(seed, ctr):
-    """(u1, u2) float32: u1 in (0, 1], u2 in [0, 1) — the two 24-bit fields of h = mix64(mix64(seed) + ctr)."""
+    """(u1, u2) float32: u1 in (0, 1], u2 in [0, 1) — the two 24-bit fields of h = mix64(mix64(seed) + ctr).
+    (The C literal 16777217.0f is not a float: it rounds to 2^24, so u1's scale is exactly 2^-24 and u1 = 1.0 occurs.)"""
     with np.errstate(over="ignore"):
         h = mix64(mix64(np.uint64(seed)) + np.asarray(ctr, np.uint64))
-    u1 = ((h >> np.uint64(40)) + np.uint64(1)).astype(np.float32) * np.float32(1.0 / 16777217.0)
-    u2 = ((h >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    u1 = ((h >> np.uint64(40)) + np.uint64(1)).astype(np.float32) * (np.float32(1.0) / np.float32(16777217.0))
+    u2 = ((h >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(np.float32) * (np.float32(1.0) / np.float32(16777216.0))
     return u1, u2
 
 

@@ -64,13 +64,14 @@ class PERBufferOracle(ReplayBufferOracle):
             self.priorities[index] = (abs(priority) + self.epsilon) ** self.alpha
 
 
-def per_update(agent, buf: PERBufferOracle, step, beta_state):
+def per_update(agent, buf: PERBufferOracle, step, beta_state, eps_next=None, eps_cur=None):
     """One agent.update(step) of an OracleAgent (oracle/agent_oracle.py) around a PERBuffer; returns
     (tuple with td_error as the [B,1] array, indices, weights)."""
     cfg = agent.cfg
     s, a, r, ns, d, w, indices = buf.sample(cfg.batch_size, beta_state["beta"])
     batch = tuple(torch.from_numpy(x) for x in (s, a, r, ns, d))
-    info = agent.update(step, batch=batch, weights=torch.from_numpy(w), noise=torch.zeros(cfg.batch_size, agent.ac_dim))
+    info = agent.update(step, batch=batch, weights=torch.from_numpy(w), noise=torch.zeros(cfg.batch_size, agent.ac_dim),
+                        eps_next=eps_next, eps_cur=eps_cur)
     td = agent.last["td_per_sample"]
     buf.update_priorities(indices, td)
     ratio = step / cfg.beta_end                                      # beta_scheduler, src/agent.py:134-138

@@ -88,5 +88,83 @@ def gen_select_action():
     np.savez_compressed(os.path.join(HERE, "select_action.npz"), **out)
 
 
+def gen_per_stochastic(kind, tag, yaml_name):
+    """The reference's SACAgent / TQCAgent around a PERBuffer (importance-sampling branches src/agent.py:577-581, :993-997):
+    like make_golden.gen_per, with the reparameterisation noise of actor.sample recorded (Normal.rsample patched to
+    loc + eps * scale with eps from a seeded generator), BatchNorm running statistics and log_alpha after every step."""
+    S, A, B, N = 10, 3, 32, 200
+    cfg = mg.load_her_config(os.path.join(mg.CFG_DIR, kind, yaml_name), kind)
+    acfg = cfg.agent.model_copy(update=dict(batch_size=B, hidden_dim=32, layer_count=2, buffer_type="PER", max_len=150, alpha=0.6,
+                                            beta=0.4, beta_end=1000, ac_update_freq=1, alpha_min_steps=1.0))
+    torch.manual_seed(1898); np.random.seed(1898); random.seed(1898)
+    cls = dict(SAC=mg.SACAgent, TQC=mg.TQCAgent)[kind]
+    agent = cls(obs_dim=S, ac_dim=A, config=acfg, weights=None, nenvs=1, gradient_step=2)
+    agent.buffer.device = "cpu"
+    if kind == "SAC":
+        crit, opts_c = [agent.critic_1, agent.critic_2], [agent.critic_1_opt, agent.critic_2_opt]
+    else:
+        crit, opts_c = list(agent.critics), list(agent.critic_opts)
+    nets = dict(actor=agent.actor, **{f"critic_{i}": c for i, c in enumerate(crit)})
+    opts = dict(actor=agent.actor_opt, **{f"critic_{i}": o for i, o in enumerate(opts_c)})
+    gen = np.random.default_rng(91 + len(kind))
+    with torch.no_grad():
+        for net in nets.values():
+            for p in net.parameters():
+                p.add_(torch.from_numpy((0.02 * gen.standard_normal(tuple(p.shape))).astype(np.float32)))
+        # trained-policy-like heads (std ~ 0.4): fresh Xavier heads put |pre-tanh| past 4, where log(1 - tanh^2 + 1e-8) has no
+        # fp32 precision left in the reference itself (DESIGN.md §2)
+        agent.actor.mean_head.weight.mul_(0.2); agent.actor.log_std_head.weight.mul_(0.1); agent.actor.log_std_head.bias.fill_(-0.9)
+    agent.update_target_network() if hasattr(agent, "update_target_network") else None
+    out = dict(kind=np.array([kind]), dims=np.array([S, A, B, N]))
+    hp = acfg.model_dump()
+    out["hparams_keys"] = np.array(list(hp.keys()))
+    out["hparams_vals"] = np.array([str(v) for v in hp.values()])
+    for name, net in nets.items():
+        out[f"init_{name}"] = mg.flat(net.parameters())
+    rows = mg.synthetic_batch(gen, N, S, A)
+    for key, v in zip(("s", "a", "r", "ns", "d"), rows):
+        out[f"rows_{key}"] = v
+    for i in range(N):
+        agent.push(torch.from_numpy(rows[0][i]), rows[1][i], float(rows[2][i, 0]), torch.from_numpy(rows[3][i]), bool(rows[4][i, 0]))
+    rec = mg.Recorder()
+    for name, opt in opts.items():
+        rec.register(name, nets[name], opt)
+    orig_clip, orig_choice, orig_rs = torch.nn.utils.clip_grad_norm_, np.random.choice, torch.distributions.Normal.rsample
+    torch.nn.utils.clip_grad_norm_ = rec.clip_hook(orig_clip)
+    drawn, queue = [], []
+    np.random.choice = lambda *a, **k: drawn.append(orig_choice(*a, **k)) or drawn[-1]
+    torch.distributions.Normal.rsample = lambda self, sample_shape=torch.Size(): self.loc + queue.pop(0) * self.scale
+    np.random.seed(4242)
+    try:
+        for i, step in enumerate((1, 2, 3, 4)):
+            e1 = gen.standard_normal((B, A)).astype(np.float32)
+            e2 = gen.standard_normal((B, A)).astype(np.float32)
+            out[f"step{i}_eps_next"], out[f"step{i}_eps_cur"] = e1, e2
+            queue[:] = [torch.from_numpy(e1), torch.from_numpy(e2)]
+            rec.reset()
+            info = agent.update(step=step)
+            assert len(info) == 9 and not queue
+            out[f"step{i}_indices"] = np.asarray(drawn[-1], dtype=np.int64)
+            out[f"step{i}_td"] = np.asarray(info[3], dtype=np.float32)
+            out[f"step{i}_tuple"] = np.array([float(np.asarray(x)) if j != 3 else float(np.mean(info[3])) for j, x in enumerate(info)])
+            out[f"step{i}_priorities"] = np.array(agent.buffer.priorities, dtype=np.float64)
+            out[f"step{i}_beta"] = np.array([agent.beta])
+            for name in opts:
+                if name in rec.pre:
+                    out[f"step{i}_gradpre_{name}"] = rec.pre[name]
+            for name, net in nets.items():
+                out[f"step{i}_param_{name}"] = mg.flat(net.parameters())
+            out[f"step{i}_log_alpha"] = agent.log_alpha.detach().numpy().copy()
+            bns = [m for m in agent.actor.base_net if isinstance(m, torch.nn.BatchNorm1d)]
+            out[f"step{i}_bn_mean"] = np.concatenate([m.running_mean.numpy() for m in bns])
+            out[f"step{i}_bn_var"] = np.concatenate([m.running_var.numpy() for m in bns])
+    finally:
+        torch.nn.utils.clip_grad_norm_, np.random.choice, torch.distributions.Normal.rsample = orig_clip, orig_choice, orig_rs
+    np.savez_compressed(os.path.join(HERE, f"per_{tag}.npz"), **out)
+    print("per", tag, "ok", out["step0_tuple"], out["step3_tuple"][-1])
+
+
 if __name__ == "__main__":
     gen_select_action()
+    gen_per_stochastic("SAC", "sac", "config_sac_slide.yaml")
+    gen_per_stochastic("TQC", "tqc", "config_tqc_push.yaml")

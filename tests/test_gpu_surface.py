@@ -174,7 +174,8 @@ def test_arbitrary_compute_reward_goes_through_the_host_callback(gcrl, rng):
     def shaped(ag, g, info):          # not a function of the distance alone: classifies as neither sparse nor dense
         assert info == {} and ag.dtype == np.float32 and ag.shape == g.shape == (3,)
         calls.append((ag.copy(), g.copy()))
-        return np.float32(-np.abs(ag - g).sum() - 0.25 * float(ag[0] > g[1]))
+        return np.float32(-np.abs(ag - g).sum() - 0.25 * float(ag[0] > g[1]))   # on axis probes this IS -distance: only the
+                                                                                # general-position check tells it apart
 
     gen = np.random.default_rng(0)
     eps = [her_oracle.synthetic_episode(gen, T, S, A) for T in (50, 13, 50)]
@@ -186,6 +187,9 @@ def test_arbitrary_compute_reward_goes_through_the_host_callback(gcrl, rng):
         for t, st in enumerate(ep):
             done = (e == 1 and t == len(ep) - 1)
             buf.push(e, st[0], st[1], st[2], st[3], done, st[5], st[6])
+            if e == 0 and t == 0:
+                assert len(calls) > 0       # the ring is created at the first push: the classification probes
+                calls.clear()
     n_calls, calls_buf = len(calls), list(calls)
     calls.clear()
     for e, ep in enumerate(eps[:2]):
@@ -539,7 +543,7 @@ def test_replay_buffer_rows_and_sample_bit_exact(gcrl):
             assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32))
 
 
-@pytest.mark.parametrize("tag", ["ddpg", "td3"])
+@pytest.mark.parametrize("tag", ["ddpg", "td3", "sac", "tqc"])
 def test_per_agent_matches_reference(gcrl, tag):
     """buffer_type="PER" end to end against the golden captured from the reference (tests/golden/make_golden.py gen_per):
     the prioritised draw (np.random.choice over float32 priorities: same indices), importance-sampling weights inside the
@@ -549,8 +553,9 @@ def test_per_agent_matches_reference(gcrl, tag):
     kind = str(g["kind"][0])
     S, A, B, N = (int(x) for x in g["dims"])
     cfg = hparams_from_golden(g)
-    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent)[kind]
-    ag = cls(S, A, cfg, None, nenvs=1, gradient_step=40, rng="engine", seed=0)
+    cls = dict(DDPG=gcrl.DDPG, TD3=gcrl.TD3Agent, SAC=gcrl.SACAgent, TQC=gcrl.TQCAgent)[kind]
+    stoch = kind in ("SAC", "TQC")        # importance-weight branches src/agent.py:577-581, :993-997; goldens: 4 steps + eps
+    ag = cls(S, A, cfg, None, nenvs=1, gradient_step=2 if stoch else 40, rng="engine", seed=0)
     assert isinstance(ag.buffer, gcrl.PERBuffer)
     views = {"actor": ag.actor, **{f"critic_{i}": c for i, c in enumerate(ag.critics)}}
     for n, v in views.items():
@@ -561,11 +566,22 @@ def test_per_agent_matches_reference(gcrl, tag):
                 bool(g["rows_d"][i, 0]))
     assert len(ag.buffer) == cfg.max_len
     np.random.seed(4242)
-    for i, step in enumerate((1, 2, 3)):
+    for i, step in enumerate((1, 2, 3, 4) if stoch else (1, 2, 3)):
         kw = dict(noise=torch.zeros(B, A)) if kind == "TD3" else {}
+        if stoch:
+            kw = dict(eps_next=torch.from_numpy(g[f"step{i}_eps_next"]), eps_cur=torch.from_numpy(g[f"step{i}_eps_cur"]))
         info = ag.update(step, **kw)
         want = g[f"step{i}_tuple"]
-        td_pos = {6: 2, 8: 3}[len(want)]
+        td_pos = {6: 2, 8: 3, 9: 3}[len(want)]
+        if stoch:
+            la = np.empty(1, np.float32)
+            gcrl._ffi.check(gcrl._ffi.lib.gcrl_agent_get(ag._h, b"log_alpha", la.ctypes.data, 1))
+            assert np.allclose(la, g[f"step{i}_log_alpha"], rtol=1e-5, atol=1e-7)
+            assert np.allclose(ag.actor._get("bn_running_mean"), g[f"step{i}_bn_mean"], rtol=1e-5, atol=1e-6)
+            assert np.allclose(ag.actor._get("bn_running_var"), g[f"step{i}_bn_var"], rtol=1e-5, atol=1e-6)
+            # continue from the reference's state (parameters below; statistics and log_alpha here)
+            ag.actor._set("bn_running_mean", g[f"step{i}_bn_mean"]); ag.actor._set("bn_running_var", g[f"step{i}_bn_var"])
+            gcrl._ffi.check(gcrl._ffi.lib.gcrl_agent_set(ag._h, b"log_alpha", np.ascontiguousarray(g[f"step{i}_log_alpha"], np.float32).ctypes.data, 1))
         assert len(info) == len(want)
         td = np.asarray(info[td_pos])
         assert td.shape == g[f"step{i}_td"].shape and np.allclose(td, g[f"step{i}_td"], rtol=1e-5, atol=1e-6)
@@ -577,7 +593,7 @@ def test_per_agent_matches_reference(gcrl, tag):
             k = f"step{i}_gradpre_{n}"
             if k in g.files:
                 gg = v.grad_flat()
-                assert float(np.max(np.abs(gg - g[k]))) <= 1e-6 + 1e-5 * float(np.max(np.abs(g[k]))), (i, n)
+                assert float(np.max(np.abs(gg - g[k]))) <= 1e-6 + (3e-5 if stoch else 1e-5) * float(np.max(np.abs(g[k]))), (i, n)
             v.set_flat(g[f"step{i}_param_{n}"])     # continue from the reference's state
         # the reference's targets follow their own cadence; keep them in step with the golden run
         if kind == "DDPG":

@@ -218,7 +218,7 @@ def test_normalizer_oracle_matches_reference_bitwise():
 
 
 # ---------------------------------------------------------------- G10: PER buffer + weighted critic losses
-@pytest.mark.parametrize("tag", ["ddpg", "td3"])
+@pytest.mark.parametrize("tag", ["ddpg", "td3", "sac", "tqc"])
 def test_per_oracle_matches_reference(tag):
     from oracle.replay_oracle import PERBufferOracle, per_update
     g = load_golden(f"per_{tag}.npz")
@@ -226,7 +226,7 @@ def test_per_oracle_matches_reference(tag):
     S, A, B, N = (int(x) for x in g["dims"])
     cfg = hparams_from_golden(g)
     torch.set_num_threads(1)
-    orc = OracleAgent(kind, S, A, cfg, nenvs=1)
+    orc = OracleAgent(kind, S, A, cfg, nenvs=1, gradient_step=2)
     nets = {"actor": orc.actor, **{f"critic_{i}": c for i, c in enumerate(orc.critics)}}
     for n, net in nets.items():
         orc.set_flat_params(net, g[f"init_{n}"])
@@ -236,14 +236,20 @@ def test_per_oracle_matches_reference(tag):
         buf.push(g["rows_s"][i], g["rows_a"][i], float(g["rows_r"][i, 0]), g["rows_ns"][i], bool(g["rows_d"][i, 0]))
     np.random.seed(4242)
     beta = dict(beta=cfg.beta, beta0=cfg.beta)
-    for i, step in enumerate((1, 2, 3)):
-        info, td, idx, w = per_update(orc, buf, step, beta)
+    stoch = kind in ("SAC", "TQC")      # their goldens hold 4 steps, the recorded rsample eps, BN statistics and log_alpha
+    for i, step in enumerate((1, 2, 3, 4) if stoch else (1, 2, 3)):
+        eps = dict(eps_next=torch.from_numpy(g[f"step{i}_eps_next"]), eps_cur=torch.from_numpy(g[f"step{i}_eps_cur"])) if stoch else {}
+        info, td, idx, w = per_update(orc, buf, step, beta, **eps)
         assert np.array_equal(idx, g[f"step{i}_indices"])
         assert np.array_equal(td, g[f"step{i}_td"])
         assert np.array_equal(np.array(buf.priorities, np.float64), g[f"step{i}_priorities"])
         want = g[f"step{i}_tuple"]
         got = np.array([float(np.asarray(x)) for x in info])
-        td_pos = {6: 2, 8: 3}[len(want)]
+        td_pos = {6: 2, 8: 3, 9: 3}[len(want)]
+        if stoch:
+            assert close(orc.log_alpha.detach().numpy(), g[f"step{i}_log_alpha"])
+            bns = [m for m in orc.actor.base_net if isinstance(m, torch.nn.BatchNorm1d)]
+            assert close(np.concatenate([m.running_mean.numpy() for m in bns]), g[f"step{i}_bn_mean"])
         got[td_pos] = float(np.mean(td))        # on this path the reference returns the per-sample array there
         assert close(got, want), (i, got, want)
         for n in nets:

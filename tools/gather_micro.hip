@@ -5,6 +5,9 @@
 // Every variant is a separate kernel name so that the profiler's statistics separate them; every launch reads a fresh
 // window of a long random index array (no launch re-reads the rows of the one before).
 #include <hip/hip_runtime.h>
+#ifdef ENGINE_KERNEL   // the library's own kernel, compiled into this program: -DENGINE_KERNEL -I<csrc> -I<include> + link libgcrl_hip.so
+#include "her_ring.hip"
+#endif
 
 #include <cstdint>
 #include <cstdio>
@@ -255,10 +258,15 @@ __global__ __launch_bounds__(256) void g_v3(Args p) {
 }
 
 __global__ void g_empty(Args) {}
+// streams through a buffer larger than the infinity cache: what 40 update steps of other traffic do between two gathers
+__global__ __launch_bounds__(256) void g_thrash(float4* buf, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { float4 v = buf[i]; v.x += 1.f; buf[i] = v; }
+}
 
 int main(int argc, char** argv) {
   const long long rows = argc > 1 ? atoll(argv[1]) : 77824;
   const int iters = argc > 2 ? atoi(argv[2]) : 40;
+  const size_t thrash_mb = argc > 3 ? (size_t)atoll(argv[3]) : 0;   // > 0: evict the caches before every launch
   const long long cap = 1000000;
   const int SA4 = 28, S4 = 24, RS = 64;
   float *ring, *sa, *nsa, *r, *d; uint32_t* idx;
@@ -271,14 +279,17 @@ int main(int argc, char** argv) {
   for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (uint32_t)(s % cap); }
   CK(hipMemcpy(idx, h.data(), nidx * 4, hipMemcpyHostToDevice));
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  float4* tb = nullptr; const size_t tn4 = thrash_mb * (1u << 20) / 16;
+  if (thrash_mb) { CK(hipMalloc(&tb, tn4 * 16)); CK(hipMemset(tb, 0, tn4 * 16)); }
+  auto thrash = [&]() { if (tb) hipLaunchKernelGGL(g_thrash, dim3(4096), dim3(256), 0, st, tb, tn4); };
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   const double alg = 416.0 * rows;
   auto run = [&](const char* name, auto launch) {
-    for (int w = 0; w < 3; ++w) launch(w % 8);
+    for (int w = 0; w < 3; ++w) { thrash(); launch(w % 8); }
     CK(hipStreamSynchronize(st));
     double tot = 0, best = 1e9;
     for (int i = 0; i < iters; ++i) {
-      CK(hipEventRecord(a, st)); launch(i % 8); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      thrash(); CK(hipEventRecord(a, st)); launch(i % 8); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b)); tot += ms; if (ms < best) best = ms;
     }
     printf("%-28s rows %8lld  event avg %7.2f us  min %7.2f us  alg %6.2f TB/s (avg)\n", name, rows, tot / iters * 1e3, best * 1e3,
@@ -296,6 +307,14 @@ int main(int argc, char** argv) {
   run("v1_u8_nts", [&](int w) { hipLaunchKernelGGL((g_v1<8, false, true, 256>), dim3(blocks(128)), dim3(256), 0, st, args(w)); });
   run("v3 (lds, contiguous stores)", [&](int w) { hipLaunchKernelGGL(g_v3<false>, dim3(blocks(64)), dim3(256), 0, st, args(w)); });
   run("v3_nts", [&](int w) { hipLaunchKernelGGL(g_v3<true>, dim3(blocks(64)), dim3(256), 0, st, args(w)); });
+#ifdef ENGINE_KERNEL
+  {
+    float* nsa_w; CK(hipMalloc(&nsa_w, (size_t)rows * SA4 * 4));     // the engine's nsa rows are SA4 wide
+    auto eargs = [&](int win) { return GatherUpdArgs{ring, idx + (size_t)win * rows, gcrl::IdxGen{}, rows, 123457, cap, SA4, S4, RS, SA4, sa, nsa_w, nullptr, r, d, nullptr, nullptr, 0}; };
+    const size_t lds = 4 * ((size_t)32 * SA4 + 32) * sizeof(float);
+    run("ENGINE her_gather_update_kernel", [&](int w) { hipLaunchKernelGGL(her_gather_update_kernel<false>, dim3(blocks(64)), dim3(256), lds, st, eargs(w)); });
+  }
+#endif
   run("copy_u4_nts (bound)", [&](int w) { hipLaunchKernelGGL(g_copy_nts<4>, dim3(blocks(64)), dim3(256), 0, st, args(w)); });
   run("copy_u4 (in-order bound)", [&](int w) { hipLaunchKernelGGL(g_copy<4>, dim3(blocks(64)), dim3(256), 0, st, args(w)); });
   return 0;

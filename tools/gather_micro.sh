@@ -3,13 +3,14 @@
 set -e
 tag=${1:-gm}; shift || true
 sizes=${*:-"10240 77824 81920 327680 1000000"}
+thrash=${THRASH_MB:-0}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for n in $sizes; do
-  $root/tools/gather_micro $n 40 > $out/event_$n.txt
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$n -o p -- $root/tools/gather_micro $n 40 > /dev/null 2>&1
+  $root/tools/gather_micro $n 40 $thrash > $out/event_$n.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$n -o p -- $root/tools/gather_micro $n 40 $thrash > /dev/null 2>&1
   f=$(find $out/prof_$n -name "*kernel_stats.csv" | head -1)
   python3 - "$f" $n > $out/rocprof_$n.txt <<'PY'
 import csv, sys
