@@ -303,7 +303,7 @@ def pmc_traffic(workload, kernel_substr):
 
 
 KERNELS = {   # short name -> substring of the profiler's kernel name
-    "gather_main": "her_gather_update_kernel<false>", "gather_head": "her_gather_update_kernel<true>",
+    "gather_main": "her_gather_update_kernel<false", "gather_head": "her_gather_update_kernel<true",
     "flush_single": "her_flush_kernel<false>", "flush_multi": "her_flush_kernel<true>", "rowchain": "rowchain_ddpg_kernel",
 }
 
@@ -494,7 +494,7 @@ def main():
                 f"HIP-event pair (profiler unavailable: {prof_why}); includes dispatch overhead"
         use_us = g_us or ev_us
         achieved = (alg_bytes_per_row * rows_per_launch) / (use_us * 1e-6) / 1e9 if use_us > 0 else 0.0
-        g_pmc = pmc_traffic(args.workload, "her_gather_update_kernel<false>") or pmc_traffic(args.workload, "her_gather")
+        g_pmc = pmc_traffic(args.workload, "her_gather_update_kernel<false") or pmc_traffic(args.workload, "her_gather")
         traffic = None
         if g_pmc and g_pmc.get("rows_per_launch"):
             traffic = g_pmc["hbm_bytes_per_launch_corrected"] / g_pmc["rows_per_launch"] * rows_per_launch

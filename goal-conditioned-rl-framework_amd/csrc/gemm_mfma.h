@@ -104,6 +104,18 @@ __device__ inline float act_deriv(float h, int mul) {
   }
 }
 
+// XCD-aware workgroup -> tile mapping.  Workgroups are handed to the 8 XCDs round-robin (workgroup w runs on XCD w % 8) and
+// every XCD has its own L2, so with tiles taken in launch order the 8 neighbours that share an operand panel (same tile row:
+// the same A rows) sit on 8 different XCDs and the panel is fetched from the infinity cache / HBM once PER XCD — measured in
+// round 2 as an 8x over-fetch (TD3's dW launch: 170 MB HBM-side for ~20 MB of operands, profiles/r02_pmc_traffic_td3_*).
+// Here XCD x takes the contiguous tile range [x * G/8, (x+1) * G/8): whole tile rows, usually whole problems of a batched
+// launch, live in ONE L2.  A wrong guess about the placement costs speed, never correctness; the arithmetic of a tile does
+// not depend on which workgroup computes it.
+__device__ inline int xcd_tile_of(int w, int G) {
+  const int per = G >> 3;
+  return w < (per << 3) ? (w & 7) * per + (w >> 3) : w;
+}
+
 template <int TM, int TN, int KSPLIT>
 __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
   static_assert(KSPLIT == 1 || (TM == 1 && TN == 1), "k-split only for single 16x16 tiles");
@@ -115,7 +127,8 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
   constexpr bool TR = KSPLIT == 1;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wtile = (KSPLIT == 4) ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  const int bid = xcd_tile_of((int)blockIdx.x, (int)gridDim.x);
+  const int wtile = (KSPLIT == 4) ? bid : bid * 4 + wave;
   int pi = 0;
 #pragma unroll
   for (int q = 1; q < kMaxProb; ++q)

@@ -325,7 +325,7 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) float ldsA[2 * kTB * kLDT];   // two buffers each (gemm_tiled_body)
   __shared__ __attribute__((aligned(16))) float ldsB[2 * kTB * kLDT];
-  const int tile = blockIdx.x;
+  const int tile = xcd_tile_of((int)blockIdx.x, (int)gridDim.x);   // an XCD owns whole tile rows: each A panel enters ONE L2 (gemm_mfma.h)
   int pi = 0;
 #pragma unroll
   for (int q = 1; q < kMaxProb; ++q)

@@ -80,6 +80,13 @@ def _classify_reward(fn, goal_dim: int, default_threshold: float):
     probing it: sparse -(d > thr) with thr found by bisection, or dense -d."""
     if fn is None:
         return 0, float(default_threshold)
+    try:
+        return _classify_reward_probe(fn, goal_dim, default_threshold)
+    except Exception:   # noqa: BLE001  a callable that cannot take the probe vectors is not a goal-distance reward: host path,
+        return 2, float(default_threshold)   # where its exception surfaces from the push that calls it, as in the reference
+
+
+def _classify_reward_probe(fn, goal_dim: int, default_threshold: float):
     zero = np.zeros(goal_dim, dtype=np.float32)
 
     def at(dist):

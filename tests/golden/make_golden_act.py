@@ -164,7 +164,95 @@ def gen_per_stochastic(kind, tag, yaml_name):
     print("per", tag, "ok", out["step0_tuple"], out["step3_tuple"][-1])
 
 
+def gen_update_fp64(tag):
+    """tests/golden/update_<tag>.npz replayed through the reference in FLOAT64 (`.double()` networks, the same inputs, the same
+    recorded noise; after every step the state is put back to the fp32 run's, as the parity tests do): returned tuple and
+    pre-clip gradients per step.  Lets the GPU test hold SAC / TQC to |hip - ref64| <= max(3 |ref32 - ref64|, 1e-5 scale) — the
+    criterion of the full-size fixtures (tests/fullsize.py) — instead of a flat relaxed tolerance: on the fresh-Xavier SAC
+    fixture the reference's own fp32 run is what sits 1e-5..1e-3 away from its fp64 run (log(1 - tanh^2 + 1e-8) at |x| > 4)."""
+    from src.utils import BaseAgentConfig, SACAgentConfig
+    g = np.load(os.path.join(HERE, f"update_{tag}.npz"))
+    kind = str(g["kind"][0])
+    S, A, B, gstep = (int(x) for x in g["dims"])
+    Model = SACAgentConfig if kind in ("SAC", "TQC") else BaseAgentConfig
+    hp = {}
+    for k, v in zip(g["hparams_keys"], g["hparams_vals"]):
+        k, v = str(k), str(v)
+        ann = Model.model_fields[k].annotation
+        hp[k] = v if ann is str else (int(float(v)) if ann is int else float(v))
+    acfg = Model(**hp)
+    torch.manual_seed(1898); np.random.seed(1898); random.seed(1898)
+    cls = dict(DDPG=mg.DDPG, TD3=mg.TD3Agent, SAC=mg.SACAgent, TQC=mg.TQCAgent)[kind]
+    agent = cls(obs_dim=S, ac_dim=A, config=acfg, weights=None, nenvs=1, gradient_step=gstep)
+    if kind == "SAC":
+        nets = dict(actor=agent.actor, critic_0=agent.critic_1, critic_1=agent.critic_2, target_critic_0=agent.target_critic_1,
+                    target_critic_1=agent.target_critic_2)
+        opts = dict(actor=agent.actor_opt, critic_0=agent.critic_1_opt, critic_1=agent.critic_2_opt)
+    else:
+        nets, opts = dict(actor=agent.actor), dict(actor=agent.actor_opt)
+        for i, (c, t, o) in enumerate(zip(agent.critics, agent.target_critics, agent.critic_opts)):
+            nets[f"critic_{i}"] = c; nets[f"target_critic_{i}"] = t; opts[f"critic_{i}"] = o
+
+    def set_flat(net, vec):
+        off = 0
+        with torch.no_grad():
+            for p in net.parameters():
+                n = p.numel()
+                p.copy_(torch.from_numpy(np.asarray(vec[off:off + n], np.float64)).view_as(p))
+                off += n
+
+    for net in nets.values():
+        net.double()
+    agent.log_alpha.data = agent.log_alpha.data.double()
+    agent.alpha = agent.log_alpha.exp()
+    for name, net in nets.items():
+        key = f"init_{name}"
+        set_flat(net, g[key] if key in g.files else g[f"init_{name.replace('target_', '')}"])
+    bns = [m for m in agent.actor.base_net if isinstance(m, torch.nn.BatchNorm1d)]
+    pre = {}
+    orig_clip, orig_rs = torch.nn.utils.clip_grad_norm_, torch.distributions.Normal.rsample
+    ids = {id(next(iter(nets[n].parameters()))): n for n in opts}
+
+    def clip(parameters, max_norm, *a, **k):
+        params = list(parameters)
+        name = ids.get(id(params[0]))
+        if name is not None:
+            pre[name] = np.concatenate([p.grad.detach().numpy().reshape(-1).astype(np.float64) for p in params])
+        return orig_clip(params, max_norm, *a, **k)
+
+    queue = []
+    torch.nn.utils.clip_grad_norm_ = clip
+    torch.distributions.Normal.rsample = lambda self, sample_shape=torch.Size(): self.loc + queue.pop(0) * self.scale
+    out = dict(kind=np.array([kind]), steps=g["steps"])
+    try:
+        for i, step in enumerate(g["steps"]):
+            tb = tuple(torch.from_numpy(g[f"step{i}_{k}"].astype(np.float64)) for k in ("s", "a", "r", "ns", "d"))
+            agent.buffer.sample = lambda bs, tb=tb: tb
+            queue[:] = [torch.from_numpy(g[f"step{i}_eps_next"].astype(np.float64)), torch.from_numpy(g[f"step{i}_eps_cur"].astype(np.float64))]
+            pre.clear()
+            info = agent.update(step=int(step))
+            out[f"step{i}_tuple"] = np.array([float(np.asarray(x)) for x in info], dtype=np.float64)
+            for name in opts:
+                out[f"step{i}_gradpre_{name}"] = pre[name]
+            for name, net in nets.items():                      # back to the fp32 run's state
+                set_flat(net, g[f"step{i}_param_{name}"])
+            with torch.no_grad():
+                agent.log_alpha.copy_(torch.from_numpy(g[f"step{i}_log_alpha"].astype(np.float64)))
+                agent.alpha = agent.log_alpha.exp()
+                H = bns[0].running_mean.numel()
+                for l, m in enumerate(bns):
+                    m.running_mean.copy_(torch.from_numpy(g[f"step{i}_bn_mean"][l * H:(l + 1) * H].astype(np.float64)))
+                    m.running_var.copy_(torch.from_numpy(g[f"step{i}_bn_var"][l * H:(l + 1) * H].astype(np.float64)))
+    finally:
+        torch.nn.utils.clip_grad_norm_, torch.distributions.Normal.rsample = orig_clip, orig_rs
+    np.savez_compressed(os.path.join(HERE, f"update_{tag}_fp64.npz"), **out)
+    d32 = max(float(np.max(np.abs(out[f"step{i}_tuple"] - g[f"step{i}_tuple"]) / np.maximum(np.abs(out[f"step{i}_tuple"]), 1e-6))) for i in range(len(g["steps"])))
+    print(f"update_{tag}_fp64 ok; the reference's own fp32 tuple error vs fp64: {d32:.2e}")
+
+
 if __name__ == "__main__":
     gen_select_action()
     gen_per_stochastic("SAC", "sac", "config_sac_slide.yaml")
     gen_per_stochastic("TQC", "tqc", "config_tqc_push.yaml")
+    gen_update_fp64("sac")
+    gen_update_fp64("tqc")

@@ -97,6 +97,16 @@ def _worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
+def _track(got, ref, rtol_rest, atol_rest, what=""):
+    """A DP run against its single-process / oracle twin: the FIRST step — same parameters on both sides, only the summation
+    order of the exchanged gradients and of the clip norm differs — is held to the north star (2e-5 covers the two sums);
+    later steps compare trajectories in which Adam has turned ~0 gradients' rounding noise into +-lr parameter moves
+    (SURVEY.md hard part 3; the reference itself moves 9.8e-4 between thread counts), hence the looser tracking bound."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert np.allclose(got[0], ref[0], rtol=2e-5, atol=2e-6), (what, "step 1", np.abs(got[0] - ref[0]).max())
+    assert np.allclose(got, ref, rtol=rtol_rest, atol=atol_rest), (what, np.abs(got - ref).max())
+
+
 @pytest.mark.parametrize("kind", ["DDPG", "TD3"])
 def test_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind):
     world = 2
@@ -161,7 +171,7 @@ def test_dp_cycle_schedule_tracks_single_process(gcrl, tmp_path, kind):
     _init_params(ag)
     ref = [[float(x) for x in t] for t in ag.update_many(1, 45)] + [[float(x) for x in t] for t in ag.update_many(46, 5)]
     ref = np.array([t + [0.0] * (9 - len(t)) for t in ref])
-    assert np.allclose(r0["tuples"], ref, rtol=2e-4, atol=2e-5)
+    _track(r0["tuples"], ref, 2e-4, 2e-5, kind)
     for k, v in (("actor", ag.actor), ("critic", ag.critics[0]), ("tactor", ag.target_actor)):
         assert float(np.max(np.abs(r0[k] - v.flat()))) < 5e-4, k
 
@@ -200,7 +210,7 @@ def test_two_ranks_local_batchnorm_matches_the_dp_oracle(gcrl, tmp_path, kind):
         want.append([[float(np.asarray(x)) for x in o] for o in outs])
     for i in range(world):
         w = np.array([t + [0.0] * (9 - len(t)) for t in (want[s][i] for s in range(3))])
-        assert np.allclose(r[i]["tuples"], w, rtol=2e-4, atol=2e-5), (kind, i, np.abs(r[i]["tuples"] - w).max())
+        _track(r[i]["tuples"], w, 2e-4, 2e-5, (kind, i))
         bns = [m for m in reps[i].actor.base_net if isinstance(m, torch.nn.BatchNorm1d)]
         # a Linear bias in front of a BatchNorm has an analytically zero gradient: Adam moves it by +-lr per step on
         # rounding noise, and the batch mean moves with it (0.1 * lr per step into the running mean)
@@ -268,7 +278,7 @@ def test_in_engine_rccl_exchange_world_size_one(gcrl, tmp_path, kind):
     ref = [[float(x) for x in t] for t in ag.update_many(1, 45)] + [[float(x) for x in ag.update(46)]]
     ref = np.array([t + [0.0] * (9 - len(t)) for t in ref])
     if kind == "DDPG":
-        assert np.allclose(r["tuples"], ref, rtol=2e-4, atol=2e-5), np.abs(r["tuples"] - ref).max()
+        _track(r["tuples"], ref, 2e-4, 2e-5, kind)
         assert float(np.max(np.abs(r["actor"] - ag.actor.flat()))) < 5e-4
     else:   # SAC draws its exploration noise from the device counter hash: same counters, same draws
-        assert np.allclose(r["tuples"][:5], ref[:5], rtol=5e-4, atol=5e-5), np.abs(r["tuples"][:5] - ref[:5]).max()
+        _track(r["tuples"][:5], ref[:5], 5e-4, 5e-5, kind)

@@ -330,11 +330,14 @@ def test_update_matches_reference(gcrl, tag, use_graph):
     ag, views = make_agent(gcrl, g, use_graph)
     kind = str(g["kind"][0])
     cfg = hparams_from_golden(g)
-    # SAC/TQC: the reference's log(1 - tanh(x)^2 + 1e-8) amplifies a 1-ulp tanh difference by
-    # 2|t|/(1-t^2) (>1e3 at |x|>4); two correctly working <=1-ulp tanh implementations therefore
-    # disagree beyond 1e-5, and the reference itself moves 9.4e-6 between 1 and 8 CPU threads
-    # (SURVEY.md §8c).  Deterministic agents are held to the north-star 1e-5.
-    rtol = 1e-5 if kind in ("DDPG", "TD3") else 5e-5
+    # Every agent is held to the north star's 1e-5 against the reference's fp32 run.  SAC / TQC quantities that miss it must
+    # pass THROUGH THE REFERENCE'S FP64 RUN of the same fixture (tests/golden/update_<tag>_fp64.npz, make_golden_act.py):
+    # |hip - ref64| <= max(3 |ref32 - ref64|, 1e-5 scale) — the criterion of the full-size fixtures (tests/fullsize.py).  The
+    # reference's log(1 - tanh(x)^2 + 1e-8) amplifies a 1-ulp tanh difference by 2|t|/(1-t^2) (> 1e3 at |x| > 4, where these
+    # fresh-Xavier fixtures sit): its own fp32 run is up to 2.7e-2 (SAC) / 6.7e-3 (TQC) away from its fp64 run on them.
+    rtol = 1e-5
+    g64 = load_golden(f"update_{tag}_fp64.npz") if kind in ("SAC", "TQC") else None
+    via64 = 0
     lr = max(cfg.actor_lr, cfg.critic_lr)
     bad = []
     worst = dict(tuple_rel=0.0, grad_rel_to_max=0.0)     # measured, written to gpurun_out/parity_small.json
@@ -354,14 +357,25 @@ def test_update_matches_reference(gcrl, tag, use_graph):
             if b != 0.0:
                 worst["tuple_rel"] = max(worst["tuple_rel"], abs(a - b) / abs(b))
             if abs(a - b) > 1e-6 + rtol * abs(b):
-                bad.append((f"step{i} tuple[{j}]", a, b))
+                b64 = float(g64[f"step{i}_tuple"][j]) if g64 is not None else None
+                if b64 is not None and abs(a - b64) <= 1e-6 + max(3.0 * abs(b - b64), rtol * abs(b64)):
+                    via64 += 1
+                else:
+                    bad.append((f"step{i} tuple[{j}]", a, b, b64))
         # pre-clip gradients (the engine keeps them unscaled; clipping is fused into the optimiser)
         for name, v in views.items():
             k = f"step{i}_gradpre_{name}"
             if k in g.files:
                 worst["grad_rel_to_max"] = max(worst["grad_rel_to_max"], float(np.max(np.abs(v.grad_flat() - g[k])) / np.max(np.abs(g[k]))))
             if k in g.files and not vec_close(v.grad_flat(), g[k], rtol=rtol):
-                bad.append((k, float(np.max(np.abs(v.grad_flat() - g[k]))), float(np.max(np.abs(g[k])))))
+                ok64 = False
+                if g64 is not None and k in g64.files:
+                    r64, r32, x = g64[k], g[k].astype(np.float64), v.grad_flat().astype(np.float64)
+                    ok64 = bool(np.all(np.abs(x - r64) <= 1e-7 + np.maximum(3.0 * np.abs(r32 - r64), rtol * np.max(np.abs(r64)))))
+                if ok64:
+                    via64 += 1
+                else:
+                    bad.append((k, float(np.max(np.abs(v.grad_flat() - g[k]))), float(np.max(np.abs(g[k])))))
             # parameters after the optimiser / Polyak step.  Adam's update is lr*m/(sqrt(v)+eps):
             # where a gradient is ~0, 1e-7 noise decides its sign and the parameter moves by up
             # to lr either way (SURVEY.md hard part 3; the reference itself differs by 9.8e-4
@@ -394,6 +408,7 @@ def test_update_matches_reference(gcrl, tag, use_graph):
             ag.actor._set("bn_running_mean", g[f"step{i}_bn_mean"])
             ag.actor._set("bn_running_var", g[f"step{i}_bn_var"])
             ag.actor._set("log_alpha", g[f"step{i}_log_alpha"])
+    worst["quantities_passed_through_the_fp64_run"] = via64
     _record_small(tag, use_graph, rtol, worst)
     assert not bad, bad[:10]
 
