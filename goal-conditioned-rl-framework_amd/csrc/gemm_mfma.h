@@ -63,6 +63,7 @@ struct GemmBatch {
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 // 16-byte fragment loads go through a buffer descriptor (raw_buffer_load_b128): a plain

@@ -1,58 +1,54 @@
 // gemm_tiled.h — LDS-tiled variant of the batched fp32-MFMA GEMM for throughput-sized problems
 // (more than 1024 tiles of 16x16: batch 2048 x hidden 512 and the like).
 //
-// A 256-thread workgroup owns a 64x64 output tile; its 4 waves own 32x32 each (2x2 MFMA tiles of
-// 16x16x4).  Per 32-wide k-step the two 64x32 operand tiles are fetched from global memory with
-// fully coalesced 16-byte loads (along k when the operand is k-contiguous, along the row index
-// otherwise — then transposed on the LDS write), held in registers for two k-steps while earlier
-// steps' MFMAs run, and stored to one of two LDS buffers as [row][k] with a 4-float pad (one barrier
-// per step).  Fragments come back as one ds_read_b128 per 16x16x16 chunk (same k-permutation as
-// gemm_mfma.h: element q of the read feeds MFMA q); the MFMAs accumulate the TRANSPOSED tile so the
-// epilogue moves 16 bytes per lane.
+// A 256-thread workgroup owns a 64x64 output tile; its 4 waves own 32x32 each: ONE v_mfma_f32_32x32x2_f32 accumulator.
+// Per 16-wide k-step the two 64x16 operand tiles are fetched from global memory with 16-byte loads (along k when the
+// operand is k-contiguous, along the row index otherwise — then transposed on the LDS write), held in registers for two
+// k-steps while earlier steps' MFMAs run, and stored to one of two LDS buffers (one barrier per step).  Fragments come
+// back as one ds_read_b128 per operand and 8 k (the k-permutation of gemm_mfma.h: element q of the read feeds MFMA q);
+// the MFMAs accumulate the TRANSPOSED tile so the epilogue moves 16 bytes per lane.
 //
-// Round-2 measurements (M=10240, N=K=512 = the 1280 tiles of TQC's 5-critic launches; the library's plain
-// fp32 GEMM on the same operands: 94-97 TFLOP/s; results bitwise equal to it):
-//   round 1 (k-step 64, per-step address arithmetic, branch per load, 2 barriers, 4-byte epilogue)   63 / 57 TFLOP/s (fwd / dX)
-//   branch-free fetch, offsets planned once, 2 register stages + 2 LDS buffers                      73 / 71
-//   + transposed accumulators, 16-byte epilogue                                                      78 / 72
-//   + k-step 32 (80 VGPRs, 36 KB LDS: 4 workgroups per CU instead of 2, all 5 tiles of a CU resident)  88 / 80
-//   (k-step 16: 86 / 89, TQC step equal, the quantile variant 3 % slower)
+// What round 3 found, in the order it was found (M = 10240, N = K = 512: the 1280 tiles of TQC's 5-critic launches; all
+// numbers by tools/gemm_micro.hip on one MI355X; round 2's kernel: 86 / 80 TFLOP/s forward / dX):
+//  * the 16x16x4 instruction SUSTAINS 98 / 134 TFLOP/s on this chip at 1 / 2+ waves per SIMD, 32x32x2 142 / 152
+//    (profiles/r03_mfma_issue_ceiling.txt) — yet swapping it in changed nothing, and neither did a conflict-free LDS image,
+//    an XCD-aware tile order, deeper or shallower prefetch, hand-interleaving every LDS / global instruction between the
+//    MFMAs, or removing the result stores: 59-62 us every time.  With ALL memory work and the barrier removed (MFMAs only)
+//    the launch still took 54 us;
+//  * wall-clock stamps per workgroup showed why: 256 of the 1280 workgroups started 36 us late.  A CU holds only FOUR
+//    workgroups of 32 768 B of LDS, although 5 x 32 KB is exactly its 160 KB and the runtime's occupancy query answers 5
+//    (tools/occupancy_probe.hip: 32 256 B -> 4 resident, 31 744 B -> 5).  So a launch of exactly five tiles per CU ran four
+//    of them, then the fifth alone — the same two rounds as round 2's 36 KB kernel;
+//  * hence this form: k-step 16 = 16 KB of LDS (the register stages keep the same two-k-step = 32-k prefetch distance), five
+//    workgroups resident, one round.
 #pragma once
 #include "gemm_mfma.h"
 
 namespace gcrl {
 
 constexpr int kTB = 64;        // block tile
-constexpr int kBK = 32;        // k-step: 32 MFMAs per wave between barriers; small enough for 4 workgroups per CU (see above)
-constexpr int kNV = kTB * kBK / 4 / 256;  // float4 per thread per operand tile
-constexpr int kNR = 4 * kNV;              // staging registers per operand
-// LDS image of an operand tile: [64 rows][32 k], NO padding; the 16-byte chunk c (= k >> 2) of row r lives at chunk position
-// c ^ (r & 7) of its row (XOR swizzle).  Conflict-free for everything that touches it: the fragment reads (one ds_read_b128
-// per lane: a b128 lane group of 16 lanes {li = 0-3, 12-15 | li = 4-11 of the next k-quarter} lands on 16 distinct 16-byte
-// bank groups), the k-contiguous stores (8 lanes = one row's 8 chunks) and the transposing stores of the row-contiguous
-// mode (tile_store: 32 lanes = 4 k x 8 rows with 8 distinct r & 7 -> 32 banks).  Round 2 padded rows to 36 floats instead:
-// 36 KB per workgroup = FOUR workgroups per CU, so a launch of 1280 tiles (TQC's five critics at batch 2048: exactly five
-// tiles per CU) ran four tiles per CU and then the fifth alone, one wave per SIMD; the transposing stores were 4-way bank
-// conflicts (profiles/r02_gemm_tiled_sq_counters.txt).  32 KB = five resident workgroups per CU.
+constexpr int kBK = 16;        // k-step: 8 MFMAs per wave between barriers
+constexpr int kNR = kTB * kBK / 256;      // staging registers per operand and stage: ONE float4 per thread
+// LDS image of an operand tile: [64 rows][16 k], no padding; the 16-byte chunk c (= k >> 2) of row r lives at chunk position
+// c ^ ((r >> 2) & 3) of its 64-byte row.  Conflict-free for everything that touches it: a fragment read (ds_read_b128: the 16
+// lanes of a lane group sit on 16 different rows at the same k-chunk -> row bits 0-1 pick the 64-byte quarter of the bank
+// space, row bits 2-3 the chunk), the k-contiguous stores (8 lanes = two rows' 4 chunks) and the transposing stores of the
+// row-contiguous mode (store_tile: 32 lanes = 4 k x 8 row quads -> 32 banks).
 constexpr int kLDT = kBK;
-constexpr int kRegStages = 1;   // register stages of the global -> LDS pipeline (2: round 2's form; see gemm_tiled_body)
-__device__ inline int lds_at(int row, int k) { return row * kLDT + ((((k >> 2) ^ (row & 7)) << 2) | (k & 3)); }
+__device__ inline int lds_at(int row, int k) { return row * kLDT + ((((k >> 2) ^ ((row >> 2) & 3)) << 2) | (k & 3)); }
 
 enum { FETCH_KC = 0, FETCH_RC = 1, FETCH_GEN = 2 };
 
-// Fetch a 64 x 64 operand tile (rows r0.., k k0..) into 16 registers per thread.
+// Fetch a 64 x 16 operand tile (rows r0.., k k0..) into 4 registers per thread.
 // element(row, k) = base[row*rs + k*cs]; rows >= R or k >= K read as 0; `ones_row`: that row := 1.
 //
-// The two vector modes are free of control flow and of per-step address arithmetic: a thread's four fragment offsets
-// (bytes, at k-step 0) are computed ONCE (`FetchPlan`; rows outside the operand get an offset past the descriptor's
-// extent, for which the hardware returns 0) and a k-step only adds a scalar offset to the buffer load.  Before, every
-// step re-derived rows, clamps and 64-bit products and branched around each load: ~1 300 instructions per k-step for
-// 64 MFMAs, issue-bound on bookkeeping (64 TFLOP/s at M=10240, N=K=512 against 94 for the library's plain fp32 GEMM;
-// a lone workgroup spent 3.1 us per k-step, 0.85 us of it in MFMAs).  The launcher grants FETCH_KC / FETCH_RC only
-// when whole 16-byte fragments are legal and K is a multiple of the k-step (no k tail); everything else is FETCH_GEN.
+// The two vector modes are free of control flow and of per-step address arithmetic: a thread's fragment offset (bytes, at
+// k-step 0) is computed ONCE (`FetchPlan`; rows outside the operand get an offset past the descriptor's extent, for which
+// the hardware returns 0) and a k-step only adds a scalar offset to the buffer load.  The launcher grants FETCH_KC /
+// FETCH_RC only when whole 16-byte fragments are legal and K is a multiple of the k-step; everything else is FETCH_GEN.
 constexpr int kOob = 0x7ffffff0;   // byte offset past any descriptor extent
 
-struct FetchPlan { int voff[kNV]; int step; bool ones[kNV][4]; bool any_one; };
+struct FetchPlan { int voff; int step; bool ones[4]; bool any_one; };
 
 // R: rows of the operand that exist in memory (for B with a synthesised ones row: N - 1)
 template <int MODE>
@@ -60,23 +56,19 @@ __device__ inline FetchPlan fetch_plan(long long rs, long long cs, int r0, int R
   FetchPlan pl;
   const int tid = threadIdx.x;
   pl.any_one = false;
+  if (MODE == FETCH_KC) {     // 4 lanes x 16 B = one row's 16 k; a wave covers 16 rows
+    const int r = r0 + (tid >> 2), k = (tid & 3) << 2;
+    pl.voff = r < R ? (int)(((long long)r * rs + k) * 4) : kOob;
 #pragma unroll
-  for (int p = 0; p < kNV; ++p) {
-    const int f = tid + 256 * p;
-    if (MODE == FETCH_KC) {
-      const int r = r0 + f / (kBK / 4), k = (f % (kBK / 4)) << 2;
-      pl.voff[p] = r < R ? (int)(((long long)r * rs + k) * 4) : kOob;
+    for (int q = 0; q < 4; ++q) { pl.ones[q] = r == ones_row; pl.any_one |= pl.ones[q]; }
+  } else {
+    // row-contiguous operand: a wave-load covers 4 k (lane & 3) x 16 row quads (lane >> 2) — per k a 256-byte run — and the
+    // workgroup's 4 waves the 4 k-quads; store_tile transposes through bank-conflict-free dword stores
+    const int l = tid & 63, wv = tid >> 6;
+    const int k = 4 * wv + (l & 3), r = r0 + ((l >> 2) << 2);
+    pl.voff = r < R ? (int)(((long long)k * cs + r) * 4) : kOob;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { pl.ones[p][q] = r == ones_row; pl.any_one |= pl.ones[p][q]; }
-    } else {
-      // row-contiguous operand: a wave-load covers 4 k (lane & 3) x 16 row quads (lane >> 2) — per k a 256-byte run —
-      // and the workgroup's 4 waves x kNV passes the 8 k-quads; tile_store transposes through bank-conflict-free dword stores
-      const int l = tid & 63, wv = tid >> 6;
-      const int k = 4 * (wv + 4 * p) + (l & 3), r = r0 + ((l >> 2) << 2);
-      pl.voff[p] = r < R ? (int)(((long long)k * cs + r) * 4) : kOob;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { pl.ones[p][q] = r + q == ones_row; pl.any_one |= pl.ones[p][q]; }
-    }
+    for (int q = 0; q < 4; ++q) { pl.ones[q] = r + q == ones_row; pl.any_one |= pl.ones[q]; }
   }
   pl.step = MODE == FETCH_KC ? kBK * 4 : (int)(cs * kBK * 4);
   return pl;
@@ -84,20 +76,15 @@ __device__ inline FetchPlan fetch_plan(long long rs, long long cs, int r0, int R
 
 // `in` false (a k-step past the end, issued to keep the pipeline free of branches): zeros
 template <int MODE>
-__device__ inline void tile_fetch(float (&reg)[kNR], const float* __restrict__ base, __amdgpu_buffer_rsrc_t rsrc, const FetchPlan& pl,
+__device__ inline void fetch_tile(float (&reg)[kNR], const float* __restrict__ base, __amdgpu_buffer_rsrc_t rsrc, const FetchPlan& pl,
                                   long long rs, long long cs, int r0, int R, int ks, int K, int ones_row, bool in) {
   if (MODE != FETCH_GEN) {
-    const int soff = in ? ks * pl.step : 0;
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, in ? pl.voff : kOob, in ? ks * pl.step : 0, 0);
 #pragma unroll
-    for (int p = 0; p < kNV; ++p) {
-      const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, in ? pl.voff[p] : kOob, soff, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) reg[4 * p + q] = __uint_as_float(v[q]);
-    }
+    for (int q = 0; q < 4; ++q) reg[q] = __uint_as_float(v[q]);
   } else {
-    // element-wise mode (first layers with K = 25, heads with K = 1..4, unaligned operands): still one buffer load per
-    // element and no branch — with `if (r < R && k < K) v = base[...]` each of a thread's 16 loads sat behind its own
-    // branch and a SINGLE k-step took 50 us (TQC's first-layer and head launches cost as much as the K = 512 ones)
+    // element-wise mode (first layers with K = 25, heads with K = 1..4, unaligned operands): one buffer load per element,
+    // no branch (with `if (r < R && k < K) v = base[...]` every load sat behind its own branch: 50 us per k-step in round 1)
     if (!in) {   // (uniform)
 #pragma unroll
       for (int p = 0; p < kNR; ++p) reg[p] = 0.f;
@@ -115,44 +102,31 @@ __device__ inline void tile_fetch(float (&reg)[kNR], const float* __restrict__ b
   }
 }
 
-// the synthesised ones row of a dW problem's B operand, applied when the registers go to LDS (not when they are
+// registers -> LDS.  The synthesised ones row of a dW problem's B operand is applied here (not when the registers are
 // requested: the select would wait for the loads one k-step early).  `in`: the tile lies inside K
 template <int MODE>
-__device__ inline void tile_ones(float (&reg)[kNR], const FetchPlan& pl, bool in) {
-  if (MODE == FETCH_GEN || !pl.any_one) return;
-#pragma unroll
-  for (int p = 0; p < kNV; ++p)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) reg[4 * p + q] = (pl.ones[p][q] && in) ? 1.f : reg[4 * p + q];
-}
-
-template <int MODE>
-__device__ inline void tile_store(const float (&reg)[kNR], float* __restrict__ lds) {
+__device__ inline void store_tile(float (&reg)[kNR], const FetchPlan& pl, float* __restrict__ lds, bool in) {
   const int tid = threadIdx.x;
+  if (MODE != FETCH_GEN && pl.any_one) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) reg[q] = (pl.ones[q] && in) ? 1.f : reg[q];
+  }
   if (MODE == FETCH_KC) {
-#pragma unroll
-    for (int p = 0; p < kNV; ++p) {
-      const int f = tid + 256 * p, row = f / (kBK / 4), c = f % (kBK / 4);
-      *reinterpret_cast<float4*>(lds + row * kLDT + ((c ^ (row & 7)) << 2)) =
-          make_float4(reg[4 * p], reg[4 * p + 1], reg[4 * p + 2], reg[4 * p + 3]);
-    }
+    const int row = tid >> 2, c = tid & 3;
+    *reinterpret_cast<float4*>(lds + row * kLDT + ((c ^ ((row >> 2) & 3)) << 2)) = make_float4(reg[0], reg[1], reg[2], reg[3]);
   } else if (MODE == FETCH_RC) {
-    // a thread holds rows r..r+3 at ONE k (fetch_plan).  Store instruction t writes row r + ((t + rot) & 3), rot = (lane >> 3) & 3:
-    // within 32 lanes (4 k x 8 row quads) the rows then show all 8 values of r & 7 -> 8 swizzled chunks x 4 k = 32 banks.
-    const int l = tid & 63, wv = tid >> 6, kq = l & 3, rq = l >> 2, rot = (rq >> 1) & 3;
+    // a thread holds rows r..r+3 at ONE k (fetch_plan).  Store instruction t writes row r + ((t + rot) & 3), rot = (lane >> 4) & 3:
+    // within 32 lanes (4 k x 8 row quads) the two row quads that share a swizzled chunk then differ in row bit 0 -> 32 banks.
+    const int l = tid & 63, wv = tid >> 6, kq = l & 3, rq = l >> 2, rot = (rq >> 2) & 3;
+    // rotate the four row values left by rot (two conditional-swap stages) so that instruction t finds its value in slot t
+    const float x0 = reg[0], x1 = reg[1], x2 = reg[2], x3 = reg[3];
+    const bool b0 = rot & 1, b1 = rot & 2;
+    const float y0 = b0 ? x1 : x0, y1 = b0 ? x2 : x1, y2 = b0 ? x3 : x2, y3 = b0 ? x0 : x3;
+    const float z[4] = {b1 ? y2 : y0, b1 ? y3 : y1, b1 ? y0 : y2, b1 ? y1 : y3};
 #pragma unroll
-    for (int p = 0; p < kNV; ++p) {
-      // rotate the four row values left by rot (two conditional-swap stages) so that instruction t finds its value in slot t
-      float x0 = reg[4 * p], x1 = reg[4 * p + 1], x2 = reg[4 * p + 2], x3 = reg[4 * p + 3];
-      const bool b0 = rot & 1, b1 = rot & 2;
-      float y0 = b0 ? x1 : x0, y1 = b0 ? x2 : x1, y2 = b0 ? x3 : x2, y3 = b0 ? x0 : x3;
-      const float z[4] = {b1 ? y2 : y0, b1 ? y3 : y1, b1 ? y0 : y2, b1 ? y1 : y3};
-      const int c = wv + 4 * p;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = (rq << 2) + ((t + rot) & 3);
-        lds[row * kLDT + (((c ^ (row & 7)) << 2) | kq)] = z[t];
-      }
+    for (int t = 0; t < 4; ++t) {
+      const int row = (rq << 2) + ((t + rot) & 3);
+      lds[row * kLDT + (((wv ^ (rq & 3)) << 2) | kq)] = z[t];       // (row >> 2) & 3 == rq & 3
     }
   } else {
 #pragma unroll
@@ -163,11 +137,29 @@ __device__ inline void tile_store(const float (&reg)[kNR], float* __restrict__ l
   }
 }
 
+// hooks for tools/gemm_micro.hip (timing experiments that drop one ingredient of the k-step, wall-clock stamps at a
+// workgroup's phase boundaries); never defined in the library
+#ifndef GCRL_ABL_READ
+#define GCRL_ABL_READ(p) (*reinterpret_cast<const float4*>(p))
+#endif
+#ifndef GCRL_ABL_STORE
+#define GCRL_ABL_STORE(x) x
+#endif
+#ifndef GCRL_ABL_FETCH
+#define GCRL_ABL_FETCH(x) x
+#endif
+#ifndef GCRL_ABL_BARRIER
+#define GCRL_ABL_BARRIER() __syncthreads()
+#endif
+#ifndef GCRL_STAMP
+#define GCRL_STAMP(i) do { } while (0)
+#endif
+
 template <int MA, int MB>
 __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, float* ldsB) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, lg = lane >> 4;
+  const int r32 = lane & 31, hk = lane >> 5;
   const int M = d.M, N = d.N, K = d.K;
   const int tn = t % d.tiles_n, tm = t / d.tiles_n;
   const int m0 = tm * kTB, n0 = tn * kTB;
@@ -177,144 +169,146 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   const float* __restrict__ Bm = d.B + sl * d.b_slot;
   const int ones_row = d.ones_col ? N - 1 : -1;
 
-  v4f acc[2][2];
+  v16f acc;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  GCRL_STAMP(0);
 
   // extents for the vector modes: whole rows of the operand (KC: R rows of rs floats; RC: K rows of cs floats)
   const int n_mem = N - (d.ones_col ? 1 : 0);   // B's rows that exist in memory (the ones column is synthesised)
   // (the last element's index + 1: exact for all three modes)
   const __amdgpu_buffer_rsrc_t rsa = wave_uniform_rsrc_n(A, (long long)(M - 1) * d.a_rs + (long long)(K - 1) * d.a_cs + 1);
   const __amdgpu_buffer_rsrc_t rsb = wave_uniform_rsrc_n(Bm, (long long)(n_mem - 1) * d.b_cs + (long long)(K - 1) * d.b_rs + 1);
-  // Software pipeline.  Operand tiles come from HBM / the infinity cache the first time they are touched (2-3 us
-  // under load), longer than one k-step's MFMAs (64 per wave, ~1.4 us): with a single register stage every step
-  // waited out the rest of that latency (a lone workgroup spent 3.1 us per k-step, 1.4 us of it computing).  Two
-  // register stages keep the fetch of tile ks+3 in flight across the MFMAs of steps ks+1 and ks+2, and two LDS
-  // buffers leave ONE barrier per step: while the waves read buffer ks&1, the tile of step ks+1 is written to the other.
   const int ksteps = (K + kBK - 1) / kBK;
-  float ra[kRegStages][kNR], rb[kRegStages][kNR];
   const FetchPlan pla = fetch_plan<MA>(d.a_rs, d.a_cs, m0, M, -1);
   const FetchPlan plb = fetch_plan<MB>(d.b_cs, d.b_rs, n0, n_mem, ones_row);
+  // fragment offsets of this lane (floats): row 32*wm + r32 of the A tile, row 32*wn + r32 of the B tile; a k-step's two
+  // 8-k groups: lane half hk reads chunk 2g + hk (4 consecutive k), MFMA q of the group takes element q of both reads, i.e.
+  // k = 8g + q from half 0 and 8g + 4 + q from half 1 — A and B permuted alike, so every product pairs the same k
+  const int rowA = 32 * wm + r32, rowB = 32 * wn + r32;
+  const int offA = rowA * kLDT, offB = rowB * kLDT;
+  const int swA = (rowA >> 2) & 3, swB = (rowB >> 2) & 3;
   auto fetch = [&](float (&xa)[kNR], float (&xb)[kNR], int ks) {
-    tile_fetch<MA>(xa, A, rsa, pla, d.a_rs, d.a_cs, m0, M, ks, K, -1, ks < ksteps);
-    tile_fetch<MB>(xb, Bm, rsb, plb, d.b_cs, d.b_rs, n0, N, ks, K, ones_row, ks < ksteps);
+    fetch_tile<MA>(xa, A, rsa, pla, d.a_rs, d.a_cs, m0, M, ks, K, -1, ks < ksteps);
+    fetch_tile<MB>(xb, Bm, rsb, plb, d.b_cs, d.b_rs, n0, N, ks, K, ones_row, ks < ksteps);
   };
-  auto store = [&](const float (&xa)[kNR], float (&xb)[kNR], int buf, int ks) {
-    tile_ones<MB>(xb, plb, ks < ksteps);
-    tile_store<MA>(xa, ldsA + buf * (kTB * kLDT));
-    tile_store<MB>(xb, ldsB + buf * (kTB * kLDT));
-  };
-  auto compute = [&](int buf, int ks) {
-    const float* la = ldsA + buf * (kTB * kLDT);
-    const float* lb = ldsB + buf * (kTB * kLDT);
-    const int nk = K - ks * kBK;   // k left from this step on: whole 16-k chunks of zeros are skipped (small-K problems)
-#pragma unroll
-    for (int kc = 0; kc < kBK / 16; ++kc) {
-      if (kc * 16 >= nk) break;
-      float4 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(la + (32 * wm + 16 * i + li) * kLDT + (((kc * 4 + lg) ^ (li & 7)) << 2));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(lb + (32 * wn + 16 * j + li) * kLDT + (((kc * 4 + lg) ^ (li & 7)) << 2));
-      // q outer: consecutive MFMAs go to the four different accumulators (an accumulator is
-      // reused every 128 cycles, above the 40-cycle dependent latency of 16x16x4 f32)
-      const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
-      const float bv[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j][q], av[i][q], acc[i][j], 0, 0, 0);   // roles swapped: see the epilogue
-    }
-  };
-  // one step: LDS[ks&1] holds tile ks; `nx` (registers) holds tile ks+1, requested two steps ago; the other register
-  // stage (tile ks+2) stays in flight.  After the MFMAs: tile ks+1 -> the other LDS buffer, then request tile ks+3
-  // into the registers just freed.  NOTHING here is conditional: with `if (ks + 3 < ksteps)` around the request the
-  // compiler could no longer count the loads in flight and waited for the newest stage before every LDS store
-  // (s_waitcnt vmcnt(0): the pipeline was one step deep again).  Steps past the end fetch zeros (tile_fetch `in`),
-  // so the step count is simply rounded up to even and the tail costs at most one k-step of MFMAs on zeros.
-  auto step = [&](float (&nxa)[kNR], float (&nxb)[kNR], int ks) {
-    compute(ks & 1, ks);
-    store(nxa, nxb, (ks + 1) & 1, ks + 1);
-    fetch(nxa, nxb, ks + 3);
-    __syncthreads();
-  };
-  if (kRegStages == 2) {
+  // (roles swapped in every MFMA — B fragment as the instruction's A: the accumulator holds the TRANSPOSED tile, see the epilogue)
+#define GCRL_MFMA(bv, av) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0)
+#define GCRL_SB() __builtin_amdgcn_sched_barrier(0)
+  if (MA != FETCH_GEN && MB != FETCH_GEN) {
+    // Vector modes (K a multiple of the k-step).  Software pipeline: LDS[ks & 1] holds tile ks; register stage (ks + 1) & 1
+    // holds tile ks+1, requested two k-steps ago; the other stage (tile ks+2) stays in flight.  During the MFMAs of step ks:
+    // tile ks+1 -> the other LDS buffer, then tile ks+3 is requested into the registers just freed.  Operand tiles come from
+    // HBM / the infinity cache the first time they are touched (2-3 us under load) — two k-steps of five co-resident waves'
+    // MFMAs.  NOTHING is conditional (with `if (ks + 3 < ksteps)` around a request the compiler could no longer count the
+    // loads in flight and waited for the newest stage before every LDS store): steps past the end fetch zeros, the step count
+    // is rounded up to even and the tail costs at most one k-step of MFMAs on zeros.
+    // The step itself is HAND-ORDERED: a wave issues in order — an MFMA occupies the matrix pipe for 64 cycles and the next
+    // one cannot issue before, but whatever stands BETWEEN two MFMAs issues while the first executes — so the LDS stores and
+    // the global requests are dealt one per MFMA gap instead of forming phases of their own; sched_barrier pins the order.
+    float ra[2][kNR], rb[2][kNR];
+    auto step = [&](int ks, float (&xa)[kNR], float (&xb)[kNR]) {
+      const int buf = ks & 1;
+      const float* la = ldsA + buf * (kTB * kLDT) + offA;
+      const float* lb = ldsB + buf * (kTB * kLDT) + offB;
+      float* na = ldsA + (buf ^ 1) * (kTB * kLDT);
+      float* nb = ldsB + (buf ^ 1) * (kTB * kLDT);
+      const bool in1 = ks + 1 < ksteps;
+      const float4 a0 = GCRL_ABL_READ(la + ((hk ^ swA) << 2)), b0 = GCRL_ABL_READ(lb + ((hk ^ swB) << 2));
+      const float4 a1 = GCRL_ABL_READ(la + (((2 + hk) ^ swA) << 2)), b1 = GCRL_ABL_READ(lb + (((2 + hk) ^ swB) << 2));
+      GCRL_SB();
+      GCRL_MFMA(b0.x, a0.x); GCRL_SB(); GCRL_ABL_STORE(store_tile<MA>(xa, pla, na, in1)); GCRL_SB();
+      GCRL_MFMA(b0.y, a0.y); GCRL_SB(); GCRL_ABL_STORE(store_tile<MB>(xb, plb, nb, in1)); GCRL_SB();
+      GCRL_MFMA(b0.z, a0.z); GCRL_SB(); GCRL_ABL_FETCH(fetch_tile<MA>(xa, A, rsa, pla, d.a_rs, d.a_cs, m0, M, ks + 3, K, -1, ks + 3 < ksteps)); GCRL_SB();
+      GCRL_MFMA(b0.w, a0.w); GCRL_SB(); GCRL_ABL_FETCH(fetch_tile<MB>(xb, Bm, rsb, plb, d.b_cs, d.b_rs, n0, N, ks + 3, K, ones_row, ks + 3 < ksteps)); GCRL_SB();
+      GCRL_MFMA(b1.x, a1.x); GCRL_MFMA(b1.y, a1.y); GCRL_MFMA(b1.z, a1.z); GCRL_MFMA(b1.w, a1.w);
+      GCRL_ABL_BARRIER();
+    };
     fetch(ra[0], rb[0], 0);
-    fetch(ra[kRegStages - 1], rb[kRegStages - 1], 1);
-    store(ra[0], rb[0], 0, 0);
+    fetch(ra[1], rb[1], 1);
+    store_tile<MA>(ra[0], pla, ldsA, true);
+    store_tile<MB>(rb[0], plb, ldsB, true);
     fetch(ra[0], rb[0], 2);
     __syncthreads();
+    GCRL_STAMP(1);
     const int kp = (ksteps + 1) & ~1;
     for (int ks = 0; ks < kp; ks += 2) {
-      step(ra[kRegStages - 1], rb[kRegStages - 1], ks);
-      step(ra[0], rb[0], ks + 1);
+      step(ks, ra[1], rb[1]);
+      step(ks + 1, ra[0], rb[0]);
     }
+    GCRL_STAMP(2);
   } else {
-    // ONE register stage: tile ks+1 is requested a whole k-step before it goes to LDS.  With five workgroups resident per
-    // CU a k-step lasts ~5 x 1024 MFMA cycles of wall time (the SIMD's matrix pipe is shared by five waves), longer than
-    // an HBM round trip, and the 16 registers of the second stage are what kept the kernel at four waves per SIMD.
-    fetch(ra[0], rb[0], 0);
-    store(ra[0], rb[0], 0, 0);
-    fetch(ra[0], rb[0], 1);
+    // element-wise fetch (first layers with K = 25, heads, unaligned operands: a few k-steps at most): plain phases
+    float ra[kNR], rb[kNR];
+    fetch(ra, rb, 0);
+    store_tile<MA>(ra, pla, ldsA, true);
+    store_tile<MB>(rb, plb, ldsB, true);
+    fetch(ra, rb, 1);
     __syncthreads();
     for (int ks = 0; ks < ksteps; ++ks) {
-      compute(ks & 1, ks);
-      store(ra[0], rb[0], (ks + 1) & 1, ks + 1);
-      fetch(ra[0], rb[0], ks + 2);
+      const float* la = ldsA + (ks & 1) * (kTB * kLDT) + offA;
+      const float* lb = ldsB + (ks & 1) * (kTB * kLDT) + offB;
+      const int nk = K - ks * kBK;   // k left from this step on: a whole 8-k group of zeros is skipped (small-K problems)
+#pragma unroll
+      for (int g = 0; g < kBK / 8; ++g) {
+        if (g * 8 >= nk) break;
+        const float4 a = *reinterpret_cast<const float4*>(la + (((2 * g + hk) ^ swA) << 2));
+        const float4 b = *reinterpret_cast<const float4*>(lb + (((2 * g + hk) ^ swB) << 2));
+        GCRL_MFMA(b.x, a.x); GCRL_MFMA(b.y, a.y); GCRL_MFMA(b.z, a.z); GCRL_MFMA(b.w, a.w);
+      }
+      store_tile<MA>(ra, pla, ldsA + ((ks + 1) & 1) * (kTB * kLDT), ks + 1 < ksteps);
+      store_tile<MB>(rb, plb, ldsB + ((ks + 1) & 1) * (kTB * kLDT), ks + 1 < ksteps);
+      fetch(ra, rb, ks + 2);
       __syncthreads();
     }
   }
+#undef GCRL_MFMA
+#undef GCRL_SB
 
   const float* __restrict__ bias = d.bias;
   const float* __restrict__ H = d.H + sl * d.h_slot;
   float* __restrict__ C = d.C + sl * d.c_slot;
   const int epi = d.epi, mul = d.mul;
   // The MFMAs ran with the operand roles swapped (B fragment as the instruction's A): the accumulator tile is the
-  // transpose, i.e. register r of lane (li, lg) is C[m = li][n = 4*lg + r] — four CONSECUTIVE columns of one row per
-  // lane, so bias / saved activations / results move as one 16-byte access per lane and 16x16 tile (16 rows x 64 B
-  // per wave instruction) instead of four dwords each.
+  // transpose — lane (r32, hk) holds row m = r32 of C, registers 4g..4g+3 its columns n = 8g + 4*hk + 0..3: four CONSECUTIVE
+  // columns per register quad, so bias / saved activations / results move as one 16-byte access per lane and quad.
   float ss = 0.f;
   const bool vec_ok = (d.c_rs % 4 == 0) && (((unsigned long long)C & 15) == 0) && !d.ones_col &&
                       (mul == MUL_NONE || (d.h_rs % 4 == 0 && (((unsigned long long)H & 15) == 0))) &&
                       (!bias || (((unsigned long long)bias & 15) == 0));
+  const int m = m0 + 32 * wm + r32;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int g = 0; g < 4; ++g) {
+    const int nq = n0 + 32 * wn + 8 * g + 4 * hk;
+    if (m >= M || nq >= N) continue;
+    if (vec_ok && nq + 3 < N) {
+      v4f v = (v4f){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      if (bias) v += *(const v4f*)(bias + nq);
+      v4f h = (v4f){0.f, 0.f, 0.f, 0.f};
+      if (mul != MUL_NONE) h = *(const v4f*)(H + (long long)m * d.h_rs + nq);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = m0 + 32 * wm + 16 * i + li, nq = n0 + 32 * wn + 16 * j + 4 * lg;
-      if (m >= M || nq >= N) continue;
-      if (vec_ok && nq + 3 < N) {
-        v4f v = acc[i][j];
-        if (bias) v += *(const v4f*)(bias + nq);
-        v4f h = (v4f){0.f, 0.f, 0.f, 0.f};
-        if (mul != MUL_NONE) h = *(const v4f*)(H + (long long)m * d.h_rs + nq);
+      for (int r = 0; r < 4; ++r) {
+        v[r] = act_apply(v[r], epi);
+        if (mul != MUL_NONE) v[r] *= act_deriv(h[r], mul);
+        ss += v[r] * v[r];
+      }
+      *(v4f*)(C + (long long)m * d.c_rs + nq) = v;
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = act_apply(v[r], epi);
-          if (mul != MUL_NONE) v[r] *= act_deriv(h[r], mul);
-          ss += v[r] * v[r];
-        }
-        *(v4f*)(C + (long long)m * d.c_rs + nq) = v;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = nq + r;
-          if (n >= N) continue;
-          float v = acc[i][j][r];
-          if (bias) v += bias[n];
-          v = act_apply(v, epi);
-          if (mul != MUL_NONE) v *= act_deriv(H[(long long)m * d.h_rs + n], mul);
-          ss += v * v;
-          if (d.ones_col && n == N - 1) d.col_out[m] = v;
-          else C[(long long)m * d.c_rs + n] = v;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int n = nq + r;
+        if (n >= N) continue;
+        float v = acc[4 * g + r];
+        if (bias) v += bias[n];
+        v = act_apply(v, epi);
+        if (mul != MUL_NONE) v *= act_deriv(H[(long long)m * d.h_rs + n], mul);
+        ss += v * v;
+        if (d.ones_col && n == N - 1) d.col_out[m] = v;
+        else C[(long long)m * d.c_rs + n] = v;
       }
     }
+  }
+  GCRL_STAMP(3);
   if (d.sumsq_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
@@ -322,7 +316,7 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmBatch gb) {
+__global__ __launch_bounds__(256, 5) void gemm_tiled_kernel(GemmBatch gb) {   // five workgroups per CU: <= 96 registers, 16 KB of LDS
   __shared__ __attribute__((aligned(16))) float ldsA[2 * kTB * kLDT];   // two buffers each (gemm_tiled_body)
   __shared__ __attribute__((aligned(16))) float ldsB[2 * kTB * kLDT];
   const int tile = xcd_tile_of((int)blockIdx.x, (int)gridDim.x);   // an XCD owns whole tile rows: each A panel enters ONE L2 (gemm_mfma.h)
