@@ -122,6 +122,7 @@ struct gcrl_agent {
   // row-block DDPG path (rowchain.h): [in][out] weight copies of actor | target actor | critic 0 |
   // target critic 0, per-layer gradient buffers, TD targets
   bool rowchain = false, wt_dirty = true;
+  bool dw_batch_off = false;  // GCRL_NO_DW_BATCH=1: a large ensemble's dW problems stay with their layers' dX launches (A/B knob)
   bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
   bool split_k = false;       // TD3: critic phase as role-parallel launches (agent_rowchain.inc)
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
@@ -492,21 +493,32 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
     TRY(launch_td_loss(st, td));
   }
 
-  // critic backward, layer L..0: dW|db and dX of a layer share a launch
+  // critic backward, layer L..0: dW|db and dX of a layer share a launch — unless the ensemble is large enough for its
+  // dW problems to fill the chip on their own (TQC at B = 2048, H = 512: 5 critics x 2 hidden layers x 72 tiles of 64x64):
+  // then the dX chain runs first, every layer's gradient kept (rc_gC: one buffer per layer instead of the two ping-pong
+  // ones), and ALL dW|db problems follow in one batch on the LDS-tiled form.  A dW problem alone is a long reduction
+  // (K = batch) into a mid-sized output: it wants the k-split 16x16 form, which re-reads its operands from L2 for every
+  // 16x16 tile (4 flop per byte) and runs the 16x16x4 instruction — 13 such launches were 30 % of TQC's step.
+  const long long dw_tiles = (long long)((H + 63) / 64) * ((H + 1 + 63) / 64);
+  const bool dw_batch = !a->dw_batch_off && L >= 2 && B >= 1024 && B % 16 == 0 && (long long)C * (L - 1) * dw_tiles >= 512;
+  auto Gbuf = [&](int c, int l) -> float* {            // gradient w.r.t. the output of hidden layer l (l < L)
+    return dw_batch ? a->rc_gC + ((long long)c * L + l) * B * H : a->gC_at(c, (l + 1) & 1);
+  };
   Launches bw;
   for (int c = 0; c < C; ++c) {
     float* Gp = a->G_critic(c);
     const float* P = a->P_critic(c);
     for (int l = L; l >= 0; --l) {
       const size_t at = (size_t)(L - l);
-      const float* G = l == L ? a->dq + (long long)c * B * a->Q : a->gC_at(c, l & 1);
+      const float* G = l == L ? a->dq + (long long)c * B * a->Q : Gbuf(c, l);
       const long long ldg = l == L ? a->Q : H;
       GemmDesc dw = bwd_dw(G, ldg, l == 0 ? a->sa : a->hC_at(c, l - 1), l == 0 ? a->ldx : H, Gp, a->critic.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
       if (variant & V_FUSED_NORM) dw.sumsq_out = a->parts_c + (long long)c * a->nparts_c + a->part_off_c[l];
-      bw.add(at, dw);
+      if (dw_batch && dw.M >= 64 && dw.N >= 64) dw.shape_hint = 4;
+      bw.add(dw_batch ? (size_t)L + 1 : at, dw);
       if (l > 0)
-        bw.add(at, bwd_dx(G, ldg, P, a->critic.lin[l], 0, H, a->gC_at(c, (l - 1) & 1), H, B, MUL_DLEAKY, a->hC_at(c, l - 1), H));
+        bw.add(at, bwd_dx(G, ldg, P, a->critic.lin[l], 0, H, Gbuf(c, l - 1), H, B, MUL_DLEAKY, a->hC_at(c, l - 1), H));
     }
   }
   TRY(bw.run(st));
@@ -1051,6 +1063,7 @@ int build(gcrl_agent* a) {
     // TD3 once the batch fills the chip (cfg 3: 183.5 -> 178.4 us/step; below that the fused launch is the shorter chain)
     a->split_k = a->rowchain && c.kind == GCRL_AGENT_TD3 && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) >= 256 &&
                  !std::getenv("GCRL_NO_SPLIT_TD3");
+    a->dw_batch_off = std::getenv("GCRL_NO_DW_BATCH") != nullptr;
     a->bn_fused = std::getenv("GCRL_BN_FUSED") != nullptr;   // measured equal at cfg 5 (204.6 vs 203.6 us/step): off by default
     if (const char* e = std::getenv("GCRL_SPLIT_RG"))   // experiment knob: four digits, rows/4 per workgroup of the four launches
       for (int i = 0; i < 4 && e[i]; ++i) a->split_rg[i] = e[i] - '0';

@@ -55,6 +55,12 @@ struct GemmDesc {
   int a_vec, b_vec;  // 16-byte loads legal along k (filled by the launcher)
   int a_rvec, b_rvec;  // 16-byte loads legal along the row index (operand stored k-major)
   int tile0, tiles_n, ntiles;  // filled by the launcher
+  // 0: the tile form follows from the problem's shape (gemm_shape_of).  Otherwise the caller's choice (1..4) — for problems
+  // it ALWAYS launches in the same company (e.g. the dW problems of a whole critic ensemble in one launch: alone, a long
+  // reduction into a 512 x 513 output is 72 tiles of 64x64 and wants the k-split form; twenty of them fill the chip with
+  // LDS-tiled workgroups).  Still a function of the problem and the agent's configuration only, never of a launch's
+  // accidental composition: a problem's summation order does not change from step to step.
+  int shape_hint;
 };
 
 struct GemmBatch {

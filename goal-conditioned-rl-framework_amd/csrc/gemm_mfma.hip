@@ -99,7 +99,7 @@ int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape) {
     d.b_vec = (d.b_rs == 1 && d.b_cs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
     d.a_rvec = (d.a_rs == 1 && d.a_cs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
     d.b_rvec = (d.b_cs == 1 && d.b_rs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
-    shapes[i] = shape ? shape : shape_of(d);
+    shapes[i] = shape ? shape : (d.shape_hint ? d.shape_hint : shape_of(d));
     GCRL_CHECK_ARG(!d.bn_part || (shapes[i] == 1 && !d.ones_col && d.c_rs >= d.N), "launch_gemm_batch: bn_part needs the k-split 16x16 form");
   }
   for (int s = 1; s <= 4; ++s) {  // one launch per shape present (almost always exactly one)

@@ -273,15 +273,16 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   // transpose — lane (r32, hk) holds row m = r32 of C, registers 4g..4g+3 its columns n = 8g + 4*hk + 0..3: four CONSECUTIVE
   // columns per register quad, so bias / saved activations / results move as one 16-byte access per lane and quad.
   float ss = 0.f;
-  const bool vec_ok = (d.c_rs % 4 == 0) && (((unsigned long long)C & 15) == 0) && !d.ones_col &&
+  const bool vec_ok = (d.c_rs % 4 == 0) && (((unsigned long long)C & 15) == 0) &&
                       (mul == MUL_NONE || (d.h_rs % 4 == 0 && (((unsigned long long)H & 15) == 0))) &&
                       (!bias || (((unsigned long long)bias & 15) == 0));
+  const int n_vec = d.ones_col ? N - 1 : N;      // (a dW problem's last column is the bias gradient: col_out, element-wise)
   const int m = m0 + 32 * wm + r32;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int nq = n0 + 32 * wn + 8 * g + 4 * hk;
     if (m >= M || nq >= N) continue;
-    if (vec_ok && nq + 3 < N) {
+    if (vec_ok && nq + 3 < n_vec) {
       v4f v = (v4f){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
       if (bias) v += *(const v4f*)(bias + nq);
       v4f h = (v4f){0.f, 0.f, 0.f, 0.f};
