@@ -516,7 +516,7 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
       if (variant & V_FUSED_NORM) dw.sumsq_out = a->parts_c + (long long)c * a->nparts_c + a->part_off_c[l];
       if (dw_batch && dw.M >= 64 && dw.N >= 64) dw.shape_hint = 4;
-      bw.add(dw_batch ? (size_t)L + 1 : at, dw);
+      bw.add(!dw_batch ? at : (dw.shape_hint ? (size_t)L + 1 : (size_t)L + 2), dw);   // the big ones together, in ONE launch
       if (l > 0)
         bw.add(at, bwd_dx(G, ldg, P, a->critic.lin[l], 0, H, Gbuf(c, l - 1), H, B, MUL_DLEAKY, a->hC_at(c, l - 1), H));
     }

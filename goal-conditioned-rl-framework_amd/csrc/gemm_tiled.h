@@ -269,37 +269,66 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   const float* __restrict__ H = d.H + sl * d.h_slot;
   float* __restrict__ C = d.C + sl * d.c_slot;
   const int epi = d.epi, mul = d.mul;
-  // The MFMAs ran with the operand roles swapped (B fragment as the instruction's A): the accumulator tile is the
-  // transpose — lane (r32, hk) holds row m = r32 of C, registers 4g..4g+3 its columns n = 8g + 4*hk + 0..3: four CONSECUTIVE
-  // columns per register quad, so bias / saved activations / results move as one 16-byte access per lane and quad.
-  float ss = 0.f;
+  // Epilogue through LDS.  The MFMAs ran with the operand roles swapped (B fragment as the instruction's A): the accumulator
+  // tile is the transpose — lane (r32, hk) holds row m = r32 of C, registers 4g..4g+3 its columns n = 8g + 4*hk + 0..3.
+  // Stored straight from there a wave instruction writes 32 rows x 32 bytes (and reads the saved activations of a dX problem
+  // the same way): 21 MB of quarter-line requests at the end of every launch, 7 of a forward launch's 52 us by the
+  // workgroup stamps of tools/gemm_micro.hip.  Instead the raw tile goes to the (now free) LDS image [64][64] with the
+  // 16-byte quad q of row r at position q ^ (r & 15) (both the transposed writes — 8 lanes on 8 rows at one column — and the
+  // row reads are conflict-free), and after one barrier thread t finishes quad t & 15 of rows (t >> 4) + 16 i: bias, saved
+  // activations and results move as whole 256-byte row segments; the bias / activation loads are issued BEFORE the barrier.
+  float* tile = ldsA;                         // 2 x 64 x 16 floats of A + the same of B = 64 x 64 floats, contiguous (gemm_tiled_kernel)
   const bool vec_ok = (d.c_rs % 4 == 0) && (((unsigned long long)C & 15) == 0) &&
                       (mul == MUL_NONE || (d.h_rs % 4 == 0 && (((unsigned long long)H & 15) == 0))) &&
                       (!bias || (((unsigned long long)bias & 15) == 0));
   const int n_vec = d.ones_col ? N - 1 : N;      // (a dW problem's last column is the bias gradient: col_out, element-wise)
-  const int m = m0 + 32 * wm + r32;
+  const int eq = threadIdx.x & 15, er = threadIdx.x >> 4;
+  const int nq = n0 + 4 * eq;
+  const bool quad_vec = vec_ok && nq + 3 < n_vec;
+  v4f bv = (v4f){0.f, 0.f, 0.f, 0.f}, hv[4];
+  if (quad_vec) {
+    if (bias) bv = *(const v4f*)(bias + nq);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int nq = n0 + 32 * wn + 8 * g + 4 * hk;
+    for (int i = 0; i < 4; ++i) {
+      hv[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+      const int m = m0 + er + 16 * i;
+      if (mul != MUL_NONE && m < M) hv[i] = *(const v4f*)(H + (long long)m * d.h_rs + nq);
+    }
+  }
+  {
+    const int row = 32 * wm + r32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int q = 8 * wn + 2 * g + hk;
+      *reinterpret_cast<float4*>(tile + row * 64 + ((q ^ (row & 15)) << 2)) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    }
+  }
+  GCRL_STAMP(4);
+  __syncthreads();
+  GCRL_STAMP(5);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = er + 16 * i, m = m0 + row;
     if (m >= M || nq >= N) continue;
-    if (vec_ok && nq + 3 < n_vec) {
-      v4f v = (v4f){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-      if (bias) v += *(const v4f*)(bias + nq);
-      v4f h = (v4f){0.f, 0.f, 0.f, 0.f};
-      if (mul != MUL_NONE) h = *(const v4f*)(H + (long long)m * d.h_rs + nq);
+    const float4 t4 = *reinterpret_cast<const float4*>(tile + row * 64 + ((eq ^ (row & 15)) << 2));
+    if (quad_vec) {
+      v4f v = (v4f){t4.x, t4.y, t4.z, t4.w};
+      v += bv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = act_apply(v[r], epi);
-        if (mul != MUL_NONE) v[r] *= act_deriv(h[r], mul);
+        if (mul != MUL_NONE) v[r] *= act_deriv(hv[i][r], mul);
         ss += v[r] * v[r];
       }
       *(v4f*)(C + (long long)m * d.c_rs + nq) = v;
     } else {
+      const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nq + r;
         if (n >= N) continue;
-        float v = acc[4 * g + r];
+        float v = tv[r];
         if (bias) v += bias[n];
         v = act_apply(v, epi);
         if (mul != MUL_NONE) v *= act_deriv(H[(long long)m * d.h_rs + n], mul);
@@ -318,8 +347,9 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
 }
 
 __global__ __launch_bounds__(256, 5) void gemm_tiled_kernel(GemmBatch gb) {   // five workgroups per CU: <= 96 registers, 16 KB of LDS
-  __shared__ __attribute__((aligned(16))) float ldsA[2 * kTB * kLDT];   // two buffers each (gemm_tiled_body)
-  __shared__ __attribute__((aligned(16))) float ldsB[2 * kTB * kLDT];
+  __shared__ __attribute__((aligned(16))) float lds[4 * kTB * kLDT];   // A: two buffers, B: two buffers; the epilogue's 64 x 64 tile
+  float* ldsA = lds;
+  float* ldsB = lds + 2 * kTB * kLDT;
   const int tile = xcd_tile_of((int)blockIdx.x, (int)gridDim.x);   // an XCD owns whole tile rows: each A panel enters ONE L2 (gemm_mfma.h)
   int pi = 0;
 #pragma unroll

@@ -24,21 +24,19 @@
 #define GCRL_ABL_BARRIER() do { } while (0)
 #endif
 #ifdef STAMPS
-__device__ unsigned long long g_stamps[4 * 8192];
-#define GCRL_STAMP(i) do { if (threadIdx.x == 0) g_stamps[4 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_stamps[8 * 8192];
+#define GCRL_STAMP(i) do { if (threadIdx.x == 0) g_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #endif
 #include "gemm_tiled.h"
 
 // the two hot instantiations alone (smaller code objects to read: hipcc -S --cuda-device-only)
 __global__ __launch_bounds__(256, 5) void k_fwd(gcrl::GemmBatch gb) {
-  __shared__ __attribute__((aligned(16))) float ldsA[2 * gcrl::kTB * gcrl::kLDT];
-  __shared__ __attribute__((aligned(16))) float ldsB[2 * gcrl::kTB * gcrl::kLDT];
-  gcrl::gemm_tiled_body<gcrl::FETCH_KC, gcrl::FETCH_KC>(gb.d[0], gcrl::xcd_tile_of((int)blockIdx.x, (int)gridDim.x), ldsA, ldsB);
+  __shared__ __attribute__((aligned(16))) float lds[4 * gcrl::kTB * gcrl::kLDT];
+  gcrl::gemm_tiled_body<gcrl::FETCH_KC, gcrl::FETCH_KC>(gb.d[0], gcrl::xcd_tile_of((int)blockIdx.x, (int)gridDim.x), lds, lds + 2 * gcrl::kTB * gcrl::kLDT);
 }
 __global__ __launch_bounds__(256, 5) void k_dx(gcrl::GemmBatch gb) {
-  __shared__ __attribute__((aligned(16))) float ldsA[2 * gcrl::kTB * gcrl::kLDT];
-  __shared__ __attribute__((aligned(16))) float ldsB[2 * gcrl::kTB * gcrl::kLDT];
-  gcrl::gemm_tiled_body<gcrl::FETCH_KC, gcrl::FETCH_RC>(gb.d[0], gcrl::xcd_tile_of((int)blockIdx.x, (int)gridDim.x), ldsA, ldsB);
+  __shared__ __attribute__((aligned(16))) float lds[4 * gcrl::kTB * gcrl::kLDT];
+  gcrl::gemm_tiled_body<gcrl::FETCH_KC, gcrl::FETCH_RC>(gb.d[0], gcrl::xcd_tile_of((int)blockIdx.x, (int)gridDim.x), lds, lds + 2 * gcrl::kTB * gcrl::kLDT);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -109,14 +107,14 @@ int main(int argc, char** argv) {
 #ifdef STAMPS
   {   // one more launch, then the stamps: 100 MHz wall clock, relative to the earliest workgroup start
     launch(); CK(hipStreamSynchronize(st));
-    std::vector<unsigned long long> z(4 * (size_t)d.ntiles);
+    std::vector<unsigned long long> z(8 * (size_t)d.ntiles);
     CK(hipMemcpyFromSymbol(z.data(), HIP_SYMBOL(g_stamps), z.size() * 8));
     unsigned long long t0 = ~0ull;
-    for (int i = 0; i < d.ntiles; ++i) t0 = std::min(t0, z[4 * i]);
-    const char* nm[4] = {"workgroup start", "main loop begins", "main loop ends", "results stored"};
-    for (int k = 0; k < 4; ++k) {
+    for (int i = 0; i < d.ntiles; ++i) t0 = std::min(t0, z[8 * i]);
+    const char* nm[6] = {"workgroup start", "main loop begins", "main loop ends", "results stored", "tile in LDS", "epilogue barrier"};
+    for (int k : {0, 1, 2, 4, 5, 3}) {
       std::vector<double> v;
-      for (int i = 0; i < d.ntiles; ++i) v.push_back((z[4 * i + k] - t0) * 0.01);
+      for (int i = 0; i < d.ntiles; ++i) v.push_back((z[8 * i + k] - t0) * 0.01);
       std::sort(v.begin(), v.end());
       printf("  %-18s us after the first workgroup started: min %6.2f  p10 %6.2f  median %6.2f  p75 %6.2f  p80 %6.2f  p85 %6.2f  p90 %6.2f  max %6.2f\n", nm[k], v.front(), v[v.size() / 10], v[v.size() / 2], v[v.size() * 3 / 4], v[v.size() * 8 / 10], v[v.size() * 85 / 100], v[v.size() * 9 / 10], v.back());
       if (k == 0) { int late = 0; for (double x : v) late += x > 8.0; printf("  workgroups that started more than 8 us after the first: %d of %d\n", late, (int)v.size()); }
