@@ -564,13 +564,19 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     if ((variant & V_ADV) && !(variant & V_ACTOR)) { ad.cur = &a->ctrl()->cur_b; ad.advance = a->ctrl(); }   // last launch of this step
     TRY(launch_adam(st, ad));
   }
+  // q_value metric from the UPDATED critics (src/agent.py:1016-1019): a full forward of the ensemble on [s | a] that feeds
+  // nothing but a logged number.  On actor steps of the layer-per-launch schedule it rides in the launches of the stepped
+  // critics' forward on [s | pi(s)] below (same parameters, layer by layer: ten problems per launch instead of two chains
+  // of five — four launches and their ramps less per step)
+  Launches re;
+  const bool re_merged = kind == GCRL_AGENT_TQC && (variant & V_ACTOR) && !a->rowchain && 2 * C <= kMaxProb;
   if (kind == GCRL_AGENT_TQC) {
-    // q_value metric from the UPDATED critics (src/agent.py:1016-1019)
-    Launches re;
     for (int c = 0; c < C; ++c)
       chain_mlp(a, re, 0, a->critic, a->P_critic(c), a->sa, a->ldx, a->slot_x, hid_TC, c, a->qt + (long long)c * B * a->Q, a->Q, 0, EPI_NONE, B);
-    TRY(re.run(st));
-    TRY(launch_mean_metric(st, a->cur(), a->qt, C * B * a->Q, 1.0f, a->metrics_dev, MET_Q));
+    if (!re_merged) {
+      TRY(re.run(st));
+      TRY(launch_mean_metric(st, a->cur(), a->qt, C * B * a->Q, 1.0f, a->metrics_dev, MET_Q));
+    }
   }
   if (kind == GCRL_AGENT_DDPG && (variant & V_POLYAK_A)) {  // before the actor step (src/agent.py:1397-1401)
     TRY(launch_polyak(st, a->P_actor(), a->P_tactor(), a->actor.numel, a->cfg.tau));
@@ -606,7 +612,11 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
   Launches c2;
   for (int c = 0; c < (a->rowchain ? 0 : nac); ++c)
     chain_mlp(a, c2, 0, a->critic, a->P_critic(c), a->spa, a->ldx, a->slot_x, hid_C, c, a->q2 + (long long)c * B * a->Q, a->Q, 0, EPI_NONE, B);
+  if (re_merged)
+    for (size_t i = 0; i < re.steps.size(); ++i)
+      for (const GemmDesc& d : re.steps[i]) c2.add(i, d);
   TRY(c2.run(st));
+  if (re_merged) TRY(launch_mean_metric(st, a->cur(), a->qt, C * B * a->Q, 1.0f, a->metrics_dev, MET_Q));
   bool sel_deferred = false;
   ActorSelArgs as_d;
   AlphaArgs al_d;

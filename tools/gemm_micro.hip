@@ -88,10 +88,31 @@ int main(int argc, char** argv) {
   d.a_vec = 1; d.b_vec = !dx; d.a_rvec = 0; d.b_rvec = dx;
   if (arow0) d.a_rs = 0;
   d.tiles_n = (N + 63) / 64; d.ntiles = ((M + 63) / 64) * d.tiles_n; d.tile0 = 0;
+  // "dw": P problems dW|db = G^T [X | 1]  (M = out, N = in + 1, K = batch; both operands row-contiguous, synthesised ones column):
+  // argv: out in batch dw P    e.g. 512 512 2048 dw 10 = the hidden-layer dW problems of TQC's five critics in one launch
+  const bool dw = argc > 4 && !strcmp(argv[4], "dw");
+  int total_tiles = d.ntiles;
+  double flops = 2.0 * M * N * K;
+  if (dw) {
+    const int P = argc > 5 ? atoi(argv[5]) : 10, out = M, in = N, batch = K;
+    float *G, *X, *dW, *db;
+    CK(hipMalloc(&G, (size_t)batch * out * 4)); CK(hipMalloc(&X, (size_t)batch * in * 4));
+    CK(hipMalloc(&dW, (size_t)P * out * in * 4)); CK(hipMalloc(&db, (size_t)P * out * 4));
+    CK(hipMemcpy(G, h.data(), (size_t)batch * out * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X, h.data(), (size_t)batch * in * 4, hipMemcpyHostToDevice));
+    gb.n = P; total_tiles = 0;
+    for (int i = 0; i < P; ++i) {
+      gcrl::GemmDesc& q = gb.d[i]; memset(&q, 0, sizeof(q));
+      q.A = G; q.a_rs = 1; q.a_cs = out; q.B = X; q.b_rs = in; q.b_cs = 1; q.C = dW + (size_t)i * out * in; q.c_rs = in;
+      q.M = out; q.N = in + 1; q.K = batch; q.ones_col = 1; q.col_out = db + (size_t)i * out;
+      q.a_rvec = 1; q.b_rvec = 1;
+      q.tiles_n = (q.N + 63) / 64; q.ntiles = ((q.M + 63) / 64) * q.tiles_n; q.tile0 = total_tiles; total_tiles += q.ntiles;
+    }
+    flops = 2.0 * P * out * (in + 1) * batch;
+  }
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   auto launch = [&]() {
-    if (!direct) hipLaunchKernelGGL(gcrl::gemm_tiled_kernel, dim3(d.ntiles), dim3(256), 0, st, gb);
+    if (!direct) hipLaunchKernelGGL(gcrl::gemm_tiled_kernel, dim3(total_tiles), dim3(256), 0, st, gb);
     else if (dx) hipLaunchKernelGGL(k_dx, dim3(d.ntiles), dim3(256), 0, st, gb);
     else hipLaunchKernelGGL(k_fwd, dim3(d.ntiles), dim3(256), 0, st, gb);
   };
@@ -103,7 +124,7 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   const double us = ms * 1e3 / reps;
-  printf("%s%s M=%d N=%d K=%d: %.1f us  %.1f TFLOP/s\n", dx ? "dX " : "fwd", direct ? " (direct)" : "", M, N, K, us, 2.0 * M * N * K / us / 1e6);
+  printf("%s%s M=%d N=%d K=%d (%d tiles): %.1f us  %.1f TFLOP/s\n", dw ? "dW " : (dx ? "dX " : "fwd"), direct ? " (direct)" : "", M, N, K, total_tiles, us, flops / us / 1e6);
 #ifdef STAMPS
   {   // one more launch, then the stamps: 100 MHz wall clock, relative to the earliest workgroup start
     launch(); CK(hipStreamSynchronize(st));
