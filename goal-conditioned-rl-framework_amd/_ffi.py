@@ -67,6 +67,7 @@ _vp, _i32, _i64, _u32, _u64, _f32, _f64 = (C.c_void_p, C.c_int32, C.c_int64, C.c
 _cp = C.c_char_p
 
 # name -> (restype, argtypes): every symbol include/gcrl.h declares
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 REWARD_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p)
 
 PROTOTYPES = {
@@ -149,6 +150,7 @@ PROTOTYPES = {
     "gcrl_bn_relu_fwd_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_bn_relu_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_her_set_reward_callback": (C.c_int, [_vp, _vp, _vp]),
+    "gcrl_agent_dp_sync_bn": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "gcrl_hash_normal_fill": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, _vp, _vp]),
     "gcrl_event_create": (_vp, []),
     "gcrl_event_destroy": (None, [_vp]),

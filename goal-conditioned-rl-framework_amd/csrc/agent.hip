@@ -122,6 +122,11 @@ struct gcrl_agent {
   // row-block DDPG path (rowchain.h): [in][out] weight copies of actor | target actor | critic 0 |
   // target critic 0, per-layer gradient buffers, TD targets
   bool rowchain = false, wt_dirty = true;
+  BnSync bn_sync;             // data-parallel SyncBN (gcrl_agent_dp_sync_bn): world > 1 -> batch statistics over every rank's rows
+  gcrl_dp* bn_sync_dp = nullptr;
+  gcrl_exchange_fn bn_sync_fn = nullptr;
+  void* bn_sync_user = nullptr;
+  float* bn_sync_buf = nullptr;
   bool dw_batch_off = false;  // GCRL_NO_DW_BATCH=1: a large ensemble's dW problems stay with their layers' dX launches (A/B knob)
   bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
   bool split_k = false;       // TD3: critic phase as role-parallel launches (agent_rowchain.inc)
@@ -349,7 +354,7 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
       GemmDesc d = fwd(X, l == 0 ? a->ldx : H, P, net.lin[l], f[i].z, H, B, EPI_NONE);
       if (l == 0 && f[i].x_slot) { d.slot = a->slot_ptr(); d.a_slot = f[i].x_slot; }
       // BatchNorm statistics out of this GEMM's epilogue when its form allows (16-row partials, at most 32 of them)
-      if (i == 0) fused_stats = a->bn_fused && gemm_shape_of(d) == 1 && (B + kBnFusedRows - 1) / kBnFusedRows <= kBnFusedMaxParts;
+      if (i == 0) fused_stats = a->bn_fused && a->bn_sync.world <= 1 && gemm_shape_of(d) == 1 && (B + kBnFusedRows - 1) / kBnFusedRows <= kBnFusedMaxParts;
       if (fused_stats) d.bn_part = f[i].bn_part;
       v.push_back(d);
     }
@@ -360,7 +365,7 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
       pb[i] = BnFwdProb{f[i].z, hbuf(f[i], l), f[i].save ? a->xhatA + (long long)l * BH : nullptr,
                         f[i].save ? a->invstdA + (long long)l * H : nullptr, f[i].bn_part};
     TRY(launch_bn_relu_fwd_multi(st, pb, nf, B, H, P + net.bn_g[l], P + net.bn_b[l], a->bn_rmean + (long long)l * H,
-                                 a->bn_rvar + (long long)l * H, fused_stats ? kBnFusedRows : 64));
+                                 a->bn_rvar + (long long)l * H, fused_stats ? kBnFusedRows : 64, a->bn_sync.world > 1 ? &a->bn_sync : nullptr));
   }
   {
     const int ldh = 2 * a->Apad;
@@ -424,7 +429,11 @@ int sac_actor_forwards(gcrl_agent* a, hipStream_t st, int variant, bool with_cur
 // from a native loop, where plain launches measured 1.5-4 % faster than replaying graphs (a graph
 // launch itself idles the GPU ~8 us).  use_graph = 2 forces graphs everywhere.
 // (SAC keeps ~35 BatchNorm / head launches per step around its two row-block launches: graphs stay on)
-bool graph_on(const gcrl_agent* a) { return a->cfg.use_graph >= 2 || (a->cfg.use_graph == 1 && (!a->rowchain || a->sac)); }
+// (SyncBN: the statistics exchanges sit between a step's launches — plain launches only)
+bool graph_on(const gcrl_agent* a) {
+  if (a->bn_sync.world > 1) return false;
+  return a->cfg.use_graph >= 2 || (a->cfg.use_graph == 1 && (!a->rowchain || a->sac));
+}
 
 #include "agent_rowchain.inc"
 
@@ -705,7 +714,8 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
       TRY(launch_bn_relu_bwd(st, dh, l == L - 1 ? a->dh2 : nullptr, a->xhatA + (long long)l * B * H,
                              a->invstdA + (long long)l * H, Pa + a->actor.bn_g[l], Pa + a->actor.bn_b[l], B, H, a->zA,
                              Ga + a->actor.bn_g[l], Ga + a->actor.bn_b[l], a->bn_part,
-                             (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * ((H + 63) / 64) : nullptr));
+                             (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * ((H + 63) / 64) : nullptr,
+                             a->bn_sync.world > 1 ? &a->bn_sync : nullptr));
       std::vector<GemmDesc> v;
       GemmDesc dw = bwd_dw(a->zA, H, l == 0 ? (a->rowchain ? a->sa : a->spa) : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
@@ -1211,6 +1221,7 @@ void gcrl_agent_destroy(gcrl_agent* a) {
   if (a->metrics_host) (void)hipHostFree(a->metrics_host);
   if (a->metrics_dev) (void)hipFree(a->metrics_dev);
   if (a->prof_clk) (void)hipFree(a->prof_clk);
+  if (a->bn_sync_buf) (void)hipFree(a->bn_sync_buf);
   if (a->act_pinned) (void)hipHostFree(a->act_pinned);
   if (a->oa_pinned) (void)hipHostFree(a->oa_pinned);
   if (a->oa_dev) (void)hipFree(a->oa_dev);
@@ -1523,6 +1534,37 @@ int gcrl_agent_dp_run_all(gcrl_agent* a, gcrl_dp* d, void* stream) {
     if (n > 0) TRY(gcrl_dp_allreduce_sum(d, ptr, n, stream ? stream : (void*)a->stream));
     if (!more) return GCRL_OK;
   }
+}
+
+// BnSync exchange: the library-owned communicator when one was given, else the caller's function
+static int bn_sync_exchange(float* dev, long long n, hipStream_t st, void* user) {
+  gcrl_agent* a = (gcrl_agent*)user;
+  if (a->bn_sync_dp) return gcrl_dp_allreduce_sum(a->bn_sync_dp, dev, (int64_t)n, (void*)st);
+  if (!a->bn_sync_fn) return gcrl::fail(GCRL_ERR_STATE, "SyncBN: no exchange function");
+  if (a->bn_sync_fn(dev, (int64_t)n, (void*)st, a->bn_sync_user) != 0) return gcrl::fail(GCRL_ERR_STATE, "SyncBN: the exchange function reported a failure");
+  return GCRL_OK;
+}
+
+int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_exchange_fn fn, void* user) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_dp_sync_bn: null handle");
+  GCRL_CHECK_ARG(world >= 1 && world <= 15 && rank >= 0 && rank < world, "gcrl_agent_dp_sync_bn: world must be 1..15 and 0 <= rank < world");
+  GCRL_CHECK_ARG(world == 1 || a->sac, "gcrl_agent_dp_sync_bn: only the BatchNorm actors (SAC / TQC) have statistics to synchronise");
+  GCRL_CHECK_ARG(world == 1 || dp || fn, "gcrl_agent_dp_sync_bn: a communicator or an exchange function is required");
+  GCRL_HIP(hipDeviceSynchronize());
+  for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);   // captured steps hold the old buffers and have no exchanges
+  a->graphs.clear();
+  a->bn_sync = BnSync{};
+  a->bn_sync_dp = nullptr; a->bn_sync_fn = nullptr; a->bn_sync_user = nullptr;
+  if (world == 1) return GCRL_OK;
+  // partial statistics of both co-scheduled forwards, every rank's slots, adjacent: ONE exchange per BatchNorm layer and pass
+  const long long n1 = 2LL * world * ((a->B + 63) / 64) * a->H;
+  if (!a->bn_sync_buf) TRY(bytes_alloc(&a->bn_sync_buf, 2 * n1));
+  a->bn_partN = a->bn_sync_buf;          // (problem 0 of sac_actor_forwards, then problem 1)
+  a->bn_part = a->bn_sync_buf + n1;      // (the old allocations stay owned by the handle's free list)
+  a->bn_sync.world = world; a->bn_sync.rank = rank;
+  a->bn_sync.exchange = bn_sync_exchange; a->bn_sync.user = a;
+  a->bn_sync_dp = dp; a->bn_sync_fn = fn; a->bn_sync_user = user;
+  return GCRL_OK;
 }
 
 int gcrl_agent_dp_phase(gcrl_agent* a, int i, int phase, void* stream) {

@@ -193,10 +193,22 @@ int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float
 // :514, so the two forwards run layer by layer in the same launches).  The running statistics take problem 0's batch
 // first, then problem 1's — the order of the reference's two forward calls.
 struct BnFwdProb { const float* z; float* h; float* xhat; float* invstd; float* scratch; };
+// Data-parallel SyncBN (new design: the reference is single-process): the batch statistics of BatchNorm1d are
+// those of the CONCATENATED batch of all ranks (rank r's rows = rows [r*B, (r+1)*B) of it), so that G ranks x B rows equal
+// 1 rank x G*B rows for the BatchNorm actors too.  Every rank writes its row-block partials into its slots of a
+// [world][...] array, zeros the other ranks' slots, `exchange` sums the array over the ranks in place (an all-gather spelt
+// as an all-reduce: exact, the other addends are zeros), and every rank merges ALL partials in the same fixed order — the
+// order a single process with the big batch uses.  scratch then holds 2 * world * ceil(B/64) * H floats per problem.
+struct BnSync {
+  int world = 1, rank = 0;
+  int (*exchange)(float* dev, long long n, hipStream_t st, void* user) = nullptr;
+  void* user = nullptr;
+};
 // rows_per_part: 64 = this launch computes the row-block partials itself (bn_stats launch); 16 = the GEMM that produced z
 // already left them in `scratch` (GemmDesc::bn_part), only the apply launch runs.  scratch: 2 * ceil(B/rows_per_part) * H floats
 int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, int B, int H, const float* gamma,
-                             const float* beta, float* running_mean, float* running_var, int rows_per_part = 64);
+                             const float* beta, float* running_mean, float* running_var, int rows_per_part = 64,
+                             const BnSync* sync = nullptr);
 constexpr int kBnFusedRows = 16;      // GEMM tile height
 constexpr int kBnFusedMaxParts = 32;  // what bn_relu_apply gathers through LDS
 // eval mode (running statistics): select_action path
@@ -206,7 +218,8 @@ int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const floa
 // backward of BN(train)+ReLU: dh -> dz, dgamma, dbeta
 int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* xhat, const float* invstd,
                        const float* gamma, const float* beta, int B, int H, float* dz, float* dgamma, float* dbeta,
-                       float* scratch, float* sumsq_out = nullptr);   // sumsq_out[ceil(H/64)]: sum of squares of dgamma | dbeta per column block
+                       float* scratch, float* sumsq_out = nullptr,    // sumsq_out[ceil(H/64)]: sum of squares of dgamma | dbeta per column block
+                       const BnSync* sync = nullptr);   // sync: dz from the sums over every rank's rows; dgamma | dbeta stay this rank's share
 
 // SACActorModel.sample (src/model.py:125-141): mean/log_std head outputs -> action + log-prob.
 struct TanhGaussArgs {

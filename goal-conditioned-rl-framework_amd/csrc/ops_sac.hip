@@ -99,14 +99,14 @@ __device__ inline void gather_store(const PartRegs& r, v4f (*sp)[kBnMaxPart][16]
 }
 
 constexpr int kBnSlabMax = 4;
-struct BnFwdPair { BnFwdProb p[2]; int n; int rpp; int slabs; };   // rpp: rows per partial (64: bn_stats_kernel, 16: GEMM epilogue)
+struct BnFwdPair { BnFwdProb p[2]; int n; int rpp; int slabs; int world, rank; };   // rpp: rows per partial (64: bn_stats_kernel, 16: GEMM epilogue); world / rank: BnSync
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(BnFwdPair pr, int B, int H) {
   __shared__ v4f red[kBnSlots][16];
   const float* __restrict__ z = pr.p[blockIdx.z].z;
-  const int nrb_ = (B + kBnRows - 1) / kBnRows;
+  const int nrb_ = (B + kBnRows - 1) / kBnRows, nrbT = nrb_ * pr.world;
   float* __restrict__ part_mean = pr.p[blockIdx.z].scratch;
-  float* __restrict__ part_m2 = part_mean + (long long)nrb_ * H;
+  float* __restrict__ part_m2 = part_mean + (long long)nrbT * H;
   const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cq;
   const int r0 = blockIdx.y * kBnRows, r1 = min(B, r0 + kBnRows);
@@ -127,8 +127,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnFwdPair pr, int B, int 
   for (int i = 0; i < NR; ++i) if (r0 + slot + kBnSlots * i < r1) { const v4f df = v[i] - mean; q += df * df; }
   const v4f m2 = slot_sum(q, red, cq, slot);
   if (ok && slot == 0) {
-    *(v4f*)(part_mean + (long long)blockIdx.y * H + col) = mean;
-    *(v4f*)(part_m2 + (long long)blockIdx.y * H + col) = m2;
+    *(v4f*)(part_mean + (long long)(pr.rank * nrb_ + blockIdx.y) * H + col) = mean;
+    *(v4f*)(part_m2 + (long long)(pr.rank * nrb_ + blockIdx.y) * H + col) = m2;
+  }
+  if (ok && pr.world > 1 && slot > 0 && slot <= pr.world) {   // BnSync: the other ranks' slots of this row block := 0 (the exchange sums)
+    const int g = slot - 1;
+    if (g != pr.rank) {
+      *(v4f*)(part_mean + (long long)(g * nrb_ + blockIdx.y) * H + col) = zero4();
+      *(v4f*)(part_m2 + (long long)(g * nrb_ + blockIdx.y) * H + col) = zero4();
+    }
   }
 }
 
@@ -139,10 +146,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnFwdPair pr, int B, int 
 // sp: the block's LDS copy of the first min(nrb, kBnMaxPart) partials; gm / gq: the arrays in memory for the rest
 // (column quad `col`; only B > 2048).  The LDS loops are unrolled so that their reads are in flight together — as a
 // plain loop every iteration waited out its own LDS latency (17.5 us per launch with 32 partials, measured).
+// BnSync: nrb = world * nrb_local partials (rank-major), each over the rows of ITS rank's block; Bt = world * B rows in all.
 __device__ inline void bn_merge4(v4f (*sp)[kBnMaxPart][16], int cq, const float* gm, const float* gq, int H, int col, bool ok,
-                                 int nrb, int B, int rpp, v4f* mean_out, v4f* var_out) {
+                                 int nrb, int B, int rpp, v4f* mean_out, v4f* var_out, int world = 1) {
   const int nl = min(nrb, kBnMaxPart);
-  auto rows = [&](int rb) { return (float)(min(B, (rb + 1) * rpp) - rb * rpp); };
+  const int nrb_l = nrb / world;
+  const int Bl = B;
+  B *= world;
+  auto rows = [&](int rb) { const int r = rb % nrb_l; return (float)(min(Bl, (r + 1) * rpp) - r * rpp); };
   v4f s = zero4();
 #pragma unroll 8
   for (int rb = 0; rb < nl; ++rb) s += sp[0][rb][cq] * rows(rb);
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
   const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cq;
   const bool ok = col < H;
-  const int rpp = pr.rpp, nrb = (B + rpp - 1) / rpp;
+  const int rpp = pr.rpp, nrb = ((B + rpp - 1) / rpp) * pr.world;      // (BnSync: every rank's partials)
   const BnFwdProb me = pr.p[blockIdx.z];
   const float* __restrict__ z = me.z;
   const float* __restrict__ part_mean = me.scratch;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
   if (blockIdx.y == 0 && blockIdx.z == 0 && slot == 0 && ok) { rm0 = ld4(rmean + col); rv0 = ld4(rvar + col); }
   gather_store(prg, sp);
   v4f mean, var;
-  bn_merge4(sp, cq, part_mean, part_m2, H, col, ok, nrb, B, rpp, &mean, &var);   // biased variance: what normalises the batch
+  bn_merge4(sp, cq, part_mean, part_m2, H, col, ok, nrb, B, rpp, &mean, &var, pr.world);   // biased variance: what normalises the batch
   v4f invstd;
 #pragma unroll
   for (int q = 0; q < 4; ++q) invstd[q] = 1.0f / sqrtf(var[q] + kBnEps);
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
   if (ok && blockIdx.y == 0 && slot == 0 && me.invstd) *(v4f*)(me.invstd + col) = invstd;
   // running statistics: problem 0's batch, then problem 1's (two forward calls, in that order)
   if (blockIdx.y == 0 && blockIdx.z == 0) {
-    const float ub = B > 1 ? (float)B / (float)(B - 1) : 1.0f;
+    const int Bt = B * pr.world;
+    const float ub = Bt > 1 ? (float)Bt / (float)(Bt - 1) : 1.0f;
     v4f rm = (1.0f - kBnMomentum) * rm0 + kBnMomentum * mean;
     v4f rv = (1.0f - kBnMomentum) * rv0 + kBnMomentum * (var * ub);
     if (second) {
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
       const float* pm1 = pr.p[1].scratch;
       const float* pq1 = pm1 + (long long)nrb * H;
       v4f m1, v1;
-      bn_merge4(sp, cq, pm1, pq1, H, col, ok, nrb, B, rpp, &m1, &v1);
+      bn_merge4(sp, cq, pm1, pq1, H, col, ok, nrb, B, rpp, &m1, &v1, pr.world);
       rm = (1.0f - kBnMomentum) * rm + kBnMomentum * m1;
       rv = (1.0f - kBnMomentum) * rv + kBnMomentum * (v1 * ub);
     }
@@ -255,7 +267,7 @@ __device__ inline v4f bn_dy(v4f dh, v4f xh, v4f g, v4f bt) {
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dh, const float* __restrict__ dh2,
                                                            const float* __restrict__ xhat, const float* gamma, const float* beta,
                                                            int B, int H, float* __restrict__ part_dy,
-                                                           float* __restrict__ part_dyx) {
+                                                           float* __restrict__ part_dyx, int world, int rank) {
   __shared__ v4f red[kBnSlots][16];
   const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cq;
@@ -284,9 +296,14 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
   }
   const v4f sum_dy = slot_sum(s1, red, cq, slot);
   const v4f sum_dyx = slot_sum(s2, red, cq, slot);
+  const int nrb_ = gridDim.y;
   if (ok && slot == 0) {
-    *(v4f*)(part_dy + (long long)blockIdx.y * H + col) = sum_dy;
-    *(v4f*)(part_dyx + (long long)blockIdx.y * H + col) = sum_dyx;
+    *(v4f*)(part_dy + (long long)(rank * nrb_ + blockIdx.y) * H + col) = sum_dy;
+    *(v4f*)(part_dyx + (long long)(rank * nrb_ + blockIdx.y) * H + col) = sum_dyx;
+  }
+  if (ok && world > 1 && slot > 0 && slot <= world && slot - 1 != rank) {   // BnSync: the other ranks' slots := 0
+    *(v4f*)(part_dy + (long long)((slot - 1) * nrb_ + blockIdx.y) * H + col) = zero4();
+    *(v4f*)(part_dyx + (long long)((slot - 1) * nrb_ + blockIdx.y) * H + col) = zero4();
   }
 }
 
@@ -296,12 +313,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ part_dy,
                                                                 const float* __restrict__ part_dyx, int B, int H,
                                                                 float* __restrict__ dz, float* dgamma, float* dbeta,
-                                                                float* sumsq_out, int slabs) {
+                                                                float* sumsq_out, int slabs, int world, int rank) {
   __shared__ v4f sp[2][kBnMaxPart][16];
   const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cq;
   const bool ok = col < H;
-  const int nrb = (B + kBnRows - 1) / kBnRows;
+  const int nrb_l = (B + kBnRows - 1) / kBnRows, nrb = nrb_l * world;   // (BnSync: every rank's partials, rank-major)
   PartRegs prg;
   gather_request(prg, part_dy, part_dyx, nrb, H, blockIdx.x * 64);
   const v4f g = ok ? ld4(gamma + col) : zero4(), bt = ok ? ld4(beta + col) : zero4(), is = ok ? ld4(invstd + col) : zero4();
@@ -317,15 +334,23 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
   }
   gather_store(prg, sp);
   v4f sum_dy = zero4(), sum_dyx = zero4();
+  v4f own_dy = zero4(), own_dyx = zero4();      // this rank's share: what dgamma | dbeta hold (the gradient exchange sums the ranks')
   const int nl = min(nrb, kBnMaxPart);
 #pragma unroll 8
-  for (int rb = 0; rb < nl; ++rb) { sum_dy += sp[0][rb][cq]; sum_dyx += sp[1][rb][cq]; }
+  for (int rb = 0; rb < nl; ++rb) {
+    const v4f a1 = sp[0][rb][cq], a2 = sp[1][rb][cq];
+    sum_dy += a1; sum_dyx += a2;
+    if (rb / nrb_l == rank) { own_dy += a1; own_dyx += a2; }
+  }
   for (int rb = nl; rb < nrb; ++rb) {
-    sum_dy += ok ? ld4(part_dy + (long long)rb * H + col) : zero4();
-    sum_dyx += ok ? ld4(part_dyx + (long long)rb * H + col) : zero4();
+    const v4f a1 = ok ? ld4(part_dy + (long long)rb * H + col) : zero4(), a2 = ok ? ld4(part_dyx + (long long)rb * H + col) : zero4();
+    sum_dy += a1; sum_dyx += a2;
+    if (rb / nrb_l == rank) { own_dy += a1; own_dyx += a2; }
   }
   const v4f k = g * is;
-  const v4f m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B;
+  const float Bt = (float)B * (float)world;
+  const v4f m1 = sum_dy / Bt, m2 = sum_dyx / Bt;
+  if (world > 1) { sum_dy = own_dy; sum_dyx = own_dyx; }
 #pragma unroll
   for (int sl = 0; sl < kBnSlabMax; ++sl) {
     const int b = (blockIdx.y * slabs + sl) * kBnSlots + slot;
@@ -662,8 +687,11 @@ int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float
 }
 
 int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, int B, int H, const float* gamma,
-                             const float* beta, float* rmean, float* rvar, int rows_per_part) {
+                             const float* beta, float* rmean, float* rvar, int rows_per_part, const BnSync* sync) {
   GCRL_CHECK_ARG(nprob == 1 || nprob == 2, "bn_relu_fwd_multi: 1 or 2 problems");
+  const int world = (sync && sync->world > 1) ? sync->world : 1;
+  GCRL_CHECK_ARG(world == 1 || (rows_per_part == kBnRows && sync->exchange && world < kBnSlots && sync->rank >= 0 && sync->rank < world),
+                 "bn_relu_fwd_multi: SyncBN needs the bn_stats form, an exchange function and world <= %d", kBnSlots - 1);
   GCRL_CHECK_ARG(rows_per_part == kBnRows || (rows_per_part == kBnFusedRows && (B + kBnFusedRows - 1) / kBnFusedRows <= kBnMaxPart),
                  "bn_relu_fwd_multi: %d rows per partial at B=%d", rows_per_part, B);
   GCRL_CHECK_ARG(H % 4 == 0 && bn_aligned(gamma) && bn_aligned(beta) && bn_aligned(rmean) && bn_aligned(rvar) &&
@@ -675,9 +703,18 @@ int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, 
   pr.p[0] = probs[0];
   pr.p[1] = nprob > 1 ? probs[1] : probs[0];
   pr.rpp = rows_per_part;
+  pr.world = world; pr.rank = world > 1 ? sync->rank : 0;
   if (rows_per_part == kBnRows) {
     hipLaunchKernelGGL(bn_stats_kernel, dim3((H + 63) / 64, nrb, nprob), dim3(256), 0, st, pr, B, H);
     GCRL_HIP(hipGetLastError());
+  }
+  if (world > 1) {   // every rank's partials to every rank: one exchange when the problems' arrays are adjacent, else one each
+    const long long n1 = 2LL * world * nrb * H;
+    int rc = GCRL_OK;
+    if (nprob == 2 && probs[1].scratch == probs[0].scratch + n1) rc = sync->exchange(probs[0].scratch, 2 * n1, st, sync->user);
+    else if (nprob == 2 && probs[0].scratch == probs[1].scratch + n1) rc = sync->exchange(probs[1].scratch, 2 * n1, st, sync->user);
+    else for (int i = 0; i < nprob && !rc; ++i) rc = sync->exchange(probs[i].scratch, n1, st, sync->user);
+    if (rc) return rc;
   }
   pr.slabs = bn_slabs(B);
   hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots * pr.slabs - 1) / (kBnSlots * pr.slabs), nprob), dim3(256), 0,
@@ -697,19 +734,23 @@ int launch_bn_relu_eval(hipStream_t st, const float* z, int B, int H, const floa
 
 int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const float* xhat, const float* invstd,
                        const float* gamma, const float* beta, int B, int H, float* dz, float* dgamma, float* dbeta,
-                       float* scratch, float* sumsq_out) {
+                       float* scratch, float* sumsq_out, const BnSync* sync) {
+  const int world = (sync && sync->world > 1) ? sync->world : 1, rank = world > 1 ? sync->rank : 0;
+  GCRL_CHECK_ARG(world == 1 || (sync->exchange && world < kBnSlots && rank >= 0 && rank < world), "bn_relu_bwd: bad SyncBN arguments");
   GCRL_CHECK_ARG(H % 4 == 0 && bn_aligned(dh) && bn_aligned(dh2) && bn_aligned(xhat) && bn_aligned(invstd) && bn_aligned(gamma) &&
                      bn_aligned(beta) && bn_aligned(dz) && bn_aligned(dgamma) && bn_aligned(dbeta) && bn_aligned(scratch),
                  "bn_relu_bwd: H must be a multiple of 4 and every operand 16-byte aligned (H=%d)", H);
   const int nrb = (B + kBnRows - 1) / kBnRows;
   float* part_dy = scratch;
-  float* part_dyx = scratch + (long long)nrb * H;
+  float* part_dyx = scratch + (long long)world * nrb * H;
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((H + 63) / 64, nrb), dim3(256), 0, st, dh, dh2, xhat, gamma, beta, B, H, part_dy,
-                     part_dyx);
+                     part_dyx, world, rank);
   GCRL_HIP(hipGetLastError());
+  if (world > 1)
+    if (int rc = sync->exchange(scratch, 2LL * world * nrb * H, st, sync->user)) return rc;
   const int slabs = bn_slabs(B);
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots * slabs - 1) / (kBnSlots * slabs)), dim3(256), 0, st, dh,
-                     dh2, xhat, invstd, gamma, beta, part_dy, part_dyx, B, H, dz, dgamma, dbeta, sumsq_out, slabs);
+                     dh2, xhat, invstd, gamma, beta, part_dy, part_dyx, B, H, dz, dgamma, dbeta, sumsq_out, slabs, world, rank);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

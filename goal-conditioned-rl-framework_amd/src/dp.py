@@ -76,10 +76,13 @@ def device_view(ptr: int, numel: int) -> torch.Tensor:
 class DataParallelUpdater:
     """Drives agent.update(step) across ranks.  `agent` is a gcrl_amd agent on this rank's GPU."""
 
-    def __init__(self, agent, group=None, require_native: bool = False):
+    def __init__(self, agent, group=None, require_native: bool = False, sync_bn: bool = False):
         """`require_native`: over RCCL, raise on EVERY rank when the in-engine communicator cannot be created on any of them
         instead of falling back to per-exchange torch.distributed calls (bench.py: a broken native path must not hide
-        behind a slower one).  `self.exchange` says which path moves the gradient bytes: "engine-rccl" or "python"."""
+        behind a slower one).  `self.exchange` says which path moves the gradient bytes: "engine-rccl" or "python".
+        `sync_bn` (SACAgent / TQCAgent): BatchNorm statistics over the concatenated batch of all ranks (gcrl_agent_dp_sync_bn)
+        instead of each rank's own rows — G ranks x B rows then equal 1 rank x G*B rows for these agents too, at the price of
+        one small exchange per BatchNorm layer and pass on the step's critical path."""
         from .. import _ffi
         self._ffi = _ffi
         self.agent = agent
@@ -117,6 +120,22 @@ class DataParallelUpdater:
                 warnings.warn("gcrl_amd.dp: in-engine RCCL communicator unavailable (" + why +
                               "); exchanging gradients through torch.distributed instead")
         self.exchange = "engine-rccl" if self._native else "python"
+        self.sync_bn = bool(sync_bn) and agent._sac and self.world > 1
+        self._bn_cb = None
+        if self.sync_bn:
+            if self._native:
+                _ffi.check(lib.gcrl_agent_dp_sync_bn(agent._h, self.world, dist.get_rank(group), self._native, None, None))
+            else:
+                def _exchange(ptr, n, _stream, _user, self=self):
+                    try:
+                        dist.all_reduce(device_view(ptr, n), op=dist.ReduceOp.SUM, group=self.group)
+                        return 0
+                    except BaseException as e:   # noqa: BLE001  (must not propagate through the C frames)
+                        self._bn_exc = e
+                        return 1
+                self._bn_exc = None
+                self._bn_cb = _ffi.EXCHANGE_FN(_exchange)
+                _ffi.check(lib.gcrl_agent_dp_sync_bn(agent._h, self.world, dist.get_rank(group), None, C.cast(self._bn_cb, C.c_void_p), None))
         for phase in (0, 1):
             p, n = C.c_void_p(), C.c_int64()
             _ffi.check(lib.gcrl_agent_grad_ptr(agent._h, phase, C.byref(p), C.byref(n)))
@@ -125,6 +144,8 @@ class DataParallelUpdater:
         self.sync_parameters()
 
     def __del__(self):
+        if getattr(self, "sync_bn", False) and getattr(self.agent, "_h", None):
+            self._ffi.lib.gcrl_agent_dp_sync_bn(self.agent._h, 1, 0, None, None, None)   # the agent outlives the callback / communicator
         h, self._native = getattr(self, "_native", None), None
         if h:
             self._ffi.lib.gcrl_dp_destroy(h)

@@ -368,6 +368,16 @@ int gcrl_dp_broadcast(gcrl_dp* d, float* buf_dev, int64_t n, int root, void* str
  * engine's schedule and, after each, the all-reduce(sum) of the gradient block it names, all enqueued on `stream`
  * (what the caller of gcrl_agent_dp_run does one Python round trip at a time). */
 int gcrl_agent_dp_run_all(gcrl_agent* a, gcrl_dp* d, void* stream);
+/* SyncBN for the data-parallel BatchNorm actors (SACAgent / TQCAgent; new design — torch's SyncBatchNorm is what a DDP port
+ * of src/model.py:100-108 would use).  After this call the batch statistics of every BatchNorm1d forward and backward are
+ * those of the CONCATENATED batch of all `world` ranks (rank r's rows = rows [r*B, (r+1)*B) of it), so that G ranks x B rows
+ * equal 1 rank x G*B rows for these agents as well: per BatchNorm layer and pass the ranks' row-block partials
+ * (2 * world * ceil(B/64) * H floats) are summed over the ranks — by the library-owned communicator `dp` when given, else by
+ * `fn` (an in-place all-reduce(sum) of n device floats, stream-ordered on `stream` or synchronous; returns 0) — and merged in
+ * the order a single process with the big batch uses.  dgamma / dbeta stay each rank's share (the gradient exchange sums
+ * them).  Steps then run as plain launches (no hipGraph replay).  Call it before the first update; world = 1 switches it off. */
+typedef int (*gcrl_exchange_fn)(float* buf_dev, int64_t n, void* stream, void* user);
+int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_exchange_fn fn, void* user);
 /* device pointer of a named vector (parameters / grads), for zero-copy interop */
 int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr_dev_out, int64_t* numel_out);
 

@@ -67,7 +67,7 @@ def _init_params(agent):
     agent.update_target_network()
 
 
-def _worker(rank, world, port, kind, out_dir):
+def _worker(rank, world, port, kind, out_dir, sync_bn=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
@@ -77,7 +77,8 @@ def _worker(rank, world, port, kind, out_dir):
     ag = cls(S, A, _cfg(kind, B), None, nenvs=1, gradient_step=2, rng="engine", seed=100 + rank)
     if rank == 0:
         _init_params(ag)            # rank 1 keeps its own random init until the broadcast
-    dp = DataParallelUpdater(ag)    # broadcasts rank 0's parameters
+    dp = DataParallelUpdater(ag, sync_bn=sync_bn)    # broadcasts rank 0's parameters
+    assert dp.sync_bn == (sync_bn and kind in ("SAC", "TQC"))
     tuples = []
     for step, (full, eps) in enumerate(zip(_global_batches(world, 3), _global_eps(world, 3)), start=1):
         mine = tuple(torch.from_numpy(x[rank * B:(rank + 1) * B]).cuda() for x in full)
@@ -232,6 +233,48 @@ def test_two_ranks_local_batchnorm_matches_the_dp_oracle(gcrl, tmp_path, kind):
             err = err[keep]
         assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
     assert abs(float(r[0]["log_alpha"][0]) - float(o.log_alpha.detach())) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["SAC", "TQC"])
+def test_sync_batchnorm_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind):
+    """cfg 5's agent with SyncBN (gcrl_agent_dp_sync_bn): BatchNorm statistics of the concatenated batch, forward and
+    backward, so the SURVEY §8e invariant holds for the BatchNorm actors as well — 2 ranks x B rows == 1 rank x 2B rows:
+    replicas bitwise identical, parameters / running statistics / log_alpha those of ONE agent fed the concatenated batch,
+    gradient-norm entries of the tuples equal to its, mean-type entries equal to it on average over the ranks."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), True), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    for k in ("actor", "critic", "critic_last", "target", "log_alpha", "bn_mean", "bn_var"):
+        assert np.array_equal(r[0][k], r[1][k]), k          # global statistics: even the running ones are identical now
+    cls = dict(SAC=gcrl.SACAgent, TQC=gcrl.TQCAgent)[kind]
+    big = cls(S, A, _cfg(kind, world * B), None, nenvs=1, gradient_step=2, rng="engine", seed=1)
+    _init_params(big)
+    ref = []
+    for step, (full, eps) in enumerate(zip(_global_batches(world, 3), _global_eps(world, 3)), start=1):
+        t = big.update(step, batch=tuple(torch.from_numpy(x).cuda() for x in full), eps_next=torch.from_numpy(eps[0]), eps_cur=torch.from_numpy(eps[1]))
+        ref.append([float(x) for x in t])
+    ref = np.array(ref)
+    got = (r[0]["tuples"] + r[1]["tuples"]) / 2.0           # losses, td, q, alpha loss: means over a rank's rows
+    norms = [5, 6, 7]                                        # gradient norms: of the summed-and-scaled gradients, the same on every rank
+    assert np.array_equal(r[0]["tuples"][:, norms], r[1]["tuples"][:, norms])
+    got[:, norms] = r[0]["tuples"][:, norms]
+    assert np.allclose(got[0], ref[0], rtol=2e-5, atol=2e-6), ("step 1", np.abs(got[0] - ref[0]).max(), got[0], ref[0])
+    assert np.allclose(got, ref, rtol=2e-4, atol=2e-5), np.abs(got - ref).max()
+    assert np.allclose(r[0]["bn_mean"], big.actor._get("bn_running_mean"), rtol=1e-4, atol=1e-5)
+    assert np.allclose(r[0]["bn_var"], big.actor._get("bn_running_var"), rtol=1e-4, atol=1e-5)
+    assert abs(float(r[0]["log_alpha"][0]) - float(big.log_alpha.detach())) < 1e-5
+    keep, off = np.ones(big.actor.numel(), bool), 0       # Linear biases in front of a BatchNorm: zero gradient, +-lr on rounding noise
+    for key, shape in big.actor._param_layout():
+        n = int(np.prod(shape))
+        if key.startswith("base_net") and key.endswith("bias") and int(key.split(".")[1]) % 3 == 0:
+            keep[off:off + n] = False
+        off += n
+    for k, v in (("actor", big.actor.flat()), ("critic", big.critics[0].flat()), ("critic_last", big.critics[-1].flat()),
+                 ("target", big.target_critics[0].flat())):
+        err = np.abs(r[0][k].astype(np.float64) - v)
+        if k == "actor":
+            err = err[keep]
+        assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
 
 
 def _worker_rccl(rank, world, port, out_dir, kind):
