@@ -260,8 +260,10 @@ def test_sync_batchnorm_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind):
     got[:, norms] = r[0]["tuples"][:, norms]
     assert np.allclose(got[0], ref[0], rtol=2e-5, atol=2e-6), ("step 1", np.abs(got[0] - ref[0]).max(), got[0], ref[0])
     assert np.allclose(got, ref, rtol=2e-4, atol=2e-5), np.abs(got - ref).max()
-    assert np.allclose(r[0]["bn_mean"], big.actor._get("bn_running_mean"), rtol=1e-4, atol=1e-5)
-    assert np.allclose(r[0]["bn_var"], big.actor._get("bn_running_var"), rtol=1e-4, atol=1e-5)
+    # (a Linear bias in front of a BatchNorm has an analytically zero gradient: Adam moves it by +-lr per step on rounding
+    # noise, and the batch mean moves with it — 0.1 * lr per step into the running mean)
+    assert np.allclose(r[0]["bn_mean"], big.actor._get("bn_running_mean"), rtol=1e-3, atol=1e-3)
+    assert np.allclose(r[0]["bn_var"], big.actor._get("bn_running_var"), rtol=1e-3, atol=1e-4)
     assert abs(float(r[0]["log_alpha"][0]) - float(big.log_alpha.detach())) < 1e-5
     keep, off = np.ones(big.actor.numel(), bool), 0       # Linear biases in front of a BatchNorm: zero gradient, +-lr on rounding noise
     for key, shape in big.actor._param_layout():
