@@ -73,16 +73,39 @@ __global__ __launch_bounds__(64) void her_stage_batch_kernel(float* stage, const
 // normaliser's update from [obs ; next_obs] (RunningNormalizer.update, src/utils.py:75-93 — float32 batch moments in
 // numpy's order, float64 merge), then every env's transition written to its staging record with the observation columns
 // normalised by the UPDATED statistics (normalize, :95-97) and the goal columns raw.
+// With a goal normaliser (g_normalize, src/env.py:167-175, :222-223): its update from [dg ; next_dg ; ag ; next_ag] (the order of
+// the trainer's np.concatenate), then the goal columns of both states and the pushed achieved goal normalised by it.
 struct ProcArgs {
-  float* stage; const float* raw; const float* pay;   // raw = [obs n*D | next_obs n*D | dg n*G | next_dg n*G]
+  float* stage; const float* raw; const float* pay;   // raw = [obs n*D | next_obs n*D | dg n*G | next_dg n*G | ag n*G | next_ag n*G (goal normaliser only)]
   double* mean; double* var; double* count; double clip;   // null mean: no normaliser
-  int update, n, env0, flush_len, D, S, A, G, SA4, S4, RG;
+  double* gmean; double* gvar; double* gcount; double gclip;   // goal normaliser (null: goals stay raw)
+  int update, gupdate, n, env0, flush_len, D, S, A, G, SA4, S4, RG;
 };
 __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
-  __shared__ double s_mean[128], s_den[128];
+  __shared__ double s_mean[128], s_den[128], s_gmean[kMaxG], s_gden[kMaxG];
   const int n = p.n, D = p.D, G = p.G;
   const float* obs = p.raw; const float* nobs = obs + (size_t)n * D;
   const float* dg = nobs + (size_t)n * D; const float* ndg = dg + (size_t)n * G;
+  if (p.gmean && threadIdx.x >= 128 && threadIdx.x < 128 + G) {     // (a second group of threads: the two updates run side by side)
+    const int j = threadIdx.x - 128;
+    double m = p.gmean[j], v = p.gvar[j];
+    if (p.gupdate) {
+      const int rows = 4 * n;                   // [dg ; next_dg ; ag ; next_ag] lie in this order
+      float s = 0.f;
+      for (int i = 0; i < rows; ++i) s = __fadd_rn(s, dg[(size_t)i * G + j]);
+      const float bm = __fdiv_rn(s, (float)rows);
+      float q = 0.f;
+      for (int i = 0; i < rows; ++i) { const float d = __fsub_rn(dg[(size_t)i * G + j], bm); q = __fadd_rn(q, __fmul_rn(d, d)); }
+      const float bv = __fdiv_rn(q, (float)rows);
+      const double c0 = *p.gcount, cb = (double)rows, total = c0 + cb;
+      const double delta = (double)bm - m;
+      const double nm = m + delta * cb / total;
+      const double M2 = v * c0 + (double)__fmul_rn(bv, (float)rows) + delta * delta * c0 * cb / total;
+      m = nm; v = M2 / total;
+      p.gmean[j] = m; p.gvar[j] = v;
+    }
+    s_gmean[j] = m; s_gden[j] = sqrt(v) + 1e-8;
+  }
   if (p.mean) {
     for (int j = threadIdx.x; j < D; j += 256) {
       double m = p.mean[j], v = p.var[j];
@@ -106,6 +129,7 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
   }
   __syncthreads();
   if (p.mean && p.update && threadIdx.x == 0) *p.count = *p.count + (double)(2 * n);   // every column has read the old count
+  if (p.gmean && p.gupdate && threadIdx.x == 128) *p.gcount = *p.gcount + (double)(4 * n);
   const int o_ns = p.SA4, o_r = p.SA4 + p.S4, RW = o_r + 2, W = RW + G;
   for (int e = threadIdx.x; e < n * W; e += 256) {
     const int i = e / W, c = e - i * W;
@@ -119,14 +143,20 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
         const double z = ((double)x - s_mean[cc]) / s_den[cc];
         return (float)fmin(fmax(z, -p.clip), p.clip);
       }
-      return g[(size_t)i * G + (cc - D)];
+      const float x = g[(size_t)i * G + (cc - D)];
+      if (!p.gmean) return x;
+      const double z = ((double)x - s_gmean[cc - D]) / s_gden[cc - D];
+      return (float)fmin(fmax(z, -p.gclip), p.gclip);
     };
     if (c < p.S) v = state_col(obs, dg, c);
     else if (c < p.S + p.A) v = pw[3 + (c - p.S)];
     else if (c >= o_ns && c < o_ns + p.S) v = state_col(nobs, ndg, c - o_ns);
     else if (c == o_r) v = pw[1];
     else if (c == o_r + 1) v = pw[2];
-    else if (c >= RW) v = pw[3 + p.A + (c - RW)];
+    else if (c >= RW) {
+      v = pw[3 + p.A + (c - RW)];
+      if (p.gmean) v = (float)fmin(fmax(((double)v - s_gmean[c - RW]) / s_gden[c - RW], -p.gclip), p.gclip);   // normalize_goal(achieved_goal)
+    }
     p.stage[((long long)(p.env0 + i) * p.flush_len + t) * p.RG + c] = v;
   }
 }
@@ -941,8 +971,17 @@ int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_s
                               const float* next_obs_host, int obs_dim, const float* dg_host, const float* next_dg_host,
                               const float* next_ag_host, const float* actions_host, const float* rewards_host,
                               const uint8_t* dones_host, int env0, int n, void* stream) {
+  return gcrl_her_process_step_g(h, nz_obs, update_stats, nullptr, 0, obs_host, next_obs_host, obs_dim, dg_host, next_dg_host, nullptr,
+                                 next_ag_host, actions_host, rewards_host, dones_host, env0, n, stream);
+}
+
+int64_t gcrl_her_process_step_g(gcrl_her* h, gcrl_normalizer* nz_obs, int update_stats, gcrl_normalizer* nz_dg, int update_goal_stats,
+                                const float* obs_host, const float* next_obs_host, int obs_dim, const float* dg_host,
+                                const float* next_dg_host, const float* ag_host, const float* next_ag_host, const float* actions_host,
+                                const float* rewards_host, const uint8_t* dones_host, int env0, int n, void* stream) {
   GCRL_CHECK_ARG(h && obs_host && next_obs_host && dg_host && next_dg_host && next_ag_host && actions_host && rewards_host && dones_host,
                  "gcrl_her_process_step: null argument");
+  GCRL_CHECK_ARG(!nz_dg || (ag_host && gcrl_normalizer_size(nz_dg) == h->G), "gcrl_her_process_step: the goal normaliser needs the state's achieved goals and size goal_dim = %d", h->G);
   GCRL_CHECK_ARG(obs_dim >= 1 && obs_dim <= 128 && obs_dim + h->G == h->S, "gcrl_her_process_step: obs_dim %d + goal_dim %d != state_dim %d (obs_dim <= 128)", obs_dim, h->G, h->S);
   GCRL_CHECK_ARG(n >= 1 && env0 >= 0 && env0 + n <= h->cfg.nenvs, "gcrl_her_process_step: envs [%d, %d) outside [0, %d)", env0, env0 + n, h->cfg.nenvs);
   GCRL_CHECK_ARG(3 + h->A + h->G <= kPayW, "gcrl_her_process_step: action_dim + goal_dim too large for the payload");
@@ -950,11 +989,11 @@ int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_s
   hipStream_t st = h->pick(stream);
   const int D = obs_dim, G = h->G;
   // ONE upload: raw rows [obs(n*D) | next_obs(n*D) | dg(n*G) | next_dg(n*G)], then the per-env payload [t | r | d | a | ag]
-  const size_t raw = (size_t)n * (2 * D + 2 * G), need = raw + (size_t)n * kPayW;
+  const size_t raw = (size_t)n * (2 * D + (nz_dg ? 4 : 2) * G), need = raw + (size_t)n * kPayW;
   if (need > h->ps_floats) {
     GCRL_HIP(hipDeviceSynchronize());
     if (h->ps_dev) GCRL_HIP(hipFree(h->ps_dev));
-    const size_t want = std::max<size_t>(need, (size_t)h->cfg.nenvs * (2 * D + 2 * G + kPayW));
+    const size_t want = std::max<size_t>(need, (size_t)h->cfg.nenvs * (2 * D + 4 * G + kPayW));
     GCRL_HIP(hipMalloc((void**)&h->ps_dev, want * sizeof(float)));
     for (int i = 0; i < gcrl_her::kSlots; ++i) {
       if (h->ps_pinned[i]) GCRL_HIP(hipHostFree(h->ps_pinned[i]));
@@ -970,6 +1009,10 @@ int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_s
   std::memcpy(pin + (size_t)n * D, next_obs_host, sizeof(float) * n * D);
   std::memcpy(pin + (size_t)2 * n * D, dg_host, sizeof(float) * n * G);
   std::memcpy(pin + (size_t)2 * n * D + (size_t)n * G, next_dg_host, sizeof(float) * n * G);
+  if (nz_dg) {
+    std::memcpy(pin + (size_t)2 * n * D + (size_t)2 * n * G, ag_host, sizeof(float) * n * G);
+    std::memcpy(pin + (size_t)2 * n * D + (size_t)3 * n * G, next_ag_host, sizeof(float) * n * G);
+  }
   float* pay = pin + raw;
   for (int i = 0; i < n; ++i) {
     float* pw = pay + (size_t)i * kPayW;
@@ -981,6 +1024,8 @@ int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_s
     std::memcpy(pw + 3 + h->A, next_ag_host + (size_t)i * G, sizeof(float) * G);
     std::memcpy(&h->ag_mirror[((size_t)(env0 + i) * h->cfg.flush_len + t) * G], next_ag_host + (size_t)i * G, sizeof(float) * G);
   }
+  GCRL_CHECK_ARG(!(nz_dg && h->cfg.reward_kind == GCRL_REWARD_HOST), "gcrl_her_process_step: a goal normaliser together with a host-callback "
+                 "compute_reward is not supported by the fused entry (the callback would need the device-normalised goals): use the separate calls");
   GCRL_HIP(hipMemcpyAsync(h->ps_dev, pin, need * sizeof(float), hipMemcpyHostToDevice, st));
   GCRL_HIP(hipEventRecord(h->epi_ev[slot], st));
   ProcArgs pa;
@@ -990,6 +1035,12 @@ int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_s
   gcrl::normalizer_view(nz_obs, &mean, &var, &pa.count, &pa.clip);
   pa.mean = const_cast<double*>(mean); pa.var = const_cast<double*>(var);
   pa.update = (nz_obs && update_stats) ? 1 : 0;
+  if (nz_dg) {
+    const double *gm = nullptr, *gv = nullptr;
+    gcrl::normalizer_view(nz_dg, &gm, &gv, &pa.gcount, &pa.gclip);
+    pa.gmean = const_cast<double*>(gm); pa.gvar = const_cast<double*>(gv);
+    pa.gupdate = update_goal_stats ? 1 : 0;
+  }
   pa.n = n; pa.env0 = env0; pa.flush_len = h->cfg.flush_len; pa.D = D; pa.S = h->S; pa.A = h->A; pa.G = G;
   pa.SA4 = h->SA4; pa.S4 = h->S4; pa.RG = h->RG;
   hipLaunchKernelGGL(her_process_step_kernel, dim3(1), dim3(256), 0, st, pa);

@@ -384,11 +384,13 @@ class _EngineAgent:
         """The reference trainer's `_process_step` (src/env.py:163-201) for one vector-env step as ONE native call:
         normaliser update with [obs ; next_obs], both normalised state matrices built on the device from the updated
         statistics, all envs pushed (episode flush + HER relabel on the device when an env finishes).  `state` /
-        `next_obs_raw`: the env's dict observations; `dones` = `terminated` (src/env.py:372).  Falls back to the separate
-        calls when the observation normaliser is a host object or goals are normalised."""
-        nz = self._device_normalizers(obs_normalize, False)
+        `next_obs_raw`: the env's dict observations; `dones` = `terminated` (src/env.py:372).  With `g_normalize` the goal
+        normaliser is updated from [dg ; next_dg ; ag ; next_ag] and goals are normalised on the device too (src/env.py:167-175,
+        :222-223).  Falls back to the separate calls when a normaliser this step needs is a host object (or, with
+        g_normalize, when compute_reward runs through the host callback)."""
+        nz = self._device_normalizers(obs_normalize, g_normalize)
         buf = self.buffer
-        if nz is None or g_normalize:
+        if nz is None or (g_normalize and getattr(buf, "_reward_cfg", (0,))[0] == 2):
             self.update_normalizers([state["observation"], next_obs_raw["observation"]],
                                     [state["desired_goal"], next_obs_raw["desired_goal"], state["achieved_goal"],
                                      next_obs_raw["achieved_goal"]], obs_normalize, g_normalize)
@@ -403,9 +405,11 @@ class _EngineAgent:
         n = obs.shape[0]
         buf._ensure(obs.shape[1] + dg.shape[1], act.shape[1], nag.shape[1])
         buf.rng.pull()
-        rows = lib.gcrl_her_process_step(buf.handle, nz[0], 1 if obs_normalize else 0, obs.ctypes.data, nobs.ctypes.data, obs.shape[1],
-                                         dg.ctypes.data, ndg.ctypes.data, nag.ctypes.data, act.ctypes.data, rew.ctypes.data,
-                                         dn.ctypes.data, 0, n, _ffi.stream_handle())
+        ag0 = f32(state["achieved_goal"]) if g_normalize else None
+        rows = lib.gcrl_her_process_step_g(buf.handle, nz[0], 1 if obs_normalize else 0, nz[1], 1 if g_normalize else 0, obs.ctypes.data,
+                                           nobs.ctypes.data, obs.shape[1], dg.ctypes.data, ndg.ctypes.data,
+                                           ag0.ctypes.data if ag0 is not None else None, nag.ctypes.data, act.ctypes.data, rew.ctypes.data,
+                                           dn.ctypes.data, 0, n, _ffi.stream_handle())
         buf._check_rows(rows)
         buf.rng.push_back()
         return int(rows)

@@ -418,11 +418,17 @@ int gcrl_agent_observe_act(gcrl_agent* a, gcrl_normalizer* nz_obs, gcrl_normaliz
 /* _process_step for one vector-env step (src/env.py:163-201) from raw host rows: normaliser update with [obs ; next_obs]
  * (when update_stats), state = [normalize(obs) | dg], next_state = [normalize(next_obs) | next_dg] built on the device
  * from the UPDATED statistics, then the n pushes of gcrl_her_push_batch (achieved goal = next_ag, done = dones).
- * Goals are not normalised (g_normalize is false in every shipped config).  Returns ring rows appended. */
+ * Goals are not normalised here; gcrl_her_process_step_g adds the goal normaliser (g_normalize = True, src/env.py:167-175,
+ * :222-223): its update from [dg ; next_dg ; ag ; next_ag] (ag_host = the state's achieved goals, only for these statistics), then
+ * the goal columns of both states and the pushed achieved goal normalised by the UPDATED goal statistics.  Returns ring rows appended. */
 int64_t gcrl_her_process_step(gcrl_her* h, gcrl_normalizer* nz_obs, int update_stats, const float* obs_host,
                               const float* next_obs_host, int obs_dim, const float* dg_host, const float* next_dg_host,
                               const float* next_ag_host, const float* actions_host, const float* rewards_host,
                               const uint8_t* dones_host, int env0, int n, void* stream);
+int64_t gcrl_her_process_step_g(gcrl_her* h, gcrl_normalizer* nz_obs, int update_stats, gcrl_normalizer* nz_dg, int update_goal_stats,
+                                const float* obs_host, const float* next_obs_host, int obs_dim, const float* dg_host,
+                                const float* next_dg_host, const float* ag_host, const float* next_ag_host, const float* actions_host,
+                                const float* rewards_host, const uint8_t* dones_host, int env0, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stand-alone ops exposed for tests / reuse.

@@ -393,11 +393,13 @@ def test_device_normalizer_bit_exact_vs_reference(gcrl):
         assert np.allclose(other.mean, nz.mean, rtol=1e-6) and other.count == nz.count
 
 
+@pytest.mark.parametrize("g_norm", [False, True])
 @pytest.mark.parametrize("kind", ["DDPG", "TD3", "SAC"])
-def test_fused_acting_entries_equal_the_separate_calls(gcrl, kind):
+def test_fused_acting_entries_equal_the_separate_calls(gcrl, kind, g_norm):
     """observe_act / process_step (one native call each per vector-env step, device normalisers) against the reference's
     call sequence made of the separate calls with host normalisers: same actions (same host RNG draws), same normaliser
-    statistics, same ring rows bit for bit — including the episode flushes (HER relabel) inside the steps."""
+    statistics, same ring rows bit for bit — including the episode flushes (HER relabel) inside the steps.  g_norm: goals
+    normalised as well (g_normalize = True, src/env.py:167-175, :222-223: the goal normaliser sees [dg ; next_dg ; ag ; next_ag])."""
     import random
     from gcrl_amd.src.utils import DeviceRunningNormalizer, RunningNormalizer
     from oracle import her_oracle
@@ -425,10 +427,10 @@ def test_fused_acting_entries_equal_the_separate_calls(gcrl, kind):
         for ag, tag in ((host, "h"), (dev, "d")):
             random.seed(100 + step); np.random.seed(100 + step); torch.manual_seed(100 + step)
             if tag == "h":
-                x = ag.normalize_state_batch(state["observation"], state["desired_goal"], True, False)
+                x = ag.normalize_state_batch(state["observation"], state["desired_goal"], True, g_norm)
                 act_h = np.asarray(ag.select_action(x, eval_action=(step % 7 == 3)), np.float64)
             else:
-                act_d = np.asarray(ag.observe_act(state["observation"], state["desired_goal"], eval_action=(step % 7 == 3)), np.float64)
+                act_d = np.asarray(ag.observe_act(state["observation"], state["desired_goal"], eval_action=(step % 7 == 3), g_normalize=g_norm), np.float64)
         assert act_h.shape == act_d.shape == (n, A)
         assert np.allclose(act_h, act_d, rtol=0, atol=2e-6), (step, np.abs(act_h - act_d).max())
         nxt = obs_dict()
@@ -437,14 +439,17 @@ def test_fused_acting_entries_equal_the_separate_calls(gcrl, kind):
         actions = act_h.astype(np.float32)
         # host: the reference's _process_step made of the separate calls
         host.update_normalizers([state["observation"], nxt["observation"]],
-                                [state["desired_goal"], nxt["desired_goal"], state["achieved_goal"], nxt["achieved_goal"]], True, False)
-        s = torch.from_numpy(host.normalize_state_batch(state["observation"], state["desired_goal"], True, False)).float().cuda()
-        ns = torch.from_numpy(host.normalize_state_batch(nxt["observation"], nxt["desired_goal"], True, False)).float().cuda()
-        host.buffer.push_batch(s, actions, ns, rewards, dones, nxt["achieved_goal"])
-        dev.process_step(state, actions, nxt, rewards, dones)
+                                [state["desired_goal"], nxt["desired_goal"], state["achieved_goal"], nxt["achieved_goal"]], True, g_norm)
+        s = torch.from_numpy(host.normalize_state_batch(state["observation"], state["desired_goal"], True, g_norm)).float().cuda()
+        ns = torch.from_numpy(host.normalize_state_batch(nxt["observation"], nxt["desired_goal"], True, g_norm)).float().cuda()
+        host.buffer.push_batch(s, actions, ns, rewards, dones, host.normalize_goal(nxt["achieved_goal"], g_norm))
+        dev.process_step(state, actions, nxt, rewards, dones, g_normalize=g_norm)
         state = nxt
     hn, dn = host.buffer.obs_normalizer, dev.buffer.obs_normalizer
     assert np.array_equal(np.asarray(hn.mean), dn.mean) and np.array_equal(np.asarray(hn.var), dn.var) and hn.count == dn.count
+    hg, dgn = host.buffer.dg_normalizer, dev.buffer.dg_normalizer
+    assert np.array_equal(np.asarray(hg.mean), dgn.mean) and np.array_equal(np.asarray(hg.var), dgn.var) and hg.count == dgn.count
+    assert (hg.count > 1) == g_norm
     assert len(host.buffer) == len(dev.buffer) == min(1000, n * 246)      # 1000-row ring: wrapped
     for a, b in zip(host.buffer.rows(), dev.buffer.rows()):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
