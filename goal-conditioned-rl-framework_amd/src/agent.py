@@ -390,7 +390,10 @@ class _EngineAgent:
         g_normalize, when compute_reward runs through the host callback)."""
         nz = self._device_normalizers(obs_normalize, g_normalize)
         buf = self.buffer
-        if nz is None or (g_normalize and getattr(buf, "_reward_cfg", (0,))[0] == 2):
+        if nz is not None and g_normalize:   # (the ring — and with it the reward kind — exists from here on)
+            buf._ensure(np.shape(state["observation"])[1] + np.shape(state["desired_goal"])[1], np.shape(actions)[1],
+                        np.shape(next_obs_raw["achieved_goal"])[1])
+        if nz is None or (g_normalize and buf._reward_cfg[0] == 2):
             self.update_normalizers([state["observation"], next_obs_raw["observation"]],
                                     [state["desired_goal"], next_obs_raw["desired_goal"], state["achieved_goal"],
                                      next_obs_raw["achieved_goal"]], obs_normalize, g_normalize)
