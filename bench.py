@@ -317,6 +317,10 @@ def profiler_child(args, w):
     import shutil
     import subprocess
     import tempfile
+    # under a profiler already (rocprofv3 -- python3 bench.py ...: its preloaded tool library has initialised the GPU before this
+    # interpreter started) a child may not be exec'ed from here: report the event clock instead
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process itself runs under a profiler"
     tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(tool):
         return None, "rocprofv3 not found"

@@ -2,7 +2,7 @@
 # SQ counters of the default bench's kernels (one --pmc pass, kernel trace only), summary per kernel name
 set -e
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 400 --warmup 80 > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-profiler --steps 400 --warmup 80 > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq.log 2>&1
 cd $GRAFT_REPO_ROOT
 ls gpurun_out/pmc_sq
 python3 - <<'PY'

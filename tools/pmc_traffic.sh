@@ -18,7 +18,7 @@ pass() {  # name, counters...
   done
   if [ -z "$have" ]; then echo "pass $name: none of [$*] listed, skipped"; return 0; fi
   echo "pass $name:$have"
-  rocprofv3 --kernel-trace --pmc $have --output-format csv -d $out/$name -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --steps 200 --warmup 40 $BENCH_ARGS > $out/$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc $have --output-format csv -d $out/$name -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --no-profiler --steps 200 --warmup 40 $BENCH_ARGS > $out/$name.log 2>&1
 }
 BENCH_ARGS="$*"
 pass fetch FETCH_SIZE
