@@ -127,6 +127,12 @@ struct gcrl_agent {
   gcrl_exchange_fn bn_sync_fn = nullptr;
   void* bn_sync_user = nullptr;
   float* bn_sync_buf = nullptr;
+  // dW problems at batch >= 1024 on the LDS-tiled form with the reduction split over dw_split_[c|a] workgroups per tile
+  // (gemm_tiled.h; 1: off): partial tiles and tickets per net and layer
+  int dw_split_c = 1, dw_split_a = 1;
+  float *dw_part = nullptr, *dw_tick = nullptr;
+  std::vector<long long> dwp_off_c, dwp_off_a, dwt_off_c, dwt_off_a;
+  long long dwp_cstride = 0, dwt_cstride = 0, dwp_actor = 0, dwt_actor = 0;
   bool dw_batch_off = false;  // GCRL_NO_DW_BATCH=1: a large ensemble's dW problems stay with their layers' dX launches (A/B knob)
   bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
   bool split_k = false;       // TD3: critic phase as role-parallel launches (agent_rowchain.inc)
@@ -285,6 +291,17 @@ GemmDesc bwd_dw(const float* G, long long ldg, const float* X, long long ldx, fl
   d.M = ln.out; d.N = ln.in + 1; d.K = B;
   d.ones_col = 1; d.col_out = Gp + ln.b;
   return d;
+}
+
+// a dW problem of critic `c` (or the actor: c < 0), layer l, onto the split LDS-tiled form when the agent's configuration
+// asks for it (build(): a function of the shapes only — a problem's summation order never changes from step to step)
+void dw_split_form(gcrl_agent* a, GemmDesc& dw, int c, int l) {
+  const int S = c >= 0 ? a->dw_split_c : a->dw_split_a;
+  if (S <= 1) return;
+  dw.shape_hint = 4;
+  dw.ksplit = S;
+  dw.kpart = a->dw_part + (c >= 0 ? (long long)c * a->dwp_cstride + a->dwp_off_c[l] : a->dwp_actor + a->dwp_off_a[l]);
+  dw.kticket = reinterpret_cast<unsigned int*>(a->dw_tick + (c >= 0 ? (long long)c * a->dwt_cstride + a->dwt_off_c[l] : a->dwt_actor + a->dwt_off_a[l]));
 }
 
 struct Launches {  // problems grouped by launch index
@@ -524,7 +541,7 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
       GemmDesc dw = bwd_dw(G, ldg, l == 0 ? a->sa : a->hC_at(c, l - 1), l == 0 ? a->ldx : H, Gp, a->critic.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
       if (variant & V_FUSED_NORM) dw.sumsq_out = a->parts_c + (long long)c * a->nparts_c + a->part_off_c[l];
-      if (dw_batch && dw.M >= 64 && dw.N >= 64) dw.shape_hint = 4;
+      if (dw_batch && dw.M >= 64 && dw.N >= 64) { dw.shape_hint = 4; dw_split_form(a, dw, c, l); }
       bw.add(!dw_batch ? at : (dw.shape_hint ? (size_t)L + 1 : (size_t)L + 2), dw);   // the big ones together, in ONE launch
       if (l > 0)
         bw.add(at, bwd_dx(G, ldg, P, a->critic.lin[l], 0, H, Gbuf(c, l - 1), H, B, MUL_DLEAKY, a->hC_at(c, l - 1), H));
@@ -1087,6 +1104,52 @@ int build(gcrl_agent* a) {
     a->bn_fused = std::getenv("GCRL_BN_FUSED") != nullptr;   // measured equal at cfg 5 (204.6 vs 203.6 us/step): off by default
     if (const char* e = std::getenv("GCRL_SPLIT_RG"))   // experiment knob: four digits, rows/4 per workgroup of the four launches
       for (int i = 0; i < 4 && e[i]; ++i) a->split_rg[i] = e[i] - '0';
+  }
+  // split dW reductions (gemm_tiled.h): at batch >= 1024 a dW problem is a long reduction into few 64x64 tiles; S workgroups
+  // per tile, S = the power of two (<= 8) that brings the phase's launch to about five workgroups per CU (1280)
+  {
+    auto tiles_of = [](const Lin& ln) { return (long long)((ln.out + 63) / 64) * ((ln.in + 63) / 64); };
+    auto layout = [&](const NetSpec& net, int S, std::vector<long long>& po, std::vector<long long>& to, long long* pn, long long* tn) {
+      long long p = 0, t = 0;
+      po.clear(); to.clear();
+      for (const Lin& ln : net.lin) {
+        po.push_back(p); to.push_back(t);
+        p += tiles_of(ln) * S * kTiledPartStride;
+        t += align_up(tiles_of(ln) * kTicketStride, 64);
+      }
+      *pn = align_up(p, 64); *tn = t;
+    };
+    auto pick = [&](long long phase_tiles) {
+      int S = 1;
+      while (S < 8 && phase_tiles * (S * 2) <= 1280 && B / (16 * S * 2) >= 8) S *= 2;
+      return S;
+    };
+    const bool on = B >= 1024 && B % 32 == 0 && !std::getenv("GCRL_NO_DW_SPLIT");
+    // rc_add_dw (DDPG / TD3 on the row-block path: every dW problem of a phase in one launch): measured, not kept — TD3 cfg 3
+    // 179.0 vs 177.6 us/step, DDPG cfg 2 68.6 vs 61.5: the launch carries the first layer's and the head's problems too
+    // (K = 27 / M = 1: element-wise fetch mode, one memory round trip per k-step), and those set its length (31.3 us either
+    // way by rocprofv3; the four 256 x 256 problems alone take 23 us at S = 8).  GCRL_DW_SPLIT_CHAIN=1 switches it on.
+    const bool chain_dw = a->rowchain && (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3) && std::getenv("GCRL_DW_SPLIT_CHAIN");
+    long long tc = 0, ta = 0, big_c = 0;
+    for (const Lin& ln : a->critic.lin) { tc += tiles_of(ln); if (ln.out >= 64 && ln.in >= 64) big_c += tiles_of(ln); }
+    for (const Lin& ln : a->actor.lin) ta += tiles_of(ln);
+    const bool ens = !a->dw_batch_off && L >= 2 && (long long)C * (L - 1) * ((H + 63) / 64) * ((H + 1 + 63) / 64) >= 512;   // enqueue_critic's dw_batch
+    if (on && chain_dw) { a->dw_split_c = pick(C * tc); a->dw_split_a = pick(ta); }
+    else if (on && ens) a->dw_split_c = pick(C * big_c);
+    if (const char* e = std::getenv("GCRL_DW_SPLIT")) {   // experiment knob
+      const int S = std::max(1, std::min(16, std::atoi(e)));
+      if (a->dw_split_c > 1) a->dw_split_c = S;
+      if (a->dw_split_a > 1) a->dw_split_a = S;
+    }
+    long long pc = 0, tcn = 0, pa = 0, tan = 0;
+    layout(a->critic, a->dw_split_c, a->dwp_off_c, a->dwt_off_c, &pc, &tcn);
+    layout(a->actor, a->dw_split_a, a->dwp_off_a, a->dwt_off_a, &pa, &tan);
+    a->dwp_cstride = pc; a->dwt_cstride = tcn;
+    a->dwp_actor = (long long)C * pc; a->dwt_actor = (long long)C * tcn;
+    if (a->dw_split_c > 1 || a->dw_split_a > 1) {
+      wants.push_back({&a->dw_part, (long long)C * pc + pa});
+      wants.push_back({&a->dw_tick, (long long)C * tcn + tan});     // (unsigned int tickets; the arena is zero-filled)
+    }
   }
   long long total = 0;
   for (auto& w : wants) total += align_up(w.second, 64);

@@ -61,7 +61,16 @@ struct GemmDesc {
   // LDS-tiled workgroups).  Still a function of the problem and the agent's configuration only, never of a launch's
   // accidental composition: a problem's summation order does not change from step to step.
   int shape_hint;
+  // LDS-tiled form only: the reduction split over `ksplit` workgroups per 64x64 tile (0 / 1: none).  Every split writes its raw
+  // partial tile to kpart[(tile * ksplit + s) * kTiledPartStride], takes a ticket (kticket[tile], zero between launches: the
+  // last arriver resets it) and the LAST one sums the partials in index order — so the result does not depend on which
+  // workgroup finishes last — and runs the epilogue.  For long reductions into few tiles (dW at batch >= 1024).
+  int ksplit;
+  float* kpart;
+  unsigned int* kticket;
 };
+constexpr int kTiledPartStride = 64 * 64 + 64;   // floats per partial: the tile + the bias-gradient row sums
+constexpr int kTicketStride = 32;                // tickets 128 bytes apart
 
 struct GemmBatch {
   int n;

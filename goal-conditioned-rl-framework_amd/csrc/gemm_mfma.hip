@@ -75,8 +75,10 @@ int launch_tiled(hipStream_t st, GemmBatch& gb) {
   for (int i = 0; i < gb.n; ++i) {
     GemmDesc& d = gb.d[i];
     const int tm = (d.M + kTB - 1) / kTB;
-    d.tiles_n = (d.N + kTB - 1) / kTB;
-    d.ntiles = tm * d.tiles_n;
+    d.tiles_n = (d.N - (d.ones_col ? 1 : 0) + kTB - 1) / kTB;      // (the bias gradient comes out of tile column 0)
+    if (d.ksplit < 1) d.ksplit = 1;
+    GCRL_CHECK_ARG(d.ksplit == 1 || (d.kpart && d.kticket), "launch_gemm_batch: a split reduction needs its partial and ticket arrays");
+    d.ntiles = tm * d.tiles_n * d.ksplit;                          // work items: (split, tile)
     d.tile0 = tiles;
     tiles += d.ntiles;
   }

@@ -40,7 +40,7 @@ __device__ inline int lds_at(int row, int k) { return row * kLDT + ((((k >> 2) ^
 enum { FETCH_KC = 0, FETCH_RC = 1, FETCH_GEN = 2 };
 
 // Fetch a 64 x 16 operand tile (rows r0.., k k0..) into 4 registers per thread.
-// element(row, k) = base[row*rs + k*cs]; rows >= R or k >= K read as 0; `ones_row`: that row := 1.
+// element(row, k) = base[row*rs + k*cs]; rows >= R or k >= K read as 0.
 //
 // The two vector modes are free of control flow and of per-step address arithmetic: a thread's fragment offset (bytes, at
 // k-step 0) is computed ONCE (`FetchPlan`; rows outside the operand get an offset past the descriptor's extent, for which
@@ -48,27 +48,22 @@ enum { FETCH_KC = 0, FETCH_RC = 1, FETCH_GEN = 2 };
 // FETCH_RC only when whole 16-byte fragments are legal and K is a multiple of the k-step; everything else is FETCH_GEN.
 constexpr int kOob = 0x7ffffff0;   // byte offset past any descriptor extent
 
-struct FetchPlan { int voff; int step; bool ones[4]; bool any_one; };
+struct FetchPlan { int voff; int step; };
 
-// R: rows of the operand that exist in memory (for B with a synthesised ones row: N - 1)
+// R: rows of the operand that exist in memory
 template <int MODE>
-__device__ inline FetchPlan fetch_plan(long long rs, long long cs, int r0, int R, int ones_row) {
+__device__ inline FetchPlan fetch_plan(long long rs, long long cs, int r0, int R) {
   FetchPlan pl;
   const int tid = threadIdx.x;
-  pl.any_one = false;
   if (MODE == FETCH_KC) {     // 4 lanes x 16 B = one row's 16 k; a wave covers 16 rows
     const int r = r0 + (tid >> 2), k = (tid & 3) << 2;
     pl.voff = r < R ? (int)(((long long)r * rs + k) * 4) : kOob;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { pl.ones[q] = r == ones_row; pl.any_one |= pl.ones[q]; }
   } else {
     // row-contiguous operand: a wave-load covers 4 k (lane & 3) x 16 row quads (lane >> 2) — per k a 256-byte run — and the
     // workgroup's 4 waves the 4 k-quads; store_tile transposes through bank-conflict-free dword stores
     const int l = tid & 63, wv = tid >> 6;
     const int k = 4 * wv + (l & 3), r = r0 + ((l >> 2) << 2);
     pl.voff = r < R ? (int)(((long long)k * cs + r) * 4) : kOob;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { pl.ones[q] = r + q == ones_row; pl.any_one |= pl.ones[q]; }
   }
   pl.step = MODE == FETCH_KC ? kBK * 4 : (int)(cs * kBK * 4);
   return pl;
@@ -77,7 +72,7 @@ __device__ inline FetchPlan fetch_plan(long long rs, long long cs, int r0, int R
 // `in` false (a k-step past the end, issued to keep the pipeline free of branches): zeros
 template <int MODE>
 __device__ inline void fetch_tile(float (&reg)[kNR], const float* __restrict__ base, __amdgpu_buffer_rsrc_t rsrc, const FetchPlan& pl,
-                                  long long rs, long long cs, int r0, int R, int ks, int K, int ones_row, bool in) {
+                                  long long rs, long long cs, int r0, int R, int ks, int K, bool in) {
   if (MODE != FETCH_GEN) {
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, in ? pl.voff : kOob, in ? ks * pl.step : 0, 0);
 #pragma unroll
@@ -94,23 +89,17 @@ __device__ inline void fetch_tile(float (&reg)[kNR], const float* __restrict__ b
 #pragma unroll
     for (int p = 0; p < kNR; ++p) {
       const int e = tid + 256 * p, r = r0 + (e & 63), k = k0 + (e >> 6);
-      const bool ok = r < R && k < K && r != ones_row;
+      const bool ok = r < R && k < K;
       const int off = ok ? (int)(((long long)r * rs + (long long)k * cs) * 4) : kOob;
-      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
-      reg[p] = (r == ones_row && k < K) ? 1.f : v;
+      reg[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
     }
   }
 }
 
-// registers -> LDS.  The synthesised ones row of a dW problem's B operand is applied here (not when the registers are
-// requested: the select would wait for the loads one k-step early).  `in`: the tile lies inside K
+// registers -> LDS
 template <int MODE>
-__device__ inline void store_tile(float (&reg)[kNR], const FetchPlan& pl, float* __restrict__ lds, bool in) {
+__device__ inline void store_tile(float (&reg)[kNR], float* __restrict__ lds) {
   const int tid = threadIdx.x;
-  if (MODE != FETCH_GEN && pl.any_one) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) reg[q] = (pl.ones[q] && in) ? 1.f : reg[q];
-  }
   if (MODE == FETCH_KC) {
     const int row = tid >> 2, c = tid & 3;
     *reinterpret_cast<float4*>(lds + row * kLDT + ((c ^ ((row >> 2) & 3)) << 2)) = make_float4(reg[0], reg[1], reg[2], reg[3]);
@@ -155,33 +144,44 @@ __device__ inline void store_tile(float (&reg)[kNR], const FetchPlan& pl, float*
 #define GCRL_STAMP(i) do { } while (0)
 #endif
 
+// The bias gradient of a dW problem (column N-1 of G^T [X | 1] = the row sums of the A operand over k) is NOT a synthesised
+// ones column of B any more: for N - 1 = 512 that column cost a ninth tile column — 8 of 72 tiles per problem computing one
+// useful column.  Instead every thread adds up the A fragments it stages anyway (4 adds per k-step), and the tiles of tile
+// column 0 reduce those over the workgroup in a fixed order: db comes out of the first tile column for free.
 template <int MA, int MB>
 __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, float* ldsB) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r32 = lane & 31, hk = lane >> 5;
-  const int M = d.M, N = d.N, K = d.K;
-  const int tn = t % d.tiles_n, tm = t / d.tiles_n;
+  const int M = d.M, K = d.K;
+  const int N = d.N - (d.ones_col ? 1 : 0);      // columns that are tiles' work (and B's rows in memory)
+  const int S = d.ksplit > 1 ? d.ksplit : 1;
+  const int tiles = d.ntiles / S;
+  const int ti = t % tiles, sp = t / tiles;      // split-major: the workgroups of one k-range are neighbours (they share operand panels)
+  const int tn = ti % d.tiles_n, tm = ti / d.tiles_n;
   const int m0 = tm * kTB, n0 = tn * kTB;
   const int wm = wave >> 1, wn = wave & 1;
   const long long sl = d.slot ? (long long)*d.slot : 0;
   const float* __restrict__ A = d.A + sl * d.a_slot;
   const float* __restrict__ Bm = d.B + sl * d.b_slot;
-  const int ones_row = d.ones_col ? N - 1 : -1;
+  const bool bias_tile = d.ones_col && tn == 0;   // (uniform)
 
   v16f acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  v4f bs = (v4f){0.f, 0.f, 0.f, 0.f};             // sums over k of the A fragments this thread staged
   GCRL_STAMP(0);
 
   // extents for the vector modes: whole rows of the operand (KC: R rows of rs floats; RC: K rows of cs floats)
-  const int n_mem = N - (d.ones_col ? 1 : 0);   // B's rows that exist in memory (the ones column is synthesised)
   // (the last element's index + 1: exact for all three modes)
   const __amdgpu_buffer_rsrc_t rsa = wave_uniform_rsrc_n(A, (long long)(M - 1) * d.a_rs + (long long)(K - 1) * d.a_cs + 1);
-  const __amdgpu_buffer_rsrc_t rsb = wave_uniform_rsrc_n(Bm, (long long)(n_mem - 1) * d.b_cs + (long long)(K - 1) * d.b_rs + 1);
-  const int ksteps = (K + kBK - 1) / kBK;
-  const FetchPlan pla = fetch_plan<MA>(d.a_rs, d.a_cs, m0, M, -1);
-  const FetchPlan plb = fetch_plan<MB>(d.b_cs, d.b_rs, n0, n_mem, ones_row);
+  const __amdgpu_buffer_rsrc_t rsb = wave_uniform_rsrc_n(Bm, (long long)(N - 1) * d.b_cs + (long long)(K - 1) * d.b_rs + 1);
+  // this workgroup's k-steps [ks0, ks1): an even number per split, so that LDS buffer parity = step parity everywhere
+  const int ksteps_all = (K + kBK - 1) / kBK;
+  const int per = (((ksteps_all + S - 1) / S) + 1) & ~1;
+  const int ks0 = sp * per, ksteps = min(ksteps_all, ks0 + per);
+  const FetchPlan pla = fetch_plan<MA>(d.a_rs, d.a_cs, m0, M);
+  const FetchPlan plb = fetch_plan<MB>(d.b_cs, d.b_rs, n0, N);
   // fragment offsets of this lane (floats): row 32*wm + r32 of the A tile, row 32*wn + r32 of the B tile; a k-step's two
   // 8-k groups: lane half hk reads chunk 2g + hk (4 consecutive k), MFMA q of the group takes element q of both reads, i.e.
   // k = 8g + q from half 0 and 8g + 4 + q from half 1 — A and B permuted alike, so every product pairs the same k
@@ -189,8 +189,12 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   const int offA = rowA * kLDT, offB = rowB * kLDT;
   const int swA = (rowA >> 2) & 3, swB = (rowB >> 2) & 3;
   auto fetch = [&](float (&xa)[kNR], float (&xb)[kNR], int ks) {
-    fetch_tile<MA>(xa, A, rsa, pla, d.a_rs, d.a_cs, m0, M, ks, K, -1, ks < ksteps);
-    fetch_tile<MB>(xb, Bm, rsb, plb, d.b_cs, d.b_rs, n0, N, ks, K, ones_row, ks < ksteps);
+    fetch_tile<MA>(xa, A, rsa, pla, d.a_rs, d.a_cs, m0, M, ks, K, ks < ksteps);
+    fetch_tile<MB>(xb, Bm, rsb, plb, d.b_cs, d.b_rs, n0, N, ks, K, ks < ksteps);
+  };
+  auto tally = [&](const float (&xa)[kNR]) {     // (steps past the end were fetched as zeros)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bs[q] += xa[q];
   };
   // (roles swapped in every MFMA — B fragment as the instruction's A: the accumulator holds the TRANSPOSED tile, see the epilogue)
 #define GCRL_MFMA(bv, av) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0)
@@ -213,26 +217,26 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
       const float* lb = ldsB + buf * (kTB * kLDT) + offB;
       float* na = ldsA + (buf ^ 1) * (kTB * kLDT);
       float* nb = ldsB + (buf ^ 1) * (kTB * kLDT);
-      const bool in1 = ks + 1 < ksteps;
       const float4 a0 = GCRL_ABL_READ(la + ((hk ^ swA) << 2)), b0 = GCRL_ABL_READ(lb + ((hk ^ swB) << 2));
       const float4 a1 = GCRL_ABL_READ(la + (((2 + hk) ^ swA) << 2)), b1 = GCRL_ABL_READ(lb + (((2 + hk) ^ swB) << 2));
       GCRL_SB();
-      GCRL_MFMA(b0.x, a0.x); GCRL_SB(); GCRL_ABL_STORE(store_tile<MA>(xa, pla, na, in1)); GCRL_SB();
-      GCRL_MFMA(b0.y, a0.y); GCRL_SB(); GCRL_ABL_STORE(store_tile<MB>(xb, plb, nb, in1)); GCRL_SB();
-      GCRL_MFMA(b0.z, a0.z); GCRL_SB(); GCRL_ABL_FETCH(fetch_tile<MA>(xa, A, rsa, pla, d.a_rs, d.a_cs, m0, M, ks + 3, K, -1, ks + 3 < ksteps)); GCRL_SB();
-      GCRL_MFMA(b0.w, a0.w); GCRL_SB(); GCRL_ABL_FETCH(fetch_tile<MB>(xb, Bm, rsb, plb, d.b_cs, d.b_rs, n0, N, ks + 3, K, ones_row, ks + 3 < ksteps)); GCRL_SB();
+      GCRL_MFMA(b0.x, a0.x); GCRL_SB(); GCRL_ABL_STORE(store_tile<MA>(xa, na)); tally(xa); GCRL_SB();
+      GCRL_MFMA(b0.y, a0.y); GCRL_SB(); GCRL_ABL_STORE(store_tile<MB>(xb, nb)); GCRL_SB();
+      GCRL_MFMA(b0.z, a0.z); GCRL_SB(); GCRL_ABL_FETCH(fetch_tile<MA>(xa, A, rsa, pla, d.a_rs, d.a_cs, m0, M, ks + 3, K, ks + 3 < ksteps)); GCRL_SB();
+      GCRL_MFMA(b0.w, a0.w); GCRL_SB(); GCRL_ABL_FETCH(fetch_tile<MB>(xb, Bm, rsb, plb, d.b_cs, d.b_rs, n0, N, ks + 3, K, ks + 3 < ksteps)); GCRL_SB();
       GCRL_MFMA(b1.x, a1.x); GCRL_MFMA(b1.y, a1.y); GCRL_MFMA(b1.z, a1.z); GCRL_MFMA(b1.w, a1.w);
       GCRL_ABL_BARRIER();
     };
-    fetch(ra[0], rb[0], 0);
-    fetch(ra[1], rb[1], 1);
-    store_tile<MA>(ra[0], pla, ldsA, true);
-    store_tile<MB>(rb[0], plb, ldsB, true);
-    fetch(ra[0], rb[0], 2);
+    fetch(ra[0], rb[0], ks0);
+    fetch(ra[1], rb[1], ks0 + 1);
+    store_tile<MA>(ra[0], ldsA);
+    store_tile<MB>(rb[0], ldsB);
+    tally(ra[0]);
+    fetch(ra[0], rb[0], ks0 + 2);
     __syncthreads();
     GCRL_STAMP(1);
-    const int kp = (ksteps + 1) & ~1;
-    for (int ks = 0; ks < kp; ks += 2) {
+    const int kp = ks0 + ((max(ksteps - ks0, 0) + 1) & ~1);     // (ks0 is even)
+    for (int ks = ks0; ks < kp; ks += 2) {
       step(ks, ra[1], rb[1]);
       step(ks + 1, ra[0], rb[0]);
     }
@@ -240,12 +244,13 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   } else {
     // element-wise fetch (first layers with K = 25, heads, unaligned operands: a few k-steps at most): plain phases
     float ra[kNR], rb[kNR];
-    fetch(ra, rb, 0);
-    store_tile<MA>(ra, pla, ldsA, true);
-    store_tile<MB>(rb, plb, ldsB, true);
-    fetch(ra, rb, 1);
+    fetch(ra, rb, ks0);
+    store_tile<MA>(ra, ldsA + (ks0 & 1) * (kTB * kLDT));
+    store_tile<MB>(rb, ldsB + (ks0 & 1) * (kTB * kLDT));
+    tally(ra);
+    fetch(ra, rb, ks0 + 1);
     __syncthreads();
-    for (int ks = 0; ks < ksteps; ++ks) {
+    for (int ks = ks0; ks < ksteps; ++ks) {
       const float* la = ldsA + (ks & 1) * (kTB * kLDT) + offA;
       const float* lb = ldsB + (ks & 1) * (kTB * kLDT) + offB;
       const int nk = K - ks * kBK;   // k left from this step on: a whole 8-k group of zeros is skipped (small-K problems)
@@ -256,14 +261,91 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
         const float4 b = *reinterpret_cast<const float4*>(lb + (((2 * g + hk) ^ swB) << 2));
         GCRL_MFMA(b.x, a.x); GCRL_MFMA(b.y, a.y); GCRL_MFMA(b.z, a.z); GCRL_MFMA(b.w, a.w);
       }
-      store_tile<MA>(ra, pla, ldsA + ((ks + 1) & 1) * (kTB * kLDT), ks + 1 < ksteps);
-      store_tile<MB>(rb, plb, ldsB + ((ks + 1) & 1) * (kTB * kLDT), ks + 1 < ksteps);
+      store_tile<MA>(ra, ldsA + ((ks + 1) & 1) * (kTB * kLDT));
+      store_tile<MB>(rb, ldsB + ((ks + 1) & 1) * (kTB * kLDT));
+      tally(ra);
       fetch(ra, rb, ks + 2);
       __syncthreads();
     }
   }
 #undef GCRL_MFMA
 #undef GCRL_SB
+
+  // bias gradient: db[m0 + r] = the sum over the workgroup's threads that staged row r, slot by slot in a fixed order.
+  // Who staged what (fetch_plan / fetch_tile): RC — thread (wave wv, lane l) rows 4*(l >> 2) + q at k = 4*wv + (l & 3) mod 16:
+  // 16 slots; KC — row tid >> 2, four consecutive k: 4 slots (tid & 3); GEN — row tid & 63 for every register: 4 slots (tid >> 6).
+  float dbv = 0.f;                                 // threads 0..63: db of row m0 + tid (this split's share)
+  if (bias_tile) {
+    float* red = ldsA;                             // [slot][64 rows]; the main loop's last barrier has passed
+    const int tid = threadIdx.x;
+    int nslot;
+    if (MA == FETCH_RC) {
+      nslot = 16;
+      *reinterpret_cast<float4*>(red + (4 * wave + (lane & 3)) * 64 + ((lane >> 2) << 2)) = make_float4(bs[0], bs[1], bs[2], bs[3]);
+    } else if (MA == FETCH_KC) {
+      nslot = 4;
+      red[(tid & 3) * 64 + (tid >> 2)] = (bs[0] + bs[1]) + (bs[2] + bs[3]);
+    } else {
+      nslot = 4;
+      red[(tid >> 6) * 64 + (tid & 63)] = (bs[0] + bs[1]) + (bs[2] + bs[3]);
+    }
+    __syncthreads();
+    if (tid < 64)
+      for (int i = 0; i < nslot; ++i) dbv += red[i * 64 + tid];
+    __syncthreads();
+  }
+
+  if (S > 1) {
+    // Split reduction: publish the raw partial, take a ticket; the last arriver sums all S partials in index order (its own
+    // comes back from memory like the others': the sum is the same whoever is last) and goes on to the epilogue.
+    // The partials move with AGENT-SCOPE accesses (sc1: written through to / read from the memory side of the per-XCD L2s), so
+    // no cache maintenance is needed: a release / acquire fence pair at agent scope (__threadfence: buffer_wbl2 + buffer_inv
+    // per wave) serialised the workgroups of a launch at ~0.15 us each — 1024 workgroups: 157 us for 9 us of arithmetic, measured.
+    constexpr int kSc1 = 16;                       // cache-policy bit of the raw buffer builtins on gfx94x / gfx950
+    const __amdgpu_buffer_rsrc_t rsp = wave_uniform_rsrc_n(d.kpart + (long long)ti * S * kTiledPartStride, (long long)S * kTiledPartStride);
+    const int mine = sp * kTiledPartStride * 4;    // byte offsets: S * 16.25 KB per tile
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const v4u v = {__float_as_uint(acc[4 * g]), __float_as_uint(acc[4 * g + 1]), __float_as_uint(acc[4 * g + 2]), __float_as_uint(acc[4 * g + 3])};
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsp, mine + (((wave * 4 + g) * 64 + lane) << 4), 0, kSc1);
+    }
+    if (bias_tile && threadIdx.x < 64) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dbv), rsp, mine + (64 * 64 + (int)threadIdx.x) * 4, 0, kSc1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // s_waitcnt vmcnt(0): this wave's stores have been acknowledged
+    unsigned int* s_ticket = reinterpret_cast<unsigned int*>(ldsB);   // (LDS is free between the main loop and the epilogue)
+    __syncthreads();
+    if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(d.kticket + ti * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned int ticket = *s_ticket;
+    __syncthreads();                               // (the epilogue's tile will overwrite the slot)
+    if (ticket != (unsigned)(S - 1)) return;       // (uniform)
+    if (threadIdx.x == 0) __hip_atomic_store(d.kticket + ti * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    dbv = 0.f;
+    // four partials' loads in flight at a time (an agent-scope load is a round trip to the memory side: ~2 us under load, and
+    // one partial per round trip made the fix-up of an 8-way split 16 us long); the adds stay in index order
+    for (int j0 = 0; j0 < S; j0 += 4) {
+      v4u v[4][4];
+      unsigned int bj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pj = (j0 + u < S) ? (j0 + u) * kTiledPartStride * 4 : kOob;     // (past the descriptor's extent: zeros)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[u][g] = __builtin_amdgcn_raw_buffer_load_b128(rsp, pj == kOob ? kOob : pj + (((wave * 4 + g) * 64 + lane) << 4), 0, kSc1);
+        bj[u] = 0;
+        if (bias_tile && threadIdx.x < 64) bj[u] = __builtin_amdgcn_raw_buffer_load_b32(rsp, pj == kOob ? kOob : pj + (64 * 64 + (int)threadIdx.x) * 4, 0, kSc1);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc[4 * g] += __uint_as_float(v[u][g][0]); acc[4 * g + 1] += __uint_as_float(v[u][g][1]);
+          acc[4 * g + 2] += __uint_as_float(v[u][g][2]); acc[4 * g + 3] += __uint_as_float(v[u][g][3]);
+        }
+        dbv += __uint_as_float(bj[u]);
+      }
+    }
+  }
 
   const float* __restrict__ bias = d.bias;
   const float* __restrict__ H = d.H + sl * d.h_slot;
@@ -281,10 +363,9 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   const bool vec_ok = (d.c_rs % 4 == 0) && (((unsigned long long)C & 15) == 0) &&
                       (mul == MUL_NONE || (d.h_rs % 4 == 0 && (((unsigned long long)H & 15) == 0))) &&
                       (!bias || (((unsigned long long)bias & 15) == 0));
-  const int n_vec = d.ones_col ? N - 1 : N;      // (a dW problem's last column is the bias gradient: col_out, element-wise)
   const int eq = threadIdx.x & 15, er = threadIdx.x >> 4;
   const int nq = n0 + 4 * eq;
-  const bool quad_vec = vec_ok && nq + 3 < n_vec;
+  const bool quad_vec = vec_ok && nq + 3 < N;
   v4f bv = (v4f){0.f, 0.f, 0.f, 0.f}, hv[4];
   if (quad_vec) {
     if (bias) bv = *(const v4f*)(bias + nq);
@@ -307,6 +388,10 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   __syncthreads();
   GCRL_STAMP(5);
   float ss = 0.f;
+  if (bias_tile && threadIdx.x < 64 && m0 + (int)threadIdx.x < M) {   // (threads of wave 0: its sum-of-squares slot takes db's share)
+    d.col_out[m0 + threadIdx.x] = dbv;
+    ss += dbv * dbv;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = er + 16 * i, m = m0 + row;
@@ -333,8 +418,7 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
         v = act_apply(v, epi);
         if (mul != MUL_NONE) v *= act_deriv(H[(long long)m * d.h_rs + n], mul);
         ss += v * v;
-        if (d.ones_col && n == N - 1) d.col_out[m] = v;
-        else C[(long long)m * d.c_rs + n] = v;
+        C[(long long)m * d.c_rs + n] = v;
       }
     }
   }
@@ -342,7 +426,7 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   if (d.sumsq_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-    if (lane == 0) d.sumsq_out[(long long)t * 4 + wave] = ss;
+    if (lane == 0) d.sumsq_out[(long long)ti * 4 + wave] = ss;
   }
 }
 
@@ -360,7 +444,7 @@ __global__ __launch_bounds__(256, 5) void gemm_tiled_kernel(GemmBatch gb) {   //
   if (t >= d.ntiles) return;
   // fetch modes are per problem and wave-uniform: 3 x 3 straight-line instances
   // (vector modes need whole 16-byte fragments: extents in multiples of 4 along the vector direction)
-  const int n_mem = d.N - (d.ones_col ? 1 : 0);
+  const int n_mem = d.N - (d.ones_col ? 1 : 0);   // (a dW problem's last column is the bias gradient: row sums, not a tile column)
   const bool kfull = d.K % kBK == 0;
   const int ma = (d.a_vec && kfull) ? FETCH_KC : ((d.a_rvec && kfull && d.M % 4 == 0) ? FETCH_RC : FETCH_GEN);
   const int mb = (d.b_vec && kfull) ? FETCH_KC : ((d.b_rvec && kfull && n_mem % 4 == 0) ? FETCH_RC : FETCH_GEN);

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <cmath>
+#include <functional>
 
 // ablations: -DABL_NOREAD / -DABL_NOSTORE / -DABL_NOFETCH / -DABL_NOBARRIER drop one ingredient of the fused k-step (results meaningless)
 #ifdef ABL_NOREAD
@@ -93,21 +95,47 @@ int main(int argc, char** argv) {
   const bool dw = argc > 4 && !strcmp(argv[4], "dw");
   int total_tiles = d.ntiles;
   double flops = 2.0 * M * N * K;
+  std::function<void()> dw_check;
   if (dw) {
     const int P = argc > 5 ? atoi(argv[5]) : 10, out = M, in = N, batch = K;
     float *G, *X, *dW, *db;
     CK(hipMalloc(&G, (size_t)batch * out * 4)); CK(hipMalloc(&X, (size_t)batch * in * 4));
     CK(hipMalloc(&dW, (size_t)P * out * in * 4)); CK(hipMalloc(&db, (size_t)P * out * 4));
     CK(hipMemcpy(G, h.data(), (size_t)batch * out * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X, h.data(), (size_t)batch * in * 4, hipMemcpyHostToDevice));
+    const int S = argc > 6 ? atoi(argv[6]) : 1;      // split of the reduction over S workgroups per tile
     gb.n = P; total_tiles = 0;
     for (int i = 0; i < P; ++i) {
       gcrl::GemmDesc& q = gb.d[i]; memset(&q, 0, sizeof(q));
       q.A = G; q.a_rs = 1; q.a_cs = out; q.B = X; q.b_rs = in; q.b_cs = 1; q.C = dW + (size_t)i * out * in; q.c_rs = in;
       q.M = out; q.N = in + 1; q.K = batch; q.ones_col = 1; q.col_out = db + (size_t)i * out;
       q.a_rvec = 1; q.b_rvec = 1;
-      q.tiles_n = (q.N + 63) / 64; q.ntiles = ((q.M + 63) / 64) * q.tiles_n; q.tile0 = total_tiles; total_tiles += q.ntiles;
+      q.tiles_n = (in + 63) / 64;
+      const int tl = ((q.M + 63) / 64) * q.tiles_n;
+      q.ksplit = S;
+      if (S > 1) {
+        CK(hipMalloc(&q.kpart, (size_t)tl * S * gcrl::kTiledPartStride * 4));
+        CK(hipMalloc(&q.kticket, (size_t)tl * 4 * gcrl::kTicketStride)); CK(hipMemset(q.kticket, 0, (size_t)tl * 4 * gcrl::kTicketStride));
+      }
+      q.ntiles = tl * S; q.tile0 = total_tiles; total_tiles += q.ntiles;
     }
     flops = 2.0 * P * out * (in + 1) * batch;
+    dw_check = [=]() {   // problem 0 and P-1 against a host fp64 sum (sampled entries) — the split / ticket path must not lose a partial
+      std::vector<float> hw((size_t)out * in), hb(out), hg((size_t)batch * out), hx((size_t)batch * in);
+      double worst = 0;
+      CK(hipMemcpy(hg.data(), G, hg.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hx.data(), X, hx.size() * 4, hipMemcpyDeviceToHost));
+      for (int pi : {0, P - 1}) {
+        CK(hipMemcpy(hw.data(), dW + (size_t)pi * out * in, hw.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hb.data(), db + (size_t)pi * out, hb.size() * 4, hipMemcpyDeviceToHost));
+        for (int smp = 0; smp < 400; ++smp) {
+          const int m = (smp * 37 + 5) % out, n = (smp * 101 + 3) % in;
+          double r = 0, rb = 0;
+          for (int k = 0; k < batch; ++k) { r += (double)hg[(size_t)k * out + m] * hx[(size_t)k * in + n]; rb += hg[(size_t)k * out + m]; }
+          worst = std::max(worst, std::abs(r - hw[(size_t)m * in + n]));
+          worst = std::max(worst, std::abs(rb - hb[m]));
+        }
+      }
+      printf("  dW check (400 sampled entries + their db, problems 0 and %d): worst |err| %.3g\n", P - 1, worst);
+    };
   }
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -124,6 +152,7 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   const double us = ms * 1e3 / reps;
+  if (dw_check) dw_check();
   printf("%s%s M=%d N=%d K=%d (%d tiles): %.1f us  %.1f TFLOP/s\n", dw ? "dW " : (dx ? "dX " : "fwd"), direct ? " (direct)" : "", M, N, K, total_tiles, us, flops / us / 1e6);
 #ifdef STAMPS
   {   // one more launch, then the stamps: 100 MHz wall clock, relative to the earliest workgroup start
