@@ -1,4 +1,5 @@
 // abi_misc.hip — small C-ABI helpers: stand-alone sort op, hipEvent timing, raw device memory.
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -51,6 +52,31 @@ int gcrl_bn_relu_bwd_f32(const float* dh, const float* xhat, const float* invstd
   GCRL_CHECK_ARG(dh && xhat && invstd && gamma && beta && dz && dgamma && dbeta && scratch && B >= 1 && H >= 4,
                  "gcrl_bn_relu_bwd_f32: bad arguments");
   return gcrl::launch_bn_relu_bwd(as_stream(stream), dh, nullptr, xhat, invstd, gamma, beta, B, H, dz, dgamma, dbeta, scratch);
+}
+
+int gcrl_bn_linear_slab_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, const float* gamma, const float* beta,
+                                int B, int H, int K, float* h, float* xhat, float* invstd, float* bstat, void* stream) {
+  GCRL_CHECK_ARG(x && w && bias && gamma && beta && h && bstat && K >= 1 && ldx >= K && gcrl::bn_slab_ok(B, H),
+                 "gcrl_bn_linear_slab_fwd_f32: bad arguments (B <= 512, H a multiple of 16)");
+  gcrl::BnSlabFwd f;
+  std::memset(&f, 0, sizeof(f));
+  f.n = 1;
+  f.p[0] = gcrl::BnSlabFwdProb{x, 0, h, xhat, invstd, bstat};
+  f.W = w; f.bias = bias; f.gamma = gamma; f.beta = beta; f.ldx = ldx; f.B = B; f.H = H; f.K = K;
+  return gcrl::launch_bn_linear_fwd_slab(as_stream(stream), f);
+}
+
+int gcrl_bn_linear_slab_bwd_f32(const float* g_up, int64_t ldg, int K_up, const float* w_up, float* xhat_dz, const float* invstd,
+                                const float* gamma, const float* beta, int B, int H, float* dgamma, float* dbeta, void* stream) {
+  GCRL_CHECK_ARG(g_up && w_up && xhat_dz && invstd && gamma && beta && dgamma && dbeta && K_up >= 1 && ldg >= K_up && gcrl::bn_slab_ok(B, H),
+                 "gcrl_bn_linear_slab_bwd_f32: bad arguments (B <= 512, H a multiple of 16)");
+  gcrl::BnSlabBwd b;
+  std::memset(&b, 0, sizeof(b));
+  b.nup = 1;
+  b.G[0] = g_up; b.ldg[0] = ldg; b.K[0] = K_up; b.W[0] = w_up; b.ldw[0] = H;
+  b.xhat_dz = xhat_dz; b.invstd = invstd; b.gamma = gamma; b.beta = beta; b.dgamma = dgamma; b.dbeta = dbeta;
+  b.B = B; b.H = H;
+  return gcrl::launch_bn_linear_bwd_slab(as_stream(stream), b);
 }
 
 int gcrl_hash_normal_fill(uint64_t seed, uint64_t ctr0, int64_t n, float* out_dev, void* stream) {

@@ -134,6 +134,12 @@ struct gcrl_agent {
   std::vector<long long> dwp_off_c, dwp_off_a, dwt_off_c, dwt_off_a;
   long long dwp_cstride = 0, dwt_cstride = 0, dwp_actor = 0, dwt_actor = 0;
   bool dw_batch_off = false;  // GCRL_NO_DW_BATCH=1: a large ensemble's dW problems stay with their layers' dX launches (A/B knob)
+  // [Linear -> BatchNorm -> ReLU] of the SAC / TQC actor as one launch per layer and direction (bn_slab.hip): B <= 512, no
+  // SyncBN (GCRL_NO_BN_SLAB=1: the GEMM + BatchNorm launches).  bn_bstat: batch statistics [input][L][2][H]
+  bool bn_slab = false;
+  bool slab_on() const { return bn_slab && bn_sync.world <= 1; }
+  float* bn_bstat = nullptr;
+  int bn_slots = 0;           // sum-of-squares slots of one BatchNorm layer's dgamma | dbeta (16-column slabs)
   bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
   bool split_k = false;       // TD3: critic phase as role-parallel launches (agent_rowchain.inc)
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
@@ -363,7 +369,26 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
   const int B = a->B, H = a->H;
   const long long BH = (long long)B * H;
   auto hbuf = [&](const ActorFwd& q, int l) { return q.save ? q.h + (long long)l * BH : q.h + (long long)(l & 1) * BH; };
-  for (int l = 0; l < net.L; ++l) {
+  const bool slab = a->slab_on();
+  for (int l = 0; l < net.L && slab; ++l) {   // one launch per layer: GEMM, batch statistics, normalise, ReLU (bn_slab.hip)
+    BnSlabFwd sf;
+    std::memset(&sf, 0, sizeof(sf));
+    sf.n = nf;
+    for (int i = 0; i < nf; ++i)
+      sf.p[i] = BnSlabFwdProb{l == 0 ? f[i].X0 : hbuf(f[i], l - 1), l == 0 ? f[i].x_slot : 0, hbuf(f[i], l),
+                              f[i].save ? a->xhatA + (long long)l * BH : nullptr, f[i].save ? a->invstdA + (long long)l * H : nullptr,
+                              a->bn_bstat + ((long long)i * net.L + l) * 2 * H};
+    sf.slot = a->slot_ptr();
+    sf.W = P + net.lin[l].w; sf.bias = P + net.lin[l].b; sf.gamma = P + net.bn_g[l]; sf.beta = P + net.bn_b[l];
+    sf.ldx = l == 0 ? a->ldx : H;
+    sf.B = B; sf.H = H; sf.K = net.lin[l].in;
+    TRY(launch_bn_linear_fwd_slab(st, sf));
+    if (extra && (size_t)l < extra->steps.size()) {   // (co-scheduled critic chains of the launch-per-layer schedule: their own launch here)
+      std::vector<GemmDesc> v = extra->steps[l];
+      for (size_t o = 0; o < v.size(); o += kMaxProb) TRY(launch_gemm_batch(st, v.data() + o, (int)std::min<size_t>(kMaxProb, v.size() - o)));
+    }
+  }
+  for (int l = 0; l < net.L && !slab; ++l) {
     std::vector<GemmDesc> v;
     bool fused_stats = false;
     for (int i = 0; i < nf; ++i) {
@@ -407,6 +432,8 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
     tg[i].B = B; tg[i].A = a->A;
     tg[i].seed = a->cfg.seed; tg[i].rng_stream = f[i].rng_stream;
   }
+  if (slab)   // the running statistics of every layer, from the batch statistics the slab launches left: input 0's, then input 1's
+    tg[0].run = BnRunning{{a->bn_bstat, nf == 2 ? a->bn_bstat + (long long)net.L * 2 * H : nullptr}, nf, a->bn_rmean, a->bn_rvar, net.L, H, B};
   if (nf == 2) TRY(launch_tanh_gauss_fwd2(st, tg[0], tg[1]));
   else TRY(launch_tanh_gauss_fwd(st, tg[0]));
   return GCRL_OK;
@@ -715,6 +742,44 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
     tb.B = B; tb.A = A;
     if (sel_deferred) TRY(launch_tanh_gauss_bwd_select(st, tb, as_d, al_d));
     else TRY(launch_tanh_gauss_bwd(st, tb));
+    if (a->slab_on()) {
+      // one launch per BatchNorm layer: the dX GEMM(s) of the consumer(s), the ReLU mask, BatchNorm's backward; dz_l takes
+      // xhat_l's place.  Then every dW | db of the actor in one launch.
+      const long long BH = (long long)B * H;
+      const int ldg = 2 * a->Apad;
+      for (int l = L - 1; l >= 0; --l) {
+        BnSlabBwd sb;
+        std::memset(&sb, 0, sizeof(sb));
+        if (l == L - 1) {
+          sb.nup = 2;
+          sb.G[0] = a->ghead; sb.G[1] = a->ghead + a->Apad; sb.ldg[0] = sb.ldg[1] = ldg; sb.K[0] = sb.K[1] = A;
+          sb.W[0] = Pa + a->actor.lin[L].w; sb.W[1] = Pa + a->actor.lin[L + 1].w; sb.ldw[0] = sb.ldw[1] = H;
+        } else {
+          sb.nup = 1;
+          sb.G[0] = a->xhatA + (long long)(l + 1) * BH; sb.ldg[0] = H; sb.K[0] = H;
+          sb.W[0] = Pa + a->actor.lin[l + 1].w; sb.ldw[0] = H;
+        }
+        sb.xhat_dz = a->xhatA + (long long)l * BH; sb.invstd = a->invstdA + (long long)l * H;
+        sb.gamma = Pa + a->actor.bn_g[l]; sb.beta = Pa + a->actor.bn_b[l];
+        sb.dgamma = Ga + a->actor.bn_g[l]; sb.dbeta = Ga + a->actor.bn_b[l];
+        sb.sumsq_out = (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * a->bn_slots : nullptr;
+        sb.B = B; sb.H = H;
+        TRY(launch_bn_linear_bwd_slab(st, sb));
+      }
+      std::vector<GemmDesc> v;
+      v.push_back(bwd_dw(a->ghead, ldg, a->hA_at(L - 1), H, Ga, a->actor.lin[L], B));
+      v.push_back(bwd_dw(a->ghead + a->Apad, ldg, a->hA_at(L - 1), H, Ga, a->actor.lin[L + 1], B));
+      if (variant & V_FUSED_NORM) { v[0].sumsq_out = a->parts_a + a->part_off_a[L]; v[1].sumsq_out = a->parts_a + a->part_off_a[L + 1]; }
+      for (int l = L - 1; l >= 0; --l) {
+        GemmDesc dw = bwd_dw(a->xhatA + (long long)l * BH, H, l == 0 ? (a->rowchain ? a->sa : a->spa) : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga,
+                             a->actor.lin[l], B);
+        if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
+        if (variant & V_FUSED_NORM) dw.sumsq_out = a->parts_a + a->part_off_a[l];
+        v.push_back(dw);
+      }
+      for (size_t o = 0; o < v.size(); o += kMaxProb) TRY(launch_gemm_batch(st, v.data() + o, (int)std::min<size_t>(kMaxProb, v.size() - o)));
+      return GCRL_OK;
+    }
     {
       const int ldg = 2 * a->Apad;
       std::vector<GemmDesc> v;
@@ -731,7 +796,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
       TRY(launch_bn_relu_bwd(st, dh, l == L - 1 ? a->dh2 : nullptr, a->xhatA + (long long)l * B * H,
                              a->invstdA + (long long)l * H, Pa + a->actor.bn_g[l], Pa + a->actor.bn_b[l], B, H, a->zA,
                              Ga + a->actor.bn_g[l], Ga + a->actor.bn_b[l], a->bn_part,
-                             (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * ((H + 63) / 64) : nullptr,
+                             (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * a->bn_slots : nullptr,
                              a->bn_sync.world > 1 ? &a->bn_sync : nullptr));
       std::vector<GemmDesc> v;
       GemmDesc dw = bwd_dw(a->zA, H, l == 0 ? (a->rowchain ? a->sa : a->spa) : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
@@ -1055,7 +1120,11 @@ int build(gcrl_agent* a) {
   };
   a->nparts_c = part_layout(a->critic, a->part_off_c);
   a->nparts_a = part_layout(a->actor, a->part_off_a);
-  if (a->sac) { a->part_off_bn = a->nparts_a; a->nparts_a += L * ((H + 63) / 64); }   // dgamma | dbeta of every BatchNorm layer
+  // dgamma | dbeta of every BatchNorm layer: one slot per 16-column slab (bn_slab.hip; the GEMM + BatchNorm launches use the
+  // first ceil(H/64) of a layer's slots, the rest stay zero)
+  a->bn_slots = (H + 15) / 16;
+  a->bn_slab = a->sac && bn_slab_ok(B, H) && !std::getenv("GCRL_NO_BN_SLAB");
+  if (a->sac) { a->part_off_bn = a->nparts_a; a->nparts_a += L * a->bn_slots; }
   // work buffers
   const long long BH = (long long)B * H;
   std::vector<std::pair<float**, long long>> wants = {
@@ -1074,7 +1143,7 @@ int build(gcrl_agent* a) {
       {&a->hC2, (long long)C * L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 15) / 16) * H},
       {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}, {&a->pi_buf, (long long)B * a->Apad},
       {&a->w_in, B}, {&a->td_abs, B},
-      {&a->zN, BH}, {&a->hN, 2 * BH}, {&a->headN, (long long)B * 2 * a->Apad}, {&a->bn_partN, 2LL * ((B + 15) / 16) * H}};
+      {&a->bn_bstat, 2LL * 2 * L * H}, {&a->zN, BH}, {&a->hN, 2 * BH}, {&a->headN, (long long)B * 2 * a->Apad}, {&a->bn_partN, 2LL * ((B + 15) / 16) * H}};
   // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
   {
     const long long per_a = (long long)round_up(S, 4) * H + (long long)(L - 1) * H * H;
@@ -1618,6 +1687,8 @@ int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_
   a->graphs.clear();
   a->bn_sync = BnSync{};
   a->bn_sync_dp = nullptr; a->bn_sync_fn = nullptr; a->bn_sync_user = nullptr;
+  if (a->sac && a->parts_a)   // (the slab launches and the BatchNorm launches fill different subsets of a layer's sum-of-squares slots)
+    GCRL_HIP(hipMemset(a->parts_a + a->part_off_bn, 0, (size_t)a->L * a->bn_slots * sizeof(float)));
   if (world == 1) return GCRL_OK;
   // partial statistics of both co-scheduled forwards, every rank's slots, adjacent: ONE exchange per BatchNorm layer and pass
   const long long n1 = 2LL * world * ((a->B + 63) / 64) * a->H;

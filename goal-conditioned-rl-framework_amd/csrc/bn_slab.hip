@@ -1,0 +1,330 @@
+// bn_slab.hip — [Linear -> BatchNorm1d(train) -> ReLU] of the SAC / TQC actor (src/model.py:100-123) as ONE launch per
+// layer and direction, for batches of up to 512 rows.
+//
+// BatchNorm's statistics are per COLUMN over all rows of the batch, so the natural owner of a statistic is a workgroup
+// that holds a column slab over every row: a workgroup here owns 16 output columns x all B rows.  It computes its slab of
+// z = X W^T + b on the matrix cores (8 waves x 64 rows, K walked in 32-wide chunks straight from L2: the operand is 512 KB
+// at most and every workgroup streams all of it), then — the accumulators still in registers — the column means, the
+// centred second moments (the two-pass form torch uses), normalises, applies the affine map and ReLU, and writes h, xhat
+// and 1/std.  The launch-per-op form was GEMM -> row-block partial statistics -> merge + apply: three launches of
+// 4.7-7.6 us each per layer for 0.13 GFLOP (profiles/r03_kernel_stats_sac_slide_b512.csv), on ONE dependency chain.
+//
+// The backward slab owns 16 columns of a layer's OUTPUT gradient: dh = sum over the consuming layers of G_up W_up (the
+// dX GEMM of the layer above — or of the two heads), ReLU mask from xhat, the two column sums BatchNorm's backward needs,
+// dz in place of xhat, dgamma / dbeta and their sum of squares for the global-norm clip: one launch instead of a GEMM and
+// two BatchNorm launches.
+//
+// Running statistics: a two-input launch (actor.sample(next_state) and actor.sample(states) co-scheduled, agent.hip) has
+// the two inputs' statistics in different workgroups, and the update order matters (next_state's batch first): the batch
+// statistics go to `bstat` and the step's tanh-Gaussian launch applies them in order (bn_running_update, ops_sac.hip).
+#include "ops.h"
+
+#include "gemm_mfma.h"
+
+namespace gcrl {
+
+namespace {
+
+constexpr float kEps = 1e-5f;          // nn.BatchNorm1d defaults (as in ops_sac.hip)
+constexpr int kWaves = 8;              // 512 threads
+constexpr int kNT = 4;                 // 16-row tiles per wave: 8 x 4 x 16 = 512 rows
+#ifndef GCRL_SLAB_NS
+#define GCRL_SLAB_NS 4
+#endif
+constexpr int kNS = GCRL_SLAB_NS;      // chunks of global loads in flight per wave
+constexpr int kCK = 16;                // k per chunk (the k-permutation of gemm_mfma.h: a lane's 4 consecutive k feed 4 MFMAs)
+
+// 4 consecutive floats at byte offset `off` (one 16-byte load, or element loads when the operand is not 16-byte
+// addressable); offsets past the descriptor's extent return 0
+template <bool VEC>
+__device__ inline v4f ld4b(__amdgpu_buffer_rsrc_t rs, int off) {
+  v4f r;
+  if (VEC) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = __uint_as_float(a[q]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * q, 0, 0));
+  }
+  return r;
+}
+
+// sum over the rows of the batch for this lane's column: lanes (i, g) hold partial sums of column i; result in every lane
+__device__ inline float col_sum(float v, float (*red)[16], int wave, int li, int lg) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  __syncthreads();
+  if (lg == 0) red[wave][li] = v;
+  __syncthreads();
+  float s = red[0][li];
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) s += red[w][li];
+  return s;
+}
+
+struct Operand { const float* p; long long ld; int K; };
+
+// acc[t] += A[rows of tile t][k] * Bm(k, col) over one operand pair.
+//   A: row-major [B][lda], k contiguous.      BROW: Bm(k, n) = W[n*ldb + k] (forward: weight rows, k contiguous)
+//                                             else: Bm(k, n) = W[k*ldb + n] (backward: the consuming layer's weight, n contiguous)
+// The A operand goes through a WAVE-PRIVATE LDS image: the MFMA wants lane i to hold row i, and loading it that way makes
+// every 16-lane group of a load instruction touch 16 different cache lines — the vector cache looks up one line per cycle,
+// so a K = 256 layer took 24 us for 7 us of MFMAs, whatever the prefetch depth (rocprofv3; first version of this file).
+// Here a load instruction covers 16 rows x 64 contiguous bytes (lane = 4 * row + quad), the quads land in LDS at
+// slot quad ^ ((row >> 1) & 3) of their 64-byte row (conflict-free for these stores and for the fragment reads: 8 lanes on 8
+// consecutive rows at one k-quad), and lane (i, g) reads row 16 t + i, quad g back.  Wave-private: LDS instructions of one
+// wave execute in order, no barrier.  Two chunks of global loads stay in flight in registers.
+template <bool VEC, bool BROW>
+__device__ inline void slab_gemm(v4f (&acc)[kNT], float* lds, const float* A, long long lda, const float* W, long long ldb, int K, int B,
+                                 int ncols, int row0, int col0, int lane) {
+  constexpr int kPast = 0x7ffffff0;
+  const int li = lane & 15, lg = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rsa = wave_uniform_rsrc_n(A, (long long)(B - 1) * lda + K);
+  const __amdgpu_buffer_rsrc_t rsw = wave_uniform_rsrc_n(W, BROW ? (long long)(ncols - 1) * ldb + K : (long long)(K - 1) * ldb + ncols);
+  const int srow = lane >> 2, sq = lane & 3;      // staging role: row srow (+16 t) of the wave's 64, k-quad sq
+  int aoff[kNT];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) aoff[t] = (int)(((long long)min(row0 + 16 * t + srow, B - 1) * lda + 4 * sq) * 4);
+  const int st_off = srow * 16 + ((sq ^ ((srow >> 1) & 3)) << 2);         // (+ 256 t floats)
+  const int rd_off = li * 16 + ((lg ^ ((li >> 1) & 3)) << 2);
+  const int col = min(col0 + li, ncols - 1);
+  const int woff = BROW ? (int)(((long long)col * ldb + 4 * lg) * 4) : (int)(((long long)(4 * lg) * ldb + col) * 4);
+  const int nfull = K / kCK;                      // whole chunks: the pipelined loop; a partial last chunk follows on its own
+  // kNS register stages of global loads in flight (the loops over them are fully unrolled: compile-time stage indices —
+  // a stage picked at run time would be a dynamically indexed array, i.e. scratch memory).  The operand was written by the
+  // previous launch and comes from the memory side of this XCD's L2: ~2 us a round trip; with two chunks in flight a K = 256
+  // layer took 17.8 us (one round trip per two chunks), measured.
+  v4f a[kNS][kNT], w[kNS];
+  auto load = [&](int c, int nc, v4f (&a)[kNT], v4f& w) {   // unconditional: chunks >= nc get offsets past the extents (zeros, no traffic)
+    const bool in = c < nc;
+    const int k0 = c * kCK;
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) a[t] = ld4b<VEC>(rsa, in ? aoff[t] + k0 * 4 : kPast);
+    if (BROW) {
+      w = ld4b<VEC>(rsw, in ? woff + k0 * 4 : kPast);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        w[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsw, (in && k0 + 4 * lg + q < K) ? woff + (int)((long long)(k0 + q) * ldb * 4) : kPast, 0, 0));
+    }
+  };
+  auto mac = [&](const v4f (&a)[kNT], const v4f& w) {
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) *reinterpret_cast<v4f*>(lds + 256 * t + st_off) = a[t];
+    // (other lanes' stores feed this lane's reads: the compiler must keep the order — the hardware does anyway)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    v4f f[kNT];
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) f[t] = *reinterpret_cast<const v4f*>(lds + 256 * t + rd_off);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < kNT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[t][q], w[q], acc[t], 0, 0, 0);
+  };
+  // NOTHING in the loop is conditional, and sched_barrier keeps every stage's consumer where it is written: with an
+  // `if (c >= nchunk) return` in mac, or with the k-tail masks inside (the scheduler hoisted all four stages' selects to
+  // the top of the body), the compiler drained every load in flight — s_waitcnt vmcnt(0) — once per round of stages and
+  // the launch ran at one memory round trip per round whatever kNS.  Chunks past the end are loaded as zeros.
+  // the partial last chunk is requested FIRST, into registers of its own (after the loop it would be one more exposed round
+  // trip: the whole launch, for a first layer with K = 22 or the heads' K = 3)
+  v4f at[kNT], wt;
+  load(nfull, (K % kCK) ? nfull + 1 : 0, at, wt);
+  // (the prologue's loads in stage order too: the loop header's wait count is the minimum over both ways into the loop)
+#pragma unroll
+  for (int s = 0; s < kNS; ++s) { __builtin_amdgcn_sched_barrier(0); load(s, nfull, a[s], w[s]); }
+  for (int c = 0; c < nfull; c += kNS) {
+#pragma unroll
+    for (int s = 0; s < kNS; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      mac(a[s], w[s]);
+      load(c + s + kNS, nfull, a[s], w[s]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (K % kCK) {   // (uniform) the partial chunk: the row's bytes past K belong to other columns or rows — mask both operands
+    const int ks = nfull * kCK + 4 * sq, kb = nfull * kCK + 4 * lg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int t = 0; t < kNT; ++t) at[t][q] = ks + q < K ? at[t][q] : 0.f;
+      wt[q] = kb + q < K ? wt[q] : 0.f;
+    }
+    mac(at, wt);
+  }
+}
+
+struct FwdProb { const float* X; long long x_slot; float* h; float* xhat; float* invstd; float* bstat; };
+struct FwdArgs {
+  FwdProb p[2];
+  const int* slot;
+  const float *W, *bias, *gamma, *beta;
+  long long ldx;
+  int B, H, K;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(64 * kWaves) void bn_linear_fwd_slab_kernel(FwdArgs g) {
+  __shared__ float red[kWaves][16];
+  __shared__ __attribute__((aligned(16))) float stage[kWaves][16 * kNT * kCK];   // wave-private images of the A operand
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const FwdProb me = g.p[blockIdx.y];
+  const int B = g.B, H = g.H;
+  const int col0 = blockIdx.x * 16, col = col0 + li, row0 = wave * 16 * kNT;
+  const long long sl = (g.slot && me.x_slot) ? (long long)*g.slot : 0;
+  v4f acc[kNT];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+  // epilogue operands first: their latency hides behind the GEMM
+  const float bias = col < H ? g.bias[col] : 0.f, gm = col < H ? g.gamma[col] : 0.f, bt = col < H ? g.beta[col] : 0.f;
+  slab_gemm<VEC, true>(acc, stage[wave], me.X + sl * me.x_slot, g.ldx, g.W, g.K, g.K, B, H, row0, col0, lane);
+  // acc[t][r] = z[row0 + 16 t + 4 lg + r][col] - bias
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[t][r] += bias;
+      if (row0 + 16 * t + 4 * lg + r < B) s += acc[t][r];
+    }
+  const float mean = col_sum(s, red, wave, li, lg) / (float)B;
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (row0 + 16 * t + 4 * lg + r < B) { const float d = acc[t][r] - mean; q += d * d; }
+  const float var = col_sum(q, red, wave, li, lg) / (float)B;       // biased: what normalises the batch
+  const float invstd = 1.0f / sqrtf(var + kEps);
+  if (col < H) {
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 16 * t + 4 * lg + r;
+        if (row >= B) continue;
+        const float xh = (acc[t][r] - mean) * invstd;
+        const float y = xh * gm + bt;
+        const long long idx = (long long)row * H + col;
+        me.h[idx] = y > 0.f ? y : 0.f;
+        if (me.xhat) me.xhat[idx] = xh;
+      }
+    if (wave == 0 && lg == 0) {
+      if (me.invstd) me.invstd[col] = invstd;
+      me.bstat[col] = mean;
+      me.bstat[H + col] = var;
+    }
+  }
+}
+
+struct BwdArgs {
+  Operand up[2]; const float* Wup[2]; long long ldw[2]; int nup;   // dh = sum_u G_u[B][K_u] . W_u[K_u][H]
+  float* xhat_dz;          // [B][H]: xhat in, dz out (same elements, same thread)
+  const float *invstd, *gamma, *beta;
+  float *dgamma, *dbeta, *sumsq_out;   // sumsq_out[slab]: sum of squares of this slab's dgamma | dbeta (may be null)
+  int B, H;
+};
+
+__global__ __launch_bounds__(64 * kWaves) void bn_linear_bwd_slab_kernel(BwdArgs g) {
+  __shared__ float red[kWaves][16];
+  __shared__ __attribute__((aligned(16))) float stage[kWaves][16 * kNT * kCK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const int B = g.B, H = g.H;
+  const int col0 = blockIdx.x * 16, col = col0 + li, row0 = wave * 16 * kNT;
+  const bool okc = col < H;
+  v4f acc[kNT], xh[kNT];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {     // xhat first: its round trip hides behind the GEMM
+    acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 16 * t + 4 * lg + r;
+      xh[t][r] = (okc && row < B) ? g.xhat_dz[(long long)row * H + col] : 0.f;
+    }
+  }
+  const float gm = okc ? g.gamma[col] : 0.f, bt = okc ? g.beta[col] : 0.f, is = okc ? g.invstd[col] : 0.f;
+  for (int u = 0; u < g.nup; ++u)
+    slab_gemm<true, false>(acc, stage[wave], g.up[u].p, g.up[u].ld, g.Wup[u], g.ldw[u], g.up[u].K, B, H, row0, col0, lane);
+  // dy = dh where the forward's output was positive (mask recomputed from xhat exactly as the forward computed y)
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool in = row0 + 16 * t + 4 * lg + r < B;
+      const float y = xh[t][r] * gm + bt;
+      const float dy = (in && y > 0.f) ? acc[t][r] : 0.f;
+      acc[t][r] = dy;
+      s1 += dy;
+      s2 += dy * xh[t][r];
+    }
+  const float sum_dy = col_sum(s1, red, wave, li, lg);
+  const float sum_dyx = col_sum(s2, red, wave, li, lg);
+  const float m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B, k = gm * is;
+  if (okc) {
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 16 * t + 4 * lg + r;
+        if (row < B) g.xhat_dz[(long long)row * H + col] = (acc[t][r] - m1 - xh[t][r] * m2) * k;
+      }
+    if (wave == 0 && lg == 0) { g.dgamma[col] = sum_dyx; g.dbeta[col] = sum_dy; }
+  }
+  if (g.sumsq_out && wave == 0) {
+    float q = (okc && lg == 0) ? sum_dyx * sum_dyx + sum_dy * sum_dy : 0.f;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);   // over the slab's 16 columns
+    if (lane == 0) g.sumsq_out[blockIdx.x] = q;
+  }
+}
+
+bool aligned16(const void* p) { return ((unsigned long long)p & 15ull) == 0; }
+
+}  // namespace
+
+bool bn_slab_ok(int B, int H) { return B >= 1 && B <= 16 * kNT * kWaves && H >= 16 && H % 16 == 0; }
+
+int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f) {
+  GCRL_CHECK_ARG(bn_slab_ok(f.B, f.H) && (f.n == 1 || f.n == 2) && f.K >= 1, "bn_linear_fwd_slab: B=%d H=%d K=%d n=%d", f.B, f.H, f.K, f.n);
+  FwdArgs g;
+  for (int i = 0; i < 2; ++i) {
+    const BnSlabFwdProb& p = f.p[i < f.n ? i : 0];
+    g.p[i] = FwdProb{p.X, p.x_slot, p.h, p.xhat, p.invstd, p.bstat};
+  }
+  g.slot = f.slot; g.W = f.W; g.bias = f.bias; g.gamma = f.gamma; g.beta = f.beta; g.ldx = f.ldx;
+  g.B = f.B; g.H = f.H; g.K = f.K;
+  bool vec = f.ldx % 4 == 0 && f.K % 4 == 0 && aligned16(f.W);
+  for (int i = 0; i < f.n; ++i) vec = vec && aligned16(f.p[i].X) && f.p[i].x_slot % 4 == 0;
+  const dim3 grid(f.H / 16, f.n);
+  if (vec) hipLaunchKernelGGL(bn_linear_fwd_slab_kernel<true>, grid, dim3(64 * kWaves), 0, st, g);
+  else hipLaunchKernelGGL(bn_linear_fwd_slab_kernel<false>, grid, dim3(64 * kWaves), 0, st, g);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_bn_linear_bwd_slab(hipStream_t st, const BnSlabBwd& b) {
+  GCRL_CHECK_ARG(bn_slab_ok(b.B, b.H) && (b.nup == 1 || b.nup == 2), "bn_linear_bwd_slab: B=%d H=%d nup=%d", b.B, b.H, b.nup);
+  BwdArgs g;
+  g.nup = b.nup;
+  for (int u = 0; u < 2; ++u) {
+    const int v = u < b.nup ? u : 0;
+    GCRL_CHECK_ARG(b.G[v] && b.W[v] && b.K[v] >= 1 && b.ldg[v] % 4 == 0 && aligned16(b.G[v]) && b.ldw[v] >= b.H,
+                   "bn_linear_bwd_slab: upstream operand %d (16-byte rows of G, W rows of at least H floats)", v);
+    g.up[u] = Operand{b.G[v], b.ldg[v], b.K[v]};
+    g.Wup[u] = b.W[v]; g.ldw[u] = b.ldw[v];
+  }
+  g.xhat_dz = b.xhat_dz; g.invstd = b.invstd; g.gamma = b.gamma; g.beta = b.beta;
+  g.dgamma = b.dgamma; g.dbeta = b.dbeta; g.sumsq_out = b.sumsq_out;
+  g.B = b.B; g.H = b.H;
+  hipLaunchKernelGGL(bn_linear_bwd_slab_kernel, dim3(b.H / 16), dim3(64 * kWaves), 0, st, g);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+}  // namespace gcrl

@@ -221,6 +221,34 @@ int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const 
                        float* scratch, float* sumsq_out = nullptr,    // sumsq_out[ceil(H/64)]: sum of squares of dgamma | dbeta per column block
                        const BnSync* sync = nullptr);   // sync: dz from the sums over every rank's rows; dgamma | dbeta stay this rank's share
 
+// ---- bn_slab.hip: [Linear -> BatchNorm1d(train) -> ReLU] as one launch per layer and direction (B <= 512) ----
+// Forward, one or two inputs of the same layer: h = relu(bn(X W^T + b)); xhat / invstd saved when non-null; the batch
+// statistics (mean [H], biased variance [H]) go to bstat — the running statistics are updated by the step's tanh-Gaussian
+// launch (BnRunning below), in input order.
+struct BnSlabFwdProb { const float* X; long long x_slot; float* h; float* xhat; float* invstd; float* bstat; };
+struct BnSlabFwd {
+  BnSlabFwdProb p[2]; int n;
+  const int* slot;                        // X rows at X + (*slot) * x_slot (null / x_slot 0: none)
+  const float *W, *bias, *gamma, *beta;   // W [H][K]
+  long long ldx;
+  int B, H, K;
+};
+// Backward of layer l: dh = sum_u G[u] . W[u] (the consuming layers: W[u] is [K[u]][ldw] row-major, its first H columns used),
+// ReLU mask from xhat, dz written over xhat, dgamma / dbeta, sumsq_out[H/16] (sum of squares of dgamma | dbeta per slab).
+struct BnSlabBwd {
+  const float* G[2]; long long ldg[2]; int K[2]; const float* W[2]; long long ldw[2]; int nup;
+  float* xhat_dz;
+  const float *invstd, *gamma, *beta;
+  float *dgamma, *dbeta, *sumsq_out;
+  int B, H;
+};
+bool bn_slab_ok(int B, int H);
+int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f);
+int launch_bn_linear_bwd_slab(hipStream_t st, const BnSlabBwd& b);
+// running_mean / running_var of `layers` BatchNorm layers from the batch statistics the slab launches left
+// (bstat[i]: [layers][2][H], input 0's batch first, then input 1's: the order of the reference's two forward calls)
+struct BnRunning { const float* bstat[2]; int n; float* rmean; float* rvar; int layers, H, B; };
+
 // SACActorModel.sample (src/model.py:125-141): mean/log_std head outputs -> action + log-prob.
 struct TanhGaussArgs {
   const StepCtrl* cur;
@@ -232,6 +260,7 @@ struct TanhGaussArgs {
   int B, A;
   int deterministic;       // act = tanh(mu), no log-prob
   unsigned long long seed; int rng_stream;
+  BnRunning run;           // layers > 0: one extra workgroup of the launch updates the running statistics
 };
 int launch_tanh_gauss_fwd(hipStream_t st, const TanhGaussArgs& a);
 int launch_tanh_gauss_fwd2(hipStream_t st, const TanhGaussArgs& a0, const TanhGaussArgs& a1);   // two heads, one launch

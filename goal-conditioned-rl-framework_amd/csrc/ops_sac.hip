@@ -403,8 +403,26 @@ __device__ inline void tanh_gauss_fwd_body(const TanhGaussArgs& a) {
   if (!a.deterministic && a.logp) a.logp[b] = lp;
 }
 
-__global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) { tanh_gauss_fwd_body(a); }
+// running statistics from the batch statistics of the slab launches (bn_slab.hip), momentum 0.1, unbiased variance
+__device__ inline void bn_running_update(const BnRunning& r) {
+  const float ub = r.B > 1 ? (float)r.B / (float)(r.B - 1) : 1.0f;
+  for (int e = threadIdx.x; e < r.layers * r.H; e += blockDim.x) {
+    const int l = e / r.H, c = e - l * r.H;
+    float rm = r.rmean[e], rv = r.rvar[e];
+    for (int i = 0; i < r.n; ++i) {
+      rm = (1.0f - kBnMomentum) * rm + kBnMomentum * r.bstat[i][(2 * l) * r.H + c];
+      rv = (1.0f - kBnMomentum) * rv + kBnMomentum * (r.bstat[i][(2 * l + 1) * r.H + c] * ub);
+    }
+    r.rmean[e] = rm; r.rvar[e] = rv;
+  }
+}
+
+__global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) {
+  if (a.run.layers && blockIdx.x == gridDim.x - 1) { bn_running_update(a.run); return; }   // (the launcher's extra workgroup)
+  tanh_gauss_fwd_body(a);
+}
 __global__ void tanh_gauss_fwd2_kernel(TanhGaussArgs a0, TanhGaussArgs a1) {
+  if (a0.run.layers && blockIdx.x == gridDim.x - 1) { if (blockIdx.y == 0) bn_running_update(a0.run); return; }
   if (blockIdx.y == 0) tanh_gauss_fwd_body(a0);
   else tanh_gauss_fwd_body(a1);
 }
@@ -756,13 +774,13 @@ int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const 
 }
 
 int launch_tanh_gauss_fwd(hipStream_t st, const TanhGaussArgs& a) {
-  hipLaunchKernelGGL(tanh_gauss_fwd_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(tanh_gauss_fwd_kernel, dim3((a.B + 255) / 256 + (a.run.layers ? 1 : 0)), dim3(256), 0, st, a);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
 
 int launch_tanh_gauss_fwd2(hipStream_t st, const TanhGaussArgs& a0, const TanhGaussArgs& a1) {
-  hipLaunchKernelGGL(tanh_gauss_fwd2_kernel, dim3((std::max(a0.B, a1.B) + 255) / 256, 2), dim3(256), 0, st, a0, a1);
+  hipLaunchKernelGGL(tanh_gauss_fwd2_kernel, dim3((std::max(a0.B, a1.B) + 255) / 256 + (a0.run.layers ? 1 : 0), 2), dim3(256), 0, st, a0, a1);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

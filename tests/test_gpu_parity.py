@@ -121,6 +121,65 @@ def test_batchnorm_relu_forward_backward_against_torch(lib, B, H):
         check("running_var", rvd, rv32, rv64)
 
 
+@pytest.mark.parametrize("B,H,K,ldx,Kup,ldg", [(512, 256, 256, 256, 256, 256), (512, 256, 24, 28, 3, 8), (300, 64, 21, 24, 64, 64),
+                                             (17, 32, 5, 5, 4, 8), (512, 16, 256, 256, 16, 16), (1, 16, 8, 8, 16, 16)])
+def test_linear_batchnorm_relu_slab_launches_against_torch(lib, B, H, K, ldx, Kup, ldg):
+    """[Linear -> BatchNorm1d(train) -> ReLU] (src/model.py:104-108) as the one-launch-per-direction slab form (csrc/bn_slab.hip):
+    forward from x, backward from the consuming layer's output gradient g_up (dh = g_up . w_up), against torch autograd in
+    fp32 with the fp64 run as the yardstick.  Shapes: the cfg 5 hidden layer, a first layer (K = 24 inside rows of 28 floats),
+    the heads as consumers (K_up = 3 inside rows of 8), element-wise operand loads (K = 21, ldx = 5), partial row tiles, one row."""
+    gen = torch.Generator().manual_seed(B * 7 + H * 3 + K)
+    x_full = torch.randn(B, ldx, generator=gen)
+    W = torch.randn(H, K, generator=gen) / K ** 0.5
+    bias = torch.randn(H, generator=gen) * 0.1
+    gamma = torch.rand(H, generator=gen) + 0.5
+    beta = torch.randn(H, generator=gen) * 0.2
+    g_full = torch.randn(B, ldg, generator=gen)
+    w_up = torch.randn(Kup, H, generator=gen) / Kup ** 0.5
+
+    def reference(dtype):
+        xx = x_full[:, :K].to(dtype)
+        Wd, bd = W.to(dtype), bias.to(dtype)
+        g, b = gamma.to(dtype).clone().requires_grad_(True), beta.to(dtype).clone().requires_grad_(True)
+        z = (xx @ Wd.T + bd).requires_grad_(True)
+        mean, var = z.mean(0), z.var(0, unbiased=False)
+        xhat = (z - mean) / torch.sqrt(var + 1e-5)
+        h = torch.relu(xhat * g + b)
+        dh = g_full[:, :Kup].to(dtype) @ w_up.to(dtype)
+        h.backward(dh)
+        return h.detach(), xhat.detach(), mean.detach(), var.detach(), z.grad, g.grad, b.grad
+
+    r32, r64 = reference(torch.float32), reference(torch.float64)
+    dev = dict(device="cuda", dtype=torch.float32)
+    h, xhat = torch.empty(B, H, **dev), torch.empty(B, H, **dev)
+    invstd, bstat = torch.empty(H, **dev), torch.empty(2, H, **dev)
+    dgamma, dbeta = torch.empty(H, **dev), torch.empty(H, **dev)
+    xd, Wd, bd, gd, btd, gud, wud = (t.cuda().contiguous() for t in (x_full, W, bias, gamma, beta, g_full, w_up))
+    assert lib.gcrl_bn_linear_slab_fwd_f32(xd.data_ptr(), ldx, Wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), btd.data_ptr(), B, H, K,
+                                           h.data_ptr(), xhat.data_ptr(), invstd.data_ptr(), bstat.data_ptr(), 1) == 0
+    torch.cuda.synchronize()
+    xhat_fwd = xhat.clone()
+    assert lib.gcrl_bn_linear_slab_bwd_f32(gud.data_ptr(), ldg, Kup, wud.data_ptr(), xhat.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
+                                           btd.data_ptr(), B, H, dgamma.data_ptr(), dbeta.data_ptr(), 1) == 0
+    torch.cuda.synchronize()
+
+    def check(name, got, a32, a64):
+        got, a32 = got.cpu().double(), a32.double()
+        scale = float(a64.abs().max()) + 1e-30
+        e_got, e_ref = float((got - a64).abs().max()) / scale, float((a32 - a64).abs().max()) / scale
+        assert e_got <= max(3.0 * e_ref, 1e-5), (name, B, H, K, e_got, e_ref)
+
+    check("h", h, r32[0], r64[0])
+    check("mean", bstat[0], r32[2], r64[2])
+    if B > 1:
+        check("xhat", xhat_fwd, r32[1], r64[1])
+        check("var", bstat[1], r32[3], r64[3])
+        check("dz", xhat, r32[4], r64[4])     # (written over xhat)
+    check("dgamma", dgamma, r32[5], r64[5])
+    check("dbeta", dbeta, r32[6], r64[6])
+    assert torch.allclose(invstd.cpu(), 1.0 / torch.sqrt(r32[3] + 1e-5), rtol=1e-5)
+
+
 # ------------------------------------------------------------------ HER rows / batches vs the reference's goldens
 CASES = ["full50", "done12", "single", "wrap300", "k8_two_envs", "tiny_cap100"]
 
