@@ -1194,11 +1194,11 @@ int build(gcrl_agent* a) {
       return S;
     };
     const bool on = B >= 1024 && B % 32 == 0 && !std::getenv("GCRL_NO_DW_SPLIT");
-    // rc_add_dw (DDPG / TD3 on the row-block path: every dW problem of a phase in one launch): measured, not kept — TD3 cfg 3
-    // 179.0 vs 177.6 us/step, DDPG cfg 2 68.6 vs 61.5: the launch carries the first layer's and the head's problems too
-    // (K = 27 / M = 1: element-wise fetch mode, one memory round trip per k-step), and those set its length (31.3 us either
-    // way by rocprofv3; the four 256 x 256 problems alone take 23 us at S = 8).  GCRL_DW_SPLIT_CHAIN=1 switches it on.
-    const bool chain_dw = a->rowchain && (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3) && std::getenv("GCRL_DW_SPLIT_CHAIN");
+    // rc_add_dw (DDPG / TD3 on the row-block path: every dW problem of a phase in one launch) at batch >= 2048: TD3 cfg 3
+    // 173.8 -> 168.7 us/step (the launch 31.2 -> 27.0 us by rocprofv3 at S = 8, 25.5 at S = 16; element-wise operands — the
+    // head's M = 1, the first layer's 27 columns — go through the pipelined k-loop too, in the plain loop they set the launch's
+    // length at one memory round trip per k-step).  Not at batch 1024 (DDPG cfg 2: 61.8 -> 67.8 us/step, 8 k-steps per split).
+    const bool chain_dw = a->rowchain && (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3) && B >= 2048;
     long long tc = 0, ta = 0, big_c = 0;
     for (const Lin& ln : a->critic.lin) { tc += tiles_of(ln); if (ln.out >= 64 && ln.in >= 64) big_c += tiles_of(ln); }
     for (const Lin& ln : a->actor.lin) ta += tiles_of(ln);

@@ -80,16 +80,13 @@ __device__ inline void fetch_tile(float (&reg)[kNR], const float* __restrict__ b
   } else {
     // element-wise mode (first layers with K = 25, heads with K = 1..4, unaligned operands): one buffer load per element,
     // no branch (with `if (r < R && k < K) v = base[...]` every load sat behind its own branch: 50 us per k-step in round 1)
-    if (!in) {   // (uniform)
-#pragma unroll
-      for (int p = 0; p < kNR; ++p) reg[p] = 0.f;
-      return;
-    }
+    // (`in` folded into the offsets, no early return: this fetch also runs inside the pipelined k-step, where any branch
+    // makes the compiler drain the loads in flight)
     const int tid = threadIdx.x, k0 = ks * kBK;
 #pragma unroll
     for (int p = 0; p < kNR; ++p) {
       const int e = tid + 256 * p, r = r0 + (e & 63), k = k0 + (e >> 6);
-      const bool ok = r < R && k < K;
+      const bool ok = in && r < R && k < K;
       const int off = ok ? (int)(((long long)r * rs + (long long)k * cs) * 4) : kOob;
       reg[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
     }
@@ -199,7 +196,10 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
   // (roles swapped in every MFMA — B fragment as the instruction's A: the accumulator holds the TRANSPOSED tile, see the epilogue)
 #define GCRL_MFMA(bv, av) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0)
 #define GCRL_SB() __builtin_amdgcn_sched_barrier(0)
-  if (MA != FETCH_GEN && MB != FETCH_GEN) {
+  // the pipelined loop for every problem with a reduction worth pipelining (element-wise operands included: a dW problem's
+  // head row or 27-column input — one memory round trip per k-step in the plain loop below, 16 of them per split, set the
+  // length of TD3's dW launch); the plain loop for a handful of k-steps (first layers' K = 25, heads' K = 1..4)
+  if ((MA != FETCH_GEN && MB != FETCH_GEN) || ksteps - ks0 >= 6) {
     // Vector modes (K a multiple of the k-step).  Software pipeline: LDS[ks & 1] holds tile ks; register stage (ks + 1) & 1
     // holds tile ks+1, requested two k-steps ago; the other stage (tile ks+2) stays in flight.  During the MFMAs of step ks:
     // tile ks+1 -> the other LDS buffer, then tile ks+3 is requested into the registers just freed.  Operand tiles come from
