@@ -355,6 +355,8 @@ void chain_mlp(gcrl_agent* a, Launches& ls, size_t at, const NetSpec& net, const
 // (:514) with the SAME actor parameters (the actor steps only afterwards), so on actor steps the two forwards are
 // independent: one GEMM launch carries both layers-l problems, one BatchNorm launch pair both batches (running
 // statistics: next_state's batch first, then the state's, as in the reference's call order).  11 launches instead of 22.
+// (Round 3, tried: the two heads computed inside the tanh-Gaussian launch, four lanes per row — one launch less, but SAC cfg 5
+// 211.0 vs 207.7 us/step and TQC cfg 4 unchanged: the sampling launch grew by what the GEMM launch had cost.  Not kept.)
 struct ActorFwd {
   const float* X0; long long x_slot;   // input rows (+ batch_slot * x_slot)
   bool save;                           // keep xhat / invstd / eps / std for the backward
@@ -802,6 +804,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
       GemmDesc dw = bwd_dw(a->zA, H, l == 0 ? (a->rowchain ? a->sa : a->spa) : a->hA_at(l - 1), l == 0 ? a->ldx : H, Ga, a->actor.lin[l], B);
       if (l == 0) { dw.slot = a->slot_ptr(); dw.b_slot = a->slot_x; }
       if (variant & V_FUSED_NORM) dw.sumsq_out = a->parts_a + a->part_off_a[l];
+      if (dw.M >= 64 && dw.N > 64) dw_split_form(a, dw, -1, l);   // (then the layer's dW and dX share ONE LDS-tiled launch)
       v.push_back(dw);
       if (l > 0) v.push_back(bwd_dx(a->zA, H, Pa, a->actor.lin[l], 0, H, a->gA[l & 1], H, B, MUL_NONE, nullptr, 0));
       TRY(launch_gemm_batch(st, v.data(), (int)v.size()));
@@ -1205,6 +1208,8 @@ int build(gcrl_agent* a) {
     const bool ens = !a->dw_batch_off && L >= 2 && (long long)C * (L - 1) * ((H + 63) / 64) * ((H + 1 + 63) / 64) >= 512;   // enqueue_critic's dw_batch
     if (on && chain_dw) { a->dw_split_c = pick(C * tc); a->dw_split_a = pick(ta); }
     else if (on && ens) a->dw_split_c = pick(C * big_c);
+    // the BatchNorm actor at batch >= 2048 (TQC cfg 4): a hidden layer's dW joins its dX problem's LDS-tiled launch
+    if (on && a->sac && B >= 2048 && !a->rowchain && !std::getenv("GCRL_NO_DW_SPLIT_ACTOR")) a->dw_split_a = pick((long long)((H + 63) / 64) * ((H + 63) / 64));
     if (const char* e = std::getenv("GCRL_DW_SPLIT")) {   // experiment knob
       const int S = std::max(1, std::min(16, std::atoi(e)));
       if (a->dw_split_c > 1) a->dw_split_c = S;
@@ -1246,6 +1251,10 @@ int build(gcrl_agent* a) {
   GCRL_HIP(hipMemset(a->metrics_dev, 0, (size_t)kMetricSlots * kMetricFloats * sizeof(float)));
   a->ticket_len.assign(kMetricSlots, 0);
 
+  // (the arenas were zero-filled on the null stream; the agent's streams are non-blocking, i.e. NOT ordered after it: without
+  // this wait the fills below can land before the arena's memset does and be wiped by it — seen once as an actor gradient of
+  // exactly 0 for a whole run, in a test that passes on its own)
+  GCRL_HIP(hipDeviceSynchronize());
   // constant upstream gradient of -Q.mean()
   TRY(launch_fill(a->stream, a->dq2, (long long)C * B * a->Q, -1.0f / (float)B));
   TRY(launch_fill(a->stream, a->alpha_dev, 1, 1.0f));  // exp(log_alpha = 0)
@@ -1446,6 +1455,7 @@ int gcrl_agent_init_weights(gcrl_agent* a, uint64_t seed, int recreate_alpha) {
     GCRL_HIP(hipMemset(a->adam_v + a->goff_alpha, 0, sizeof(float)));
     a->t_alpha = 0;
   }
+  GCRL_HIP(hipDeviceSynchronize());   // (null-stream memsets vs the agent's non-blocking streams)
   return GCRL_OK;
 }
 
@@ -1689,6 +1699,7 @@ int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_
   a->bn_sync_dp = nullptr; a->bn_sync_fn = nullptr; a->bn_sync_user = nullptr;
   if (a->sac && a->parts_a)   // (the slab launches and the BatchNorm launches fill different subsets of a layer's sum-of-squares slots)
     GCRL_HIP(hipMemset(a->parts_a + a->part_off_bn, 0, (size_t)a->L * a->bn_slots * sizeof(float)));
+  GCRL_HIP(hipDeviceSynchronize());
   if (world == 1) return GCRL_OK;
   // partial statistics of both co-scheduled forwards, every rank's slots, adjacent: ONE exchange per BatchNorm layer and pass
   const long long n1 = 2LL * world * ((a->B + 63) / 64) * a->H;
@@ -1698,6 +1709,7 @@ int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_
   a->bn_sync.world = world; a->bn_sync.rank = rank;
   a->bn_sync.exchange = bn_sync_exchange; a->bn_sync.user = a;
   a->bn_sync_dp = dp; a->bn_sync_fn = fn; a->bn_sync_user = user;
+  GCRL_HIP(hipDeviceSynchronize());
   return GCRL_OK;
 }
 

@@ -370,9 +370,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
   }
 }
 
+__device__ inline void tanh_gauss_fwd_row(const TanhGaussArgs& a, int b);
 __device__ inline void tanh_gauss_fwd_body(const TanhGaussArgs& a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
+  tanh_gauss_fwd_row(a, b);
+}
+__device__ inline void tanh_gauss_fwd_row(const TanhGaussArgs& a, int b) {
   const StepCtrl c = *a.cur;
   float* act = a.act + (long long)c.batch_slot * a.act_slot_stride + (long long)b * a.ld_act;
   float lp = 0.f;
