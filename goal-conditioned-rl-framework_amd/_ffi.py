@@ -148,6 +148,7 @@ PROTOTYPES = {
     "gcrl_her_process_step_g": (_i64, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "gcrl_sort_truncate_mean": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp]),
     "gcrl_gemm_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "gcrl_gemm_dw_split_f32": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "gcrl_bn_relu_fwd_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_bn_relu_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_bn_linear_slab_fwd_f32": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),

@@ -1,5 +1,6 @@
 // abi_misc.hip — small C-ABI helpers: stand-alone sort op, hipEvent timing, raw device memory.
 #include <cstring>
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,6 +40,48 @@ int gcrl_gemm_f32(const float* a, int64_t a_rs, int64_t a_cs, const float* b, in
   d.M = M; d.N = N; d.K = K;
   d.epi = act;
   return gcrl::launch_gemm_batch(as_stream(stream), &d, 1, shape);
+}
+
+int gcrl_gemm_dw_split_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, float* db, int out, int in, int batch,
+                           int ksplit, float* sumsq, void* stream) {
+  GCRL_CHECK_ARG(g && x && dw && db && out >= 1 && in >= 1 && batch >= 1 && ldg >= out && ldx >= in && ksplit >= 1 && ksplit <= 64,
+                 "gcrl_gemm_dw_split_f32: bad arguments");
+  hipStream_t st = as_stream(stream);
+  const long long tiles = (long long)((out + 63) / 64) * ((in + 63) / 64);
+  float *part = nullptr, *ss = nullptr;
+  unsigned int* tick = nullptr;
+  gcrl::GemmDesc d;
+  std::memset(&d, 0, sizeof(d));
+  d.A = g; d.a_rs = 1; d.a_cs = ldg;
+  d.B = x; d.b_rs = ldx; d.b_cs = 1;
+  d.C = dw; d.c_rs = in;
+  d.M = out; d.N = in + 1; d.K = batch;
+  d.ones_col = 1; d.col_out = db;
+  d.ksplit = ksplit;
+  int rc = GCRL_OK;
+  auto cleanup = [&]() { (void)hipStreamSynchronize(st); if (part) (void)hipFree(part); if (tick) (void)hipFree(tick); if (ss) (void)hipFree(ss); };
+  if (ksplit > 1) {
+    GCRL_HIP(hipMalloc((void**)&part, (size_t)tiles * ksplit * gcrl::kTiledPartStride * sizeof(float)));
+    if (hipMalloc((void**)&tick, (size_t)tiles * gcrl::kTicketStride * sizeof(unsigned int)) != hipSuccess ||
+        hipMemsetAsync(tick, 0, (size_t)tiles * gcrl::kTicketStride * sizeof(unsigned int), st) != hipSuccess) { cleanup(); return gcrl::fail(GCRL_ERR_HIP, "gcrl_gemm_dw_split_f32: scratch"); }
+    d.kpart = part; d.kticket = tick;
+  }
+  if (sumsq) {
+    if (hipMalloc((void**)&ss, (size_t)tiles * 4 * sizeof(float)) != hipSuccess ||
+        hipMemsetAsync(ss, 0, (size_t)tiles * 4 * sizeof(float), st) != hipSuccess) { cleanup(); return gcrl::fail(GCRL_ERR_HIP, "gcrl_gemm_dw_split_f32: scratch"); }
+    d.sumsq_out = ss;
+  }
+  rc = gcrl::launch_gemm_batch(st, &d, 1, 4);
+  if (!rc && ksplit > 1) rc = gcrl::launch_gemm_batch(st, &d, 1, 4);   // twice: the tickets must come back to zero by themselves
+  if (!rc && sumsq) {
+    std::vector<float> h((size_t)tiles * 4);
+    if (hipMemcpyAsync(h.data(), ss, h.size() * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = GCRL_ERR_HIP;
+    float tot = 0.f;
+    for (float v : h) tot += v;
+    if (!rc && hipMemcpyAsync(sumsq, &tot, sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) rc = GCRL_ERR_HIP;
+  }
+  cleanup();
+  return rc;
 }
 
 int gcrl_bn_relu_fwd_f32(const float* z, int B, int H, const float* gamma, const float* beta, float* h, float* xhat, float* invstd,

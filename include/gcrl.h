@@ -449,6 +449,16 @@ int gcrl_gemm_f32(const float* a_dev, int64_t a_rs, int64_t a_cs, const float* b
                   int64_t b_cs, float* c_dev, int64_t c_rs, const float* bias_dev, int M, int N,
                   int K, int act, int shape, void* stream);
 
+/* The weight / bias gradient of a Linear layer as the engine computes it at batch >= 1024 (csrc/gemm_tiled.h): dW [out, in] =
+ * G^T X and db [out] = column sums of G, for G [batch, ldg] (first `out` columns) and X [batch, ldx] (first `in` columns), on
+ * the LDS-tiled form with the reduction over the batch split over `ksplit` workgroups per 64x64 tile (1: no split) — partial
+ * tiles through a scratch array, a ticket per tile, the last arriver sums them in index order (deterministic).  Stand-alone
+ * for tests: allocates and frees its scratch per call (the engine keeps it per layer).  `sumsq_dev`, if not null, receives the
+ * sum of squares of dW | db (one float), as the fused global-norm clip consumes it.  Reference: the backward of
+ * `nn.Linear` (src/model.py:18,57,63). */
+int gcrl_gemm_dw_split_f32(const float* g_dev, int64_t ldg, const float* x_dev, int64_t ldx, float* dw_dev, float* db_dev,
+                           int out, int in, int batch, int ksplit, float* sumsq_dev, void* stream);
+
 /* nn.BatchNorm1d in training mode followed by ReLU, as the SAC / TQC actors run it per hidden layer
  * (src/model.py:106-108: Linear -> BatchNorm1d -> ReLU; eps 1e-5, momentum 0.1, running variance unbiased), forward and
  * backward as single problems.  All pointers are device memory, row-major [B, H]; H must be a multiple of 4 and every

@@ -66,6 +66,46 @@ def test_gemm_asymmetric_identity(lib):
         assert torch.equal(Cc, B)
 
 
+# ------------------------------------------------------------------ dW | db on the split LDS-tiled form
+@pytest.mark.parametrize("out,inn,batch,S,ldg,ldx", [
+    (512, 512, 2048, 2, 512, 512),      # TQC's ensemble batch: two splits per tile
+    (256, 256, 2048, 8, 256, 256),      # TD3's hidden layers
+    (256, 27, 2048, 8, 256, 28),        # a first layer: 27 input columns inside rows of 28 (element-wise B operand, pipelined loop)
+    (1, 256, 2048, 8, 1, 256),          # a critic's head: one output row (element-wise A operand)
+    (4, 256, 2048, 8, 4, 256),          # an actor's head
+    (70, 100, 300, 4, 72, 100),         # nothing a multiple of anything: partial tiles, a reduction of 18.75 k-steps
+    (130, 65, 1024, 3, 132, 68),        # three splits; tile columns 64 | 1
+    (256, 256, 2048, 1, 256, 256),      # no split: the row-sum bias gradient alone
+    (64, 64, 64, 4, 64, 64)])           # more splits than k-steps per split can fill: empty splits
+def test_dw_split_reduction_matches_fp64(lib, out, inn, batch, S, ldg, ldx):
+    """dW = G^T X, db = colsum(G) on csrc/gemm_tiled.h with the reduction split over S workgroups per tile (partials + ticket,
+    last arriver sums in index order) and the bias gradient taken from the A operand's row sums: against an fp64 product, at the
+    accuracy of a plain fp32 sum of `batch` terms; run twice inside the entry point (the tickets must reset themselves); the
+    sum-of-squares partials must add up to ||dW|db||^2; and the result must be bitwise reproducible."""
+    gen = torch.Generator().manual_seed(out * 3 + inn * 5 + batch)
+    G = torch.randn(batch, ldg, generator=gen)
+    X = torch.randn(batch, ldx, generator=gen)
+    Gd, Xd = G.cuda(), X.cuda()
+    runs = []
+    for _ in range(2):
+        dW = torch.full((out, inn), float("nan"), device="cuda")
+        db = torch.full((out,), float("nan"), device="cuda")
+        ss = torch.zeros(1, device="cuda")
+        assert lib.gcrl_gemm_dw_split_f32(Gd.data_ptr(), ldg, Xd.data_ptr(), ldx, dW.data_ptr(), db.data_ptr(), out, inn, batch, S, ss.data_ptr(), 1) == 0
+        torch.cuda.synchronize()
+        runs.append((dW.cpu(), db.cpu(), float(ss)))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    G64, X64 = G[:, :out].double(), X[:, :inn].double()
+    ref_w, ref_b = G64.T @ X64, G64.sum(0)
+    mag_w = (G64.abs().T @ X64.abs())          # the size of what is being summed, term by term
+    mag_b = G64.abs().sum(0)
+    dW, db, ss = runs[0]
+    assert float(((dW.double() - ref_w).abs() / mag_w).max()) < 2e-6
+    assert float(((db.double() - ref_b).abs() / mag_b).max()) < 2e-6
+    want_ss = float((ref_w ** 2).sum() + (ref_b ** 2).sum())
+    assert abs(ss - want_ss) <= 1e-5 * want_ss
+
+
 # ------------------------------------------------------------------ BatchNorm1d(train) + ReLU kernels vs torch (fp32 op, fp64 yardstick)
 @pytest.mark.parametrize("B,H", [(512, 256), (64, 64), (100, 48), (33, 4), (2048, 512), (2100, 68), (1, 8)])
 def test_batchnorm_relu_forward_backward_against_torch(lib, B, H):
