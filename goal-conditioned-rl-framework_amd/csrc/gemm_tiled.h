@@ -20,7 +20,15 @@
 //    (tools/occupancy_probe.hip: 32 256 B -> 4 resident, 31 744 B -> 5).  So a launch of exactly five tiles per CU ran four
 //    of them, then the fifth alone — the same two rounds as round 2's 36 KB kernel;
 //  * hence this form: k-step 16 = 16 KB of LDS (the register stages keep the same two-k-step = 32-k prefetch distance), five
-//    workgroups resident, one round.
+//    workgroups resident, one round;
+//  * what is left (same harness at this form, gpurun_out -> profiles/r03_gemm_tiled_ablation.txt): forward 52.8 us = 102 TFLOP/s;
+//    without the LDS reads 49.9, without the LDS stores 49.6, without the global fetches 50.4, without the barrier 52.6, with
+//    NONE of them (MFMAs + epilogue only) 46.9 us = 115 TFLOP/s.  By the workgroup stamps the main loop itself runs at the
+//    matrix pipe's rate (median 36.5 us for 1280 MFMAs per SIMD = 34 us at 2.4 GHz); the rest is the launch ramp (the median
+//    workgroup enters its loop 2.8 us after the first one started) and the epilogue, which all 1280 workgroups reach together:
+//    7 us from the last MFMA to the last store, 21 MB of results at once.  One round of lock-stepped workgroups cannot overlap
+//    its epilogue with anything; non-temporal result stores gain 3 % alone and lose 0.7 % inside TQC's step (the next layer
+//    re-reads the result).
 #pragma once
 #include "gemm_mfma.h"
 
@@ -406,7 +414,7 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
         if (mul != MUL_NONE) v[r] *= act_deriv(hv[i][r], mul);
         ss += v[r] * v[r];
       }
-      *(v4f*)(C + (long long)m * d.c_rs + nq) = v;
+      *(v4f*)(C + (long long)m * d.c_rs + nq) = v;      // (non-temporal here: +3 % alone, -0.7 % inside TQC's step — the next layer re-reads it)
     } else {
       const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
