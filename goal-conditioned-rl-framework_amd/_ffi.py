@@ -143,6 +143,8 @@ PROTOTYPES = {
     "gcrl_normalizer_normalize": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "gcrl_normalizer_get": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gcrl_normalizer_set": (C.c_int, [_vp, _vp, _vp, _f64, _f64]),
+    "gcrl_normalizer_set_float32": (C.c_int, [_vp, C.c_int]),
+    "gcrl_normalizer_is_float32": (C.c_int, [_vp]),
     "gcrl_agent_observe_act": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "gcrl_her_process_step": (_i64, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "gcrl_her_process_step_g": (_i64, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),

@@ -1904,8 +1904,8 @@ int gcrl_agent_observe_act(gcrl_agent* a, gcrl_normalizer* nz_obs, gcrl_normaliz
     ra.obs = d_f; ra.ld_obs = a->S; ra.out = a->dact; ra.ld_out = a->Apad;
     ra.n = n; ra.S = a->S; ra.A = A; ra.ldl = a->row_ldl;
     ra.D = D;
-    gcrl::normalizer_view(nz_obs, &ra.nz_mean, &ra.nz_var, nullptr, &ra.nz_clip);
-    gcrl::normalizer_view(nz_dg, &ra.nzg_mean, &ra.nzg_var, nullptr, &ra.nzg_clip);
+    gcrl::normalizer_view(nz_obs, &ra.nz_mean, &ra.nz_var, nullptr, &ra.nz_clip, &ra.nz_f32);
+    gcrl::normalizer_view(nz_dg, &ra.nzg_mean, &ra.nzg_var, nullptr, &ra.nzg_clip, &ra.nzg_f32);
     ra.post = mode == 1 ? 1 : (mode == 0 ? 2 : 3);
     ra.noise = with_noise ? d_noise : nullptr; ra.out64 = d_out;
     TRY(launch_rowchain_act(st, ra));

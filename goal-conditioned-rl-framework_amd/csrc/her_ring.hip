@@ -6,6 +6,7 @@
 //   sample    src/buffer.py:121-135  -> gcrl_her_sample (her_gather_kernel)
 // Record layout and ring indexing: her_ring.h.
 #include "her_ring.h"
+#include "norm_math.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -80,6 +81,7 @@ struct ProcArgs {
   double* mean; double* var; double* count; double clip;   // null mean: no normaliser
   double* gmean; double* gvar; double* gcount; double gclip;   // goal normaliser (null: goals stay raw)
   int update, gupdate, n, env0, flush_len, D, S, A, G, SA4, S4, RG;
+  int f32, gf32;   // loaded normalisers: float32 arithmetic (norm_math.h)
 };
 __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
   __shared__ double s_mean[128], s_den[128], s_gmean[kMaxG], s_gden[kMaxG];
@@ -97,14 +99,10 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
       float q = 0.f;
       for (int i = 0; i < rows; ++i) { const float d = __fsub_rn(dg[(size_t)i * G + j], bm); q = __fadd_rn(q, __fmul_rn(d, d)); }
       const float bv = __fdiv_rn(q, (float)rows);
-      const double c0 = *p.gcount, cb = (double)rows, total = c0 + cb;
-      const double delta = (double)bm - m;
-      const double nm = m + delta * cb / total;
-      const double M2 = v * c0 + (double)__fmul_rn(bv, (float)rows) + delta * delta * c0 * cb / total;
-      m = nm; v = M2 / total;
+      gcrl::norm_merge(m, v, bm, bv, rows, *p.gcount, p.gf32 != 0);
       p.gmean[j] = m; p.gvar[j] = v;
     }
-    s_gmean[j] = m; s_gden[j] = sqrt(v) + 1e-8;
+    s_gmean[j] = m; s_gden[j] = gcrl::norm_den(v, p.gf32 != 0);
   }
   if (p.mean) {
     for (int j = threadIdx.x; j < D; j += 256) {
@@ -117,14 +115,10 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
         float q = 0.f;
         for (int i = 0; i < rows; ++i) { const float d = __fsub_rn(obs[(size_t)i * D + j], bm); q = __fadd_rn(q, __fmul_rn(d, d)); }
         const float bv = __fdiv_rn(q, (float)rows);
-        const double c0 = *p.count, cb = (double)rows, total = c0 + cb;
-        const double delta = (double)bm - m;
-        const double nm = m + delta * cb / total;
-        const double M2 = v * c0 + (double)__fmul_rn(bv, (float)rows) + delta * delta * c0 * cb / total;
-        m = nm; v = M2 / total;
+        gcrl::norm_merge(m, v, bm, bv, rows, *p.count, p.f32 != 0);
         p.mean[j] = m; p.var[j] = v;
       }
-      s_mean[j] = m; s_den[j] = sqrt(v) + 1e-8;
+      s_mean[j] = m; s_den[j] = gcrl::norm_den(v, p.f32 != 0);
     }
   }
   __syncthreads();
@@ -140,13 +134,11 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
       if (cc < D) {
         const float x = o[(size_t)i * D + cc];
         if (!p.mean) return x;
-        const double z = ((double)x - s_mean[cc]) / s_den[cc];
-        return (float)fmin(fmax(z, -p.clip), p.clip);
+        return gcrl::norm_apply(x, s_mean[cc], s_den[cc], p.clip, p.f32 != 0);
       }
       const float x = g[(size_t)i * G + (cc - D)];
       if (!p.gmean) return x;
-      const double z = ((double)x - s_gmean[cc - D]) / s_gden[cc - D];
-      return (float)fmin(fmax(z, -p.gclip), p.gclip);
+      return gcrl::norm_apply(x, s_gmean[cc - D], s_gden[cc - D], p.gclip, p.gf32 != 0);
     };
     if (c < p.S) v = state_col(obs, dg, c);
     else if (c < p.S + p.A) v = pw[3 + (c - p.S)];
@@ -155,7 +147,7 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
     else if (c == o_r + 1) v = pw[2];
     else if (c >= RW) {
       v = pw[3 + p.A + (c - RW)];
-      if (p.gmean) v = (float)fmin(fmax(((double)v - s_gmean[c - RW]) / s_gden[c - RW], -p.gclip), p.gclip);   // normalize_goal(achieved_goal)
+      if (p.gmean) v = gcrl::norm_apply(v, s_gmean[c - RW], s_gden[c - RW], p.gclip, p.gf32 != 0);   // normalize_goal(achieved_goal)
     }
     p.stage[((long long)(p.env0 + i) * p.flush_len + t) * p.RG + c] = v;
   }
@@ -240,7 +232,7 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
         float df = __fsub_rn(rec_lds[li][p.RW + q], ag_lds[f * p.G + q]);
         acc = __fadd_rn(acc, __fmul_rn(df, df));
       }
-      float dist = __fsqrt_rn(acc);
+      float dist = sqrtf(acc);
       rew = (p.reward_kind == GCRL_REWARD_SPARSE) ? ((dist > p.thr) ? -1.0f : -0.0f) : -dist;
       if (p.rew_ext) rew = p.rew_ext[p.fut_off[e] + i * p.k + (rep - 1)];
       done = 0.f;
@@ -1032,12 +1024,12 @@ int64_t gcrl_her_process_step_g(gcrl_her* h, gcrl_normalizer* nz_obs, int update
   std::memset(&pa, 0, sizeof(pa));
   pa.stage = h->stage; pa.raw = h->ps_dev; pa.pay = h->ps_dev + raw;
   const double *mean = nullptr, *var = nullptr;
-  gcrl::normalizer_view(nz_obs, &mean, &var, &pa.count, &pa.clip);
+  gcrl::normalizer_view(nz_obs, &mean, &var, &pa.count, &pa.clip, &pa.f32);
   pa.mean = const_cast<double*>(mean); pa.var = const_cast<double*>(var);
   pa.update = (nz_obs && update_stats) ? 1 : 0;
   if (nz_dg) {
     const double *gm = nullptr, *gv = nullptr;
-    gcrl::normalizer_view(nz_dg, &gm, &gv, &pa.gcount, &pa.gclip);
+    gcrl::normalizer_view(nz_dg, &gm, &gv, &pa.gcount, &pa.gclip, &pa.gf32);
     pa.gmean = const_cast<double*>(gm); pa.gvar = const_cast<double*>(gv);
     pa.gupdate = update_goal_stats ? 1 : 0;
   }

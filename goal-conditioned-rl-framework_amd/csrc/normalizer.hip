@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "her_ring.h"
+#include "norm_math.h"
 
 struct gcrl_normalizer {
   int size = 0, device = 0;
@@ -27,12 +28,13 @@ struct gcrl_normalizer {
   float* xdev = nullptr;     // staging of host rows
   float* xpin = nullptr;
   size_t xcap = 0;           // floats
+  bool f32 = false;          // loaded statistics: float32 arithmetic from then on (norm_math.h)
 };
 
 namespace {
 
-// one thread per feature: the batch moments in float32 (numpy's order), the merge in float64
-__global__ void norm_update_kernel(const float* __restrict__ x, int n, int ld, int D, double* mean, double* var, double* count) {
+// one thread per feature: the batch moments in float32 (numpy's order), the merge in float64 — or float32 once loaded
+__global__ void norm_update_kernel(const float* __restrict__ x, int n, int ld, int D, double* mean, double* var, double* count, int f32) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= D) return;
   float s = 0.f;
@@ -44,31 +46,22 @@ __global__ void norm_update_kernel(const float* __restrict__ x, int n, int ld, i
     q = __fadd_rn(q, __fmul_rn(d, d));
   }
   const float bv = __fdiv_rn(q, (float)n);
-  const double c0 = *count, cb = (double)n;
-  const double total = c0 + cb;
-  const double delta = (double)bm - mean[j];
-  const double new_mean = mean[j] + delta * cb / total;               // (delta * count) / total_count
-  // `var * count`: a float32 array times a Python int stays float32 in numpy (1.x value-based casting and 2.x alike)
-  const double m_a = var[j] * c0, m_b = (double)__fmul_rn(bv, (float)n);
-  const double M2 = m_a + m_b + delta * delta * c0 * cb / total;      // ((square(delta) * self.count) * count) / total_count
-  mean[j] = new_mean;
-  var[j] = M2 / total;
+  double m = mean[j], v = var[j];
+  gcrl::norm_merge(m, v, bm, bv, n, *count, f32 != 0);
+  mean[j] = m;
+  var[j] = v;
 }
 __global__ void norm_count_kernel(double* count, int n) { *count = *count + (double)n; }
 
 // out[i][col0 + j] = float32(clip((x[i][j] - mean[j]) / (sqrt(var[j]) + 1e-8)))   (mean == null: plain copy)
 __global__ void norm_apply_kernel(const float* __restrict__ x, int n, int ld, int D, const double* mean, const double* var,
-                                  double clip, float* out, int ld_out, int col0) {
+                                  double clip, float* out, int ld_out, int col0, int f32) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * D) return;
   const int i = t / D, j = t - i * D;
   const float v = x[(long long)i * ld + j];
   float r = v;
-  if (mean) {
-    double z = ((double)v - mean[j]) / (sqrt(var[j]) + 1e-8);
-    z = fmin(fmax(z, -clip), clip);
-    r = (float)z;
-  }
+  if (mean) r = gcrl::norm_apply(v, mean[j], gcrl::norm_den(var[j], f32 != 0), clip, f32 != 0);
   out[(long long)i * ld_out + col0 + j] = r;
 }
 
@@ -89,12 +82,13 @@ hipStream_t pick_stream(void* s) { return s == GCRL_STREAM_LEGACY ? (hipStream_t
 }  // namespace
 
 namespace gcrl {
-void normalizer_view(const gcrl_normalizer* z, const double** mean, const double** var, double** count, double* clip) {
+void normalizer_view(const gcrl_normalizer* z, const double** mean, const double** var, double** count, double* clip, int* f32) {
   *mean = z ? z->mean : nullptr; *var = z ? z->var : nullptr; if (count) *count = z ? z->count : nullptr; *clip = z ? z->clip : 0.0;
+  if (f32) *f32 = (z && z->f32) ? 1 : 0;
 }
 // device rows in, statistics updated (used by the fused entry points)
 int normalizer_update_dev(gcrl_normalizer* z, const float* x_dev, int n, int ld, hipStream_t st) {
-  hipLaunchKernelGGL(norm_update_kernel, dim3((z->size + 63) / 64), dim3(64), 0, st, x_dev, n, ld, z->size, z->mean, z->var, z->count);
+  hipLaunchKernelGGL(norm_update_kernel, dim3((z->size + 63) / 64), dim3(64), 0, st, x_dev, n, ld, z->size, z->mean, z->var, z->count, z->f32 ? 1 : 0);
   hipLaunchKernelGGL(norm_count_kernel, dim3(1), dim3(1), 0, st, z->count, n);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
@@ -102,7 +96,7 @@ int normalizer_update_dev(gcrl_normalizer* z, const float* x_dev, int n, int ld,
 // out[:, col0 : col0 + D] = normalize(x) (z == null: copy)
 int normalizer_apply_dev(const gcrl_normalizer* z, const float* x_dev, int n, int ld, int D, float* out_dev, int ld_out, int col0, hipStream_t st) {
   hipLaunchKernelGGL(norm_apply_kernel, dim3((n * D + 255) / 256), dim3(256), 0, st, x_dev, n, ld, D, z ? z->mean : nullptr,
-                     z ? z->var : nullptr, z ? z->clip : 0.0, out_dev, ld_out, col0);
+                     z ? z->var : nullptr, z ? z->clip : 0.0, out_dev, ld_out, col0, (z && z->f32) ? 1 : 0);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
@@ -195,5 +189,14 @@ int gcrl_normalizer_set(gcrl_normalizer* z, const double* mean, const double* va
   z->clip = clip_range;
   return GCRL_OK;
 }
+
+int gcrl_normalizer_set_float32(gcrl_normalizer* z, int on) {
+  GCRL_CHECK_ARG(z, "gcrl_normalizer_set_float32: null handle");
+  GCRL_HIP(hipDeviceSynchronize());
+  z->f32 = on != 0;
+  return GCRL_OK;
+}
+
+int gcrl_normalizer_is_float32(const gcrl_normalizer* z) { return (z && z->f32) ? 1 : 0; }
 
 }  // extern "C"

@@ -134,7 +134,9 @@ __device__ inline void alpha_step(const AlphaStep& a, const StepCtrl& c) {
   float m = *a.m, v = *a.v;
   m = __fadd_rn(m, __fmul_rn(a.w1, __fsub_rn(g, m)));
   v = __fadd_rn(__fmul_rn(v, a.beta2), __fmul_rn(__fmul_rn(a.w2, g), g));
-  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), c.bc2s_alpha), a.eps);
+  // (sqrtf: correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt, as torch's CPU sqrt is; __fsqrt_rn is the
+  // NATIVE square root in this toolchain unless OCML_BASIC_ROUNDED_OPERATIONS is defined — 1 ulp off)
+  const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), c.bc2s_alpha), a.eps);
   p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-c.step_size_alpha, m), denom));
   *a.log_alpha = p; *a.m = m; *a.v = v;
   *a.alpha = expf(p);

@@ -325,7 +325,7 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
     if (decay != 1.0f) pi = __fmul_rn(pi, decay);
     mi = __fadd_rn(mi, __fmul_rn(w1, __fsub_rn(gi, mi)));
     const float vi = __fadd_rn(__fmul_rn(v_old, a.beta2), __fmul_rn(__fmul_rn(w2, gi), gi));
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2s), a.eps);
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), bc2s), a.eps);
     pi = __fadd_rn(pi, __fdiv_rn(__fmul_rn(-step_size, mi), denom));
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (pk) { *ti = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, t_old)); tp[i] = *ti; }

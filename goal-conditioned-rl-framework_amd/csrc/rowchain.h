@@ -285,6 +285,7 @@ struct RowActArgs {
   // mode 2 (post == 2): clip(tanh(y), -1, 1), mode 3: y   (select_action's arithmetic, src/agent.py:1345-1366, :253-270)
   const double* nz_mean; const double* nz_var; double nz_clip; int D;
   const double* nzg_mean; const double* nzg_var; double nzg_clip;
+  int nz_f32, nzg_f32;   // loaded normalisers: float32 arithmetic (norm_math.h)
   int post; const double* noise; double* out64;
 };
 int launch_rowchain_act(hipStream_t st, const RowActArgs& a);

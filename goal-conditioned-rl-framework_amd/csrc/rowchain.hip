@@ -9,6 +9,7 @@
 //       [s|a] -> q2 (= -loss*B); critic input-gradient chain down to the action columns;
 //       d(pre-tanh) = da*(1-a^2); actor gradient chain, saved for dW.
 #include "rowchain.h"
+#include "norm_math.h"
 
 #include <algorithm>
 
@@ -577,8 +578,8 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a)
           const int j = ob ? c : c - a.D;
           const double* v = ob ? a.nz_var : a.nzg_var;
           const double clip = ob ? a.nz_clip : a.nzg_clip;
-          double z = ((double)s_x.v[u] - m[j]) / (sqrt(v[j]) + 1e-8);
-          s_x.v[u] = (float)fmin(fmax(z, -clip), clip);
+          const bool f32 = (ob ? a.nz_f32 : a.nzg_f32) != 0;
+          s_x.v[u] = norm_apply(s_x.v[u], m[j], norm_den(v[j], f32), clip, f32);
         }
       }
     }

@@ -483,7 +483,8 @@ class _EngineAgent:
             nz = getattr(self.buffer, name, None)
             if nz is not None:
                 meta[name] = dict(mean=np.asarray(nz.mean, np.float64).tolist(), var=np.asarray(nz.var, np.float64).tolist(),
-                                  count=float(nz.count), clip_range=float(nz.clip_range))
+                                  count=float(nz.count), clip_range=float(nz.clip_range),
+                                  float32=bool(np.asarray(nz.mean).dtype == np.float32))   # (the regime after RunningNormalizer.load)
         with open(os.path.join(path, "meta.json"), "w") as f:
             json.dump(meta, f)
 
@@ -503,9 +504,10 @@ class _EngineAgent:
             if name in meta and nz is not None:
                 d = meta[name]
                 if hasattr(nz, "set_state"):     # DeviceRunningNormalizer: its statistics live on the device
-                    nz.set_state(np.array(d["mean"]), np.array(d["var"]), d["count"], d["clip_range"])
+                    nz.set_state(np.array(d["mean"]), np.array(d["var"]), d["count"], d["clip_range"], float32=bool(d.get("float32", False)))
                 else:
-                    nz.mean, nz.var = np.array(d["mean"]), np.array(d["var"])
+                    dt = np.float32 if d.get("float32", False) else np.float64
+                    nz.mean, nz.var = np.array(d["mean"], dtype=dt), np.array(d["var"], dtype=dt)
                     nz.count, nz.clip_range = d["count"], d["clip_range"]
         self._metric_cache.clear()
 

@@ -172,17 +172,26 @@ class DeviceRunningNormalizer:
         self._ffi.check(self._ffi.lib.gcrl_normalizer_get(self._h, mean.ctypes.data, var.ctypes.data, C.byref(cnt)))
         return mean, var, cnt.value
 
-    mean = property(lambda self: self._state()[0])
-    var = property(lambda self: self._state()[1])
+    mean = property(lambda self: self._state()[0].astype(np.float32) if self.float32 else self._state()[0])
+    var = property(lambda self: self._state()[1].astype(np.float32) if self.float32 else self._state()[1])
     count = property(lambda self: self._state()[2])
     clip_range = property(lambda self: self._clip)
 
-    def set_state(self, mean, var, count, clip_range=None):
+    def set_state(self, mean, var, count, clip_range=None, float32=None):
+        """float32: None = from the arrays' dtype (float32 arrays, as `load` makes them, select the reference's float32
+        regime: after `RunningNormalizer.load` the reference normalises and merges in float32, src/utils.py:108-117)."""
+        if float32 is None:
+            float32 = np.asarray(mean).dtype == np.float32 and np.asarray(var).dtype == np.float32
         mean = np.ascontiguousarray(mean, np.float64).reshape(-1)
         var = np.ascontiguousarray(var, np.float64).reshape(-1)
         if clip_range is not None:
             self._clip = float(clip_range)
         self._ffi.check(self._ffi.lib.gcrl_normalizer_set(self._h, mean.ctypes.data, var.ctypes.data, float(count), self._clip))
+        self._ffi.check(self._ffi.lib.gcrl_normalizer_set_float32(self._h, 1 if float32 else 0))
+
+    @property
+    def float32(self):
+        return bool(self._ffi.lib.gcrl_normalizer_is_float32(self._h))
 
     def update(self, x):
         x = np.ascontiguousarray(x, np.float32)
@@ -196,7 +205,7 @@ class DeviceRunningNormalizer:
         out = np.empty_like(x2)
         self._ffi.check(self._ffi.lib.gcrl_normalizer_normalize(self._h, x2.ctypes.data, x2.shape[0], self.size, 0, out.ctypes.data,
                                                                 self.size, 0, self._ffi.stream_handle()))
-        return out.astype(np.float64).reshape(x.shape)
+        return (out if self.float32 else out.astype(np.float64)).reshape(x.shape)     # (the reference's result dtype: float32 once loaded)
 
     def save(self, path: str):
         mean, var, count = self._state()
@@ -207,7 +216,8 @@ class DeviceRunningNormalizer:
     def load(self, path: str):
         with open(path, "r") as fh:
             d = yaml.safe_load(fh)
-        # (the reference keeps float32 copies after load, src/utils.py:113-114; the values are the same)
+        # the reference keeps float32 arrays after load (src/utils.py:113-114) and computes in float32 from then on: so does
+        # the handle (set_state sees the dtype)
         self.set_state(np.array(d["mean"], dtype=np.float32), np.array(d["var"], dtype=np.float32), float(d["count"]), float(d["clip_range"]))
 
 

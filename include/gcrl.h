@@ -407,6 +407,12 @@ int gcrl_normalizer_normalize(gcrl_normalizer* z, const float* x, int n, int ld,
                               int out_on_device, void* stream);
 int gcrl_normalizer_get(gcrl_normalizer* z, double* mean_host, double* var_host, double* count_host);   /* save :99-108 */
 int gcrl_normalizer_set(gcrl_normalizer* z, const double* mean_host, const double* var_host, double count, double clip_range);
+/* The reference's `RunningNormalizer.load` (src/utils.py:108-117) brings mean / var back as FLOAT32 arrays, and everything it
+ * computes afterwards — normalize and the merge of update — then runs in float32 (only the count stays a Python float).  `on`
+ * != 0 puts the handle in that regime (the statistics set before should be float32 values); pinned by
+ * tests/golden/normalizer_loaded.npz.  A created normaliser starts in the float64 regime. */
+int gcrl_normalizer_set_float32(gcrl_normalizer* z, int on);
+int gcrl_normalizer_is_float32(const gcrl_normalizer* z);
 /* select_action for one vector-env step from RAW host rows (src/env.py:348-355 + src/agent.py:1345-1366 / :253-270 /
  * :641-647): normalize_state_batch with the given normalisers (NULL: that part raw), actor, post-processing —
  * mode 0: clip(tanh(net), -1, 1); 1: clip(tanh(net) + noise, -1, 1), noise = np.random.normal draws [n, A] float64;

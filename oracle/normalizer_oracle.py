@@ -2,7 +2,8 @@
 
 CPU restatement of the reference's RunningNormalizer (src/utils.py:68-98), with the batch moments written out as
 the explicit float32 sequential sums numpy's axis-0 reductions perform — the order the device kernel
-(csrc/normalizer.hip) follows.  Pinned by tests/golden/normalizer.npz, captured from the reference's own class.
+(csrc/normalizer.hip) follows.  Pinned by tests/golden/normalizer.npz and normalizer_loaded.npz (the float32 regime after
+`load`), both captured from the reference's own class.
 """
 from __future__ import annotations
 
@@ -42,6 +43,14 @@ class RunningNormalizerOracle:
         m_b = var * count
         M2 = m_a + m_b + np.square(delta) * self.count * count / total_count
         self.mean, self.var, self.count = new_mean, M2 / total_count, total_count
+
+    def load_state(self, mean, var, count, clip_range):             # load(), :108-117, after the yaml has been read
+        """float32 arrays from here on: numpy's type rules then keep every later operation of update / normalize in float32
+        (Python scalars are weak), exactly as in the reference — the expressions below are the reference's own."""
+        self.mean = np.array(mean, dtype=np.float32)
+        self.var = np.array(var, dtype=np.float32)
+        self.count = float(count)
+        self.clip_range = float(clip_range)
 
     def normalize(self, x):                                         # :95-97
         z = (x - self.mean) / (np.sqrt(self.var) + 1e-8)

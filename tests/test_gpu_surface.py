@@ -396,6 +396,38 @@ def test_device_normalizer_bit_exact_vs_reference(gcrl):
 @pytest.mark.parametrize("g_norm", [False, True])
 @pytest.mark.parametrize("kind", ["DDPG", "TD3", "SAC"])
 def test_fused_acting_entries_equal_the_separate_calls(gcrl, kind, g_norm):
+    _fused_vs_separate(gcrl, kind, g_norm, False)
+
+
+@pytest.mark.parametrize("g_norm", [False, True])
+def test_fused_acting_entries_with_loaded_normalizers(gcrl, g_norm, tmp_path):
+    """The same with normalisers that were LOADED from the reference's yaml files (src/utils.py:108-117): float32 statistics
+    and float32 arithmetic from then on (what a resumed or evaluating run does) — host numpy and the device agree bit for bit."""
+    _fused_vs_separate(gcrl, "DDPG", g_norm, True, tmp_path)
+
+
+def test_device_normalizer_after_load_bit_exact_vs_reference(gcrl, tmp_path):
+    """csrc/normalizer.hip in the float32 regime against tests/golden/normalizer_loaded.npz, captured from the reference's
+    RunningNormalizer after load(): statistics, normalised probes (float32 results), merges — bit for bit."""
+    from conftest import load_golden
+    from gcrl_amd.src.utils import DeviceRunningNormalizer
+    g = load_golden("normalizer_loaded.npz")
+    path = tmp_path / "obs.yaml"
+    path.write_text(str(g["yaml_text"]))
+    nz = DeviceRunningNormalizer(int(g["D"][0]))
+    assert not nz.float32
+    nz.load(str(path))
+    assert nz.float32 and nz.mean.dtype == np.float32
+    assert np.array_equal(nz.mean, g["load_mean"]) and np.array_equal(nz.var, g["load_var"]) and nz.count == g["load_count"][0]
+    z = nz.normalize(g["probe"])
+    assert z.dtype == np.float32 and np.array_equal(z, g["load_norm"])
+    for i in range(len(g["sizes"])):
+        nz.update(g[f"x{i}"])
+        assert np.array_equal(nz.mean, g[f"mean{i}"]) and np.array_equal(nz.var, g[f"var{i}"]) and nz.count == g[f"count{i}"][0], i
+        assert np.array_equal(nz.normalize(g["probe"]), g[f"norm{i}"]), i
+
+
+def _fused_vs_separate(gcrl, kind, g_norm, loaded, tmp_path=None):
     """observe_act / process_step (one native call each per vector-env step, device normalisers) against the reference's
     call sequence made of the separate calls with host normalisers: same actions (same host RNG draws), same normaliser
     statistics, same ring rows bit for bit — including the episode flushes (HER relabel) inside the steps.  g_norm: goals
@@ -416,6 +448,15 @@ def test_fused_acting_entries_equal_the_separate_calls(gcrl, kind, g_norm):
     host, dev = build(False), build(True)
     for v, w in zip([host.actor] + host.critics, [dev.actor] + dev.critics):
         w.set_flat(v.flat())
+    if loaded:
+        for name, dim, sc in (("obs_normalizer", D, 3.0), ("dg_normalizer", G, 0.2)):
+            warm = RunningNormalizer(dim)
+            for _ in range(3):
+                warm.update((gen.standard_normal((40, dim)) * sc + 0.5).astype(np.float32))
+            warm.save(str(tmp_path / name / "n.yaml"))
+            for ag in (host, dev):
+                getattr(ag.buffer, name).load(str(tmp_path / name / "n.yaml"))
+            assert getattr(host.buffer, name).mean.dtype == np.float32 and getattr(dev.buffer, name).float32
 
     def obs_dict():
         return dict(observation=gen.standard_normal((n, D)).astype(np.float32) * 3 + 1,
@@ -449,7 +490,7 @@ def test_fused_acting_entries_equal_the_separate_calls(gcrl, kind, g_norm):
     assert np.array_equal(np.asarray(hn.mean), dn.mean) and np.array_equal(np.asarray(hn.var), dn.var) and hn.count == dn.count
     hg, dgn = host.buffer.dg_normalizer, dev.buffer.dg_normalizer
     assert np.array_equal(np.asarray(hg.mean), dgn.mean) and np.array_equal(np.asarray(hg.var), dgn.var) and hg.count == dgn.count
-    assert (hg.count > 1) == g_norm
+    assert (hg.count > (121 if loaded else 1)) == g_norm      # (loaded: warmed with 120 rows before)
     assert len(host.buffer) == len(dev.buffer) == min(1000, n * 246)      # 1000-row ring: wrapped
     for a, b in zip(host.buffer.rows(), dev.buffer.rows()):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -217,6 +217,30 @@ def test_normalizer_oracle_matches_reference_bitwise():
         assert np.array_equal(z, g[f"norm64_{i}"]) and np.array_equal(z.astype(np.float32), g[f"norm32_{i}"]), i
 
 
+def test_normalizer_oracle_after_load_matches_reference_bitwise():
+    """The float32 regime the reference enters with RunningNormalizer.load (src/utils.py:108-117): statistics, float32
+    normalised probes and float32 merges, against tests/golden/normalizer_loaded.npz (make_golden_norm_load.py)."""
+    import yaml
+    from oracle.normalizer_oracle import RunningNormalizerOracle
+    g = load_golden("normalizer_loaded.npz")
+    D = int(g["D"][0])
+    pre = RunningNormalizerOracle(D)
+    for i in range(int(g["n_pre"][0])):
+        pre.update(g[f"pre_x{i}"])
+    d = yaml.safe_load(str(g["yaml_text"]))
+    assert d["mean"] == pre.mean.tolist() and d["var"] == pre.var.tolist() and d["count"] == float(pre.count)   # what save() wrote
+    nz = RunningNormalizerOracle(D)
+    nz.load_state(d["mean"], d["var"], d["count"], d["clip_range"])
+    assert np.array_equal(nz.mean, g["load_mean"]) and np.array_equal(nz.var, g["load_var"]) and nz.count == g["load_count"][0]
+    z = nz.normalize(g["probe"])
+    assert z.dtype == np.float32 and np.array_equal(z, g["load_norm"])
+    for i in range(len(g["sizes"])):
+        nz.update(g[f"x{i}"])
+        assert nz.mean.dtype == np.float32 and nz.var.dtype == np.float32
+        assert np.array_equal(nz.mean, g[f"mean{i}"]) and np.array_equal(nz.var, g[f"var{i}"]) and nz.count == g[f"count{i}"][0], i
+        assert np.array_equal(nz.normalize(g["probe"]), g[f"norm{i}"]), i
+
+
 # ---------------------------------------------------------------- G10: PER buffer + weighted critic losses
 @pytest.mark.parametrize("tag", ["ddpg", "td3", "sac", "tqc"])
 def test_per_oracle_matches_reference(tag):
