@@ -83,6 +83,34 @@ def test_update_many_is_bitwise_repeated_update(gcrl, kind, H, L, B, use_graph):
         assert any(t[-1] != 0.0 for t in t_one) and t_one[0][-1] == 0.0       # alpha_loss: off for step <= alpha_min_steps, live after
 
 
+@pytest.mark.parametrize("kind,H,L,B", [("TD3", 256, 3, 2048), ("TQC", 512, 3, 2048), ("SAC", 256, 3, 512)])
+def test_update_many_is_bitwise_at_the_benchmarked_sizes(gcrl, kind, H, L, B):
+    """The same identity at BASELINE's shapes, where the round-3 forms run: dW reductions split over workgroups with a ticket
+    fix-up (TD3 / TQC at batch 2048: the result must not depend on which workgroup arrives last), the BatchNorm slab launches
+    (SAC at batch 512).  update_many (multi-step graphs) vs one update() per step: tuples and every parameter bitwise."""
+    gstep = 4
+    cfg = _cfg(kind, H, L, B, max_len=20000)
+
+    def build():
+        ag = _cls(gcrl, kind)(S, A, cfg, None, nenvs=2, gradient_step=gstep, rng="engine", seed=33)
+        gen = np.random.default_rng(5)
+        ep = 0
+        while len(ag.buffer) < B + 500:
+            for st in her_oracle.synthetic_episode(gen, 50, S, A):
+                ag.push_her(ep % 2, *st)
+            ep += 1
+        return ag
+
+    one, many = build(), build()
+    t_many = [tuple(float(x) for x in t) for t in many.update_many(1, 5)] + [tuple(float(x) for x in t) for t in many.update_many(6, 4)]
+    t_one = [tuple(float(x) for x in one.update(step)) for step in range(1, 10)]
+    for step, (a, b) in enumerate(zip(t_one, t_many), start=1):
+        assert a == b, (kind, step, a, b)
+    for x, y in zip(_state(one), _state(many)):
+        assert np.array_equal(x, y)
+    assert all(np.isfinite(v) for t in t_one for v in t)
+
+
 def _engine_noise(seed, stream, step_index, B, n_cols):
     """What the engine draws for the step planned `step_index`-th since the agent was created (csrc/agent.hip plan_step:
     counter base += 16 * B per step; csrc/ops.h hash_normal(seed + stream, base + b * A + j)): TD3 smoothing noise is stream 0,
