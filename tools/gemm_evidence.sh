@@ -10,11 +10,11 @@ mkdir -p $out
 {
   echo "== tools/occupancy_probe"; $root/tools/occupancy_probe
   echo "== tools/gemm_micro (HIP-event clock, 30 back-to-back launches)"
-  $root/tools/gemm_micro 10240 512 512 fwd; $root/tools/gemm_micro 10240 512 512 dx; $root/tools/gemm_micro 512 512 2048 dw 10
+  $root/tools/gemm_micro 10240 512 512 fwd; $root/tools/gemm_micro 10240 512 512 dx; $root/tools/gemm_micro 512 512 2048 dw 10 1; $root/tools/gemm_micro 512 512 2048 dw 10 2; $root/tools/gemm_micro 256 256 2048 dw 4 8
   $root/tools/gemm_micro 40960 512 512 fwd; $root/tools/gemm_micro 2048 512 512 fwd
 } > $out/gemm_micro.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-for mode in "10240 512 512 fwd" "10240 512 512 dx" "512 512 2048 dw 10"; do
+for mode in "10240 512 512 fwd" "10240 512 512 dx" "512 512 2048 dw 10 1" "512 512 2048 dw 10 2" "256 256 2048 dw 4 8"; do
   n=$(echo $mode | tr ' ' '_')
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$n -o p -- $root/tools/gemm_micro $mode > /dev/null 2>&1
   f=$(find $out/prof_$n -name "*kernel_stats.csv" | head -1)
