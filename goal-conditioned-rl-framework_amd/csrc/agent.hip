@@ -180,6 +180,7 @@ struct gcrl_agent {
   // update_n: batches 1..n-1 are drawn / uploaded / gathered AFTER the first step's launches have been issued (the host
   // draws ~2 us per batch from the MT stream: with all n batches up front the GPU idled ~40 us at the start of a cycle)
   struct { gcrl_her* her = nullptr; int n = 0; int slot = 0; int next = 0; } deferred;   // batches [next, n) not yet drawn
+  int head_batches = 2;       // batches drawn and gathered before a call's first launch (the rest: behind that many queued steps)
   std::vector<StepPlan> dp_plans;  // steps of the data-parallel cycle begun by gcrl_agent_dp_begin
   std::vector<DpSeg> dp_segs;      // ... as segments separated by gradient exchanges
   size_t dp_pos = 0;
@@ -975,8 +976,10 @@ int stage_injected(gcrl_agent* a, const gcrl_update_inputs* in, hipStream_t st, 
 
 // phase-0 entry of `n` steps: control table + indices upload, batch gather / pack
 // Draw and gather the batches a call left for later ([deferred.next, n); same MT stream order as drawing them all up
-// front).  Called once steps 0 and 1 have been issued: the GPU then has two steps (~110 us) queued, more than the host
-// needs for the draw, and the upload + gather run in order behind step 1.  (Round-2 history: gathering everything up
+// front).  Called once the head's steps have been issued, so that the GPU has more work queued than the host needs for the
+// draw, and the upload + gather run in order behind them.  Two steps for TD3 / SAC / TQC (>= 340 us); THREE for the DDPG
+// pipeline (round 3: with two — 110 us of GPU work — the trace of a 20-step call still showed 25 us of idle GPU before the
+// main gather, in every call and trainer cycle: the six launches of two steps cost the host ~30 us before it can start drawing).  (Round-2 history: gathering everything up
 // front delayed step 0 by the whole draw; deferring batches 1.. behind step 0 left the GPU idle for 21 us per call while
 // the host was still drawing; a second stream for the deferred part removed the wait on the driver's 20-step line but
 // cost 1-3 % in steady state and depended on how HIP maps streams to hardware queues.)
@@ -1033,8 +1036,9 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
     for (int i = 0; i < a->B; ++i) idx[i] = in->idx_host[i];
     bytes += (size_t)a->B * sizeof(uint32_t);
   } else if (!injected && !device_rng) {
-    defer_rest = defer_rest && n > 2;
-    const int now = defer_rest ? 2 : n;      // same MT stream order either way: batches 0 and 1 now, 2..n-1 once steps 0 and 1 are issued
+    const int head = a->head_batches;
+    defer_rest = defer_rest && n > head;
+    const int now = defer_rest ? head : n;   // same MT stream order either way: the head's batches now, the rest once that many steps are issued
     for (int i = 0; i < now; ++i)
       TRY(gcrl_mt_sample_indices(her->rng, (uint32_t)her->len, (uint32_t)a->B, idx + (size_t)i * a->B));
     bytes += (size_t)now * a->B * sizeof(uint32_t);
@@ -1046,7 +1050,7 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
   }
   const bool host_idx = !injected && !(device_rng && !explicit_idx);
   const int64_t rows_now = (int64_t)(a->deferred.her ? a->deferred.next : n) * a->B;
-  if (!injected && (!host_idx || rows_now <= 2 * a->B)) {
+  if (!injected && (!host_idx || rows_now <= (int64_t)a->head_batches * a->B)) {
     // One launch starts the call: the gather reads its (<= 2 B) indices straight from the pinned block and carries the
     // control block to the device (header + the n table entries in use) — before, two staged copies and their launch
     // gaps (19 us) preceded the first gather.
@@ -1172,6 +1176,8 @@ int build(gcrl_agent* a) {
     // TD3 once the batch fills the chip (cfg 3: 183.5 -> 178.4 us/step; below that the fused launch is the shorter chain)
     a->split_k = a->rowchain && c.kind == GCRL_AGENT_TD3 && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) >= 256 &&
                  !std::getenv("GCRL_NO_SPLIT_TD3");
+    a->head_batches = (c.kind == GCRL_AGENT_DDPG && c.pipeline_steps != 0) ? 3 : 2;
+    if (const char* e = std::getenv("GCRL_HEAD_BATCHES")) a->head_batches = std::max(1, std::min(8, std::atoi(e)));   // experiment knob
     a->dw_batch_off = std::getenv("GCRL_NO_DW_BATCH") != nullptr;
     a->bn_fused = std::getenv("GCRL_BN_FUSED") != nullptr;   // measured equal at cfg 5 (204.6 vs 203.6 us/step): off by default
     if (const char* e = std::getenv("GCRL_SPLIT_RG"))   // experiment knob: four digits, rows/4 per workgroup of the four launches
@@ -1610,7 +1616,7 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
         if (!a->deferred.her)
           while (j < m && j - i < 8 && var_of(j) == var_of(i)) ++j;
         TRY(run_step(a, st, var_of(i), 7, j - i));
-        if (i == 1 || j > 1) TRY(finish_deferred_draw(a, st));   // steps 0 and 1 are in flight: now draw and gather batches 2..m-1
+        if (j >= a->head_batches) TRY(finish_deferred_draw(a, st));   // the head's steps are in flight: now draw and gather the other batches
         i = j;
       }
     }
