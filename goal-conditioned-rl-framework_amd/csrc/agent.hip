@@ -977,8 +977,7 @@ int stage_injected(gcrl_agent* a, const gcrl_update_inputs* in, hipStream_t st, 
 // phase-0 entry of `n` steps: control table + indices upload, batch gather / pack
 // Draw and gather the batches a call left for later ([deferred.next, n); same MT stream order as drawing them all up
 // front).  Called once the head's steps have been issued, so that the GPU has more work queued than the host needs for the
-// draw, and the upload + gather run in order behind them.  Two steps for TD3 / SAC / TQC (>= 340 us); THREE for the DDPG
-// pipeline (round 3: with two — 110 us of GPU work — the trace of a 20-step call still showed 25 us of idle GPU before the
+// draw, and the upload + gather run in order behind them.  THREE steps (round 3: with two — 110 us of GPU work — the trace of a 20-step call still showed 25 us of idle GPU before the
 // main gather, in every call and trainer cycle: the six launches of two steps cost the host ~30 us before it can start drawing).  (Round-2 history: gathering everything up
 // front delayed step 0 by the whole draw; deferring batches 1.. behind step 0 left the GPU idle for 21 us per call while
 // the host was still drawing; a second stream for the deferred part removed the wait on the driver's 20-step line but
@@ -1176,7 +1175,7 @@ int build(gcrl_agent* a) {
     // TD3 once the batch fills the chip (cfg 3: 183.5 -> 178.4 us/step; below that the fused launch is the shorter chain)
     a->split_k = a->rowchain && c.kind == GCRL_AGENT_TD3 && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) >= 256 &&
                  !std::getenv("GCRL_NO_SPLIT_TD3");
-    a->head_batches = (c.kind == GCRL_AGENT_DDPG && c.pipeline_steps != 0) ? 3 : 2;
+    a->head_batches = 3;   // (TD3 at batch 2048: the host draws 38 x 2048 indices in ~390 us, more than two 170 us steps)
     if (const char* e = std::getenv("GCRL_HEAD_BATCHES")) a->head_batches = std::max(1, std::min(8, std::atoi(e)));   // experiment knob
     a->dw_batch_off = std::getenv("GCRL_NO_DW_BATCH") != nullptr;
     a->bn_fused = std::getenv("GCRL_BN_FUSED") != nullptr;   // measured equal at cfg 5 (204.6 vs 203.6 us/step): off by default
