@@ -153,8 +153,8 @@ PROTOTYPES = {
     "gcrl_gemm_dw_split_f32": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "gcrl_bn_relu_fwd_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gcrl_bn_relu_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
-    "gcrl_bn_linear_slab_fwd_f32": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
-    "gcrl_bn_linear_slab_bwd_f32": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "gcrl_bn_linear_slab_fwd_f32": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "gcrl_bn_linear_slab_bwd_f32": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "gcrl_her_set_reward_callback": (C.c_int, [_vp, _vp, _vp]),
     "gcrl_agent_dp_sync_bn": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "gcrl_hash_normal_fill": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, _vp, _vp]),

@@ -97,8 +97,25 @@ int gcrl_bn_relu_bwd_f32(const float* dh, const float* xhat, const float* invstd
   return gcrl::launch_bn_relu_bwd(as_stream(stream), dh, nullptr, xhat, invstd, gamma, beta, B, H, dz, dgamma, dbeta, scratch);
 }
 
+// row-group exchange scratch of the stand-alone slab entries (allocated on first use, process lifetime: test entry points)
+static int slab_scratch(int H, float** xchg, unsigned int** bar) {
+  static float* x = nullptr; static unsigned int* b = nullptr; static int cap = 0;
+  if (H > cap) {
+    GCRL_HIP(hipDeviceSynchronize());
+    if (x) (void)hipFree(x);
+    if (b) (void)hipFree(b);
+    GCRL_HIP(hipMalloc((void**)&x, (size_t)gcrl::bn_slab_xchg_floats(H) * sizeof(float)));
+    GCRL_HIP(hipMalloc((void**)&b, (size_t)gcrl::bn_slab_bar_words(H) * sizeof(unsigned int)));
+    GCRL_HIP(hipMemset(b, 0, (size_t)gcrl::bn_slab_bar_words(H) * sizeof(unsigned int)));
+    GCRL_HIP(hipDeviceSynchronize());
+    cap = H;
+  }
+  *xchg = x; *bar = b;
+  return GCRL_OK;
+}
+
 int gcrl_bn_linear_slab_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, const float* gamma, const float* beta,
-                                int B, int H, int K, float* h, float* xhat, float* invstd, float* bstat, void* stream) {
+                                int B, int H, int K, float* h, float* xhat, float* invstd, float* bstat, int row_split, void* stream) {
   GCRL_CHECK_ARG(x && w && bias && gamma && beta && h && bstat && K >= 1 && ldx >= K && gcrl::bn_slab_ok(B, H),
                  "gcrl_bn_linear_slab_fwd_f32: bad arguments (B <= 512, H a multiple of 16)");
   gcrl::BnSlabFwd f;
@@ -106,11 +123,12 @@ int gcrl_bn_linear_slab_fwd_f32(const float* x, int64_t ldx, const float* w, con
   f.n = 1;
   f.p[0] = gcrl::BnSlabFwdProb{x, 0, h, xhat, invstd, bstat};
   f.W = w; f.bias = bias; f.gamma = gamma; f.beta = beta; f.ldx = ldx; f.B = B; f.H = H; f.K = K;
+  if (row_split > 1) { f.rsplit = row_split; if (int rc = slab_scratch(H, &f.xchg, &f.bar)) return rc; }
   return gcrl::launch_bn_linear_fwd_slab(as_stream(stream), f);
 }
 
 int gcrl_bn_linear_slab_bwd_f32(const float* g_up, int64_t ldg, int K_up, const float* w_up, float* xhat_dz, const float* invstd,
-                                const float* gamma, const float* beta, int B, int H, float* dgamma, float* dbeta, void* stream) {
+                                const float* gamma, const float* beta, int B, int H, float* dgamma, float* dbeta, int row_split, void* stream) {
   GCRL_CHECK_ARG(g_up && w_up && xhat_dz && invstd && gamma && beta && dgamma && dbeta && K_up >= 1 && ldg >= K_up && gcrl::bn_slab_ok(B, H),
                  "gcrl_bn_linear_slab_bwd_f32: bad arguments (B <= 512, H a multiple of 16)");
   gcrl::BnSlabBwd b;
@@ -119,6 +137,7 @@ int gcrl_bn_linear_slab_bwd_f32(const float* g_up, int64_t ldg, int K_up, const 
   b.G[0] = g_up; b.ldg[0] = ldg; b.K[0] = K_up; b.W[0] = w_up; b.ldw[0] = H;
   b.xhat_dz = xhat_dz; b.invstd = invstd; b.gamma = gamma; b.beta = beta; b.dgamma = dgamma; b.dbeta = dbeta;
   b.B = B; b.H = H;
+  if (row_split > 1) { b.rsplit = row_split; if (int rc = slab_scratch(H, &b.xchg, &b.bar)) return rc; }
   return gcrl::launch_bn_linear_bwd_slab(as_stream(stream), b);
 }
 

@@ -139,10 +139,14 @@ struct gcrl_agent {
   bool bn_slab = false;
   bool slab_on() const { return bn_slab && bn_sync.world <= 1; }
   float* bn_bstat = nullptr;
+  float *bn_xchg = nullptr, *bn_bar = nullptr;   // row-group exchange of the slab launches (bn_slab.hip): partials, barrier words
+  int bn_rsplit = 1;          // > 1: K >= 128 slab launches split their rows over ceil(B/128) workgroups (GCRL_NO_BN_RSPLIT=1: off)
   int bn_slots = 0;           // sum-of-squares slots of one BatchNorm layer's dgamma | dbeta (16-column slabs)
   bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
   bool split_k = false;       // TD3: critic phase as role-parallel launches (agent_rowchain.inc)
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
+  bool rc_merge = false;      // ... forward and backward part in ONE launch each (part 3; GCRL_NO_RC_MERGE=1: two launches)
+  float* rc_bar = nullptr;    // barrier words of the row blocks [2][nblk][32]
   int split_rg[4] = {1, 1, 1, 1};
   int row_rg = 1, row_ldl = 0;
   float *wt = nullptr, *rc_gC = nullptr, *rc_gA = nullptr, *ybuf = nullptr;
@@ -385,6 +389,7 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
     sf.W = P + net.lin[l].w; sf.bias = P + net.lin[l].b; sf.gamma = P + net.bn_g[l]; sf.beta = P + net.bn_b[l];
     sf.ldx = l == 0 ? a->ldx : H;
     sf.B = B; sf.H = H; sf.K = net.lin[l].in;
+    sf.rsplit = sf.K >= 128 ? a->bn_rsplit : 1; sf.xchg = a->bn_xchg; sf.bar = reinterpret_cast<unsigned int*>(a->bn_bar);
     TRY(launch_bn_linear_fwd_slab(st, sf));
     if (extra && (size_t)l < extra->steps.size()) {   // (co-scheduled critic chains of the launch-per-layer schedule: their own launch here)
       std::vector<GemmDesc> v = extra->steps[l];
@@ -769,6 +774,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
         sb.dgamma = Ga + a->actor.bn_g[l]; sb.dbeta = Ga + a->actor.bn_b[l];
         sb.sumsq_out = (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * a->bn_slots : nullptr;
         sb.B = B; sb.H = H;
+        sb.rsplit = l == L - 1 ? 1 : a->bn_rsplit; sb.xchg = a->bn_xchg; sb.bar = reinterpret_cast<unsigned int*>(a->bn_bar);
         TRY(launch_bn_linear_bwd_slab(st, sb));
       }
       std::vector<GemmDesc> v;
@@ -1132,6 +1138,7 @@ int build(gcrl_agent* a) {
   // first ceil(H/64) of a layer's slots, the rest stay zero)
   a->bn_slots = (H + 15) / 16;
   a->bn_slab = a->sac && bn_slab_ok(B, H) && !std::getenv("GCRL_NO_BN_SLAB");
+  a->bn_rsplit = (a->bn_slab && B > 128 && !std::getenv("GCRL_NO_BN_RSPLIT")) ? 4 : 1;
   if (a->sac) { a->part_off_bn = a->nparts_a; a->nparts_a += L * a->bn_slots; }
   // work buffers
   const long long BH = (long long)B * H;
@@ -1151,7 +1158,7 @@ int build(gcrl_agent* a) {
       {&a->hC2, (long long)C * L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 15) / 16) * H},
       {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}, {&a->pi_buf, (long long)B * a->Apad},
       {&a->w_in, B}, {&a->td_abs, B},
-      {&a->bn_bstat, 2LL * 2 * L * H}, {&a->zN, BH}, {&a->hN, 2 * BH}, {&a->headN, (long long)B * 2 * a->Apad}, {&a->bn_partN, 2LL * ((B + 15) / 16) * H}};
+      {&a->bn_bstat, 2LL * 2 * L * H}, {&a->bn_xchg, bn_slab_xchg_floats(H)}, {&a->bn_bar, bn_slab_bar_words(H)}, {&a->zN, BH}, {&a->hN, 2 * BH}, {&a->headN, (long long)B * 2 * a->Apad}, {&a->bn_partN, 2LL * ((B + 15) / 16) * H}};
   // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
   {
     const long long per_a = (long long)round_up(S, 4) * H + (long long)(L - 1) * H * H;
@@ -1174,6 +1181,12 @@ int build(gcrl_agent* a) {
     a->split_roles = a->rowchain && c.kind == GCRL_AGENT_SAC && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) <= 256 &&
                      !std::getenv("GCRL_NO_SPLIT_ROLES");
     for (int i = 0; i < 4; ++i) a->split_rg[i] = a->row_rg;
+    {
+      const long long nblk = (B + 4 * a->row_rg - 1) / (4 * a->row_rg);
+      a->rc_merge = a->split_roles && 2 * C * nblk <= 512 && 2 * rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H, C) <= 160 * 1024 &&
+                    !std::getenv("GCRL_NO_RC_MERGE") && !std::getenv("GCRL_SPLIT_RG");
+      if (a->rc_merge) wants.push_back({&a->rc_bar, 2 * nblk * 32});
+    }
     // TD3 once the batch fills the chip (cfg 3: 183.5 -> 178.4 us/step; below that the fused launch is the shorter chain)
     a->split_k = a->rowchain && c.kind == GCRL_AGENT_TD3 && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) >= 256 &&
                  !std::getenv("GCRL_NO_SPLIT_TD3");

@@ -27,7 +27,8 @@ namespace {
 
 constexpr float kEps = 1e-5f;          // nn.BatchNorm1d defaults (as in ops_sac.hip)
 constexpr int kWaves = 8;              // 512 threads
-constexpr int kNT = 4;                 // 16-row tiles per wave: 8 x 4 x 16 = 512 rows
+// 16-row tiles per wave (template parameter NT): 4 = a workgroup holds all 512 rows of its 16 columns; 1 = a workgroup holds 128
+// rows and the row groups of a slab exchange their column partials through memory (see slab_exchange)
 #ifndef GCRL_SLAB_NS
 #define GCRL_SLAB_NS 4
 #endif
@@ -75,7 +76,7 @@ struct Operand { const float* p; long long ld; int K; };
 // slot quad ^ ((row >> 1) & 3) of their 64-byte row (conflict-free for these stores and for the fragment reads: 8 lanes on 8
 // consecutive rows at one k-quad), and lane (i, g) reads row 16 t + i, quad g back.  Wave-private: LDS instructions of one
 // wave execute in order, no barrier.  Two chunks of global loads stay in flight in registers.
-template <bool VEC, bool BROW>
+template <bool VEC, bool BROW, int kNT>
 __device__ inline void slab_gemm(v4f (&acc)[kNT], float* lds, const float* A, long long lda, const float* W, long long ldb, int K, int B,
                                  int ncols, int row0, int col0, int lane) {
   constexpr int kPast = 0x7ffffff0;
@@ -159,51 +160,120 @@ __device__ inline void slab_gemm(v4f (&acc)[kNT], float* lds, const float* A, lo
   }
 }
 
+// ---- row groups of a slab exchanging their column partials (NT = 1: a workgroup holds 128 rows) -------------------------------
+// With all 512 rows in one workgroup a K = 256 layer is ~7 us of MFMAs on 16-32 CUs.  Split over RS row groups the GEMM is
+// 1/RS of that on RS times the CUs, and the groups need each other's column partials ONCE per launch: every group publishes two
+// 16-float vectors with agent-scope stores, arrives at a counter, and waits until the generation word changes (the last arriver
+// resets the counter and bumps the generation: the words are ready for the next launch, graph replays included).  All RS x slabs x
+// inputs workgroups (<= 128 of 512 threads) are resident at once on 256 CUs, so a waiting group never keeps an awaited one from
+// being scheduled; the wait is BOUNDED all the same (kSpinMax polls of ~1 us), after which the launch poisons its statistics with
+// NaN instead of hanging.  Every group then merges the RS partials in index order: the same result in all of them.
+constexpr int kSc1 = 16;                 // agent-scope cache policy of the raw buffer builtins (gfx94x / gfx950)
+constexpr int kSpinMax = 1 << 20;
+struct Xchg { float* buf; unsigned int* bar; };     // buf [slot][RS][32] floats; bar [slot][32] words: [0] arrivals, [16] generation
+
+// a, b: this group's two values for column li (valid in wave 0, lanes lg == 0).  Returns false on a timed-out wait.
+__device__ inline bool slab_exchange(const Xchg& x, int slot, int RS, int r, float a, float b, int wave, int li, int lg, float (&oa)[4],
+                                     float (&ob)[4], unsigned int* s_flag) {
+  const __amdgpu_buffer_rsrc_t rs = wave_uniform_rsrc(x.buf + (long long)slot * RS * 32);
+  if (wave == 0 && lg == 0) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), rs, (r * 32 + li) * 4, 0, kSc1);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b), rs, (r * 32 + 16 + li) * 4, 0, kSc1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // s_waitcnt: the stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int* cnt = x.bar + (long long)slot * 32;
+    unsigned int* gen = cnt + 16;
+    const unsigned int g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int ok = 1;
+    if (t == (unsigned)(RS - 1)) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      int spins = 0;
+      while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0 && ++spins < kSpinMax) __builtin_amdgcn_s_sleep(4);
+      ok = spins < kSpinMax ? 1u : 0u;
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  const bool ok = *s_flag != 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    oa[j] = j < RS ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (j * 32 + li) * 4, 0, kSc1)) : 0.f;
+    ob[j] = j < RS ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (j * 32 + 16 + li) * 4, 0, kSc1)) : 0.f;
+  }
+  return ok;
+}
+
 struct FwdProb { const float* X; long long x_slot; float* h; float* xhat; float* invstd; float* bstat; };
 struct FwdArgs {
   FwdProb p[2];
   const int* slot;
   const float *W, *bias, *gamma, *beta;
   long long ldx;
-  int B, H, K;
+  int B, H, K, RS;
+  Xchg x;
 };
 
-template <bool VEC>
+template <bool VEC, int NT>
 __global__ __launch_bounds__(64 * kWaves) void bn_linear_fwd_slab_kernel(FwdArgs g) {
   __shared__ float red[kWaves][16];
-  __shared__ __attribute__((aligned(16))) float stage[kWaves][16 * kNT * kCK];   // wave-private images of the A operand
+  __shared__ unsigned int s_flag;
+  __shared__ __attribute__((aligned(16))) float stage[kWaves][16 * NT * kCK];   // wave-private images of the A operand
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-  const FwdProb me = g.p[blockIdx.y];
+  const int prob = NT == 1 ? (int)blockIdx.z : (int)blockIdx.y, rgrp = NT == 1 ? (int)blockIdx.y : 0;
+  const FwdProb me = g.p[prob];
   const int B = g.B, H = g.H;
-  const int col0 = blockIdx.x * 16, col = col0 + li, row0 = wave * 16 * kNT;
+  constexpr int kRowsWg = 16 * NT * kWaves;
+  const int col0 = blockIdx.x * 16, col = col0 + li, row0 = rgrp * kRowsWg + wave * 16 * NT;
+  const int nl = min(kRowsWg, B - rgrp * kRowsWg);              // rows of this workgroup (>= 1: launcher)
   const long long sl = (g.slot && me.x_slot) ? (long long)*g.slot : 0;
-  v4f acc[kNT];
+  v4f acc[NT];
 #pragma unroll
-  for (int t = 0; t < kNT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
   // epilogue operands first: their latency hides behind the GEMM
   const float bias = col < H ? g.bias[col] : 0.f, gm = col < H ? g.gamma[col] : 0.f, bt = col < H ? g.beta[col] : 0.f;
-  slab_gemm<VEC, true>(acc, stage[wave], me.X + sl * me.x_slot, g.ldx, g.W, g.K, g.K, B, H, row0, col0, lane);
+  slab_gemm<VEC, true, NT>(acc, stage[wave], me.X + sl * me.x_slot, g.ldx, g.W, g.K, g.K, B, H, row0, col0, lane);
   // acc[t][r] = z[row0 + 16 t + 4 lg + r][col] - bias
   float s = 0.f;
 #pragma unroll
-  for (int t = 0; t < kNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       acc[t][r] += bias;
       if (row0 + 16 * t + 4 * lg + r < B) s += acc[t][r];
     }
-  const float mean = col_sum(s, red, wave, li, lg) / (float)B;
+  float mean = col_sum(s, red, wave, li, lg) / (float)nl;      // of this workgroup's rows
   float q = 0.f;
 #pragma unroll
-  for (int t = 0; t < kNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (row0 + 16 * t + 4 * lg + r < B) { const float d = acc[t][r] - mean; q += d * d; }
-  const float var = col_sum(q, red, wave, li, lg) / (float)B;       // biased: what normalises the batch
+  float m2 = col_sum(q, red, wave, li, lg);
+  if (NT == 1 && g.RS > 1) {
+    // merge of the row groups' (n_j, mean_j, M2_j) in index order: mean = sum n_j mean_j / B, M2 = sum (M2_j + n_j (mean_j - mean)^2)
+    float pm[4], pq[4];
+    const bool ok = slab_exchange(g.x, prob * (H / 16) + (int)blockIdx.x, g.RS, rgrp, mean, m2, wave, li, lg, pm, pq, &s_flag);
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < g.RS) sm += pm[j] * (float)min(kRowsWg, B - j * kRowsWg);
+    mean = sm / (float)B;
+    m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < g.RS) { const float dm = pm[j] - mean; m2 += pq[j] + dm * dm * (float)min(kRowsWg, B - j * kRowsWg); }
+    if (!ok) mean = __builtin_nanf("");                        // a timed-out exchange must not pass for a result
+  }
+  const float var = m2 / (float)B;                              // biased: what normalises the batch
   const float invstd = 1.0f / sqrtf(var + kEps);
   if (col < H) {
 #pragma unroll
-    for (int t = 0; t < kNT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + 16 * t + 4 * lg + r;
@@ -214,7 +284,7 @@ __global__ __launch_bounds__(64 * kWaves) void bn_linear_fwd_slab_kernel(FwdArgs
         me.h[idx] = y > 0.f ? y : 0.f;
         if (me.xhat) me.xhat[idx] = xh;
       }
-    if (wave == 0 && lg == 0) {
+    if (rgrp == 0 && wave == 0 && lg == 0) {
       if (me.invstd) me.invstd[col] = invstd;
       me.bstat[col] = mean;
       me.bstat[H + col] = var;
@@ -227,19 +297,24 @@ struct BwdArgs {
   float* xhat_dz;          // [B][H]: xhat in, dz out (same elements, same thread)
   const float *invstd, *gamma, *beta;
   float *dgamma, *dbeta, *sumsq_out;   // sumsq_out[slab]: sum of squares of this slab's dgamma | dbeta (may be null)
-  int B, H;
+  int B, H, RS;
+  Xchg x;
 };
 
+template <int NT>
 __global__ __launch_bounds__(64 * kWaves) void bn_linear_bwd_slab_kernel(BwdArgs g) {
   __shared__ float red[kWaves][16];
-  __shared__ __attribute__((aligned(16))) float stage[kWaves][16 * kNT * kCK];
+  __shared__ unsigned int s_flag;
+  __shared__ __attribute__((aligned(16))) float stage[kWaves][16 * NT * kCK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   const int B = g.B, H = g.H;
-  const int col0 = blockIdx.x * 16, col = col0 + li, row0 = wave * 16 * kNT;
+  constexpr int kRowsWg = 16 * NT * kWaves;
+  const int rgrp = NT == 1 ? (int)blockIdx.y : 0;
+  const int col0 = blockIdx.x * 16, col = col0 + li, row0 = rgrp * kRowsWg + wave * 16 * NT;
   const bool okc = col < H;
-  v4f acc[kNT], xh[kNT];
+  v4f acc[NT], xh[NT];
 #pragma unroll
-  for (int t = 0; t < kNT; ++t) {     // xhat first: its round trip hides behind the GEMM
+  for (int t = 0; t < NT; ++t) {     // xhat first: its round trip hides behind the GEMM
     acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -249,11 +324,11 @@ __global__ __launch_bounds__(64 * kWaves) void bn_linear_bwd_slab_kernel(BwdArgs
   }
   const float gm = okc ? g.gamma[col] : 0.f, bt = okc ? g.beta[col] : 0.f, is = okc ? g.invstd[col] : 0.f;
   for (int u = 0; u < g.nup; ++u)
-    slab_gemm<true, false>(acc, stage[wave], g.up[u].p, g.up[u].ld, g.Wup[u], g.ldw[u], g.up[u].K, B, H, row0, col0, lane);
+    slab_gemm<true, false, NT>(acc, stage[wave], g.up[u].p, g.up[u].ld, g.Wup[u], g.ldw[u], g.up[u].K, B, H, row0, col0, lane);
   // dy = dh where the forward's output was positive (mask recomputed from xhat exactly as the forward computed y)
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int t = 0; t < kNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool in = row0 + 16 * t + 4 * lg + r < B;
@@ -263,20 +338,28 @@ __global__ __launch_bounds__(64 * kWaves) void bn_linear_bwd_slab_kernel(BwdArgs
       s1 += dy;
       s2 += dy * xh[t][r];
     }
-  const float sum_dy = col_sum(s1, red, wave, li, lg);
-  const float sum_dyx = col_sum(s2, red, wave, li, lg);
+  float sum_dy = col_sum(s1, red, wave, li, lg);
+  float sum_dyx = col_sum(s2, red, wave, li, lg);
+  if (NT == 1 && g.RS > 1) {
+    float pa[4], pb[4];
+    const bool ok = slab_exchange(g.x, (int)blockIdx.x, g.RS, rgrp, sum_dy, sum_dyx, wave, li, lg, pa, pb, &s_flag);
+    sum_dy = 0.f; sum_dyx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < g.RS) { sum_dy += pa[j]; sum_dyx += pb[j]; }
+    if (!ok) sum_dy = __builtin_nanf("");
+  }
   const float m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B, k = gm * is;
   if (okc) {
 #pragma unroll
-    for (int t = 0; t < kNT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + 16 * t + 4 * lg + r;
         if (row < B) g.xhat_dz[(long long)row * H + col] = (acc[t][r] - m1 - xh[t][r] * m2) * k;
       }
-    if (wave == 0 && lg == 0) { g.dgamma[col] = sum_dyx; g.dbeta[col] = sum_dy; }
+    if (rgrp == 0 && wave == 0 && lg == 0) { g.dgamma[col] = sum_dyx; g.dbeta[col] = sum_dy; }
   }
-  if (g.sumsq_out && wave == 0) {
+  if (g.sumsq_out && rgrp == 0 && wave == 0) {
     float q = (okc && lg == 0) ? sum_dyx * sum_dyx + sum_dy * sum_dy : 0.f;
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);   // over the slab's 16 columns
@@ -288,7 +371,15 @@ bool aligned16(const void* p) { return ((unsigned long long)p & 15ull) == 0; }
 
 }  // namespace
 
-bool bn_slab_ok(int B, int H) { return B >= 1 && B <= 16 * kNT * kWaves && H >= 16 && H % 16 == 0; }
+bool bn_slab_ok(int B, int H) { return B >= 1 && B <= 16 * 4 * kWaves && H >= 16 && H % 16 == 0; }
+long long bn_slab_xchg_floats(int H) { return 2LL * (H / 16) * 4 * 32; }
+long long bn_slab_bar_words(int H) { return 2LL * (H / 16) * 32; }
+
+// rows split: 1 (a workgroup holds all rows) or ceil(B / 128) row groups that exchange their partials (scratch required)
+static int row_split(int want, int B, const float* xchg, const unsigned int* bar) {
+  if (want <= 1 || B <= 128 || !xchg || !bar) return 1;
+  return (B + 127) / 128;
+}
 
 int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f) {
   GCRL_CHECK_ARG(bn_slab_ok(f.B, f.H) && (f.n == 1 || f.n == 2) && f.K >= 1, "bn_linear_fwd_slab: B=%d H=%d K=%d n=%d", f.B, f.H, f.K, f.n);
@@ -299,11 +390,19 @@ int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f) {
   }
   g.slot = f.slot; g.W = f.W; g.bias = f.bias; g.gamma = f.gamma; g.beta = f.beta; g.ldx = f.ldx;
   g.B = f.B; g.H = f.H; g.K = f.K;
+  g.RS = row_split(f.rsplit, f.B, f.xchg, f.bar);
+  g.x = Xchg{f.xchg, f.bar};
   bool vec = f.ldx % 4 == 0 && f.K % 4 == 0 && aligned16(f.W);
   for (int i = 0; i < f.n; ++i) vec = vec && aligned16(f.p[i].X) && f.p[i].x_slot % 4 == 0;
-  const dim3 grid(f.H / 16, f.n);
-  if (vec) hipLaunchKernelGGL(bn_linear_fwd_slab_kernel<true>, grid, dim3(64 * kWaves), 0, st, g);
-  else hipLaunchKernelGGL(bn_linear_fwd_slab_kernel<false>, grid, dim3(64 * kWaves), 0, st, g);
+  if (g.RS > 1) {
+    const dim3 grid(f.H / 16, g.RS, f.n);
+    if (vec) hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<true, 1>), grid, dim3(64 * kWaves), 0, st, g);
+    else hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<false, 1>), grid, dim3(64 * kWaves), 0, st, g);
+  } else {
+    const dim3 grid(f.H / 16, f.n);
+    if (vec) hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<true, 4>), grid, dim3(64 * kWaves), 0, st, g);
+    else hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<false, 4>), grid, dim3(64 * kWaves), 0, st, g);
+  }
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
@@ -322,7 +421,10 @@ int launch_bn_linear_bwd_slab(hipStream_t st, const BnSlabBwd& b) {
   g.xhat_dz = b.xhat_dz; g.invstd = b.invstd; g.gamma = b.gamma; g.beta = b.beta;
   g.dgamma = b.dgamma; g.dbeta = b.dbeta; g.sumsq_out = b.sumsq_out;
   g.B = b.B; g.H = b.H;
-  hipLaunchKernelGGL(bn_linear_bwd_slab_kernel, dim3(b.H / 16), dim3(64 * kWaves), 0, st, g);
+  g.RS = row_split(b.rsplit, b.B, b.xchg, b.bar);
+  g.x = Xchg{b.xchg, b.bar};
+  if (g.RS > 1) hipLaunchKernelGGL(bn_linear_bwd_slab_kernel<1>, dim3(b.H / 16, g.RS), dim3(64 * kWaves), 0, st, g);
+  else hipLaunchKernelGGL(bn_linear_bwd_slab_kernel<4>, dim3(b.H / 16), dim3(64 * kWaves), 0, st, g);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

@@ -234,6 +234,9 @@ struct BnSlabFwd {
   const float *W, *bias, *gamma, *beta;   // W [H][K]
   long long ldx;
   int B, H, K;
+  // rsplit > 1 (and B > 128): the rows split over ceil(B/128) workgroups per slab that exchange their column partials through
+  // `xchg` (bn_slab_xchg_floats(H) floats) and wait on `bar` (bn_slab_bar_words(H) words, zero-initialised) — bn_slab.hip
+  int rsplit; float* xchg; unsigned int* bar;
 };
 // Backward of layer l: dh = sum_u G[u] . W[u] (the consuming layers: W[u] is [K[u]][ldw] row-major, its first H columns used),
 // ReLU mask from xhat, dz written over xhat, dgamma / dbeta, sumsq_out[H/16] (sum of squares of dgamma | dbeta per slab).
@@ -243,8 +246,11 @@ struct BnSlabBwd {
   const float *invstd, *gamma, *beta;
   float *dgamma, *dbeta, *sumsq_out;
   int B, H;
+  int rsplit; float* xchg; unsigned int* bar;   // as in BnSlabFwd
 };
 bool bn_slab_ok(int B, int H);
+long long bn_slab_xchg_floats(int H);
+long long bn_slab_bar_words(int H);
 int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f);
 int launch_bn_linear_bwd_slab(hipStream_t st, const BnSlabBwd& b);
 // running_mean / running_var of `layers` BatchNorm layers from the batch statistics the slab launches left

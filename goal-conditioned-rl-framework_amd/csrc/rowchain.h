@@ -260,6 +260,9 @@ struct RowChainArgs {
   unsigned long long* clk;   // profiling: {first block start, last block end} in wall_clock64 ticks, or null
   // split form (launch_rowchain_split): the roles of a phase run in DIFFERENT workgroups, two launches per phase
   float* qt;       // [C][B] target-critic outputs (written by the forward launch, read by the backward launch)
+  // part 3 (both parts in ONE launch): barrier words of the row blocks, [2 phases][nblk][32] (word 0 arrivals, word 16 generation),
+  // zero-initialised; see rowchain_split_kernel
+  unsigned int* bar;
 };
 
 // Twin-critic phases as role-parallel launches (SAC; TD3 at small batches).  In the fused kernel a workgroup
@@ -270,6 +273,13 @@ struct RowChainArgs {
 // run each role in its own workgroups: L passes + (L-1) passes on the critical path, the whole chip busy.
 // Same per-row arithmetic in the same order as the fused kernel (bitwise the same results).
 //   phase 0 = K (critic phase), 1 = P (actor phase, critic-only form); part 1 | 2
+// part 3 = parts 1 and 2 in ONE launch (round 3): what part 2 needs from other workgroups is a handful of scalars per ROW BLOCK
+// (the target critics' outputs for the TD target; the other critic's Q for the min-selection), so the role workgroups of a row
+// block meet at a counter — published with agent-scope stores, a bounded wait on a generation word (the last arriver resets the
+// counter and bumps it: ready for the next launch, graph replays included) — and the online-critic workgroups go straight on to
+// their backward chains.  All role x block workgroups of a launch are resident at once (<= 2 per CU at SAC's 512 rows: the
+// launcher checks), so a waiting workgroup never keeps an awaited one off the chip; a wait that times out poisons the gradient
+// with NaN instead of hanging.  Same per-row arithmetic: bitwise the results of the two-launch form.
 int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part);
 
 // Batched actor inference (select_action, src/agent.py:1345-1366) as one row-block launch: 4 observation

@@ -378,6 +378,35 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
 }
 
 // ---- role-parallel form (rowchain.h: launch_rowchain_split) -------------------------------------------------
+// part 3: the role workgroups of a row block meet.  Every workgroup arrives (its agent-scope stores acknowledged first); those that
+// need the others' values wait for the generation word to change.  Returns false on a timed-out wait.
+constexpr int kRcSpinMax = 1 << 20;
+__device__ inline bool rc_meet(unsigned int* words, int arrivals, bool wait, unsigned int* s_flag) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // s_waitcnt: this wave's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int* cnt = words;
+    unsigned int* gen = words + 16;
+    const unsigned int g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int ok = 1;
+    if (t == (unsigned)(arrivals - 1)) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (wait) {
+      int spins = 0;
+      while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0 && ++spins < kRcSpinMax) __builtin_amdgcn_s_sleep(4);
+      ok = spins < kRcSpinMax ? 1u : 0u;
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+__device__ inline void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArgs a, int phase, int part) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -401,9 +430,13 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
   const long long BH = (long long)B * H;
   const int tid = threadIdx.x;
   const StepCtrl c = phase == 0 ? *a.cur_k : *a.cur_p;
-  if (phase == 0 && part == 1 && blockIdx.x == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
+  const bool merged = part == 3;                 // parts 1 and 2 in this launch (rowchain.h)
+  __shared__ unsigned int s_flag;
+  unsigned int* meet = merged ? a.bar + ((long long)phase * nblk + blk) * 32 : nullptr;
+  bool met = true;
+  if (phase == 0 && part != 2 && blockIdx.x == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
 
-  if (phase == 0 && part == 1 && role < C) {
+  if (phase == 0 && part != 2 && role < C) {
     // ---- target critic `role` on [ns | a'] (a' given: SAC; else the target actor runs first: TD3)
     const int k = role;
     const float* ns_rows = a.nsa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
@@ -440,8 +473,12 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
     h = mlp_hidden<RG>(a.tcritic[k], X0, X1, X2, ldl, part_ + R * 16, nullptr, BH, row0, rv);
     rows_head<RG>(h, ldl, H, hw_tc, H, hb + 16, 1, EPI_NONE, sm);
     __syncthreads();
-    if (tid < rv) a.qt[(long long)k * B + row0 + tid] = sm[tid * 16];
-  } else if (phase == 0 && part == 1) {
+    if (tid < rv) st_agent(a.qt + (long long)k * B + row0 + tid, sm[tid * 16]);
+    if (merged) rc_meet(meet, 2 * C, false, &s_flag);        // (the target roles only report in)
+    return;
+  }
+  int k2 = role;                                 // the critic whose backward part runs in this workgroup
+  if (phase == 0 && part != 2) {
     // ---- online critic `role - C` on [s | a]: forward, activations saved
     const int k = role - C;
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
@@ -453,9 +490,13 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
     rows_head<RG>(h, ldl, H, hw, H, hb + 18, 1, EPI_NONE, sm);
     __syncthreads();
     if (tid < rv) a.q[(long long)k * B + row0 + tid] = sm[tid * 16];
-  } else if (phase == 0) {
-    // ---- part 2: TD target, loss gradient and input-gradient chain of critic `role`
-    const int k = role;
+    if (!merged) return;
+    met = rc_meet(meet, 2 * C, true, &s_flag);               // both target critics' outputs of these rows are out
+    k2 = k;
+  }
+  if (phase == 0) {
+    // ---- part 2: TD target, loss gradient and input-gradient chain of critic `k2`
+    const int k = k2;
     const int L = a.critic[k].L;
     const float* hs = a.hC + (long long)k * L * BH;
     const float* hsrc = hs + (L - 1) * BH + row0 * H;
@@ -469,7 +510,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
       float g = 0.f;
       if (r < rv) {
         const float rew = a.rbuf[(long long)c.batch_slot * a.slot_rd + row0 + r], dn = a.dbuf[(long long)c.batch_slot * a.slot_rd + row0 + r];
-        const float t0 = a.qt[row0 + r], t1 = C > 1 ? a.qt[(long long)B + row0 + r] : t0;
+        const float t0 = ld_agent(a.qt + row0 + r), t1 = C > 1 ? ld_agent(a.qt + (long long)B + row0 + r) : t0;
         float tq = a.target_kind == TGT_DDPG ? t0 : fminf(t0, t1);
         if (a.target_kind == TGT_MIN_ENT) tq = __fsub_rn(tq, __fmul_rn(a.alpha, a.logp_next[row0 + r]));
         float y = __fadd_rn(rew, __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, dn)), tq));
@@ -478,6 +519,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
         const float diff = __fsub_rn(q, y);
         if (a.loss_kind == LOSS_MSE) g = (2.0f / (float)B) * diff;
         else { const float n1 = 1.0f / (float)B; g = (diff < -1.0f) ? -n1 : (diff > 1.0f ? n1 : n1 * diff); }
+        if (!met) g = __builtin_nanf("");          // a timed-out meeting must not pass for a result
         if (k == 0) a.y[row0 + r] = y;
         a.dq[(long long)k * B + row0 + r] = g;
       }
@@ -488,7 +530,9 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
     head_backward<RG>(XS, ldl, H, hw, 1, sm2, gsave + (L - 1) * BH + row0 * H, rv);
     __syncthreads();
     grad_chain<RG>(a.critic[k], XS, X1, X2, ldl, part_ + R * 16, hs, gsave, BH, row0, rv);
-  } else if (part == 1) {
+    return;
+  }
+  if (part != 2) {
     // ---- P, part 1: critic `role` forward on [s | pi(s)]
     const int k = role;
     const float* s_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
@@ -508,8 +552,11 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
     float* h = mlp_hidden<RG>(a.critic[k], X0, X1, X2, ldl, part_ + R * 16, a.hC2 + (long long)k * a.critic[k].L * BH, BH, row0, rv);
     rows_head<RG>(h, ldl, H, hw, H, hb, 1, EPI_NONE, sm);
     __syncthreads();
-    if (tid < rv) a.q2[(long long)k * B + row0 + tid] = sm[tid * 16];
-  } else {
+    if (tid < rv) st_agent(a.q2 + (long long)k * B + row0 + tid, sm[tid * 16]);
+    if (!merged) return;
+    met = rc_meet(meet, C, true, &s_flag);                   // the other critic's Q of these rows is out
+  }
+  {
     // ---- P, part 2: d(-mean min(q1, q2))/dq_k, input-gradient chain of critic `role` down to the action columns
     const int k = role;
     const int L = a.critic[k].L;
@@ -526,10 +573,11 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
       const int r = tid;
       float g = 0.f;
       if (r < rv) {
-        const float q0 = a.q2[row0 + r], q1 = C > 1 ? a.q2[(long long)B + row0 + r] : INFINITY;
+        const float q0 = ld_agent(a.q2 + row0 + r), q1 = C > 1 ? ld_agent(a.q2 + (long long)B + row0 + r) : INFINITY;
         const float gb = -1.0f / (float)B;
         const float w0 = q0 < q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
         g = k == 0 ? gb * w0 : gb * (1.f - w0);
+        if (!met) g = __builtin_nanf("");
       }
       sm2[r * 16] = g;
     }
@@ -654,12 +702,14 @@ int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
 int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part) {
   GCRL_CHECK_ARG(rg == 1 || rg == 2 || rg == 4, "rowchain: rows per block must be 4, 8 or 16");
   GCRL_CHECK_ARG(a.critic[0].H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16 && a.C >= 1 && a.C <= 2 && (phase == 0 || phase == 1) &&
-                     (part == 1 || part == 2) && (phase == 0 || a.p_critic_only) && a.qt,
+                     (part >= 1 && part <= 3) && (part != 3 || a.bar) && (phase == 0 || a.p_critic_only) && a.qt,
                  "rowchain split: unsupported shape (H=%d, A=%d, C=%d, phase %d part %d)", a.critic[0].H, a.A, a.C, phase, part);
   const size_t lds = rowchain_lds_bytes(rg, a.ldl, a.A, a.critic[0].H, a.C);
   GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain: %zu bytes of LDS needed", lds);
   const int nblk = (a.B + 4 * rg - 1) / (4 * rg);
-  const int roles = (phase == 0 && part == 1) ? 2 * a.C : a.C;
+  const int roles = (phase == 0 && part != 2) ? 2 * a.C : a.C;
+  // part 3: every workgroup of the launch must be resident at once (two per CU at most here: LDS allows it, checked above)
+  GCRL_CHECK_ARG(part != 3 || ((long long)roles * nblk <= 512 && 2 * lds <= 160 * 1024), "rowchain split: %d workgroups of %zu bytes of LDS cannot all be resident", roles * nblk, lds);
   auto go = [&](auto kern) -> int {
     static thread_local size_t raised = 0;
     if (lds > 64 * 1024 && lds > raised) {

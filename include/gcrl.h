@@ -485,13 +485,16 @@ int gcrl_bn_relu_bwd_f32(const float* dh_dev, const float* xhat_dev, const float
  *        invstd [H] (either may be null); bstat [2][H] = the batch mean and the biased batch variance (the running statistics
  *        are updated from these by the step's tanh-Gaussian launch).
  *   bwd: dh = g_up [B, ldg] (first K_up columns) . w_up [K_up, H]  — the input gradient of the consuming Linear layer —
- *        -> dz written over xhat_dz [B, H] (xhat on entry), dgamma [H], dbeta [H].  ldg % 4 == 0, g_up 16-byte aligned. */
+ *        -> dz written over xhat_dz [B, H] (xhat on entry), dgamma [H], dbeta [H].  ldg % 4 == 0, g_up 16-byte aligned.
+ *   row_split > 1 (and B > 128): the rows of a slab split over ceil(B / 128) workgroups that exchange their column partials once
+ *        per launch through agent-scope memory and a bounded wait (what the engine uses for its K >= 128 layers); <= 1: one
+ *        workgroup per slab holds every row. */
 int gcrl_bn_linear_slab_fwd_f32(const float* x_dev, int64_t ldx, const float* w_dev, const float* bias_dev,
                                 const float* gamma_dev, const float* beta_dev, int B, int H, int K, float* h_dev,
-                                float* xhat_dev, float* invstd_dev, float* bstat_dev, void* stream);
+                                float* xhat_dev, float* invstd_dev, float* bstat_dev, int row_split, void* stream);
 int gcrl_bn_linear_slab_bwd_f32(const float* g_up_dev, int64_t ldg, int K_up, const float* w_up_dev, float* xhat_dz_dev,
                                 const float* invstd_dev, const float* gamma_dev, const float* beta_dev, int B, int H,
-                                float* dgamma_dev, float* dbeta_dev, void* stream);
+                                float* dgamma_dev, float* dbeta_dev, int row_split, void* stream);
 
 /* The device-RNG mode's Gaussian: out[i] = hash_normal(seed, ctr0 + i), the counter-hash Box-Muller normal that stands in
  * for torch.randn_like (src/agent.py:175, TD3 target smoothing) and Normal.rsample's eps (src/model.py:134) whenever an

@@ -161,13 +161,16 @@ def test_batchnorm_relu_forward_backward_against_torch(lib, B, H):
         check("running_var", rvd, rv32, rv64)
 
 
+@pytest.mark.parametrize("rsplit", [1, 4])
 @pytest.mark.parametrize("B,H,K,ldx,Kup,ldg", [(512, 256, 256, 256, 256, 256), (512, 256, 24, 28, 3, 8), (300, 64, 21, 24, 64, 64),
-                                             (17, 32, 5, 5, 4, 8), (512, 16, 256, 256, 16, 16), (1, 16, 8, 8, 16, 16)])
-def test_linear_batchnorm_relu_slab_launches_against_torch(lib, B, H, K, ldx, Kup, ldg):
+                                             (17, 32, 5, 5, 4, 8), (512, 16, 256, 256, 16, 16), (1, 16, 8, 8, 16, 16), (129, 48, 128, 128, 48, 48)])
+def test_linear_batchnorm_relu_slab_launches_against_torch(lib, B, H, K, ldx, Kup, ldg, rsplit):
     """[Linear -> BatchNorm1d(train) -> ReLU] (src/model.py:104-108) as the one-launch-per-direction slab form (csrc/bn_slab.hip):
     forward from x, backward from the consuming layer's output gradient g_up (dh = g_up . w_up), against torch autograd in
     fp32 with the fp64 run as the yardstick.  Shapes: the cfg 5 hidden layer, a first layer (K = 24 inside rows of 28 floats),
-    the heads as consumers (K_up = 3 inside rows of 8), element-wise operand loads (K = 21, ldx = 5), partial row tiles, one row."""
+    the heads as consumers (K_up = 3 inside rows of 8), element-wise operand loads (K = 21, ldx = 5), partial row tiles, one row.
+    rsplit = 4: the rows of a slab split over ceil(B / 128) workgroups that exchange their partials inside the launch (129 rows:
+    a second group of ONE row); run twice so that the barrier words of the first launch are what the second one finds."""
     gen = torch.Generator().manual_seed(B * 7 + H * 3 + K)
     x_full = torch.randn(B, ldx, generator=gen)
     W = torch.randn(H, K, generator=gen) / K ** 0.5
@@ -195,13 +198,14 @@ def test_linear_batchnorm_relu_slab_launches_against_torch(lib, B, H, K, ldx, Ku
     invstd, bstat = torch.empty(H, **dev), torch.empty(2, H, **dev)
     dgamma, dbeta = torch.empty(H, **dev), torch.empty(H, **dev)
     xd, Wd, bd, gd, btd, gud, wud = (t.cuda().contiguous() for t in (x_full, W, bias, gamma, beta, g_full, w_up))
-    assert lib.gcrl_bn_linear_slab_fwd_f32(xd.data_ptr(), ldx, Wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), btd.data_ptr(), B, H, K,
-                                           h.data_ptr(), xhat.data_ptr(), invstd.data_ptr(), bstat.data_ptr(), 1) == 0
-    torch.cuda.synchronize()
-    xhat_fwd = xhat.clone()
-    assert lib.gcrl_bn_linear_slab_bwd_f32(gud.data_ptr(), ldg, Kup, wud.data_ptr(), xhat.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
-                                           btd.data_ptr(), B, H, dgamma.data_ptr(), dbeta.data_ptr(), 1) == 0
-    torch.cuda.synchronize()
+    for _ in range(2):
+        assert lib.gcrl_bn_linear_slab_fwd_f32(xd.data_ptr(), ldx, Wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), btd.data_ptr(), B, H, K,
+                                               h.data_ptr(), xhat.data_ptr(), invstd.data_ptr(), bstat.data_ptr(), rsplit, 1) == 0
+        torch.cuda.synchronize()
+        xhat_fwd = xhat.clone()
+        assert lib.gcrl_bn_linear_slab_bwd_f32(gud.data_ptr(), ldg, Kup, wud.data_ptr(), xhat.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
+                                               btd.data_ptr(), B, H, dgamma.data_ptr(), dbeta.data_ptr(), rsplit, 1) == 0
+        torch.cuda.synchronize()
 
     def check(name, got, a32, a64):
         got, a32 = got.cpu().double(), a32.double()
