@@ -145,6 +145,7 @@ struct gcrl_agent {
   bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
   bool split_k = false;       // TD3: critic phase as role-parallel launches (agent_rowchain.inc)
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
+  int n_cus = 0;              // compute units of the device (residency checks of the launches whose workgroups meet)
   bool rc_merge = false;      // ... forward and backward part in ONE launch each (part 3; GCRL_NO_RC_MERGE=1: two launches)
   float* rc_bar = nullptr;    // barrier words of the row blocks [2][nblk][32]
   int split_rg[4] = {1, 1, 1, 1};
@@ -1138,7 +1139,14 @@ int build(gcrl_agent* a) {
   // first ceil(H/64) of a layer's slots, the rest stay zero)
   a->bn_slots = (H + 15) / 16;
   a->bn_slab = a->sac && bn_slab_ok(B, H) && !std::getenv("GCRL_NO_BN_SLAB");
-  a->bn_rsplit = (a->bn_slab && B > 128 && !std::getenv("GCRL_NO_BN_RSPLIT")) ? 4 : 1;
+  {
+    // (the row groups of a slab wait for each other inside the launch: all (H/16) x 4 x 2 workgroups of 512 threads must be
+    // resident at once — at most two per CU on THIS device's CUs, bn_slab.hip)
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess) cus = 0;
+    a->n_cus = cus;
+    a->bn_rsplit = (a->bn_slab && B > 128 && (long long)(H / 16) * 4 * 2 <= 2LL * cus && !std::getenv("GCRL_NO_BN_RSPLIT")) ? 4 : 1;
+  }
   if (a->sac) { a->part_off_bn = a->nparts_a; a->nparts_a += L * a->bn_slots; }
   // work buffers
   const long long BH = (long long)B * H;
@@ -1183,7 +1191,9 @@ int build(gcrl_agent* a) {
     for (int i = 0; i < 4; ++i) a->split_rg[i] = a->row_rg;
     {
       const long long nblk = (B + 4 * a->row_rg - 1) / (4 * a->row_rg);
-      a->rc_merge = a->split_roles && 2 * C * nblk <= 512 && 2 * rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H, C) <= 160 * 1024 &&
+      // (workgroups that wait for each other inside a launch must all be resident at once: two per CU by LDS on THIS device's CUs)
+      const int cus = a->n_cus;
+      a->rc_merge = a->split_roles && 2 * C * nblk <= 2LL * cus && 2 * rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H, C) <= 160 * 1024 &&
                     !std::getenv("GCRL_NO_RC_MERGE") && !std::getenv("GCRL_SPLIT_RG");
       if (a->rc_merge) wants.push_back({&a->rc_bar, 2 * nblk * 32});
     }
