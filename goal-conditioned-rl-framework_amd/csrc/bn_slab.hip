@@ -37,16 +37,17 @@ constexpr int kCK = 16;                // k per chunk (the k-permutation of gemm
 
 // 4 consecutive floats at byte offset `off` (one 16-byte load, or element loads when the operand is not 16-byte
 // addressable); offsets past the descriptor's extent return 0
+// (`soff`: a wave-uniform byte offset — the chunk's — added by the load instruction itself: no vector arithmetic per chunk)
 template <bool VEC>
-__device__ inline v4f ld4b(__amdgpu_buffer_rsrc_t rs, int off) {
+__device__ inline v4f ld4b(__amdgpu_buffer_rsrc_t rs, int off, int soff) {
   v4f r;
   if (VEC) {
-    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) r[q] = __uint_as_float(a[q]);
   } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * q, 0, 0));
+    for (int q = 0; q < 4; ++q) r[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * q, soff, 0));
   }
   return r;
 }
@@ -91,23 +92,30 @@ __device__ inline void slab_gemm(v4f (&acc)[kNT], float* lds, const float* A, lo
   const int rd_off = li * 16 + ((lg ^ ((li >> 1) & 3)) << 2);
   const int col = min(col0 + li, ncols - 1);
   const int woff = BROW ? (int)(((long long)col * ldb + 4 * lg) * 4) : (int)(((long long)(4 * lg) * ldb + col) * 4);
+  const int ldb4 = (int)(ldb * 4);                // (operands are < 2 GiB)
   const int nfull = K / kCK;                      // whole chunks: the pipelined loop; a partial last chunk follows on its own
   // kNS register stages of global loads in flight (the loops over them are fully unrolled: compile-time stage indices —
   // a stage picked at run time would be a dynamically indexed array, i.e. scratch memory).  The operand was written by the
   // previous launch and comes from the memory side of this XCD's L2: ~2 us a round trip; with two chunks in flight a K = 256
   // layer took 17.8 us (one round trip per two chunks), measured.
   v4f a[kNS][kNT], w[kNS];
-  auto load = [&](int c, int nc, v4f (&a)[kNT], v4f& w) {   // unconditional: chunks >= nc get offsets past the extents (zeros, no traffic)
+  // unconditional: chunks >= nc get offsets past the extents (zeros, no traffic).  A WHOLE chunk's offset rides in the load
+  // instruction's scalar offset (no vector arithmetic per chunk: a 64-bit multiply per W load was 2.3 us of the backward launch's
+  // 15); the scalar offset is not part of the descriptor's range check, so the partial last chunk — whose reads do run past
+  // rows and past the operand — keeps everything in the checked vector offset.
+  auto load = [&](int c, int nc, v4f (&a)[kNT], v4f& w, bool tail = false) {
     const bool in = c < nc;
     const int k0 = c * kCK;
+    const int so = (in && !tail) ? k0 * 4 : 0, vo = tail ? k0 * 4 : 0;
 #pragma unroll
-    for (int t = 0; t < kNT; ++t) a[t] = ld4b<VEC>(rsa, in ? aoff[t] + k0 * 4 : kPast);
+    for (int t = 0; t < kNT; ++t) a[t] = ld4b<VEC>(rsa, in ? aoff[t] + vo : kPast, so);
     if (BROW) {
-      w = ld4b<VEC>(rsw, in ? woff + k0 * 4 : kPast);
+      w = ld4b<VEC>(rsw, in ? woff + vo : kPast, so);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        w[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsw, (in && k0 + 4 * lg + q < K) ? woff + (int)((long long)(k0 + q) * ldb * 4) : kPast, 0, 0));
+        w[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsw, (in && k0 + 4 * lg + q < K) ? woff + (tail ? (k0 + q) * ldb4 : 0) : kPast,
+                                                                    (in && !tail) ? (k0 + q) * ldb4 : 0, 0));
     }
   };
   auto mac = [&](const v4f (&a)[kNT], const v4f& w) {
@@ -135,7 +143,7 @@ __device__ inline void slab_gemm(v4f (&acc)[kNT], float* lds, const float* A, lo
   // the partial last chunk is requested FIRST, into registers of its own (after the loop it would be one more exposed round
   // trip: the whole launch, for a first layer with K = 22 or the heads' K = 3)
   v4f at[kNT], wt;
-  load(nfull, (K % kCK) ? nfull + 1 : 0, at, wt);
+  load(nfull, (K % kCK) ? nfull + 1 : 0, at, wt, /*tail=*/true);
   // (the prologue's loads in stage order too: the loop header's wait count is the minimum over both ways into the loop)
 #pragma unroll
   for (int s = 0; s < kNS; ++s) { __builtin_amdgcn_sched_barrier(0); load(s, nfull, a[s], w[s]); }
