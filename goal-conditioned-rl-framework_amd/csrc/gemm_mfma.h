@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
   const __amdgpu_buffer_rsrc_t rs_a = wave_uniform_rsrc(A);
   const __amdgpu_buffer_rsrc_t rs_b = wave_uniform_rsrc(Bm);
   int aoff[TM], boff[TN];
+  const int acs4 = (int)(a_cs * 4), brs4 = (int)(b_rs * 4);   // byte strides along k (operands are < 2 GiB)
 #pragma unroll
   for (int i = 0; i < TM; ++i) aoff[i] = (int)((ap[i] - A) * 4);
 #pragma unroll
@@ -286,10 +287,10 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
               const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff[i] + kb * 4, 0, 0);
 #pragma unroll
               for (int q = 0; q < 4; ++q) a[u][i][q] = __uint_as_float(v[q]);
-            } else {
-              const float* p = ap[i] + (long long)kb * a_cs;
+            } else {   // (32-bit byte offsets into the descriptor: 64-bit pointer arithmetic per element was measurable, see bn_slab.hip)
+              const int o = aoff[i] + kb * acs4;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) a[u][i][q] = p[q * a_cs];
+              for (int q = 0; q < 4; ++q) a[u][i][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, o + q * acs4, 0, 0));
             }
           }
 #pragma unroll
@@ -299,9 +300,9 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) b[u][j][q] = __uint_as_float(v[q]);
             } else {
-              const float* p = bp[j] + (long long)kb * b_rs;
+              const int o = boff[j] + kb * brs4;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) b[u][j][q] = p[q * b_rs];
+              for (int q = 0; q < 4; ++q) b[u][j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, o + q * brs4, 0, 0));
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) b[u][j][q] = bone[j] ? 1.f : b[u][j][q];
