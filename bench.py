@@ -94,8 +94,13 @@ def episode_arrays(steps):
             np.array(r, np.float32), np.zeros(len(steps), np.float32), np.array(ag, np.float32))
 
 
-def flops_per_step(w, actor_step=True):
-    """fwd = dX = dW = 2*B*P per network pass."""
+def flops_per_step(w, actor_step=None):
+    """fwd = dX = dW = 2*B*P per network pass.  actor_step None: the MEAN over a trainer cycle — TD3 steps its
+    actor every `ac_update_freq`-th update only (src/agent.py:281-317), the other agents every update."""
+    if actor_step is None and w["kind"] == "TD3":
+        f = int(w.get("freq", 2))
+        return (flops_per_step(w, True) + (f - 1) * flops_per_step(w, False)) / f
+    actor_step = True if actor_step is None else actor_step
     S, A, H, L, B = w["S"], w["A"], w["H"], w["L"], w["B"]
     Pa = S * H + (L - 1) * H * H + H * A
     Pc = (S + A) * H + (L - 1) * H * H + H
@@ -110,6 +115,11 @@ def flops_per_step(w, actor_step=True):
         Pc += H * (w["n_quantiles"] - 1)
         return 2 * B * (4 * Pa + 7 * w["num_critics"] * Pc)
     return 2 * B * (4 * Pa + 7 * 5 * Pc)
+
+
+def head_batches(gstep):
+    """batches of a call's head gather launch (csrc/agent.hip build(): 3 by default, GCRL_HEAD_BATCHES overrides)"""
+    return min(int(gstep), max(1, min(8, int(os.environ.get("GCRL_HEAD_BATCHES", "3")))))
 
 
 def chain_flops_per_launch(w):
@@ -527,11 +537,11 @@ def main():
                                 "algorithmic_bytes_per_row": alg_bytes_per_row, "timing": clock,
                                 "hip_event_us": ev_us, "hip_event_launches": launches.value,
                                 "achieved_hip_event": (alg_bytes_per_row * rows_per_launch) / (ev_us * 1e-6) / 1e9 if ev_us > 0 else None,
-                                "head_launch": ({"kernel": "her_gather_update_kernel<true>", "rows": 2 * w["B"], **ks["gather_head"]} if "gather_head" in ks else None),
+                                "head_launch": ({"kernel": "her_gather_update_kernel<true>", "rows": head_batches(gstep) * w["B"], **ks["gather_head"]} if "gather_head" in ks else None),
                                 "profiler": ks.get("gather_main"),
-                                "note": "a call's first launch gathers batches 0-1 (indices read from the pinned upload block, carries the control "
-                                        "block) so that step 0 starts while the host draws the rest; the main launch gathers the other "
-                                        "gradient_step - 2 batches.  Below ~1e5 rows a launch is bounded by the ~1.3 us dispatch + two dependent "
+                                "note": "a call's first launch gathers its first %d batches (indices read from the pinned upload block, carries the control "
+                                        "block) so that the first steps start while the host draws the rest; the main launch gathers the other "
+                                        "gradient_step - %d batches." % (head_batches(gstep), head_batches(gstep)) + "  Below ~1e5 rows a launch is bounded by the ~1.3 us dispatch + two dependent "
                                         "memory latencies, not by bandwidth (profiles/r03_gather_rows_curve.txt)"},
             "update_flops": {"gflop_per_step": flops_per_step(w) / 1e9,
                              "achieved_tflops": flops_per_step(w) * args.steps / elapsed / 1e12,

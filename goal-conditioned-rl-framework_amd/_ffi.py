@@ -145,6 +145,7 @@ PROTOTYPES = {
     "gcrl_normalizer_set": (C.c_int, [_vp, _vp, _vp, _f64, _f64]),
     "gcrl_normalizer_set_float32": (C.c_int, [_vp, C.c_int]),
     "gcrl_normalizer_is_float32": (C.c_int, [_vp]),
+    "gcrl_normalizer_set_rows_float64": (C.c_int, [_vp, C.c_int]),
     "gcrl_agent_observe_act": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "gcrl_her_process_step": (_i64, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "gcrl_her_process_step_g": (_i64, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
@@ -157,6 +158,19 @@ PROTOTYPES = {
     "gcrl_bn_linear_slab_bwd_f32": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "gcrl_her_set_reward_callback": (C.c_int, [_vp, _vp, _vp]),
     "gcrl_agent_dp_sync_bn": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "gcrl_xchg_create": (_vp, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gcrl_xchg_destroy": (None, [_vp]),
+    "gcrl_xchg_handles": (C.c_int, [_vp, _vp, _i64]),
+    "gcrl_xchg_connect": (C.c_int, [_vp, _vp, _i64]),
+    "gcrl_xchg_world": (C.c_int, [_vp]),
+    "gcrl_xchg_allreduce": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "gcrl_xchg_reset": (C.c_int, [_vp]),
+    "gcrl_xchg_get_partials": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    "gcrl_agent_xchg_create": (_vp, [_vp, C.c_int, C.c_int]),
+    "gcrl_agent_set_exchange": (C.c_int, [_vp, _vp]),
+    "gcrl_set_shared_device": (C.c_int, [C.c_int]),
+    "gcrl_agent_set_meetings": (C.c_int, [_vp, C.c_int]),
+    "gcrl_agent_debug_meet_fault": (C.c_int, [_vp]),
     "gcrl_hash_normal_fill": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, _vp, _vp]),
     "gcrl_event_create": (_vp, []),
     "gcrl_event_destroy": (None, [_vp]),

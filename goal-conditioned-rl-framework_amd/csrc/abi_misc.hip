@@ -1,4 +1,5 @@
 // abi_misc.hip — small C-ABI helpers: stand-alone sort op, hipEvent timing, raw device memory.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <hip/hip_runtime.h>
@@ -7,7 +8,39 @@
 
 #include "common.h"
 #include "gemm_mfma.h"
+#include "meet.h"
 #include "ops.h"
+
+// ---- host side of meet.h ---------------------------------------------------------------------------------------------------
+namespace gcrl {
+namespace {
+int g_shared = -1;   // -1: not decided yet (GCRL_SHARED_GPU in the environment)
+}
+bool meet_device_shared() {
+  if (g_shared < 0) {
+    const char* e = std::getenv("GCRL_SHARED_GPU");
+    g_shared = (e && *e && *e != '0') ? 1 : 0;
+  }
+  return g_shared == 1;
+}
+void meet_set_device_shared(bool on) { g_shared = on ? 1 : 0; }
+
+long long meet_capacity(const void* kernel, int threads, size_t lds_bytes) {
+  if (meet_device_shared()) return 0;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  // LDS: the query divides 160 KB by the request, the hardware allocates in larger granules (32 256 B -> 4 resident, 31 744 B -> 5:
+  // tools/occupancy_probe.hip) — recount with 1 KB granules and one granule held back
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, kernel) == hipSuccess) {
+    const size_t lds = ((fa.sharedSizeBytes + lds_bytes + 1023) / 1024) * 1024;
+    if (lds > 0) per_cu = std::min<long long>(per_cu, (long long)((160 * 1024 - 1024) / lds));
+  }
+  return (long long)cus * std::max(0, per_cu);
+}
+}  // namespace gcrl
 
 namespace {
 hipStream_t as_stream(void* s) {
@@ -113,6 +146,13 @@ static int slab_scratch(int H, float** xchg, unsigned int** bar) {
   *xchg = x; *bar = b;
   return GCRL_OK;
 }
+// The meeting counters are monotonic and must be a multiple of a launch's row-group count when it starts (meet.h): an agent's
+// own counters always are (its row-group count never changes); this process-wide scratch serves launches of ANY shape, so
+// every launch starts from zeroed counters (stream-ordered)
+static int slab_scratch_reset(int H, unsigned int* bar, hipStream_t st) {
+  GCRL_HIP(hipMemsetAsync(bar, 0, (size_t)gcrl::bn_slab_bar_words(H) * sizeof(unsigned int), st));
+  return GCRL_OK;
+}
 
 int gcrl_bn_linear_slab_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, const float* gamma, const float* beta,
                                 int B, int H, int K, float* h, float* xhat, float* invstd, float* bstat, int row_split, void* stream) {
@@ -123,7 +163,11 @@ int gcrl_bn_linear_slab_fwd_f32(const float* x, int64_t ldx, const float* w, con
   f.n = 1;
   f.p[0] = gcrl::BnSlabFwdProb{x, 0, h, xhat, invstd, bstat};
   f.W = w; f.bias = bias; f.gamma = gamma; f.beta = beta; f.ldx = ldx; f.B = B; f.H = H; f.K = K;
-  if (row_split > 1) { f.rsplit = row_split; if (int rc = slab_scratch(H, &f.xchg, &f.bar)) return rc; }
+  if (row_split > 1) {
+    f.rsplit = row_split;
+    if (int rc = slab_scratch(H, &f.xchg, &f.bar)) return rc;
+    if (int rc = slab_scratch_reset(H, f.bar, as_stream(stream))) return rc;
+  }
   return gcrl::launch_bn_linear_fwd_slab(as_stream(stream), f);
 }
 
@@ -137,8 +181,17 @@ int gcrl_bn_linear_slab_bwd_f32(const float* g_up, int64_t ldg, int K_up, const 
   b.G[0] = g_up; b.ldg[0] = ldg; b.K[0] = K_up; b.W[0] = w_up; b.ldw[0] = H;
   b.xhat_dz = xhat_dz; b.invstd = invstd; b.gamma = gamma; b.beta = beta; b.dgamma = dgamma; b.dbeta = dbeta;
   b.B = B; b.H = H;
-  if (row_split > 1) { b.rsplit = row_split; if (int rc = slab_scratch(H, &b.xchg, &b.bar)) return rc; }
+  if (row_split > 1) {
+    b.rsplit = row_split;
+    if (int rc = slab_scratch(H, &b.xchg, &b.bar)) return rc;
+    if (int rc = slab_scratch_reset(H, b.bar, as_stream(stream))) return rc;
+  }
   return gcrl::launch_bn_linear_bwd_slab(as_stream(stream), b);
+}
+
+int gcrl_set_shared_device(int shared) {
+  gcrl::meet_set_device_shared(shared != 0);
+  return GCRL_OK;
 }
 
 int gcrl_hash_normal_fill(uint64_t seed, uint64_t ctr0, int64_t n, float* out_dev, void* stream) {

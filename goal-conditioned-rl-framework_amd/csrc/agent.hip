@@ -29,8 +29,10 @@
 
 #include "gemm_mfma.h"
 #include "her_ring.h"
+#include "meet.h"
 #include "ops.h"
 #include "rowchain.h"
+#include "xchg_ipc.h"
 
 using namespace gcrl;
 
@@ -127,6 +129,7 @@ struct gcrl_agent {
   gcrl_exchange_fn bn_sync_fn = nullptr;
   void* bn_sync_user = nullptr;
   float* bn_sync_buf = nullptr;
+  long long bn_sync_cap = 0;   // floats allocated
   // dW problems at batch >= 1024 on the LDS-tiled form with the reduction split over dw_split_[c|a] workgroups per tile
   // (gemm_tiled.h; 1: off): partial tiles and tickets per net and layer
   int dw_split_c = 1, dw_split_a = 1;
@@ -147,7 +150,16 @@ struct gcrl_agent {
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
   int n_cus = 0;              // compute units of the device (residency checks of the launches whose workgroups meet)
   bool rc_merge = false;      // ... forward and backward part in ONE launch each (part 3; GCRL_NO_RC_MERGE=1: two launches)
-  float* rc_bar = nullptr;    // barrier words of the row blocks [2][nblk][32]
+  float* rc_bar = nullptr;    // meeting counters of the row blocks [2][nblk][32 words]
+  long long rc_bar_words = 0;
+  // host-visible status word of the launches whose workgroups wait for each other (meet.h): a timed-out wait sets a bit, the
+  // next host synchronisation of this handle returns GCRL_ERR_STATE, zeroes the counters and clears it (meet_check below)
+  unsigned int *status_host = nullptr, *status_dev = nullptr;
+  // data-parallel gradient exchange inside the launch sequence (xchg_ipc.hip; gcrl_agent_set_exchange): segments 0..C-1 = the
+  // critics, C = the actor, C+1 = log_alpha (BatchNorm actors).  Not owned by the handle.
+  gcrl_xchg* xchg = nullptr;
+  bool xchg_sep_norm = false;   // GCRL_XCHG_SEPARATE_NORM=1 (A/B and the bitwise test against the RCCL / gloo exchange): the clip norm from a sum-of-squares launch over the reduced gradients instead of the exchange kernel's partials
+  float xchg_scale() const { return xchg ? 1.0f / (float)gcrl_xchg_world(xchg) : 1.0f; }
   int split_rg[4] = {1, 1, 1, 1};
   int row_rg = 1, row_ldl = 0;
   float *wt = nullptr, *rc_gC = nullptr, *rc_gA = nullptr, *ybuf = nullptr;
@@ -390,7 +402,7 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
     sf.W = P + net.lin[l].w; sf.bias = P + net.lin[l].b; sf.gamma = P + net.bn_g[l]; sf.beta = P + net.bn_b[l];
     sf.ldx = l == 0 ? a->ldx : H;
     sf.B = B; sf.H = H; sf.K = net.lin[l].in;
-    sf.rsplit = sf.K >= 128 ? a->bn_rsplit : 1; sf.xchg = a->bn_xchg; sf.bar = reinterpret_cast<unsigned int*>(a->bn_bar);
+    sf.rsplit = sf.K >= 128 ? a->bn_rsplit : 1; sf.xchg = a->bn_xchg; sf.bar = reinterpret_cast<unsigned int*>(a->bn_bar); sf.status = a->status_dev;
     TRY(launch_bn_linear_fwd_slab(st, sf));
     if (extra && (size_t)l < extra->steps.size()) {   // (co-scheduled critic chains of the launch-per-layer schedule: their own launch here)
       std::vector<GemmDesc> v = extra->steps[l];
@@ -457,8 +469,20 @@ int sac_actor_forwards(gcrl_agent* a, hipStream_t st, int variant, bool with_cur
 // V_PRE / V_ADV (SAC on the row-block path, update_n): the step's LAST optimiser launch also advances the control block
 // for the next step (V_ADV; it reads the cur_b copy the first row-block launch refreshed), so that step starts without
 // a begin_step launch (V_PRE)
+// V_XCHG (round 4): the gradients are all-reduced over the ranks INSIDE the launch sequence (xchg_ipc.hip) — after the critic
+// backward and after the actor backward — and the exchange kernel leaves the sum-of-squares partials of the REDUCED gradients:
+// no dW-epilogue partials (they would be the local gradients'), no sumsq launch
 enum { V_ACTOR = 1, V_POLYAK_C = 2, V_POLYAK_A = 4, V_NOISE = 8, V_EPSN = 16, V_EPSC = 32, V_FUSED_NORM = 64, V_WEIGHTS = 128,
-       V_PRE = 256, V_ADV = 512 };
+       V_PRE = 256, V_ADV = 512, V_XCHG = 1024 };
+// how the clip norm reaches the optimiser launches of a step issued by the update entry points
+int norm_bits(const gcrl_agent* a) { return a->xchg ? V_XCHG : V_FUSED_NORM; }
+// exchange of the critic gradients (which = 1), the actor's (+ log_alpha) (2), or both blocks at once (3: overlapped DDPG step)
+int xchg_launch(gcrl_agent* a, hipStream_t st, int which) {
+  const int C = a->C, na = a->sac ? 2 : 1;
+  const int seg0 = (which & 1) ? 0 : C, nseg = ((which & 1) ? C : 0) + ((which & 2) ? na : 0);
+  return gcrl_xchg_allreduce(a->xchg, seg0, nseg, (void*)st);
+}
+int xchg_parts(gcrl_agent* a, bool critic, const float** p, int* n) { return gcrl_xchg_seg_parts(a->xchg, critic ? 0 : a->C, p, n); }
 
 int adam_common(gcrl_agent* a, AdamArgs& ad);
 int finish_deferred_draw(gcrl_agent* a, hipStream_t st);
@@ -502,7 +526,9 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
     TRY(rc_launch_chain(a, st, kc, kc, 1, (variant & V_NOISE) ? a->noise_in : nullptr));
     Launches dw;
     rc_add_dw(a, dw, kc, true, (variant & V_FUSED_NORM) != 0);
-    return dw.run(st);
+    TRY(dw.run(st));
+    if (variant & V_XCHG) TRY(xchg_launch(a, st, 1));
+    return GCRL_OK;
   }
   Launches crit;  // online critics on [s|a], activations kept for the backward
   for (int c = 0; c < C; ++c)
@@ -586,6 +612,7 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
     }
   }
   TRY(bw.run(st));
+  if (variant & V_XCHG) TRY(xchg_launch(a, st, 1));
   return GCRL_OK;
 }
 
@@ -605,16 +632,23 @@ int adam_common(gcrl_agent* a, AdamArgs& ad) {
 }
 
 // ---------------------------------------------------------------- phase 1
+int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant);
 int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
+  TRY(enqueue_phase1_body(a, st, variant));
+  if ((variant & V_XCHG) && (variant & V_ACTOR)) TRY(xchg_launch(a, st, 2));   // the actor's (+ log_alpha) gradients are complete
+  return GCRL_OK;
+}
+int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
   const int kind = a->cfg.kind, B = a->B, C = a->C, S = a->S, A = a->A, L = a->L, H = a->H;
   // critic optimiser: global-norm clip + Adam(W) (+ Polyak into the target critics)
-  const bool fused = (variant & V_FUSED_NORM) != 0;
-  if (!fused) TRY(launch_sumsq(st, a->G_critic(0), a->critic.numel, a->critic_stride, C, a->norm_partial));
+  const bool fused = (variant & V_FUSED_NORM) != 0, xc = (variant & V_XCHG) != 0 && !a->xchg_sep_norm;
+  if (!fused && !xc) TRY(launch_sumsq(st, a->G_critic(0), a->critic.numel, a->critic_stride, C, a->norm_partial));
   {
     AdamArgs ad;
     std::memset(&ad, 0, sizeof(ad));
     adam_common(a, ad);
     if (fused) { ad.partial = a->parts_c; ad.nparts = a->nparts_c; ad.part_stride = a->nparts_c; }
+    if (xc) { TRY(xchg_parts(a, true, &ad.partial, &ad.nparts)); ad.part_stride = ad.nparts; }
     ad.which = 1;
     ad.p = a->P_critic(0); ad.g = a->G_critic(0);
     ad.m = a->adam_m + a->goff_critic; ad.v = a->adam_v + a->goff_critic;
@@ -775,7 +809,7 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
         sb.dgamma = Ga + a->actor.bn_g[l]; sb.dbeta = Ga + a->actor.bn_b[l];
         sb.sumsq_out = (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * a->bn_slots : nullptr;
         sb.B = B; sb.H = H;
-        sb.rsplit = l == L - 1 ? 1 : a->bn_rsplit; sb.xchg = a->bn_xchg; sb.bar = reinterpret_cast<unsigned int*>(a->bn_bar);
+        sb.rsplit = l == L - 1 ? 1 : a->bn_rsplit; sb.xchg = a->bn_xchg; sb.bar = reinterpret_cast<unsigned int*>(a->bn_bar); sb.status = a->status_dev;
         TRY(launch_bn_linear_bwd_slab(st, sb));
       }
       std::vector<GemmDesc> v;
@@ -827,12 +861,13 @@ int enqueue_phase1(gcrl_agent* a, hipStream_t st, int variant) {
 int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   if (!(variant & V_ACTOR)) return GCRL_OK;
   const int kind = a->cfg.kind;
-  const bool fused = (variant & V_FUSED_NORM) != 0;   // (BatchNorm gradients: their launches leave partials too)
-  if (!fused) TRY(launch_sumsq(st, a->G_actor(), a->actor.numel, 0, 1, a->norm_partial));
+  const bool fused = (variant & V_FUSED_NORM) != 0, xc = (variant & V_XCHG) != 0 && !a->xchg_sep_norm;   // (BatchNorm gradients: their launches leave partials too)
+  if (!fused && !xc) TRY(launch_sumsq(st, a->G_actor(), a->actor.numel, 0, 1, a->norm_partial));
   AdamArgs ad;
   std::memset(&ad, 0, sizeof(ad));
   adam_common(a, ad);
   if (fused) { ad.partial = a->parts_a; ad.nparts = a->nparts_a; ad.part_stride = a->nparts_a; }
+  if (xc) { TRY(xchg_parts(a, false, &ad.partial, &ad.nparts)); ad.part_stride = ad.nparts; }
   ad.which = 0;
   ad.p = a->P_actor(); ad.g = a->G_actor();
   ad.m = a->adam_m + a->goff_actor; ad.v = a->adam_v + a->goff_actor;
@@ -880,7 +915,7 @@ int run_step(gcrl_agent* a, hipStream_t st, int variant, int mask, int count = 1
     for (int c = 0; c < count; ++c) TRY(enqueue_phases(a, st, variant, mask));
     return GCRL_OK;
   }
-  static_assert(2 * V_ADV <= (1 << 12), "graph key: the variant flags must stay below the phase-mask bits");
+  static_assert(2 * V_XCHG <= (1 << 12), "graph key: the variant flags must stay below the phase-mask bits");
   const int key = variant | (mask << 12) | (count > 1 ? (0x40000000 | (count << 16)) : 0);
   auto it = a->graphs.find(key);
   if (it == a->graphs.end()) {
@@ -1084,6 +1119,31 @@ int end_call(gcrl_agent* a, hipStream_t st) {
   return GCRL_OK;
 }
 
+// A wait inside a launch timed out (meet.h): the launch poisoned its result with NaN and set a bit of the status word.
+// Called after every host synchronisation of the handle: the error surfaces ONCE, the meeting counters are zeroed (a
+// timed-out round may have left them off a multiple of the arrival count) and the next launch works again.  The reference
+// raises on any failed step (src/agent.py:659-699).
+int meet_check(gcrl_agent* a) {
+  if (!a->status_host) return GCRL_OK;
+  const unsigned int bits = __atomic_load_n(a->status_host, __ATOMIC_ACQUIRE);
+  if (!bits) return GCRL_OK;
+  (void)hipDeviceSynchronize();
+  if (a->bn_bar) (void)hipMemset(a->bn_bar, 0, (size_t)bn_slab_bar_words(a->H) * sizeof(unsigned int));
+  if (a->rc_bar && a->rc_bar_words) (void)hipMemset(a->rc_bar, 0, (size_t)a->rc_bar_words * sizeof(unsigned int));
+  if (bits & (MEET_ERR_XCHG_READY | MEET_ERR_XCHG_DONE)) {
+    (void)hipDeviceSynchronize();
+    __atomic_store_n(a->status_host, 0u, __ATOMIC_RELEASE);
+    return fail(GCRL_ERR_STATE, "the in-engine gradient exchange timed out waiting for a peer (status 0x%x:%s%s): a rank is missing, late by more than ~1 s, or enqueued "
+                                "a different exchange sequence; this step's gradients are NaN on this rank.  Re-synchronise the ranks and call gcrl_xchg_reset on each",
+                bits, (bits & MEET_ERR_XCHG_READY) ? " peers' gradients not ready" : "", (bits & MEET_ERR_XCHG_DONE) ? " peers' chunks not delivered" : "");
+  }
+  (void)hipDeviceSynchronize();
+  __atomic_store_n(a->status_host, 0u, __ATOMIC_RELEASE);
+  return fail(GCRL_ERR_STATE, "a wait between workgroups inside a launch timed out (status 0x%x:%s%s); the affected step's statistics / gradients are NaN. "
+                              "The device is probably shared with other work: set GCRL_SHARED_GPU=1 (or gcrl_set_shared_device) to use the launch forms without such waits",
+              bits, (bits & MEET_ERR_BN_SLAB) ? " BatchNorm slab row groups" : "", (bits & MEET_ERR_ROWCHAIN) ? " row-chain roles" : "");
+}
+
 int bytes_alloc(float** p, long long n) {
   GCRL_HIP(hipMalloc((void**)p, (size_t)n * sizeof(float)));
   GCRL_HIP(hipMemset(*p, 0, (size_t)n * sizeof(float)));
@@ -1140,12 +1200,15 @@ int build(gcrl_agent* a) {
   a->bn_slots = (H + 15) / 16;
   a->bn_slab = a->sac && bn_slab_ok(B, H) && !std::getenv("GCRL_NO_BN_SLAB");
   {
-    // (the row groups of a slab wait for each other inside the launch: all (H/16) x 4 x 2 workgroups of 512 threads must be
-    // resident at once — at most two per CU on THIS device's CUs, bn_slab.hip)
+    // (the row groups of a slab wait for each other inside the launch: all (H/16) x ceil(B/128) x 2 workgroups of 512 threads
+    // must be resident at once — by the kernels' own occupancy on a device this process has to itself: bn_slab_row_split, meet.h)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess) cus = 0;
     a->n_cus = cus;
-    a->bn_rsplit = (a->bn_slab && B > 128 && (long long)(H / 16) * 4 * 2 <= 2LL * cus && !std::getenv("GCRL_NO_BN_RSPLIT")) ? 4 : 1;
+    a->bn_rsplit = (a->bn_slab && B > 128 && !std::getenv("GCRL_NO_BN_RSPLIT") && bn_slab_row_split(B, H, 2) > 1) ? 4 : 1;
+    GCRL_HIP(hipHostMalloc((void**)&a->status_host, 64, hipHostMallocMapped));
+    std::memset(a->status_host, 0, 64);
+    GCRL_HIP(hipHostGetDevicePointer((void**)&a->status_dev, a->status_host, 0));
   }
   if (a->sac) { a->part_off_bn = a->nparts_a; a->nparts_a += L * a->bn_slots; }
   // work buffers
@@ -1191,11 +1254,11 @@ int build(gcrl_agent* a) {
     for (int i = 0; i < 4; ++i) a->split_rg[i] = a->row_rg;
     {
       const long long nblk = (B + 4 * a->row_rg - 1) / (4 * a->row_rg);
-      // (workgroups that wait for each other inside a launch must all be resident at once: two per CU by LDS on THIS device's CUs)
-      const int cus = a->n_cus;
-      a->rc_merge = a->split_roles && 2 * C * nblk <= 2LL * cus && 2 * rowchain_lds_bytes(a->row_rg, a->row_ldl, A, H, C) <= 160 * 1024 &&
-                    !std::getenv("GCRL_NO_RC_MERGE") && !std::getenv("GCRL_SPLIT_RG");
-      if (a->rc_merge) wants.push_back({&a->rc_bar, 2 * nblk * 32});
+      // (workgroups that wait for each other inside a launch must all be resident at once: rowchain_merge_ok asks the kernel's
+      // occupancy at this LDS size and refuses on a shared device)
+      a->rc_merge = a->split_roles && !std::getenv("GCRL_NO_RC_MERGE") && !std::getenv("GCRL_SPLIT_RG") &&
+                    rowchain_merge_ok(a->row_rg, a->row_ldl, A, H, C, B);
+      if (a->rc_merge) { a->rc_bar_words = 2 * nblk * 32; wants.push_back({&a->rc_bar, a->rc_bar_words}); }
     }
     // TD3 once the batch fills the chip (cfg 3: 183.5 -> 178.4 us/step; below that the fused launch is the shorter chain)
     a->split_k = a->rowchain && c.kind == GCRL_AGENT_TD3 && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) >= 256 &&
@@ -1389,6 +1452,7 @@ void gcrl_agent_destroy(gcrl_agent* a) {
     if (a->upload_ev[i]) (void)hipEventDestroy(a->upload_ev[i]);
   }
   for (int i = 0; i < kEventRing; ++i) if (a->call_ev[i]) (void)hipEventDestroy(a->call_ev[i]);
+  if (a->status_host) (void)hipHostFree(a->status_host);
   if (a->metrics_host) (void)hipHostFree(a->metrics_host);
   if (a->metrics_dev) (void)hipFree(a->metrics_dev);
   if (a->prof_clk) (void)hipFree(a->prof_clk);
@@ -1433,6 +1497,7 @@ int gcrl_agent_get(gcrl_agent* a, const char* name, float* dst, int64_t n) {
   TRY(find_vec(a, name, &p, &numel));
   GCRL_CHECK_ARG(dst && n == numel, "gcrl_agent_get('%s'): n=%lld but the vector has %lld elements", name, (long long)n, (long long)numel);
   GCRL_HIP(hipDeviceSynchronize());
+  TRY(meet_check(a));
   GCRL_HIP(hipMemcpy(dst, p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   return GCRL_OK;
 }
@@ -1521,6 +1586,7 @@ int64_t gcrl_agent_state_size(const gcrl_agent* a) { return a ? (int64_t)agent_s
 int gcrl_agent_save_state(gcrl_agent* a, void* dst_host, int64_t n) {
   GCRL_CHECK_ARG(a && dst_host && n == (int64_t)agent_state_bytes(a), "gcrl_agent_save_state: buffer must be gcrl_agent_state_size() bytes");
   GCRL_HIP(hipDeviceSynchronize());
+  TRY(meet_check(a));
   const long long bn = std::max(1, a->L * a->H);
   AgentStateHeader h{kAgentMagic, 1, a->cfg.kind, a->S, a->A, a->H, a->L, a->B, a->C, 0, a->n_params, a->n_grads, bn,
                      a->t_actor, a->t_critic, a->t_alpha, a->lr_actor, a->lr_critic, a->rng_ctr};
@@ -1598,10 +1664,10 @@ int gcrl_agent_update(gcrl_agent* a, gcrl_her* her, int64_t step, const gcrl_upd
   hipStream_t st = a->pick(stream);
   std::vector<StepPlan> plans;
   int32_t len = 0;
-  TRY(begin_call(a, her, step, 1, in, 1.0f, st, plans, ticket_out, &len));
-  int variant = plans[0].variant | V_FUSED_NORM;
+  TRY(begin_call(a, her, step, 1, in, a->xchg_scale(), st, plans, ticket_out, &len));
+  int variant = plans[0].variant | norm_bits(a);
   if (in) TRY(stage_injected(a, in, st, &variant));
-  if (a->rowchain && a->cfg.kind == GCRL_AGENT_DDPG && variant == (V_ACTOR | V_FUSED_NORM)) {
+  if (a->rowchain && a->cfg.kind == GCRL_AGENT_DDPG && variant == (V_ACTOR | norm_bits(a))) {
     TRY(run_ddpg_pipe(a, st, 1));   // the phases of a plain DDPG step, row-block kernels
     TRY(run_ddpg_pipe(a, st, 2));
   } else {
@@ -1622,7 +1688,7 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
     const bool ddpg_pipe = a->cfg.kind == GCRL_AGENT_DDPG && a->cfg.pipeline_steps != 0;
     const int adv = (a->rowchain && !ddpg_pipe) ? V_ADV : 0;   // SAC / TD3 on the row-block path (the call's last step advances into table[m]: never read)
     const bool pre = ddpg_pipe || adv != 0;                 // these paths start from the uploaded cur: no begin_step launch at all
-    TRY(begin_call(a, her, step0 + done, m, nullptr, 1.0f, st, plans, tickets_out ? tickets_out + done : nullptr,
+    TRY(begin_call(a, her, step0 + done, m, nullptr, a->xchg_scale(), st, plans, tickets_out ? tickets_out + done : nullptr,
                    lens_out ? lens_out + done : nullptr, /*defer_rest=*/true, pre));
     if (ddpg_pipe) {
       // plain actor steps overlap pairwise: P(i) shares its launches with K(i+1)
@@ -1630,7 +1696,7 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
       for (int i = 0; i < m; ++i) variants[i] = plans[i].variant;
       TRY(run_steps_ddpg(a, st, variants.data(), m, /*first_pre=*/true));
     } else {
-      auto var_of = [&](int i) { return plans[i].variant | V_FUSED_NORM | adv | (adv ? V_PRE : 0); };
+      auto var_of = [&](int i) { return plans[i].variant | norm_bits(a) | adv | (adv ? V_PRE : 0); };
       int i = 0;
       while (i < m) {
         int j = i + 1;
@@ -1658,8 +1724,8 @@ int gcrl_agent_update_phase(gcrl_agent* a, gcrl_her* her, int64_t step, int phas
   if (phase == 0) {
     std::vector<StepPlan> plans;
     int32_t l = 0;
-    TRY(begin_call(a, her, step, 1, in, grad_scale, st, plans, ticket_out, &l));
-    int variant = plans[0].variant;
+    TRY(begin_call(a, her, step, 1, in, a->xchg ? a->xchg_scale() : grad_scale, st, plans, ticket_out, &l));
+    int variant = plans[0].variant | (a->xchg ? V_XCHG : 0);
     if (in) TRY(stage_injected(a, in, st, &variant));
     a->pending_variant = variant;
     len = l;
@@ -1672,6 +1738,7 @@ int gcrl_agent_update_phase(gcrl_agent* a, gcrl_her* her, int64_t step, int phas
 int gcrl_agent_dp_begin(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, float grad_scale, int64_t* tickets_out,
                         int32_t* lens_out, void* stream) {
   GCRL_CHECK_ARG(a && her, "gcrl_agent_dp_begin: null handle");
+  if (a->xchg) return fail(GCRL_ERR_STATE, "gcrl_agent_dp_begin: an in-engine exchange is attached (gcrl_agent_set_exchange): the update entry points exchange by themselves");
   hipStream_t st = a->pick(stream);
   a->dp_plans.clear();
   TRY(begin_call(a, her, step0, n, nullptr, grad_scale, st, a->dp_plans, tickets_out, lens_out));
@@ -1733,7 +1800,13 @@ int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_
   if (world == 1) return GCRL_OK;
   // partial statistics of both co-scheduled forwards, every rank's slots, adjacent: ONE exchange per BatchNorm layer and pass
   const long long n1 = 2LL * world * ((a->B + 63) / 64) * a->H;
-  if (!a->bn_sync_buf) TRY(bytes_alloc(&a->bn_sync_buf, 2 * n1));
+  if (2 * n1 > a->bn_sync_cap) {   // a later call may name a larger world (2 -> 4): the buffer grows with it
+    if (a->bn_sync_buf) { (void)hipFree(a->bn_sync_buf); a->bn_sync_buf = nullptr; a->bn_sync_cap = 0; }
+    TRY(bytes_alloc(&a->bn_sync_buf, 2 * n1));
+    a->bn_sync_cap = 2 * n1;
+  } else {
+    GCRL_HIP(hipMemset(a->bn_sync_buf, 0, (size_t)a->bn_sync_cap * sizeof(float)));   // (other ranks' slots must start from zero)
+  }
   a->bn_partN = a->bn_sync_buf;          // (problem 0 of sac_actor_forwards, then problem 1)
   a->bn_part = a->bn_sync_buf + n1;      // (the old allocations stay owned by the handle's free list)
   a->bn_sync.world = world; a->bn_sync.rank = rank;
@@ -1753,6 +1826,53 @@ int gcrl_agent_dp_end(gcrl_agent* a, void* stream) {
   GCRL_CHECK_ARG(a, "gcrl_agent_dp_end: null handle");
   a->dp_plans.clear();
   return end_call(a, a->pick(stream));
+}
+
+gcrl_xchg* gcrl_agent_xchg_create(gcrl_agent* a, int rank, int world) {
+  if (!a) { fail(GCRL_ERR_ARG, "gcrl_agent_xchg_create: null handle"); return nullptr; }
+  std::vector<int64_t> off, n;
+  for (int c = 0; c < a->C; ++c) { off.push_back(a->goff_critic + c * a->critic_stride); n.push_back(a->critic.numel); }
+  off.push_back(a->goff_actor); n.push_back(a->actor.numel);
+  if (a->sac) { off.push_back(a->goff_alpha); n.push_back(1); }
+  gcrl_xchg* x = gcrl_xchg_create(a->grads, a->n_grads, off.data(), n.data(), (int)off.size(), rank, world, a->cfg.device);
+  if (x) gcrl_xchg_set_status(x, a->status_dev);
+  return x;
+}
+
+int gcrl_agent_set_exchange(gcrl_agent* a, gcrl_xchg* x) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_set_exchange: null handle");
+  GCRL_HIP(hipDeviceSynchronize());
+  for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);   // captured steps hold the other sequence
+  a->graphs.clear();
+  a->xchg = x;
+  a->xchg_sep_norm = std::getenv("GCRL_XCHG_SEPARATE_NORM") != nullptr;
+  return GCRL_OK;
+}
+
+int gcrl_agent_set_meetings(gcrl_agent* a, int on) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_set_meetings: null handle");
+  GCRL_HIP(hipDeviceSynchronize());
+  for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);   // captured steps hold the old launch forms
+  a->graphs.clear();
+  const gcrl_agent_config& c = a->cfg;
+  const bool want = on != 0 && !meet_device_shared();
+  a->bn_rsplit = (want && a->bn_slab && a->B > 128 && !std::getenv("GCRL_NO_BN_RSPLIT") && bn_slab_row_split(a->B, a->H, 2) > 1) ? 4 : 1;
+  a->rc_merge = want && a->rc_bar && a->split_roles && !std::getenv("GCRL_NO_RC_MERGE") && !std::getenv("GCRL_SPLIT_RG") &&
+                rowchain_merge_ok(a->row_rg, a->row_ldl, c.ac_dim, a->H, a->C, a->B);
+  return (a->bn_rsplit > 1 ? 1 : 0) | (a->rc_merge ? 2 : 0);
+}
+
+int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_debug_meet_fault: null handle");
+  GCRL_HIP(hipDeviceSynchronize());
+  // one meeting counter off its multiple-of-arrivals state (7: not a multiple of 2, 3 or 4, and 3 of 4 arrivers of a 4-way point
+  // land in the NEXT round): those arrivers compute a target that is never reached and time out (~1 s) — what a workgroup
+  // kept off the chip would cause
+  const unsigned long long one = 7;
+  float* words = a->rc_merge ? a->rc_bar : (a->bn_rsplit > 1 ? a->bn_bar : nullptr);
+  GCRL_CHECK_ARG(words, "gcrl_agent_debug_meet_fault: this agent's launches contain no waits (meetings off or not applicable)");
+  GCRL_HIP(hipMemcpy(words, &one, sizeof(one), hipMemcpyHostToDevice));
+  return GCRL_OK;
 }
 
 int gcrl_agent_grad_ptr(gcrl_agent* a, int phase, float** ptr, int64_t* numel) {
@@ -1791,6 +1911,7 @@ int gcrl_agent_metrics(gcrl_agent* a, int64_t ticket, double* out, int n) {
       from += cnt;
     }
     a->fetched_upto = upto;
+    TRY(meet_check(a));
   }
   const float* m = a->metrics_host + (ticket % kMetricSlots) * kMetricFloats;
   const int C = a->C;
@@ -1934,8 +2055,8 @@ int gcrl_agent_observe_act(gcrl_agent* a, gcrl_normalizer* nz_obs, gcrl_normaliz
     ra.obs = d_f; ra.ld_obs = a->S; ra.out = a->dact; ra.ld_out = a->Apad;
     ra.n = n; ra.S = a->S; ra.A = A; ra.ldl = a->row_ldl;
     ra.D = D;
-    gcrl::normalizer_view(nz_obs, &ra.nz_mean, &ra.nz_var, nullptr, &ra.nz_clip, &ra.nz_f32);
-    gcrl::normalizer_view(nz_dg, &ra.nzg_mean, &ra.nzg_var, nullptr, &ra.nzg_clip, &ra.nzg_f32);
+    gcrl::normalizer_view(nz_obs, &ra.nz_mean, &ra.nz_var, nullptr, &ra.nz_clip, &ra.nz_mode);
+    gcrl::normalizer_view(nz_dg, &ra.nzg_mean, &ra.nzg_var, nullptr, &ra.nzg_clip, &ra.nzg_mode);
     ra.post = mode == 1 ? 1 : (mode == 0 ? 2 : 3);
     ra.noise = with_noise ? d_noise : nullptr; ra.out64 = d_out;
     TRY(launch_rowchain_act(st, ra));

@@ -20,6 +20,7 @@
 #include "ops.h"
 
 #include "gemm_mfma.h"
+#include "meet.h"
 
 namespace gcrl {
 
@@ -171,14 +172,13 @@ __device__ inline void slab_gemm(v4f (&acc)[kNT], float* lds, const float* A, lo
 // ---- row groups of a slab exchanging their column partials (NT = 1: a workgroup holds 128 rows) -------------------------------
 // With all 512 rows in one workgroup a K = 256 layer is ~7 us of MFMAs on 16-32 CUs.  Split over RS row groups the GEMM is
 // 1/RS of that on RS times the CUs, and the groups need each other's column partials ONCE per launch: every group publishes two
-// 16-float vectors with agent-scope stores, arrives at a counter, and waits until the generation word changes (the last arriver
-// resets the counter and bumps the generation: the words are ready for the next launch, graph replays included).  All RS x slabs x
-// inputs workgroups (<= 128 of 512 threads) are resident at once on 256 CUs, so a waiting group never keeps an awaited one from
-// being scheduled; the wait is BOUNDED all the same (kSpinMax polls of ~1 us), after which the launch poisons its statistics with
-// NaN instead of hanging.  Every group then merges the RS partials in index order: the same result in all of them.
+// 16-float vectors with agent-scope stores and meets the others at the slab's counter (meet.h: stores drained before the
+// arrival, one monotonic 64-bit counter per slab, bounded wait, host-visible status bit on a timeout).  All RS x slabs x inputs
+// workgroups are resident at once (the launcher checks against the kernel's occupancy on a device the process has to itself), so a
+// waiting group never keeps an awaited one from being scheduled.  Every group then merges the RS partials in index order: the
+// same result in all of them.
 constexpr int kSc1 = 16;                 // agent-scope cache policy of the raw buffer builtins (gfx94x / gfx950)
-constexpr int kSpinMax = 1 << 20;
-struct Xchg { float* buf; unsigned int* bar; };     // buf [slot][RS][32] floats; bar [slot][32] words: [0] arrivals, [16] generation
+struct Xchg { float* buf; unsigned int* bar; unsigned int* status; };     // buf [slot][RS][32] floats; bar [slot][32] words: a 64-bit counter per 128-byte line
 
 // a, b: this group's two values for column li (valid in wave 0, lanes lg == 0).  Returns false on a timed-out wait.
 __device__ inline bool slab_exchange(const Xchg& x, int slot, int RS, int r, float a, float b, int wave, int li, int lg, float (&oa)[4],
@@ -188,27 +188,7 @@ __device__ inline bool slab_exchange(const Xchg& x, int slot, int RS, int r, flo
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), rs, (r * 32 + li) * 4, 0, kSc1);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b), rs, (r * 32 + 16 + li) * 4, 0, kSc1);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // s_waitcnt: the stores have been acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned int* cnt = x.bar + (long long)slot * 32;
-    unsigned int* gen = cnt + 16;
-    const unsigned int g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned int t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int ok = 1;
-    if (t == (unsigned)(RS - 1)) {
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      int spins = 0;
-      while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0 && ++spins < kSpinMax) __builtin_amdgcn_s_sleep(4);
-      ok = spins < kSpinMax ? 1u : 0u;
-    }
-    *s_flag = ok;
-  }
-  __syncthreads();
-  const bool ok = *s_flag != 0;
+  const bool ok = meet(reinterpret_cast<unsigned long long*>(x.bar + (long long)slot * 32), (unsigned)RS, true, s_flag, x.status, MEET_ERR_BN_SLAB);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     oa[j] = j < RS ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (j * 32 + li) * 4, 0, kSc1)) : 0.f;
@@ -383,10 +363,20 @@ bool bn_slab_ok(int B, int H) { return B >= 1 && B <= 16 * 4 * kWaves && H >= 16
 long long bn_slab_xchg_floats(int H) { return 2LL * (H / 16) * 4 * 32; }
 long long bn_slab_bar_words(int H) { return 2LL * (H / 16) * 32; }
 
-// rows split: 1 (a workgroup holds all rows) or ceil(B / 128) row groups that exchange their partials (scratch required)
-static int row_split(int want, int B, const float* xchg, const unsigned int* bar) {
+// rows split: 1 (a workgroup holds all rows) or ceil(B / 128) row groups that exchange their partials (scratch required).  The
+// split form waits inside the launch: admitted only when all `slabs_x_inputs` x groups workgroups are resident at once by the
+// kernel's own occupancy, on a device this process has to itself (meet.h).  A function of the shapes, the device and the
+// process-wide sharing switch only: a launch's summation order never changes from step to step.
+static int row_split(int want, int B, const float* xchg, const unsigned int* bar, const void* kernel, long long slabs_x_inputs) {
   if (want <= 1 || B <= 128 || !xchg || !bar) return 1;
-  return (B + 127) / 128;
+  const int rs = (B + 127) / 128;
+  return slabs_x_inputs * rs <= meet_capacity(kernel, 64 * kWaves, 0) ? rs : 1;
+}
+int bn_slab_row_split(int B, int H, int n_inputs) {   // what the launchers will choose for a layer that asks for the split (agent.hip: build)
+  static float dummy_x; static unsigned int dummy_b;
+  const int f = row_split(4, B, &dummy_x, &dummy_b, (const void*)bn_linear_fwd_slab_kernel<true, 1>, (long long)(H / 16) * n_inputs);
+  const int b = row_split(4, B, &dummy_x, &dummy_b, (const void*)bn_linear_bwd_slab_kernel<1>, (long long)(H / 16));
+  return (f > 1 && b > 1) ? f : 1;
 }
 
 int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f) {
@@ -398,10 +388,11 @@ int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f) {
   }
   g.slot = f.slot; g.W = f.W; g.bias = f.bias; g.gamma = f.gamma; g.beta = f.beta; g.ldx = f.ldx;
   g.B = f.B; g.H = f.H; g.K = f.K;
-  g.RS = row_split(f.rsplit, f.B, f.xchg, f.bar);
-  g.x = Xchg{f.xchg, f.bar};
   bool vec = f.ldx % 4 == 0 && f.K % 4 == 0 && aligned16(f.W);
   for (int i = 0; i < f.n; ++i) vec = vec && aligned16(f.p[i].X) && f.p[i].x_slot % 4 == 0;
+  g.RS = row_split(f.rsplit, f.B, f.xchg, f.bar, vec ? (const void*)bn_linear_fwd_slab_kernel<true, 1> : (const void*)bn_linear_fwd_slab_kernel<false, 1>,
+                   (long long)(f.H / 16) * f.n);
+  g.x = Xchg{f.xchg, f.bar, f.status};
   if (g.RS > 1) {
     const dim3 grid(f.H / 16, g.RS, f.n);
     if (vec) hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<true, 1>), grid, dim3(64 * kWaves), 0, st, g);
@@ -429,8 +420,8 @@ int launch_bn_linear_bwd_slab(hipStream_t st, const BnSlabBwd& b) {
   g.xhat_dz = b.xhat_dz; g.invstd = b.invstd; g.gamma = b.gamma; g.beta = b.beta;
   g.dgamma = b.dgamma; g.dbeta = b.dbeta; g.sumsq_out = b.sumsq_out;
   g.B = b.B; g.H = b.H;
-  g.RS = row_split(b.rsplit, b.B, b.xchg, b.bar);
-  g.x = Xchg{b.xchg, b.bar};
+  g.RS = row_split(b.rsplit, b.B, b.xchg, b.bar, (const void*)bn_linear_bwd_slab_kernel<1>, (long long)(b.H / 16));
+  g.x = Xchg{b.xchg, b.bar, b.status};
   if (g.RS > 1) hipLaunchKernelGGL(bn_linear_bwd_slab_kernel<1>, dim3(b.H / 16, g.RS), dim3(64 * kWaves), 0, st, g);
   else hipLaunchKernelGGL(bn_linear_bwd_slab_kernel<4>, dim3(b.H / 16), dim3(64 * kWaves), 0, st, g);
   GCRL_HIP(hipGetLastError());

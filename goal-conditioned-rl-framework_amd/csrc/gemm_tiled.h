@@ -319,7 +319,10 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
       __builtin_amdgcn_raw_buffer_store_b128(v, rsp, mine + (((wave * 4 + g) * 64 + lane) << 4), 0, kSc1);
     }
     if (bias_tile && threadIdx.x < 64) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dbv), rsp, mine + (64 * 64 + (int)threadIdx.x) * 4, 0, kSc1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // s_waitcnt vmcnt(0): this wave's stores have been acknowledged
+    // EVERY wave waits for the memory side's acknowledgement of its write-through stores before the barrier that precedes the
+    // ticket (a workgroup-scope release fence emits no vmcnt wait on gfx950: without this the ticket could overtake the
+    // partials of waves 1-3 and the last arriver sum a previous step's values — ADVICE r3; tools/check_release_isa.py greps the ISA)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned int* s_ticket = reinterpret_cast<unsigned int*>(ldsB);   // (LDS is free between the main loop and the epilogue)
     __syncthreads();
     if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(d.kticket + ti * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -153,7 +153,8 @@ namespace gcrl {
 
 // device RunningNormalizer (normalizer.hip): statistics update from device rows; out[:, col0:col0+D] = normalize(x)
 // (z == null: plain copy)
-void normalizer_view(const gcrl_normalizer* z, const double** mean, const double** var, double** count, double* clip, int* f32 = nullptr);
+void normalizer_view(const gcrl_normalizer* z, const double** mean, const double** var, double** count, double* clip, int* mode = nullptr);   // mode: norm_math.h bits
+void normalizer_updated(gcrl_normalizer* z);   // call after enqueuing a launch that updates z
 int normalizer_update_dev(gcrl_normalizer* z, const float* x_dev, int n, int ld, hipStream_t st);
 int normalizer_apply_dev(const gcrl_normalizer* z, const float* x_dev, int n, int ld, int D, float* out_dev, int ld_out, int col0,
                          hipStream_t st);

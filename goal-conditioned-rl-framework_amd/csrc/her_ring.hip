@@ -81,44 +81,35 @@ struct ProcArgs {
   double* mean; double* var; double* count; double clip;   // null mean: no normaliser
   double* gmean; double* gvar; double* gcount; double gclip;   // goal normaliser (null: goals stay raw)
   int update, gupdate, n, env0, flush_len, D, S, A, G, SA4, S4, RG;
-  int f32, gf32;   // loaded normalisers: float32 arithmetic (norm_math.h)
+  int mode, gmode;   // norm_math.h bits: float32 statistics (loaded normalisers), float64 rows (the trainer's observation batches)
 };
 __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
   __shared__ double s_mean[128], s_den[128], s_gmean[kMaxG], s_gden[kMaxG];
   const int n = p.n, D = p.D, G = p.G;
   const float* obs = p.raw; const float* nobs = obs + (size_t)n * D;
   const float* dg = nobs + (size_t)n * D; const float* ndg = dg + (size_t)n * G;
+  int mode = p.mode, gmode = p.gmode;         // as of AFTER this launch's updates (float64 rows leave float64 statistics)
+  if (p.update && (mode & gcrl::NORM_ROWS64)) mode &= ~gcrl::NORM_F32;
+  if (p.gupdate && (gmode & gcrl::NORM_ROWS64)) gmode &= ~gcrl::NORM_F32;
   if (p.gmean && threadIdx.x >= 128 && threadIdx.x < 128 + G) {     // (a second group of threads: the two updates run side by side)
     const int j = threadIdx.x - 128;
     double m = p.gmean[j], v = p.gvar[j];
     if (p.gupdate) {
-      const int rows = 4 * n;                   // [dg ; next_dg ; ag ; next_ag] lie in this order
-      float s = 0.f;
-      for (int i = 0; i < rows; ++i) s = __fadd_rn(s, dg[(size_t)i * G + j]);
-      const float bm = __fdiv_rn(s, (float)rows);
-      float q = 0.f;
-      for (int i = 0; i < rows; ++i) { const float d = __fsub_rn(dg[(size_t)i * G + j], bm); q = __fadd_rn(q, __fmul_rn(d, d)); }
-      const float bv = __fdiv_rn(q, (float)rows);
-      gcrl::norm_merge(m, v, bm, bv, rows, *p.gcount, p.gf32 != 0);
+      int md = p.gmode;
+      gcrl::norm_update_col(m, v, 4 * n, *p.gcount, md, [&](int i) { return dg[(size_t)i * G + j]; });   // [dg ; next_dg ; ag ; next_ag] lie in this order
       p.gmean[j] = m; p.gvar[j] = v;
     }
-    s_gmean[j] = m; s_gden[j] = gcrl::norm_den(v, p.gf32 != 0);
+    s_gmean[j] = m; s_gden[j] = gcrl::norm_den(v, (gmode & gcrl::NORM_F32) != 0);
   }
   if (p.mean) {
     for (int j = threadIdx.x; j < D; j += 256) {
       double m = p.mean[j], v = p.var[j];
       if (p.update) {
-        const int rows = 2 * n;                 // np.concatenate([obs, next_obs]) is how the two blocks lie
-        float s = 0.f;
-        for (int i = 0; i < rows; ++i) s = __fadd_rn(s, obs[(size_t)i * D + j]);
-        const float bm = __fdiv_rn(s, (float)rows);
-        float q = 0.f;
-        for (int i = 0; i < rows; ++i) { const float d = __fsub_rn(obs[(size_t)i * D + j], bm); q = __fadd_rn(q, __fmul_rn(d, d)); }
-        const float bv = __fdiv_rn(q, (float)rows);
-        gcrl::norm_merge(m, v, bm, bv, rows, *p.count, p.f32 != 0);
+        int md = p.mode;
+        gcrl::norm_update_col(m, v, 2 * n, *p.count, md, [&](int i) { return obs[(size_t)i * D + j]; });   // np.concatenate([obs, next_obs]) is how the two blocks lie
         p.mean[j] = m; p.var[j] = v;
       }
-      s_mean[j] = m; s_den[j] = gcrl::norm_den(v, p.f32 != 0);
+      s_mean[j] = m; s_den[j] = gcrl::norm_den(v, (mode & gcrl::NORM_F32) != 0);
     }
   }
   __syncthreads();
@@ -134,11 +125,11 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
       if (cc < D) {
         const float x = o[(size_t)i * D + cc];
         if (!p.mean) return x;
-        return gcrl::norm_apply(x, s_mean[cc], s_den[cc], p.clip, p.f32 != 0);
+        return gcrl::norm_apply(x, s_mean[cc], s_den[cc], p.clip, gcrl::norm_apply_f32(mode));
       }
       const float x = g[(size_t)i * G + (cc - D)];
       if (!p.gmean) return x;
-      return gcrl::norm_apply(x, s_gmean[cc - D], s_gden[cc - D], p.gclip, p.gf32 != 0);
+      return gcrl::norm_apply(x, s_gmean[cc - D], s_gden[cc - D], p.gclip, gcrl::norm_apply_f32(gmode));
     };
     if (c < p.S) v = state_col(obs, dg, c);
     else if (c < p.S + p.A) v = pw[3 + (c - p.S)];
@@ -147,7 +138,7 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
     else if (c == o_r + 1) v = pw[2];
     else if (c >= RW) {
       v = pw[3 + p.A + (c - RW)];
-      if (p.gmean) v = gcrl::norm_apply(v, s_gmean[c - RW], s_gden[c - RW], p.gclip, p.gf32 != 0);   // normalize_goal(achieved_goal)
+      if (p.gmean) v = gcrl::norm_apply(v, s_gmean[c - RW], s_gden[c - RW], p.gclip, gcrl::norm_apply_f32(gmode));   // normalize_goal(achieved_goal)
     }
     p.stage[((long long)(p.env0 + i) * p.flush_len + t) * p.RG + c] = v;
   }
@@ -1024,12 +1015,12 @@ int64_t gcrl_her_process_step_g(gcrl_her* h, gcrl_normalizer* nz_obs, int update
   std::memset(&pa, 0, sizeof(pa));
   pa.stage = h->stage; pa.raw = h->ps_dev; pa.pay = h->ps_dev + raw;
   const double *mean = nullptr, *var = nullptr;
-  gcrl::normalizer_view(nz_obs, &mean, &var, &pa.count, &pa.clip, &pa.f32);
+  gcrl::normalizer_view(nz_obs, &mean, &var, &pa.count, &pa.clip, &pa.mode);
   pa.mean = const_cast<double*>(mean); pa.var = const_cast<double*>(var);
   pa.update = (nz_obs && update_stats) ? 1 : 0;
   if (nz_dg) {
     const double *gm = nullptr, *gv = nullptr;
-    gcrl::normalizer_view(nz_dg, &gm, &gv, &pa.gcount, &pa.gclip, &pa.gf32);
+    gcrl::normalizer_view(nz_dg, &gm, &gv, &pa.gcount, &pa.gclip, &pa.gmode);
     pa.gmean = const_cast<double*>(gm); pa.gvar = const_cast<double*>(gv);
     pa.gupdate = update_goal_stats ? 1 : 0;
   }
@@ -1037,6 +1028,8 @@ int64_t gcrl_her_process_step_g(gcrl_her* h, gcrl_normalizer* nz_obs, int update
   pa.SA4 = h->SA4; pa.S4 = h->S4; pa.RG = h->RG;
   hipLaunchKernelGGL(her_process_step_kernel, dim3(1), dim3(256), 0, st, pa);
   GCRL_HIP(hipGetLastError());
+  if (pa.update) gcrl::normalizer_updated(nz_obs);
+  if (pa.gupdate) gcrl::normalizer_updated(nz_dg);
   return finish_vector_step(h, env0, n, dones_host, st);
 }
 

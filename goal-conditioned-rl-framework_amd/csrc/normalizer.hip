@@ -28,26 +28,19 @@ struct gcrl_normalizer {
   float* xdev = nullptr;     // staging of host rows
   float* xpin = nullptr;
   size_t xcap = 0;           // floats
-  bool f32 = false;          // loaded statistics: float32 arithmetic from then on (norm_math.h)
+  bool f32 = false;          // loaded statistics: float32 arrays (norm_math.h NORM_F32)
+  bool rows64 = false;       // the trainer's rows are float64 arrays (NORM_ROWS64): moments / merge / normalize in float64
+  int mode() const { return (f32 ? gcrl::NORM_F32 : 0) | (rows64 ? gcrl::NORM_ROWS64 : 0); }
 };
 
 namespace {
 
-// one thread per feature: the batch moments in float32 (numpy's order), the merge in float64 — or float32 once loaded
-__global__ void norm_update_kernel(const float* __restrict__ x, int n, int ld, int D, double* mean, double* var, double* count, int f32) {
+// one thread per feature: the batch moments and the merge in the types numpy would use (norm_math.h)
+__global__ void norm_update_kernel(const float* __restrict__ x, int n, int ld, int D, double* mean, double* var, double* count, int mode) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= D) return;
-  float s = 0.f;
-  for (int i = 0; i < n; ++i) s = __fadd_rn(s, x[(long long)i * ld + j]);
-  const float bm = __fdiv_rn(s, (float)n);
-  float q = 0.f;
-  for (int i = 0; i < n; ++i) {
-    const float d = __fsub_rn(x[(long long)i * ld + j], bm);
-    q = __fadd_rn(q, __fmul_rn(d, d));
-  }
-  const float bv = __fdiv_rn(q, (float)n);
   double m = mean[j], v = var[j];
-  gcrl::norm_merge(m, v, bm, bv, n, *count, f32 != 0);
+  gcrl::norm_update_col(m, v, n, *count, mode, [&](int i) { return x[(long long)i * ld + j]; });
   mean[j] = m;
   var[j] = v;
 }
@@ -55,13 +48,13 @@ __global__ void norm_count_kernel(double* count, int n) { *count = *count + (dou
 
 // out[i][col0 + j] = float32(clip((x[i][j] - mean[j]) / (sqrt(var[j]) + 1e-8)))   (mean == null: plain copy)
 __global__ void norm_apply_kernel(const float* __restrict__ x, int n, int ld, int D, const double* mean, const double* var,
-                                  double clip, float* out, int ld_out, int col0, int f32) {
+                                  double clip, float* out, int ld_out, int col0, int mode) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * D) return;
   const int i = t / D, j = t - i * D;
   const float v = x[(long long)i * ld + j];
   float r = v;
-  if (mean) r = gcrl::norm_apply(v, mean[j], gcrl::norm_den(var[j], f32 != 0), clip, f32 != 0);
+  if (mean) r = gcrl::norm_apply(v, mean[j], gcrl::norm_den(var[j], (mode & gcrl::NORM_F32) != 0), clip, gcrl::norm_apply_f32(mode));
   out[(long long)i * ld_out + col0 + j] = r;
 }
 
@@ -82,13 +75,16 @@ hipStream_t pick_stream(void* s) { return s == GCRL_STREAM_LEGACY ? (hipStream_t
 }  // namespace
 
 namespace gcrl {
-void normalizer_view(const gcrl_normalizer* z, const double** mean, const double** var, double** count, double* clip, int* f32) {
+void normalizer_view(const gcrl_normalizer* z, const double** mean, const double** var, double** count, double* clip, int* mode) {
   *mean = z ? z->mean : nullptr; *var = z ? z->var : nullptr; if (count) *count = z ? z->count : nullptr; *clip = z ? z->clip : 0.0;
-  if (f32) *f32 = (z && z->f32) ? 1 : 0;
+  if (mode) *mode = z ? z->mode() : 0;
 }
+// a launch that updates `z` has been enqueued: float64 rows leave float64 statistics behind (later launches see them in stream order)
+void normalizer_updated(gcrl_normalizer* z) { if (z && z->rows64) z->f32 = false; }
 // device rows in, statistics updated (used by the fused entry points)
 int normalizer_update_dev(gcrl_normalizer* z, const float* x_dev, int n, int ld, hipStream_t st) {
-  hipLaunchKernelGGL(norm_update_kernel, dim3((z->size + 63) / 64), dim3(64), 0, st, x_dev, n, ld, z->size, z->mean, z->var, z->count, z->f32 ? 1 : 0);
+  hipLaunchKernelGGL(norm_update_kernel, dim3((z->size + 63) / 64), dim3(64), 0, st, x_dev, n, ld, z->size, z->mean, z->var, z->count, z->mode());
+  normalizer_updated(z);
   hipLaunchKernelGGL(norm_count_kernel, dim3(1), dim3(1), 0, st, z->count, n);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
@@ -96,7 +92,7 @@ int normalizer_update_dev(gcrl_normalizer* z, const float* x_dev, int n, int ld,
 // out[:, col0 : col0 + D] = normalize(x) (z == null: copy)
 int normalizer_apply_dev(const gcrl_normalizer* z, const float* x_dev, int n, int ld, int D, float* out_dev, int ld_out, int col0, hipStream_t st) {
   hipLaunchKernelGGL(norm_apply_kernel, dim3((n * D + 255) / 256), dim3(256), 0, st, x_dev, n, ld, D, z ? z->mean : nullptr,
-                     z ? z->var : nullptr, z ? z->clip : 0.0, out_dev, ld_out, col0, (z && z->f32) ? 1 : 0);
+                     z ? z->var : nullptr, z ? z->clip : 0.0, out_dev, ld_out, col0, z ? z->mode() : 0);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
@@ -198,5 +194,11 @@ int gcrl_normalizer_set_float32(gcrl_normalizer* z, int on) {
 }
 
 int gcrl_normalizer_is_float32(const gcrl_normalizer* z) { return (z && z->f32) ? 1 : 0; }
+
+int gcrl_normalizer_set_rows_float64(gcrl_normalizer* z, int on) {
+  GCRL_CHECK_ARG(z, "gcrl_normalizer_set_rows_float64: null handle");
+  z->rows64 = on != 0;   // (host state read when a launch is enqueued: no synchronisation needed)
+  return GCRL_OK;
+}
 
 }  // extern "C"

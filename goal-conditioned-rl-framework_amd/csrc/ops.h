@@ -236,7 +236,8 @@ struct BnSlabFwd {
   int B, H, K;
   // rsplit > 1 (and B > 128): the rows split over ceil(B/128) workgroups per slab that exchange their column partials through
   // `xchg` (bn_slab_xchg_floats(H) floats) and wait on `bar` (bn_slab_bar_words(H) words, zero-initialised) — bn_slab.hip
-  int rsplit; float* xchg; unsigned int* bar;
+  // `status`: host-visible word that takes MEET_ERR_BN_SLAB when a wait inside the launch times out (meet.h; may be null)
+  int rsplit; float* xchg; unsigned int* bar; unsigned int* status;
 };
 // Backward of layer l: dh = sum_u G[u] . W[u] (the consuming layers: W[u] is [K[u]][ldw] row-major, its first H columns used),
 // ReLU mask from xhat, dz written over xhat, dgamma / dbeta, sumsq_out[H/16] (sum of squares of dgamma | dbeta per slab).
@@ -246,11 +247,12 @@ struct BnSlabBwd {
   const float *invstd, *gamma, *beta;
   float *dgamma, *dbeta, *sumsq_out;
   int B, H;
-  int rsplit; float* xchg; unsigned int* bar;   // as in BnSlabFwd
+  int rsplit; float* xchg; unsigned int* bar; unsigned int* status;   // as in BnSlabFwd
 };
 bool bn_slab_ok(int B, int H);
 long long bn_slab_xchg_floats(int H);
 long long bn_slab_bar_words(int H);
+int bn_slab_row_split(int B, int H, int n_inputs);   // row groups the launchers use when a layer asks for the split (1: none) on this device
 int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f);
 int launch_bn_linear_bwd_slab(hipStream_t st, const BnSlabBwd& b);
 // running_mean / running_var of `layers` BatchNorm layers from the batch statistics the slab launches left

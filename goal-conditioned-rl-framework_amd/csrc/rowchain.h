@@ -260,9 +260,10 @@ struct RowChainArgs {
   unsigned long long* clk;   // profiling: {first block start, last block end} in wall_clock64 ticks, or null
   // split form (launch_rowchain_split): the roles of a phase run in DIFFERENT workgroups, two launches per phase
   float* qt;       // [C][B] target-critic outputs (written by the forward launch, read by the backward launch)
-  // part 3 (both parts in ONE launch): barrier words of the row blocks, [2 phases][nblk][32] (word 0 arrivals, word 16 generation),
-  // zero-initialised; see rowchain_split_kernel
+  // part 3 (both parts in ONE launch): meeting counters of the row blocks, [2 phases][nblk][32 words] (a 64-bit counter at the
+  // head of each 128-byte line, meet.h), zero-initialised; `status`: host-visible word that takes MEET_ERR_ROWCHAIN on a timed-out wait
   unsigned int* bar;
+  unsigned int* status;
 };
 
 // Twin-critic phases as role-parallel launches (SAC; TD3 at small batches).  In the fused kernel a workgroup
@@ -281,6 +282,7 @@ struct RowChainArgs {
 // launcher checks), so a waiting workgroup never keeps an awaited one off the chip; a wait that times out poisons the gradient
 // with NaN instead of hanging.  Same per-row arithmetic: bitwise the results of the two-launch form.
 int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part);
+bool rowchain_merge_ok(int rg, int ldl, int A, int H, int C, int B);   // part 3 admissible: all its workgroups resident at once on an unshared device
 
 // Batched actor inference (select_action, src/agent.py:1345-1366) as one row-block launch: 4 observation
 // rows per workgroup through the actor's hidden layers and its tanh head.
@@ -295,7 +297,7 @@ struct RowActArgs {
   // mode 2 (post == 2): clip(tanh(y), -1, 1), mode 3: y   (select_action's arithmetic, src/agent.py:1345-1366, :253-270)
   const double* nz_mean; const double* nz_var; double nz_clip; int D;
   const double* nzg_mean; const double* nzg_var; double nzg_clip;
-  int nz_f32, nzg_f32;   // loaded normalisers: float32 arithmetic (norm_math.h)
+  int nz_mode, nzg_mode;   // norm_math.h bits (float32 statistics of loaded normalisers, float64 rows)
   int post; const double* noise; double* out64;
 };
 int launch_rowchain_act(hipStream_t st, const RowActArgs& a);

@@ -10,6 +10,7 @@
 //       d(pre-tanh) = da*(1-a^2); actor gradient chain, saved for dW.
 #include "rowchain.h"
 #include "norm_math.h"
+#include "meet.h"
 
 #include <algorithm>
 
@@ -378,31 +379,10 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
 }
 
 // ---- role-parallel form (rowchain.h: launch_rowchain_split) -------------------------------------------------
-// part 3: the role workgroups of a row block meet.  Every workgroup arrives (its agent-scope stores acknowledged first); those that
-// need the others' values wait for the generation word to change.  Returns false on a timed-out wait.
-constexpr int kRcSpinMax = 1 << 20;
-__device__ inline bool rc_meet(unsigned int* words, int arrivals, bool wait, unsigned int* s_flag) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // s_waitcnt: this wave's stores have been acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned int* cnt = words;
-    unsigned int* gen = words + 16;
-    const unsigned int g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned int t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int ok = 1;
-    if (t == (unsigned)(arrivals - 1)) {
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (wait) {
-      int spins = 0;
-      while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0 && ++spins < kRcSpinMax) __builtin_amdgcn_s_sleep(4);
-      ok = spins < kRcSpinMax ? 1u : 0u;
-    }
-    *s_flag = ok;
-  }
-  __syncthreads();
-  return *s_flag != 0;
+// part 3: the role workgroups of a row block meet (meet.h: every wave drains its agent-scope stores before the arrival; one
+// monotonic 64-bit counter per row block and phase; those that need the others' values wait, bounded).  Returns false on a timed-out wait.
+__device__ inline bool rc_meet(unsigned int* words, int arrivals, bool wait, unsigned int* s_flag, unsigned int* status) {
+  return meet(reinterpret_cast<unsigned long long*>(words), (unsigned)arrivals, wait, s_flag, status, MEET_ERR_ROWCHAIN);
 }
 __device__ inline void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -474,7 +454,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
     rows_head<RG>(h, ldl, H, hw_tc, H, hb + 16, 1, EPI_NONE, sm);
     __syncthreads();
     if (tid < rv) st_agent(a.qt + (long long)k * B + row0 + tid, sm[tid * 16]);
-    if (merged) rc_meet(meet, 2 * C, false, &s_flag);        // (the target roles only report in)
+    if (merged) rc_meet(meet, 2 * C, false, &s_flag, a.status);        // (the target roles only report in)
     return;
   }
   int k2 = role;                                 // the critic whose backward part runs in this workgroup
@@ -491,7 +471,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
     __syncthreads();
     if (tid < rv) a.q[(long long)k * B + row0 + tid] = sm[tid * 16];
     if (!merged) return;
-    met = rc_meet(meet, 2 * C, true, &s_flag);               // both target critics' outputs of these rows are out
+    met = rc_meet(meet, 2 * C, true, &s_flag, a.status);               // both target critics' outputs of these rows are out
     k2 = k;
   }
   if (phase == 0) {
@@ -554,7 +534,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
     __syncthreads();
     if (tid < rv) st_agent(a.q2 + (long long)k * B + row0 + tid, sm[tid * 16]);
     if (!merged) return;
-    met = rc_meet(meet, C, true, &s_flag);                   // the other critic's Q of these rows is out
+    met = rc_meet(meet, C, true, &s_flag, a.status);                   // the other critic's Q of these rows is out
   }
   {
     // ---- P, part 2: d(-mean min(q1, q2))/dq_k, input-gradient chain of critic `role` down to the action columns
@@ -626,8 +606,8 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a)
           const int j = ob ? c : c - a.D;
           const double* v = ob ? a.nz_var : a.nzg_var;
           const double clip = ob ? a.nz_clip : a.nzg_clip;
-          const bool f32 = (ob ? a.nz_f32 : a.nzg_f32) != 0;
-          s_x.v[u] = norm_apply(s_x.v[u], m[j], norm_den(v[j], f32), clip, f32);
+          const int md = ob ? a.nz_mode : a.nzg_mode;
+          s_x.v[u] = norm_apply(s_x.v[u], m[j], norm_den(v[j], (md & NORM_F32) != 0), clip, norm_apply_f32(md));
         }
       }
     }
@@ -676,6 +656,16 @@ size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C) {
   return (size_t)(4 * R * ldl + (rg == 1 ? 2 : 1) * 4 * R * kRowChunk + 4 * R * 16 + std::max(std::max(2 * A + 1, A + 2 * C), C * (A + 1)) * H + 32) * sizeof(float);
 }
 
+// the merged (part 3) launches wait inside the kernel: all 2C x nblk workgroups of the larger one must be resident at once
+bool rowchain_merge_ok(int rg, int ldl, int A, int H, int C, int B) {
+  const size_t lds = rowchain_lds_bytes(rg, ldl, A, H, C);
+  if (lds > 160 * 1024) return false;
+  const void* k = rg == 1 ? (const void*)rowchain_split_kernel<1> : (rg == 2 ? (const void*)rowchain_split_kernel<2> : (const void*)rowchain_split_kernel<4>);
+  if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+  const long long nblk = (B + 4 * rg - 1) / (4 * rg);
+  return 2LL * C * nblk <= meet_capacity(k, kRowThreads, lds);
+}
+
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
   GCRL_CHECK_ARG(rg == 1 || rg == 2 || rg == 4, "rowchain: rows per block must be 4, 8 or 16");
   GCRL_CHECK_ARG(a.critic[0].H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16 && a.C >= 1 && a.C <= 2,
@@ -708,8 +698,9 @@ int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int pha
   GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain: %zu bytes of LDS needed", lds);
   const int nblk = (a.B + 4 * rg - 1) / (4 * rg);
   const int roles = (phase == 0 && part != 2) ? 2 * a.C : a.C;
-  // part 3: every workgroup of the launch must be resident at once (two per CU at most here: LDS allows it, checked above)
-  GCRL_CHECK_ARG(part != 3 || ((long long)roles * nblk <= 512 && 2 * lds <= 160 * 1024), "rowchain split: %d workgroups of %zu bytes of LDS cannot all be resident", roles * nblk, lds);
+  // part 3: every workgroup of the launch must be resident at once (rowchain_merge_ok: the kernel's occupancy at this LDS size
+  // on a device the process has to itself)
+  GCRL_CHECK_ARG(part != 3 || rowchain_merge_ok(rg, a.ldl, a.A, a.critic[0].H, a.C, a.B), "rowchain split: %d workgroups of %zu bytes of LDS cannot all be resident (or the device is shared)", roles * nblk, lds);
   auto go = [&](auto kern) -> int {
     static thread_local size_t raised = 0;
     if (lds > 64 * 1024 && lds > raised) {

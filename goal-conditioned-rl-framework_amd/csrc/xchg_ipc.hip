@@ -1,0 +1,304 @@
+// xchg_ipc.hip — the data-parallel gradient exchange as ONE kernel of the engine's own launch sequence: a two-shot
+// all-reduce over IPC-mapped gradient arenas, peer to peer, that returns the clip norm's partial sums with the reduced bytes.
+//
+// New design — the reference is single-process; BASELINE.json's north star asks for the gradient
+// all-reduce over xGMI.  Round 2-3 issued a stock ncclAllReduce of the flat block (csrc/dp_rccl.cc, still selectable) plus a
+// sum-of-squares launch: a library collective on the critical path of a 58 us step, outside hipGraph capture, with the
+// control-advance riders and multi-step graphs of the single-GPU path switched off around it.
+//
+// Shape of the exchange (world W <= 8 ranks of ONE node, one process per GPU):
+//   * every rank's gradient arena (one hipMalloc: all critics | actor | log_alpha) and a small control block are exported with
+//     hipIpcGetMemHandle and mapped by every peer (handles travel through whatever the host side has: torch.distributed's
+//     store).  xGMI is point to point: each rank talks to each peer directly, one hop, no ring.
+//   * the block is cut into 1024-float chunks, net by net; chunk c belongs to rank c mod W.  The owner reads the chunk from
+//     EVERY rank's arena (W loads in flight per lane), adds them in RANK ORDER — the same sum whoever computes it, so the
+//     replicas stay bitwise identical — forms the chunk's sum of squares, and writes chunk and partial back into every rank's
+//     arena / partial array IN PLACE (only the owner ever touches a chunk anywhere, so in-place is race-free).  The optimiser
+//     launch that follows reads the reduced gradients and ~N/1024 partials per net: no separate norm launch.
+//   * ordering by two monotonic 64-bit counters per (rank, source) pair, each on its own 128-byte line of the TARGET's control
+//     block: ready[src] ("src's gradients of exchange e are complete": stream order on src, announced by its first workgroup),
+//     done[src] ("src has delivered every chunk it owns for exchange e").  A rank reads peers only after their `ready`, and the
+//     kernel ends only after every peer's `done`: the kernel boundary then publishes the peers' writes to the optimiser launch,
+//     and a rank's next backward pass cannot overwrite gradients a peer is still reading.  The exchange number lives in device
+//     memory and is advanced by the kernel itself, so the launch is capturable in hipGraphs (multi-step graphs stay on).
+//   * all cross-device traffic uses system-scope (sc0 sc1) loads / stores; every storing wave drains (`s_waitcnt vmcnt(0)`)
+//     before its workgroup's arrival (meet.h); waits are bounded and report through the handle's status word.
+// Nothing here has been timed over xGMI (1-GPU boxes): proven bitwise against the RCCL / gloo result with two processes on one
+// GPU (tests/test_gpu_dp.py), world-size-1 cost measured (profiles/r04_dp_overhead_world1.json).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+#include "meet.h"
+#include "ops.h"
+#include "xchg_ipc.h"
+
+namespace gcrl {
+
+namespace {
+
+constexpr int kSys = 17;                       // sc0 | sc1 of the raw buffer builtins: system scope (gfx94x / gfx950)
+constexpr long long kFlagStride = 16;          // 64-bit words per flag: one 128-byte line each
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+struct XChunk { long long off; int n; int pad; };   // floats from the arena base; n <= kXchgChunk (a multiple of 4 except a net's tail)
+
+struct XArgs {
+  float* arena[kXchgMaxWorld];                 // every rank's gradient arena (own: the local pointer)
+  unsigned long long* ctl[kXchgMaxWorld];      // every rank's control block: ready[W] | done[W] | epoch | ticket (128-byte lines)
+  float* parts[kXchgMaxWorld];                 // every rank's partial array
+  const XChunk* chunks;                        // local copy of the chunk table
+  int world, rank, c0, c1;                     // chunks [c0, c1) take part
+  unsigned int* status;
+};
+
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// wave-uniform descriptor over [p, p + nfloats): loads past the extent return 0, stores past it are dropped (per dword)
+__device__ inline __amdgpu_buffer_rsrc_t rsrc_n(const float* p, int nfloats) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  void* q = (void*)(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(nfloats * 4), 0x00020000);
+}
+
+__global__ __launch_bounds__(256) void xchg_two_shot_kernel(XArgs a) {
+  __shared__ float red[4];
+  __shared__ unsigned int s_ok;
+  const int W = a.world, me = a.rank, tid = threadIdx.x;
+  unsigned long long* ctl = a.ctl[me];
+  unsigned long long* ready = ctl;                                   // [src]
+  unsigned long long* done = ctl + (long long)kXchgMaxWorld * kFlagStride;       // [src]
+  unsigned long long* epoch = ctl + 2LL * kXchgMaxWorld * kFlagStride;
+  unsigned long long* ticket = epoch + kFlagStride;
+  // the exchange this launch performs: every workgroup reads the number before it takes its ticket, the workgroup with the last
+  // ticket advances it — after all of them have read it
+  const unsigned long long e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+  if (blockIdx.x == 0 && tid < W && tid != me)                       // my gradients are complete (stream order): tell every peer
+    st_sys(a.ctl[tid] + (long long)me * kFlagStride, e);
+  if (tid == 0) s_ok = 1u;
+  __syncthreads();
+  if (tid < W && tid != me) {                                        // every peer's gradients are complete
+    int spins = 0;
+    while (ld_sys(ready + (long long)tid * kFlagStride) < e && ++spins < kMeetSpinMax) __builtin_amdgcn_s_sleep(2);
+    if (spins >= kMeetSpinMax) { s_ok = 0u; if (a.status) __hip_atomic_fetch_or(a.status, (unsigned)MEET_ERR_XCHG_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0u;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int boff = 16 * tid;                                         // this lane's four floats of a chunk (byte offset)
+  for (int c = a.c0 + me + W * (int)blockIdx.x; c < a.c1; c += W * (int)gridDim.x) {
+    const XChunk ch = a.chunks[c];
+    // branch-free over the 8 possible peers: a rank beyond the world gets a descriptor of extent 0 — its load returns zeros
+    // without touching memory, its store is dropped — so that all W loads are in flight together (a branch per peer made the
+    // compiler wait for each load before the next: W serial round trips over the fabric)
+    v4u v[kXchgMaxWorld];
+#pragma unroll
+    for (int q = 0; q < kXchgMaxWorld; ++q)
+      v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n(a.arena[q < W ? q : 0] + ch.off, q < W ? ch.n : 0), boff, 0, kSys);
+    float s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s[u] = __uint_as_float(v[0][u]);
+#pragma unroll
+      for (int q = 1; q < kXchgMaxWorld; ++q) {                      // rank order; (x + 0 would turn a -0 into +0: select instead)
+        const float t = __fadd_rn(s[u], __uint_as_float(v[q][u]));
+        s[u] = q < W ? t : s[u];
+      }
+    }
+    if (!ok) { s[0] = s[1] = s[2] = s[3] = __builtin_nanf(""); }     // a timed-out wait must not pass for a result
+    const v4u r = {__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3])};
+#pragma unroll
+    for (int q = 0; q < kXchgMaxWorld; ++q)
+      __builtin_amdgcn_raw_buffer_store_b128(r, rsrc_n(a.arena[q < W ? q : 0] + ch.off, q < W ? ch.n : 0), boff, 0, kSys);   // (past the chunk: dropped)
+    // the chunk's sum of squares, in a fixed order: lane's four (zeros past the chunk), wave tree, four waves
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (4 * tid + u < ch.n) ss = __fadd_rn(ss, __fmul_rn(s[u], s[u]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off, 64));
+    __syncthreads();                                                 // (red[] of the previous chunk has been read)
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    if (tid < W) {
+      const float tot = __fadd_rn(__fadd_rn(red[0], red[1]), __fadd_rn(red[2], red[3]));
+      __hip_atomic_store(a.parts[tid] + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  drain_stores();                                                    // every wave: its write-through stores have been acknowledged
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                    // system scope (the stores above were write-through: ordering only)
+    const unsigned long long t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ok = (t == gridDim.x - 1) ? 2u : 0u;
+    if (s_ok) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody waits on the ticket: ready for the next launch
+  }
+  __syncthreads();
+  if (s_ok != 2u) return;
+  // the last workgroup of this rank: everything this rank owns has been delivered everywhere
+  if (tid < W && tid != me) {
+    st_sys(a.ctl[tid] + ((long long)kXchgMaxWorld + me) * kFlagStride, e);
+    int spins = 0;
+    while (ld_sys(done + (long long)tid * kFlagStride) < e && ++spins < kMeetSpinMax) __builtin_amdgcn_s_sleep(2);
+    if (spins >= kMeetSpinMax && a.status) __hip_atomic_fetch_or(a.status, (unsigned)MEET_ERR_XCHG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+}  // namespace gcrl
+
+using namespace gcrl;
+
+struct gcrl_xchg {
+  int rank = 0, world = 1, device = 0;
+  float* arena = nullptr; long long arena_floats = 0;
+  char* ctl = nullptr; size_t ctl_bytes = 0;          // control block + partial array (one hipMalloc, IPC-exported)
+  size_t parts_off = 0;
+  XChunk* chunks_dev = nullptr;
+  std::vector<XChunk> chunks;
+  std::vector<int> seg_c0;                            // first chunk of segment s; seg_c0[nseg] = total
+  void* peer_arena[kXchgMaxWorld] = {};
+  void* peer_ctl[kXchgMaxWorld] = {};
+  bool connected = false;
+  unsigned int* status = nullptr;                     // device-visible status word of the owner (may be null)
+};
+
+extern "C" {
+
+gcrl_xchg* gcrl_xchg_create(float* arena_dev, int64_t arena_floats, const int64_t* seg_off, const int64_t* seg_n, int nseg, int rank,
+                            int world, int device) {
+  auto bad = [](const char* m) -> gcrl_xchg* { fail(GCRL_ERR_ARG, "gcrl_xchg_create: %s", m); return nullptr; };
+  if (!arena_dev || arena_floats < 1 || !seg_off || !seg_n || nseg < 1) return bad("null / empty argument");
+  if (world < 1 || world > kXchgMaxWorld || rank < 0 || rank >= world) return bad("1 <= world <= 8 and 0 <= rank < world required (one node, point-to-point xGMI)");
+  if (((uintptr_t)arena_dev & 15) != 0) return bad("the arena must be 16-byte aligned");
+  gcrl_xchg* x = new gcrl_xchg;
+  x->rank = rank; x->world = world; x->device = device;
+  x->arena = arena_dev; x->arena_floats = arena_floats;
+  for (int s = 0; s < nseg; ++s) {
+    if (seg_off[s] < 0 || seg_n[s] < 1 || seg_off[s] % 4 != 0 || seg_off[s] + seg_n[s] > arena_floats) { delete x; return bad("segment outside the arena or not 16-byte aligned"); }
+    x->seg_c0.push_back((int)x->chunks.size());
+    for (long long o = 0; o < seg_n[s]; o += kXchgChunk)
+      x->chunks.push_back(XChunk{seg_off[s] + o, (int)std::min<long long>(kXchgChunk, seg_n[s] - o), 0});
+  }
+  x->seg_c0.push_back((int)x->chunks.size());
+  const size_t flags = (size_t)(2 * kXchgMaxWorld + 2) * kFlagStride * sizeof(unsigned long long);
+  x->parts_off = flags;
+  x->ctl_bytes = flags + ((x->chunks.size() * sizeof(float) + 255) / 256) * 256;
+  bool ok = hipSetDevice(device) == hipSuccess && hipMalloc((void**)&x->ctl, x->ctl_bytes) == hipSuccess &&
+            hipMemset(x->ctl, 0, x->ctl_bytes) == hipSuccess &&
+            hipMalloc((void**)&x->chunks_dev, x->chunks.size() * sizeof(XChunk)) == hipSuccess &&
+            hipMemcpy(x->chunks_dev, x->chunks.data(), x->chunks.size() * sizeof(XChunk), hipMemcpyHostToDevice) == hipSuccess &&
+            hipDeviceSynchronize() == hipSuccess;
+  if (!ok) { fail(GCRL_ERR_HIP, "gcrl_xchg_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); gcrl_xchg_destroy(x); return nullptr; }
+  x->peer_arena[rank] = x->arena;
+  x->peer_ctl[rank] = x->ctl;
+  x->connected = world == 1;
+  return x;
+}
+
+void gcrl_xchg_destroy(gcrl_xchg* x) {
+  if (!x) return;
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < x->world; ++q) {
+    if (q == x->rank) continue;
+    if (x->peer_arena[q]) (void)hipIpcCloseMemHandle(x->peer_arena[q]);
+    if (x->peer_ctl[q]) (void)hipIpcCloseMemHandle(x->peer_ctl[q]);
+  }
+  if (x->ctl) (void)hipFree(x->ctl);
+  if (x->chunks_dev) (void)hipFree(x->chunks_dev);
+  delete x;
+}
+
+int gcrl_xchg_handles(gcrl_xchg* x, uint8_t* out, int64_t n) {
+  GCRL_CHECK_ARG(x && out && n == GCRL_XCHG_HANDLE_BYTES, "gcrl_xchg_handles: the buffer must hold GCRL_XCHG_HANDLE_BYTES bytes");
+  static_assert(2 * sizeof(hipIpcMemHandle_t) + 2 * sizeof(int64_t) <= GCRL_XCHG_HANDLE_BYTES, "handle record");
+  hipIpcMemHandle_t h[2];
+  GCRL_HIP(hipIpcGetMemHandle(&h[0], x->arena));
+  GCRL_HIP(hipIpcGetMemHandle(&h[1], x->ctl));
+  std::memset(out, 0, (size_t)n);
+  std::memcpy(out, h, sizeof(h));
+  const int64_t meta[2] = {(int64_t)x->arena_floats, (int64_t)x->chunks.size()};
+  std::memcpy(out + sizeof(h), meta, sizeof(meta));
+  return GCRL_OK;
+}
+
+int gcrl_xchg_connect(gcrl_xchg* x, const uint8_t* all, int64_t n) {
+  GCRL_CHECK_ARG(x && all && n == (int64_t)x->world * GCRL_XCHG_HANDLE_BYTES, "gcrl_xchg_connect: world x GCRL_XCHG_HANDLE_BYTES bytes expected");
+  GCRL_HIP(hipSetDevice(x->device));
+  for (int q = 0; q < x->world; ++q) {
+    if (q == x->rank) continue;
+    const uint8_t* rec = all + (size_t)q * GCRL_XCHG_HANDLE_BYTES;
+    hipIpcMemHandle_t h[2];
+    int64_t meta[2];
+    std::memcpy(h, rec, sizeof(h));
+    std::memcpy(meta, rec + sizeof(h), sizeof(meta));
+    if (meta[0] != x->arena_floats || meta[1] != (int64_t)x->chunks.size())
+      return fail(GCRL_ERR_STATE, "gcrl_xchg_connect: rank %d exchanges a different layout (%lld floats / %lld chunks, here %lld / %zu): the replicas must be built alike",
+                  q, (long long)meta[0], (long long)meta[1], (long long)x->arena_floats, x->chunks.size());
+    GCRL_HIP(hipIpcOpenMemHandle(&x->peer_arena[q], h[0], hipIpcMemLazyEnablePeerAccess));
+    GCRL_HIP(hipIpcOpenMemHandle(&x->peer_ctl[q], h[1], hipIpcMemLazyEnablePeerAccess));
+  }
+  x->connected = true;
+  return GCRL_OK;
+}
+
+int gcrl_xchg_world(const gcrl_xchg* x) { return x ? x->world : 0; }
+
+void gcrl_xchg_set_status(gcrl_xchg* x, unsigned int* status_dev) { if (x) x->status = status_dev; }
+
+int gcrl_xchg_seg_parts(const gcrl_xchg* x, int seg, const float** parts_dev, int* nparts) {
+  GCRL_CHECK_ARG(x && seg >= 0 && seg + 1 < (int)x->seg_c0.size() && parts_dev && nparts, "gcrl_xchg_seg_parts: bad segment");
+  *parts_dev = reinterpret_cast<const float*>(x->ctl + x->parts_off) + x->seg_c0[seg];
+  *nparts = x->seg_c0[seg + 1] - x->seg_c0[seg];
+  return GCRL_OK;
+}
+
+int gcrl_xchg_get_partials(gcrl_xchg* x, int seg, float* out_host, int n) {
+  const float* p = nullptr; int np = 0;
+  if (int rc = gcrl_xchg_seg_parts(x, seg, &p, &np)) return rc;
+  GCRL_CHECK_ARG(out_host && n >= np, "gcrl_xchg_get_partials: segment %d has %d partials, room for %d", seg, np, n);
+  GCRL_HIP(hipDeviceSynchronize());
+  GCRL_HIP(hipMemcpy(out_host, p, (size_t)np * sizeof(float), hipMemcpyDeviceToHost));
+  return np;
+}
+
+int gcrl_xchg_allreduce(gcrl_xchg* x, int seg0, int nseg, void* stream) {
+  GCRL_CHECK_ARG(x && seg0 >= 0 && nseg >= 1 && seg0 + nseg < (int)x->seg_c0.size(), "gcrl_xchg_allreduce: segments [%d, %d) outside the table", seg0, seg0 + nseg);
+  if (!x->connected) return fail(GCRL_ERR_STATE, "gcrl_xchg_allreduce: the peers' handles have not been connected (gcrl_xchg_connect)");
+  XArgs a;
+  std::memset(&a, 0, sizeof(a));
+  for (int q = 0; q < x->world; ++q) {
+    a.arena[q] = (float*)x->peer_arena[q];
+    a.ctl[q] = (unsigned long long*)x->peer_ctl[q];
+    a.parts[q] = reinterpret_cast<float*>((char*)x->peer_ctl[q] + x->parts_off);
+  }
+  a.chunks = x->chunks_dev;
+  a.world = x->world; a.rank = x->rank;
+  a.c0 = x->seg_c0[seg0]; a.c1 = x->seg_c0[seg0 + nseg];
+  a.status = x->status;
+  const int mine = (a.c1 - a.c0 + x->world - 1) / x->world;
+  const int grid = std::max(1, std::min(mine, 1024));
+  hipStream_t st = stream == GCRL_STREAM_LEGACY ? (hipStream_t) nullptr : (hipStream_t)stream;
+  hipLaunchKernelGGL(xchg_two_shot_kernel, dim3(grid), dim3(256), 0, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+// after a timed-out exchange (status word): every rank's counters back to a common state.  Collective in spirit: the caller
+// synchronises the ranks around it (the host side does: src/dp.py)
+int gcrl_xchg_reset(gcrl_xchg* x) {
+  GCRL_CHECK_ARG(x, "gcrl_xchg_reset: null handle");
+  GCRL_HIP(hipDeviceSynchronize());
+  GCRL_HIP(hipMemset(x->ctl, 0, x->parts_off));
+  GCRL_HIP(hipDeviceSynchronize());
+  return GCRL_OK;
+}
+
+}  // extern "C"

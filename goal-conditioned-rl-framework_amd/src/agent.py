@@ -202,6 +202,12 @@ class _EngineAgent:
         if h:
             lib.gcrl_agent_destroy(h)
 
+    def set_meetings(self, on: bool = True) -> int:
+        """Switch the launch forms whose workgroups wait for each other inside a kernel (csrc/meet.h) on (where the device
+        admits them) or off; returns the bit mask of the forms now active.  Off is the safe setting whenever the GPU is
+        shared with other processes or streams (`gcrl_set_shared_device` / GCRL_SHARED_GPU=1 do it process-wide)."""
+        return _ffi.check(lib.gcrl_agent_set_meetings(self._h, 1 if on else 0))
+
     # ------------------------------------------------------------------ update
     def _metrics(self, ticket: int, n: int):
         vals = self._metric_cache.get(ticket)
@@ -349,6 +355,14 @@ class _EngineAgent:
             return None
         return (on.handle if obs_normalize else None, gn.handle if g_normalize else None)
 
+    def _rows_dtypes(self, obs_rows, goal_rows, obs_normalize: bool, g_normalize: bool):
+        """numpy's type rules decide the reference normaliser's arithmetic: tell the device normalisers which dtype the rows
+        have on the caller's side (the trainer's observation batches are float64 arrays, its goal batches float32)."""
+        if obs_normalize:
+            self.buffer.obs_normalizer.rows_dtype(np.asarray(obs_rows).dtype)
+        if g_normalize:
+            self.buffer.dg_normalizer.rows_dtype(np.asarray(goal_rows).dtype)
+
     _ACT_MODE_EXPLORE, _ACT_MODE_EVAL = 1, 0      # DDPG; TD3 overrides eval (raw network output)
 
     def observe_act(self, observation, desired_goal, eval_action: bool = False, obs_normalize: bool = True,
@@ -364,6 +378,7 @@ class _EngineAgent:
         if nz is None or obs.shape[0] > int(self.config.batch_size):
             return self.select_action(self.normalize_state_batch(obs, dg, obs_normalize, g_normalize), eval_action)
         self.set_eval()
+        self._rows_dtypes(observation, desired_goal, obs_normalize, g_normalize)
         n = obs.shape[0]
         noise, mode = self._act_noise(n, eval_action)
         if mode is None:
@@ -401,6 +416,10 @@ class _EngineAgent:
             ns = torch.from_numpy(self.normalize_state_batch(next_obs_raw["observation"], next_obs_raw["desired_goal"], obs_normalize, g_normalize)).float().cuda()
             return buf.push_batch(s, actions, ns, rewards, dones, self.normalize_goal(next_obs_raw["achieved_goal"], g_normalize))
         f32 = lambda x: np.ascontiguousarray(x, np.float32)
+        self._rows_dtypes(np.result_type(np.asarray(state["observation"]).dtype, np.asarray(next_obs_raw["observation"]).dtype).type(0),
+                          np.result_type(*[np.asarray(g).dtype for g in (state["desired_goal"], next_obs_raw["desired_goal"],
+                                                                         state["achieved_goal"], next_obs_raw["achieved_goal"])]).type(0),
+                          obs_normalize, g_normalize)
         obs, nobs = f32(state["observation"]), f32(next_obs_raw["observation"])
         dg, ndg, nag = f32(state["desired_goal"]), f32(next_obs_raw["desired_goal"]), f32(next_obs_raw["achieved_goal"])
         act, rew = f32(actions), f32(rewards).reshape(-1)

@@ -17,7 +17,12 @@ statistics per rank (stated divergence from a single big batch).  Each exchange 
 buffer: messages are 37 KB - 11 MB, latency-bound on point-to-point xGMI, so fewer, larger
 collectives beat per-tensor ones.
 
-Over RCCL the exchange itself lives in the engine too: `DataParallelUpdater` creates a library-owned
+Round 4: the default on one node is the engine's own peer-to-peer exchange kernel over IPC-mapped gradient arenas
+(`exchange="ipc"`, csrc/xchg_ipc.hip): the all-reduce is a launch of the update's own sequence, so `update_many` under data
+parallelism IS the single-GPU entry point (multi-step hipGraphs, control-advance riders, deferred draws) with two more kernels per
+step (one per overlapped DDPG step), and the clip norm's partials come back with the reduced gradients.
+
+Over RCCL (`exchange="rccl"`) the exchange lives in the engine too: `DataParallelUpdater` creates a library-owned
 communicator (`gcrl_dp_create`, csrc/dp_rccl.cc; the 128-byte id travels through torch.distributed's store)
 and a whole trainer cycle is ONE native call (`gcrl_agent_dp_run_all`) that enqueues every graph segment and
 every all-reduce on the engine's stream — no Python round trip per exchange.  With any other backend (gloo in
@@ -76,10 +81,19 @@ def device_view(ptr: int, numel: int) -> torch.Tensor:
 class DataParallelUpdater:
     """Drives agent.update(step) across ranks.  `agent` is a gcrl_amd agent on this rank's GPU."""
 
-    def __init__(self, agent, group=None, require_native: bool = False, sync_bn: bool = False):
-        """`require_native`: over RCCL, raise on EVERY rank when the in-engine communicator cannot be created on any of them
-        instead of falling back to per-exchange torch.distributed calls (bench.py: a broken native path must not hide
-        behind a slower one).  `self.exchange` says which path moves the gradient bytes: "engine-rccl" or "python".
+    def __init__(self, agent, group=None, require_native: bool = False, sync_bn: bool = False, exchange: str = "auto"):
+        """`exchange` — who moves the gradient bytes (`self.exchange` says which one runs):
+          "ipc"     "engine-ipc": the engine's own peer-to-peer kernel over IPC-mapped gradient arenas (csrc/xchg_ipc.hip): the
+                    exchange is a launch of the step's sequence — hipGraph replay, multi-step graphs and the control-advance riders
+                    of the single-GPU path stay on, the clip norm's partials come back with the reduced gradients.  One node,
+                    world <= 8; any torch.distributed backend (it only carries the handles);
+          "rccl"    "engine-rccl": a library-owned RCCL communicator, one native call per trainer cycle (csrc/dp_rccl.cc; needs
+                    the nccl backend and one GPU per rank);
+          "python"  torch.distributed calls between the engine's segments (any backend; the tests' gloo rehearsals);
+          "auto"    ipc when every rank is on this host, else rccl over the nccl backend, else python.
+        GCRL_DP_EXCHANGE in the environment overrides the argument (bench.py's A/B legs); GCRL_DP_PYTHON_EXCHANGE=1 = "python".
+        `require_native`: raise on EVERY rank when the asked-for in-engine exchange cannot be set up on any of them instead of
+        falling back to torch.distributed calls (bench.py: a broken native path must not hide behind a slower one).
         `sync_bn` (SACAgent / TQCAgent): BatchNorm statistics over the concatenated batch of all ranks (gcrl_agent_dp_sync_bn)
         instead of each rank's own rows — G ranks x B rows then equal 1 rank x G*B rows for these agents too, at the price of
         one small exchange per BatchNorm layer and pass on the step's critical path."""
@@ -88,26 +102,75 @@ class DataParallelUpdater:
         self.agent = agent
         self.group = group
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         self.scale = 1.0 / self.world
         lib = _ffi.lib
         self._views = {}
         self._blocks = []
         self._block_ptrs = []
         self._native = None
-        if dist.get_backend(group) == "nccl" and not int(os.environ.get("GCRL_DP_PYTHON_EXCHANGE", "0")):
+        self._xchg = None
+        exchange = os.environ.get("GCRL_DP_EXCHANGE", exchange)
+        if int(os.environ.get("GCRL_DP_PYTHON_EXCHANGE", "0")):
+            exchange = "python"
+        if exchange not in ("auto", "ipc", "rccl", "python"):
+            raise ValueError(f"exchange must be auto | ipc | rccl | python, got {exchange!r}")
+        nccl = dist.get_backend(group) == "nccl"
+        flag_dev = "cuda" if nccl else "cpu"
+
+        def all_ok(ok: bool) -> bool:      # every rank must take the same path
+            t = torch.tensor([1 if ok else 0], device=flag_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t.item()))
+
+        # who shares what: hosts (IPC handles only mean something on one node) and devices (launch forms whose workgroups wait
+        # for each other inside a kernel assume the process has the GPU to itself: csrc/meet.h)
+        import socket
+        props = torch.cuda.get_device_properties(agent.device_index)
+        dev_id = str(getattr(props, "uuid", "")) or f"{getattr(props, 'pci_bus_id', agent.device_index)}"
+        where = [None] * self.world
+        dist.all_gather_object(where, (socket.gethostname(), dev_id), group=group)
+        one_host = len({h for h, _ in where}) == 1
+        shared_gpu = len(set(where)) < self.world
+        if exchange == "auto":
+            exchange = "ipc" if (one_host and self.world <= 8) else ("rccl" if nccl else "python")
+        if exchange == "ipc":
+            why = ""
+            x = lib.gcrl_agent_xchg_create(agent._h, self.rank, self.world) if (one_host and self.world <= 8) else None
+            rec = (C.c_uint8 * 160)()
+            ok = bool(x) and lib.gcrl_xchg_handles(x, rec, 160) == 0
+            if not ok:
+                why = _ffi.last_error() or "the ranks are not on one host / more than 8 ranks"
+            recs = [None] * self.world
+            dist.all_gather_object(recs, bytes(rec) if ok else b"", group=group)
+            ok = all(len(r) == 160 for r in recs)
+            if ok:
+                ok = lib.gcrl_xchg_connect(x, b"".join(recs), 160 * self.world) == 0
+                why = why or (_ffi.last_error() if not ok else "")
+            if all_ok(ok):
+                self._xchg = x
+                _ffi.check(lib.gcrl_agent_set_exchange(agent._h, x))
+            else:
+                if x:
+                    lib.gcrl_xchg_destroy(x)
+                if require_native:
+                    raise _ffi.GcrlError("gcrl_amd.dp: the in-engine IPC exchange could not be set up on every rank (this rank: " + (why or "ok") +
+                                         "); refusing a fallback (require_native)")
+                import warnings
+                warnings.warn("gcrl_amd.dp: in-engine IPC exchange unavailable (" + (why or "another rank failed") + "); falling back")
+                exchange = "rccl" if nccl else "python"
+        if exchange == "rccl" and nccl:
             # the librccl PyTorch itself uses (two RCCL / HIP runtime copies in one process do not mix)
             path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
             uid = (C.c_uint8 * 128)()
             ok = 1
-            if dist.get_rank(group) == 0:
+            if self.rank == 0:
                 ok = 1 if lib.gcrl_dp_unique_id(uid, path) == 0 else 0
             box = [bytes(uid), ok]
             dist.broadcast_object_list(box, src=0, group=group)
-            h = lib.gcrl_dp_create(dist.get_rank(group), self.world, box[0], agent.device_index, path) if box[1] else None
+            h = lib.gcrl_dp_create(self.rank, self.world, box[0], agent.device_index, path) if box[1] else None
             # every rank must take the same path: the in-engine exchange only if ALL ranks got their communicator
-            good = torch.tensor([1 if h else 0], device="cuda")
-            dist.all_reduce(good, op=dist.ReduceOp.MIN, group=group)
-            if int(good.item()):
+            if all_ok(bool(h)):
                 self._native = h
             else:
                 why = _ffi.last_error()
@@ -119,7 +182,15 @@ class DataParallelUpdater:
                 import warnings
                 warnings.warn("gcrl_amd.dp: in-engine RCCL communicator unavailable (" + why +
                               "); exchanging gradients through torch.distributed instead")
-        self.exchange = "engine-rccl" if self._native else "python"
+        elif exchange == "rccl" and require_native:
+            raise _ffi.GcrlError("gcrl_amd.dp: exchange='rccl' needs the nccl backend")
+        self.exchange = "engine-ipc" if self._xchg else ("engine-rccl" if self._native else "python")
+        # waits between workgroups inside a launch (csrc/meet.h) assume an exclusive GPU: off when ranks share a device, and
+        # under the Python exchange (torch's own collectives and copies run beside the engine's stream)
+        if shared_gpu or self.exchange == "python":
+            if shared_gpu:
+                lib.gcrl_set_shared_device(1)
+            _ffi.check(lib.gcrl_agent_set_meetings(agent._h, 0))
         self.sync_bn = bool(sync_bn) and agent._sac and self.world > 1
         self._bn_cb = None
         if self.sync_bn:
@@ -146,6 +217,11 @@ class DataParallelUpdater:
     def __del__(self):
         if getattr(self, "sync_bn", False) and getattr(self.agent, "_h", None):
             self._ffi.lib.gcrl_agent_dp_sync_bn(self.agent._h, 1, 0, None, None, None)   # the agent outlives the callback / communicator
+        x, self._xchg = getattr(self, "_xchg", None), None
+        if x:
+            if getattr(self.agent, "_h", None):
+                self._ffi.lib.gcrl_agent_set_exchange(self.agent._h, None)
+            self._ffi.lib.gcrl_xchg_destroy(x)
         h, self._native = getattr(self, "_native", None), None
         if h:
             self._ffi.lib.gcrl_dp_destroy(h)
@@ -175,6 +251,8 @@ class DataParallelUpdater:
         and gathered by ONE launch; the engine then hands back graph segments and the gradient
         block to all-reduce after each (two per ordinary step, one per pipelined DDPG step)."""
         a, lib, ffi = self.agent, self._ffi.lib, self._ffi
+        if self._xchg:      # the exchanges are launches of the engine's own sequence: the ordinary entry point, graphs and all
+            return a.update_many(step0, n)
         her = a.buffer.handle
         st = ffi.stream_handle()
         tickets, lens = (C.c_int64 * n)(), (C.c_int32 * n)()
@@ -201,6 +279,8 @@ class DataParallelUpdater:
         """One step.  `batch` = (s, a, r, ns, d) cuda tensors injects this rank's rows, `noise` / `eps_*` its
         TD3 smoothing noise / SAC-TQC reparameterisation draws (tests)."""
         a, lib, ffi = self.agent, self._ffi.lib, self._ffi
+        if self._xchg:
+            return a.update(step, batch=batch, noise=noise, eps_next=eps_next, eps_cur=eps_cur)
         ticket = C.c_int64(-1)
         inputs, keep = a._inject(batch, noise, eps_next, eps_cur)
         her = a.buffer.handle if batch is None else None

@@ -193,7 +193,19 @@ class DeviceRunningNormalizer:
     def float32(self):
         return bool(self._ffi.lib.gcrl_normalizer_is_float32(self._h))
 
+    def rows_dtype(self, dtype):
+        """Tell the handle which dtype the rows have on the reference's side (numpy's type rules decide its arithmetic):
+        float64 for the trainer's observation batches, float32 for goals and for tensors cast by the caller.  `update` and
+        `normalize` call this with their argument's own dtype; the agents' fused entries with the dtype of the arrays they
+        were given."""
+        on = 1 if np.dtype(dtype) == np.float64 else 0
+        if on != getattr(self, "_rows64", 0):
+            self._ffi.check(self._ffi.lib.gcrl_normalizer_set_rows_float64(self._h, on))
+            self._rows64 = on
+
     def update(self, x):
+        x = np.asarray(x)
+        self.rows_dtype(x.dtype)
         x = np.ascontiguousarray(x, np.float32)
         if x.ndim == 1:
             x = x[None, :]
@@ -201,11 +213,13 @@ class DeviceRunningNormalizer:
 
     def normalize(self, x):
         x = np.asarray(x)
+        self.rows_dtype(x.dtype)
+        f32_result = self.float32 and x.dtype != np.float64     # (the reference's result dtype: float32 only for float32 rows on loaded statistics)
         x2 = np.ascontiguousarray(x.reshape(-1, self.size), np.float32)
         out = np.empty_like(x2)
         self._ffi.check(self._ffi.lib.gcrl_normalizer_normalize(self._h, x2.ctypes.data, x2.shape[0], self.size, 0, out.ctypes.data,
                                                                 self.size, 0, self._ffi.stream_handle()))
-        return (out if self.float32 else out.astype(np.float64)).reshape(x.shape)     # (the reference's result dtype: float32 once loaded)
+        return (out if f32_result else out.astype(np.float64)).reshape(x.shape)
 
     def save(self, path: str):
         mean, var, count = self._state()

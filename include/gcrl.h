@@ -364,6 +364,43 @@ void gcrl_dp_destroy(gcrl_dp* d);
 int gcrl_dp_world(const gcrl_dp* d);
 int gcrl_dp_allreduce_sum(gcrl_dp* d, float* buf_dev, int64_t n, void* stream); /* in place, fp32 */
 int gcrl_dp_broadcast(gcrl_dp* d, float* buf_dev, int64_t n, int root, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * The gradient exchange INSIDE the engine's launch sequence (csrc/xchg_ipc.hip; round 4).  New design: the reference is
+ * single-process, BASELINE.json's north star asks for the all-reduce of actor/critic gradients over xGMI.  One process per GPU of
+ * ONE node (world <= 8); every rank's gradient arena is mapped by every peer through HIP IPC handles and one kernel per exchange
+ * performs a two-shot all-reduce peer to peer: the owner of a 1024-float chunk (chunk c: rank c mod world) adds the chunk of
+ * every rank in RANK ORDER (bitwise identical replicas), forms its sum of squares, and writes both back to every rank in
+ * place — the optimiser launch reads the reduced gradients and the clip norm's partials, no separate norm launch, and the
+ * exchange is a plain kernel node: hipGraph replay, control-advance riders and multi-step graphs stay on.
+ *   gcrl_xchg_create    over an arena (a hipMalloc base pointer, 16-byte aligned) cut into `nseg` segments (offset / length in
+ *                       floats: the nets); every rank must pass the same layout
+ *   gcrl_xchg_handles   this rank's record (GCRL_XCHG_HANDLE_BYTES) for the peers; gather the records of all ranks in rank
+ *                       order (torch.distributed's store / all_gather) and pass them to gcrl_xchg_connect on every rank
+ *   gcrl_xchg_allreduce in-place sum over the ranks of segments [seg0, seg0 + nseg), stream-ordered; EVERY rank must enqueue
+ *                       the same sequence of exchanges.  Waits are bounded (~1 s): a rank that never arrives leaves NaN and
+ *                       a status bit that the owner's next synchronising call reports (GCRL_ERR_STATE)
+ *   gcrl_agent_xchg_create / gcrl_agent_set_exchange   the same over an agent's own gradient arena (segments: every critic, the
+ *                       actor, log_alpha), and attaching it: from then on EVERY update entry point (gcrl_agent_update,
+ *                       _update_n, _update_phase) exchanges the critic gradients after the critic backward and the actor
+ *                       (+ log_alpha) gradients after the actor backward — one exchange per overlapped DDPG step — and scales
+ *                       by 1 / world inside the optimiser launches.  Reference semantics kept: the actor loss goes through the
+ *                       STEPPED critic (src/agent.py:1389-1401, :548-639).  NULL detaches.
+ * xGMI time is unmeasured (1-GPU boxes); world-size-1 cost: profiles/r04_dp_overhead_world1.json. */
+#define GCRL_XCHG_HANDLE_BYTES 160
+typedef struct gcrl_xchg gcrl_xchg;
+gcrl_xchg* gcrl_xchg_create(float* arena_dev, int64_t arena_floats, const int64_t* seg_off, const int64_t* seg_n, int nseg, int rank,
+                            int world, int device);
+void gcrl_xchg_destroy(gcrl_xchg* x);
+int gcrl_xchg_handles(gcrl_xchg* x, uint8_t* out, int64_t n);
+int gcrl_xchg_connect(gcrl_xchg* x, const uint8_t* all_ranks_records, int64_t n);
+int gcrl_xchg_world(const gcrl_xchg* x);
+int gcrl_xchg_allreduce(gcrl_xchg* x, int seg0, int nseg, void* stream);
+/* sums of squares of segment `seg`'s reduced 1024-float chunks as the last exchange left them (what the optimiser launch sums
+ * for the clip norm); returns how many (synchronises the device; tests) */
+int gcrl_xchg_get_partials(gcrl_xchg* x, int seg, float* out_host, int n);
+int gcrl_xchg_reset(gcrl_xchg* x);   /* counters back to zero after a reported failure (call on every rank, ranks synchronised around it) */
+gcrl_xchg* gcrl_agent_xchg_create(gcrl_agent* a, int rank, int world);
+int gcrl_agent_set_exchange(gcrl_agent* a, gcrl_xchg* x);
 /* The whole data-parallel trainer cycle begun by gcrl_agent_dp_begin as ONE host call: every segment of the
  * engine's schedule and, after each, the all-reduce(sum) of the gradient block it names, all enqueued on `stream`
  * (what the caller of gcrl_agent_dp_run does one Python round trip at a time). */
@@ -378,6 +415,21 @@ int gcrl_agent_dp_run_all(gcrl_agent* a, gcrl_dp* d, void* stream);
  * them).  Steps then run as plain launches (no hipGraph replay).  Call it before the first update; world = 1 switches it off. */
 typedef int (*gcrl_exchange_fn)(float* buf_dev, int64_t n, void* stream, void* user);
 int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_exchange_fn fn, void* user);
+/* Launches whose workgroups WAIT for each other inside the kernel (csrc/meet.h: the row groups of a BatchNorm slab, the role
+ * workgroups of a twin-critic row block) are admitted only when every workgroup of the launch is resident at once — judged by
+ * the kernel's occupancy on a device this process has to itself.  New design (the reference is eager PyTorch: no such forms).
+ *   gcrl_set_shared_device(1)   process-wide (also GCRL_SHARED_GPU=1 in the environment, read at first use): the device is
+ *                               shared with other processes / streams that hold CUs (several ranks on one GPU, another
+ *                               library's collectives) — handles created afterwards use the launch forms without waits;
+ *   gcrl_agent_set_meetings     switches an existing handle (0: off; 1: on where admissible); captured graphs are dropped;
+ *                               returns a bit mask of the forms now active (1 slab row groups, 2 merged row-chain phases);
+ *   a wait that times out (~1 s) poisons that launch's statistics / gradients with NaN AND is reported: the next call that
+ *   synchronises the handle (gcrl_agent_metrics, _get, _save_state) returns GCRL_ERR_STATE once, after which the handle works
+ *   again — the reference raises on any failed step (src/agent.py:659-699);
+ *   gcrl_agent_debug_meet_fault injects such a failure into the handle's next launch (tests). */
+int gcrl_set_shared_device(int shared);
+int gcrl_agent_set_meetings(gcrl_agent* a, int on);
+int gcrl_agent_debug_meet_fault(gcrl_agent* a);
 /* device pointer of a named vector (parameters / grads), for zero-copy interop */
 int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr_dev_out, int64_t* numel_out);
 
@@ -413,6 +465,14 @@ int gcrl_normalizer_set(gcrl_normalizer* z, const double* mean_host, const doubl
  * tests/golden/normalizer_loaded.npz.  A created normaliser starts in the float64 regime. */
 int gcrl_normalizer_set_float32(gcrl_normalizer* z, int on);
 int gcrl_normalizer_is_float32(const gcrl_normalizer* z);
+/* The dtype of the rows the REFERENCE's trainer would pass decides numpy's arithmetic.  Observation batches are float64
+ * arrays there (the vector env allocates them with the observation space's dtype, which TimeFeatureWrapper declares float64,
+ * src/utils.py:156; the values inside are float32-valued, so the float32 rows of this ABI carry them exactly), goal batches
+ * float32.  `on` != 0: treat the rows of every later update / normalize / fused entry as float64 — batch moments, merge,
+ * subtraction and division in float64 (`self.var * self.count` and sqrt(var) + 1e-8 of a LOADED normaliser stay float32 values),
+ * and the first update after a load turns the statistics back into float64 (gcrl_normalizer_is_float32 then reports 0).
+ * Pinned by tests/golden/normalizer_f64.npz.  Default off (float32 rows: normalizer.npz, normalizer_loaded.npz). */
+int gcrl_normalizer_set_rows_float64(gcrl_normalizer* z, int on);
 /* select_action for one vector-env step from RAW host rows (src/env.py:348-355 + src/agent.py:1345-1366 / :253-270 /
  * :641-647): normalize_state_batch with the given normalisers (NULL: that part raw), actor, post-processing —
  * mode 0: clip(tanh(net), -1, 1); 1: clip(tanh(net) + noise, -1, 1), noise = np.random.normal draws [n, A] float64;

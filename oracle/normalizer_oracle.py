@@ -2,8 +2,8 @@
 
 CPU restatement of the reference's RunningNormalizer (src/utils.py:68-98), with the batch moments written out as
 the explicit float32 sequential sums numpy's axis-0 reductions perform — the order the device kernel
-(csrc/normalizer.hip) follows.  Pinned by tests/golden/normalizer.npz and normalizer_loaded.npz (the float32 regime after
-`load`), both captured from the reference's own class.
+(csrc/normalizer.hip) follows.  Pinned by tests/golden/normalizer.npz, normalizer_loaded.npz (the float32 regime after
+`load`) and normalizer_f64.npz (float64 rows, created and loaded), all captured from the reference's own class.
 """
 from __future__ import annotations
 
@@ -19,18 +19,22 @@ class RunningNormalizerOracle:
 
     @staticmethod
     def batch_moments(x):
-        """np.mean(x, axis=0), np.var(x, axis=0) of float32 rows: row after row, every operation rounded to float32."""
-        x = np.asarray(x, np.float32)
+        """np.mean(x, axis=0), np.var(x, axis=0): numpy reduces the row axis row after row, every operation rounded to the
+        rows' own type — float32 for float32 rows, float64 for the float64 batches the trainer's vector env hands over for
+        observations (TimeFeatureWrapper declares the space float64, src/utils.py:156).  The order csrc/norm_math.h follows."""
+        x = np.asarray(x)
+        ft = np.float64 if x.dtype == np.float64 else np.float32
+        x = np.asarray(x, ft)
         n, D = x.shape
-        s = np.zeros(D, np.float32)
+        s = np.zeros(D, ft)
         for i in range(n):
             s = s + x[i]
-        mean = s / np.float32(n)
-        q = np.zeros(D, np.float32)
+        mean = s / ft(n)
+        q = np.zeros(D, ft)
         for i in range(n):
             d = x[i] - mean
             q = q + d * d
-        return mean, q / np.float32(n), n
+        return mean, q / ft(n), n
 
     def update(self, x):                                            # :75-81
         self._update_from_moments(*self.batch_moments(x))

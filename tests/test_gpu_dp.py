@@ -67,8 +67,10 @@ def _init_params(agent):
     agent.update_target_network()
 
 
-def _worker(rank, world, port, kind, out_dir, sync_bn=False):
+def _worker(rank, world, port, kind, out_dir, sync_bn=False, exchange="auto", tag="rank", sep_norm=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if sep_norm:
+        os.environ["GCRL_XCHG_SEPARATE_NORM"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     import gcrl_amd
@@ -77,7 +79,8 @@ def _worker(rank, world, port, kind, out_dir, sync_bn=False):
     ag = cls(S, A, _cfg(kind, B), None, nenvs=1, gradient_step=2, rng="engine", seed=100 + rank)
     if rank == 0:
         _init_params(ag)            # rank 1 keeps its own random init until the broadcast
-    dp = DataParallelUpdater(ag, sync_bn=sync_bn)    # broadcasts rank 0's parameters
+    dp = DataParallelUpdater(ag, sync_bn=sync_bn, exchange=exchange)    # broadcasts rank 0's parameters
+    assert dp.exchange == {"auto": "engine-ipc", "ipc": "engine-ipc", "python": "python"}[exchange], dp.exchange
     assert dp.sync_bn == (sync_bn and kind in ("SAC", "TQC"))
     tuples = []
     for step, (full, eps) in enumerate(zip(_global_batches(world, 3), _global_eps(world, 3)), start=1):
@@ -92,7 +95,7 @@ def _worker(rank, world, port, kind, out_dir, sync_bn=False):
     if kind in ("SAC", "TQC"):
         extra = dict(bn_mean=ag.actor._get("bn_running_mean"), bn_var=ag.actor._get("bn_running_var"),
                      log_alpha=ag.log_alpha.detach().numpy())
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), actor=ag.actor.flat(), critic=ag.critics[0].flat(),
+    np.savez(os.path.join(out_dir, f"{tag}{rank}.npz"), actor=ag.actor.flat(), critic=ag.critics[0].flat(),
              critic_last=ag.critics[-1].flat(), target=ag.target_critics[0].flat(), tuples=np.array(tuples), **extra)
     dist.barrier()
     dist.destroy_process_group()
@@ -108,10 +111,13 @@ def _track(got, ref, rtol_rest, atol_rest, what=""):
     assert np.allclose(got, ref, rtol=rtol_rest, atol=atol_rest), (what, np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("exchange", ["ipc", "python"])
 @pytest.mark.parametrize("kind", ["DDPG", "TD3"])
-def test_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind):
+def test_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind, exchange):
+    """exchange: the engine's own peer-to-peer kernel over IPC-mapped gradient arenas (csrc/xchg_ipc.hip; two processes sharing
+    this box's one GPU) | torch.distributed (gloo) calls between the engine's segments."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), False, exchange), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k in ("actor", "critic", "target"):
         assert np.array_equal(r0[k], r1[k]), k                 # replicas stay bitwise identical
@@ -126,14 +132,16 @@ def test_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind):
         assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
 
 
-def _worker_cycle(rank, world, port, out_dir, kind="DDPG"):
+def _worker_cycle(rank, world, port, out_dir, kind="DDPG", exchange="auto", tag="cycle", sep_norm=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if sep_norm:
+        os.environ["GCRL_XCHG_SEPARATE_NORM"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     import gcrl_amd
     from gcrl_amd.src.dp import DataParallelUpdater
     from oracle import her_oracle
-    cls = dict(DDPG=gcrl_amd.DDPG, TD3=gcrl_amd.TD3Agent)[kind]
+    cls = dict(DDPG=gcrl_amd.DDPG, TD3=gcrl_amd.TD3Agent, SAC=gcrl_amd.SACAgent)[kind]
     ag = cls(S, A, _cfg(kind, B), None, nenvs=1, gradient_step=45, rng="engine", seed=7)   # same seed on both ranks
     gen = np.random.default_rng(3)
     for _ in range(3):
@@ -141,25 +149,47 @@ def _worker_cycle(rank, world, port, out_dir, kind="DDPG"):
             ag.push_her(0, *st)
     if rank == 0:
         _init_params(ag)
-    dp = DataParallelUpdater(ag)
+    dp = DataParallelUpdater(ag, exchange=exchange)
     out = [[float(x) for x in t] for t in dp.update_many(1, 45)]      # crosses the Polyak step 40
     out += [[float(x) for x in t] for t in dp.update_many(46, 5)]
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, f"cycle{rank}.npz"), actor=ag.actor.flat(), critic=ag.critics[0].flat(),
-             tactor=ag.target_actor.flat(), tuples=np.array([t + [0.0] * (9 - len(t)) for t in out]))
+    tgt = ag.target_actor.flat() if hasattr(ag, "target_actor") else ag.target_critics[0].flat()
+    np.savez(os.path.join(out_dir, f"{tag}{rank}.npz"), actor=ag.actor.flat(), critic=ag.critics[0].flat(),
+             tactor=tgt, tuples=np.array([t + [0.0] * (9 - len(t)) for t in out]))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("kind", ["DDPG", "TD3", "SAC"])
+def test_ipc_exchange_is_bitwise_the_gloo_exchange(gcrl, tmp_path, kind):
+    """the engine's two-shot peer-to-peer exchange over IPC-mapped gradient arenas (csrc/xchg_ipc.hip),
+    two processes on this box's one GPU, against the torch.distributed (gloo) all-reduce between the engine's segments —
+    BITWISE: tuples, parameters and targets of a 50-step trainer cycle (update_many: pipelined DDPG segments with one exchange
+    per overlapped step, Polyak step, multi-step graphs on the IPC side) and of three injected-batch update() steps.  With two
+    ranks the rank-order sum a + b is the all-reduce's; the clip norm is taken from a sum-of-squares launch on both sides here
+    (GCRL_XCHG_SEPARATE_NORM=1) because the exchange kernel's own partials sum the squares in another order (1 ulp on the
+    norm: covered by the tracking tests below and above, which run with the partials)."""
+    world = 2
+    for exchange, tag, sep in (("ipc", "i_", True), ("python", "p_", False)):
+        mp.spawn(_worker_cycle, args=(world, _free_port(), str(tmp_path), kind, exchange, tag + "cycle", sep), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), False, exchange, tag + "rank", sep), nprocs=world, join=True)
+    for base, keys in (("cycle", ("actor", "critic", "tactor", "tuples")), ("rank", ("actor", "critic", "critic_last", "target", "tuples"))):
+        for r in range(world):
+            i, p = np.load(tmp_path / f"i_{base}{r}.npz"), np.load(tmp_path / f"p_{base}{r}.npz")
+            for k in keys:
+                assert np.array_equal(i[k], p[k]), (kind, base, r, k, float(np.abs(i[k].astype(np.float64) - p[k]).max()))
+
+
+@pytest.mark.parametrize("exchange", ["ipc", "python"])
 @pytest.mark.parametrize("kind", ["DDPG", "TD3"])
-def test_dp_cycle_schedule_tracks_single_process(gcrl, tmp_path, kind):
+def test_dp_cycle_schedule_tracks_single_process(gcrl, tmp_path, kind, exchange):
     """Engine-scheduled DP cycle (pipelined DDPG segments with ONE exchange per step, ordinary
     phases around the Polyak step): two ranks holding IDENTICAL rings and RNG seeds draw identical
     batches, so the averaged gradients equal each rank's own and the run must track a single-process
     update_many (same math; the clip norm is summed by a different kernel, hence a tolerance)."""
     from oracle import her_oracle
     world = 2
-    mp.spawn(_worker_cycle, args=(world, _free_port(), str(tmp_path), kind), nprocs=world, join=True)
+    mp.spawn(_worker_cycle, args=(world, _free_port(), str(tmp_path), kind, exchange), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "cycle0.npz"), np.load(tmp_path / "cycle1.npz")
     for k in ("actor", "critic", "tactor", "tuples"):
         assert np.array_equal(r0[k], r1[k]), k
@@ -279,7 +309,7 @@ def test_sync_batchnorm_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind):
         assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
 
 
-def _worker_rccl(rank, world, port, out_dir, kind):
+def _worker_rccl(rank, world, port, out_dir, kind, exchange="rccl"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
@@ -294,8 +324,8 @@ def _worker_rccl(rank, world, port, out_dir, kind):
         for st in her_oracle.synthetic_episode(gen, 50, S, A):
             ag.push_her(0, *st)
     _init_params(ag)
-    dp = DataParallelUpdater(ag)
-    assert dp._native, "the RCCL process group must select the in-engine exchange"
+    dp = DataParallelUpdater(ag, exchange=exchange, require_native=True)
+    assert dp.exchange == {"rccl": "engine-rccl", "ipc": "engine-ipc"}[exchange], dp.exchange
     out = [[float(x) for x in t] for t in dp.update_many(1, 45)]      # one native call: segments + all-reduces
     out += [[float(x) for x in dp.update(46)]]                        # the per-phase entry, collectives native too
     torch.cuda.synchronize()
@@ -305,13 +335,15 @@ def _worker_rccl(rank, world, port, out_dir, kind):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "ipc"])
 @pytest.mark.parametrize("kind", ["DDPG", "SAC"])
-def test_in_engine_rccl_exchange_world_size_one(gcrl, tmp_path, kind):
-    """The library-owned RCCL communicator (csrc/dp_rccl.cc) and the one-call trainer cycle
-    (gcrl_agent_dp_run_all) on the one GPU this box has: a single-rank all-reduce is the identity, so the run
-    must track a single-process update_many (the clip norm is summed by a different kernel: tolerance)."""
+def test_in_engine_exchange_world_size_one(gcrl, tmp_path, kind, exchange):
+    """The library-owned RCCL communicator (csrc/dp_rccl.cc) with the one-call trainer cycle (gcrl_agent_dp_run_all), and the
+    engine's own exchange kernel (csrc/xchg_ipc.hip, the default) under an RCCL process group, on the one GPU this box has: a
+    single-rank all-reduce is the identity, so the run must track a single-process update_many (the clip norm is summed by a
+    different kernel: tolerance)."""
     from oracle import her_oracle
-    mp.spawn(_worker_rccl, args=(1, _free_port(), str(tmp_path), kind), nprocs=1, join=True)
+    mp.spawn(_worker_rccl, args=(1, _free_port(), str(tmp_path), kind, exchange), nprocs=1, join=True)
     r = np.load(tmp_path / "rccl.npz")
     cls = dict(DDPG=gcrl.DDPG, SAC=gcrl.SACAgent)[kind]
     ag = cls(S, A, _cfg(kind, B), None, nenvs=1, gradient_step=45, rng="engine", seed=7)
@@ -327,3 +359,96 @@ def test_in_engine_rccl_exchange_world_size_one(gcrl, tmp_path, kind):
         assert float(np.max(np.abs(r["actor"] - ag.actor.flat()))) < 5e-4
     else:   # SAC draws its exploration noise from the device counter hash: same counters, same draws
         _track(r["tuples"][:5], ref[:5], 5e-4, 5e-5, kind)
+
+
+# ------------------------------------------------------------------ the exchange kernel by itself (csrc/xchg_ipc.hip)
+_XSEGS = [(0, 5000), (5056, 1025), (6144, 3), (6208, 1), (6272, 4096)]       # (offset, floats): ragged tails, one-float segment, exact chunks
+_XARENA = 10368
+
+
+def _xchg_expected(world):
+    gens = [np.random.default_rng(900 + r) for r in range(world)]
+    arenas = [g.standard_normal(_XARENA).astype(np.float32) for g in gens]
+    want = arenas[0].copy()
+    for off, n in _XSEGS:
+        acc = arenas[0][off:off + n].copy()
+        for r in range(1, world):
+            acc = (acc + arenas[r][off:off + n]).astype(np.float32)      # rank order
+        want[off:off + n] = acc
+    return arenas, want
+
+
+def _worker_xchg_raw(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import ctypes as C
+    import gcrl_amd
+    lib, ffi = gcrl_amd._ffi.lib, gcrl_amd._ffi
+    arenas, _ = _xchg_expected(world)
+    buf = torch.from_numpy(arenas[rank]).cuda()
+    off = (C.c_int64 * len(_XSEGS))(*[o for o, _ in _XSEGS])
+    num = (C.c_int64 * len(_XSEGS))(*[n for _, n in _XSEGS])
+    x = ffi.check_ptr(lib.gcrl_xchg_create(buf.data_ptr(), buf.numel(), off, num, len(_XSEGS), rank, world, 0), "gcrl_xchg_create")
+    rec = (C.c_uint8 * 160)()
+    ffi.check(lib.gcrl_xchg_handles(x, rec, 160))
+    recs = [None] * world
+    dist.all_gather_object(recs, bytes(rec))
+    ffi.check(lib.gcrl_xchg_connect(x, b"".join(recs), 160 * world))
+    dist.barrier()
+    st = ffi.stream_handle()
+    # exchange 1: segments 0..2; exchange 2: segments 3..4 (a second launch on the same counters); then both again inside a hipGraph
+    ffi.check(lib.gcrl_xchg_allreduce(x, 0, 3, st))
+    ffi.check(lib.gcrl_xchg_allreduce(x, 3, 2, st))
+    torch.cuda.synchronize()
+    first = buf.cpu().numpy().copy()
+    parts = []
+    for sgi in range(len(_XSEGS)):
+        pb = np.zeros(8, np.float32)
+        k = ffi.check(lib.gcrl_xchg_get_partials(x, sgi, pb.ctypes.data, 8))
+        parts.append(pb[:k].copy())
+    g = torch.cuda.CUDAGraph()
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        buf.copy_(torch.from_numpy(arenas[rank]))
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s2):
+            ffi.check(lib.gcrl_xchg_allreduce(x, 0, 5, int(s2.cuda_stream)))
+        dist.barrier()
+        for _ in range(3):                 # replays: the exchange number lives on the device
+            buf.copy_(torch.from_numpy(arenas[rank]))
+            torch.cuda.synchronize()
+            dist.barrier()
+            g.replay()
+            torch.cuda.synchronize()
+            dist.barrier()
+    np.savez(os.path.join(out_dir, f"x{rank}.npz"), first=first, replay=buf.cpu().numpy(), parts=np.concatenate(parts))
+    dist.barrier()
+    lib.gcrl_xchg_destroy(x)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_exchange_kernel_sums_in_rank_order_on_every_rank(gcrl, tmp_path, world):
+    """gcrl_xchg_* over a raw arena: every rank ends with the rank-order sum of the segments' floats (ragged segment tails, a
+    one-float segment, bytes outside the segments untouched), two exchanges back to back on the same counters, and three
+    replays of the exchange captured in a hipGraph (the exchange number is device state)."""
+    mp.spawn(_worker_xchg_raw, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    arenas, want = _xchg_expected(world)
+    for r in range(world):
+        got = np.load(tmp_path / f"x{r}.npz")
+        exp = want.copy()
+        mask = np.zeros(_XARENA, bool)
+        for off, n in _XSEGS:
+            mask[off:off + n] = True
+        exp[~mask] = arenas[r][~mask]                      # outside the segments: this rank's own bytes
+        assert np.array_equal(got["first"].view(np.uint32), exp.view(np.uint32)), r
+        assert np.array_equal(got["replay"].view(np.uint32), exp.view(np.uint32)), r
+        # the clip norm's partials: one per 1024-float chunk of every segment, of the REDUCED values, the same on every rank
+        wantp = []
+        for off, n in _XSEGS:
+            for c0 in range(0, n, 1024):
+                v = want[off + c0:off + min(n, c0 + 1024)].astype(np.float64)
+                wantp.append(float(np.dot(v, v)))
+        assert got["parts"].shape == (len(wantp),) and np.allclose(got["parts"], wantp, rtol=2e-6, atol=0), r
+        assert np.array_equal(got["parts"], np.load(tmp_path / "x0.npz")["parts"])

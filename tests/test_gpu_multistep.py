@@ -158,3 +158,40 @@ def test_sampled_noisy_updates_track_oracle(gcrl, kind):
         worst = max(worst, float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-2))))
         assert np.allclose(got, want, rtol=5e-5, atol=5e-6), (kind, step, got, want)
     print(f"sampled noisy updates [{kind}]: worst relative tuple error {worst:.2e}")
+
+
+def test_failed_meeting_inside_a_launch_is_reported_and_the_handle_recovers(gcrl, tmp_path):
+    """SAC at batch 512: the BatchNorm slab launches split their rows over four workgroups that wait for each other inside the
+    launch, and so do the role workgroups of the twin-critic row chains (csrc/meet.h).  A wait that times out used to leave NaN
+    statistics / gradients and nothing else: now the status word makes the next synchronising call fail ONCE with
+    GCRL_ERR_STATE — the reference raises on any failed step (src/agent.py:659-699) — and the handle works again afterwards.
+    The fault is injected by knocking one meeting counter off its multiple-of-arrivals state (gcrl_agent_debug_meet_fault)."""
+    from gcrl_amd import _ffi
+    kind, H, L, B = "SAC", 256, 3, 512
+    cfg = _cfg(kind, H, L, B, max_len=20000)
+    ag = _cls(gcrl, kind)(S, A, cfg, None, nenvs=2, gradient_step=4, rng="engine", seed=33)
+    gen = np.random.default_rng(5)
+    ep = 0
+    while len(ag.buffer) < B + 500:
+        for st in her_oracle.synthetic_episode(gen, 50, S, A):
+            ag.push_her(ep % 2, *st)
+        ep += 1
+    active = ag.set_meetings(True)
+    if not active:
+        pytest.skip("no launch form with an in-kernel wait is admissible on this device (shared GPU?)")
+    good = [float(x) for x in ag.update(1)]
+    assert all(np.isfinite(good))
+    ag.save_state(str(tmp_path / "ckpt"))
+    _ffi.check(_ffi.lib.gcrl_agent_debug_meet_fault(ag._h))
+    t = ag.update(2)
+    with pytest.raises(_ffi.GcrlError, match="timed out"):
+        [float(x) for x in t]
+    # the error was consumed and the counters were reset: the next steps run and are finite again (the parameters took one
+    # poisoned step: back to the last checkpoint first, what a trainer would do)
+    ag.load_state(str(tmp_path / "ckpt"))
+    after = [float(x) for x in ag.update(3)]
+    assert all(np.isfinite(after)), after
+    # ... and with the meetings switched off the same step sequence never waits
+    assert ag.set_meetings(False) == 0
+    off = [float(x) for x in ag.update(4)]
+    assert all(np.isfinite(off)), off

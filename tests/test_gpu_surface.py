@@ -427,7 +427,56 @@ def test_device_normalizer_after_load_bit_exact_vs_reference(gcrl, tmp_path):
         assert np.array_equal(nz.normalize(g["probe"]), g[f"norm{i}"]), i
 
 
-def _fused_vs_separate(gcrl, kind, g_norm, loaded, tmp_path=None):
+def test_device_normalizer_with_float64_rows_bit_exact_vs_reference(gcrl, tmp_path):
+    """csrc/normalizer.hip fed the float64 rows the reference's trainer feeds its observation normaliser (src/utils.py:156: the
+    vector env's observation batches are float64 arrays) against tests/golden/normalizer_f64.npz: created normaliser; loaded
+    normaliser whose float32 statistics turn float64 with the first update (the float32 regime is not sticky
+    there); float32 rows followed by float64 rows.  The rows cross the ABI as float32 (their values are float32-valued)."""
+    from conftest import load_golden
+    from gcrl_amd.src.utils import DeviceRunningNormalizer
+    g = load_golden("normalizer_f64.npz")
+    D, probe = int(g["D"][0]), g["probe"]
+    r32 = lambda z: np.asarray(z, np.float64).astype(np.float32)      # what the trainer keeps of a normalised row (src/env.py:189-190)
+    nz = DeviceRunningNormalizer(D)
+    for i in range(len(g["a_sizes"])):
+        x = g[f"a_x{i}"]
+        assert x.dtype == np.float64 and np.array_equal(x.astype(np.float32).astype(np.float64), x)
+        nz.update(x)
+        assert np.array_equal(nz.mean, g[f"a_mean{i}"]) and np.array_equal(nz.var, g[f"a_var{i}"]) and nz.count == g[f"a_count{i}"][0], i
+        z = nz.normalize(probe)
+        assert z.dtype == np.float64 and np.array_equal(r32(z), r32(g[f"a_norm{i}"])), i
+    path = tmp_path / "obs.yaml"
+    path.write_text(str(g["yaml_text"]))
+    ld = DeviceRunningNormalizer(D)
+    ld.load(str(path))
+    assert ld.float32 and np.array_equal(ld.mean, g["load_mean"])
+    z = ld.normalize(probe)
+    assert z.dtype == np.float64 and np.array_equal(r32(z), r32(g["b_load_norm"]))
+    for i in range(len(g["b_sizes"])):
+        ld.update(g[f"b_x{i}"])
+        assert not ld.float32 and ld.mean.dtype == np.float64, i
+        assert np.array_equal(ld.mean, g[f"b_mean{i}"]) and np.array_equal(ld.var, g[f"b_var{i}"]) and ld.count == g[f"b_count{i}"][0], i
+        assert np.array_equal(r32(ld.normalize(probe)), r32(g[f"b_norm{i}"])), i
+    ld2 = DeviceRunningNormalizer(D)
+    ld2.load(str(path))
+    ld2.update(g["c_x32"])
+    assert ld2.float32 and np.array_equal(ld2.mean, g["c_mean0"]) and np.array_equal(ld2.var, g["c_var0"])
+    z32 = ld2.normalize(probe.astype(np.float32))
+    assert z32.dtype == np.float32 and np.array_equal(z32, g["c_norm0_f32rows"])
+    assert np.array_equal(r32(ld2.normalize(probe)), r32(g["c_norm0_f64rows"]))
+    ld2.update(g["c_x64"])
+    assert not ld2.float32 and np.array_equal(ld2.mean, g["c_mean1"]) and np.array_equal(ld2.var, g["c_var1"]) and ld2.count == g["c_count1"][0]
+    assert np.array_equal(r32(ld2.normalize(probe)), r32(g["c_norm1"]))
+
+
+@pytest.mark.parametrize("loaded", [False, True])
+def test_fused_acting_entries_with_float64_observation_rows(gcrl, loaded, tmp_path):
+    """The trainer's own dtypes: float64 observation batches (src/utils.py:156), float32 goal batches — fused device entries vs
+    the separate calls with host numpy normalisers, bit for bit, with created and with loaded normalisers."""
+    _fused_vs_separate(gcrl, "DDPG", True, loaded, tmp_path, obs64=True)
+
+
+def _fused_vs_separate(gcrl, kind, g_norm, loaded, tmp_path=None, obs64=False):
     """observe_act / process_step (one native call each per vector-env step, device normalisers) against the reference's
     call sequence made of the separate calls with host normalisers: same actions (same host RNG draws), same normaliser
     statistics, same ring rows bit for bit — including the episode flushes (HER relabel) inside the steps.  g_norm: goals
@@ -459,7 +508,7 @@ def _fused_vs_separate(gcrl, kind, g_norm, loaded, tmp_path=None):
             assert getattr(host.buffer, name).mean.dtype == np.float32 and getattr(dev.buffer, name).float32
 
     def obs_dict():
-        return dict(observation=gen.standard_normal((n, D)).astype(np.float32) * 3 + 1,
+        return dict(observation=(gen.standard_normal((n, D)).astype(np.float32) * 3 + 1).astype(np.float64 if obs64 else np.float32),
                     desired_goal=gen.uniform(-0.2, 0.2, (n, G)).astype(np.float32),
                     achieved_goal=gen.uniform(-0.2, 0.2, (n, G)).astype(np.float32))
 

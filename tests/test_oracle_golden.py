@@ -241,6 +241,44 @@ def test_normalizer_oracle_after_load_matches_reference_bitwise():
         assert np.array_equal(nz.normalize(g["probe"]), g[f"norm{i}"]), i
 
 
+def test_normalizer_oracle_with_float64_rows_matches_reference_bitwise():
+    """float64 rows — what the reference's trainer feeds the observation normaliser (the vector env allocates observation
+    batches with the float64 dtype TimeFeatureWrapper declares, src/utils.py:156) — against tests/golden/normalizer_f64.npz
+    (make_golden_norm_f64.py): created normaliser; loaded normaliser (float32 statistics turn float64 with the first update);
+    float32 rows then float64 rows on a loaded one."""
+    import yaml
+    from oracle.normalizer_oracle import RunningNormalizerOracle
+    g = load_golden("normalizer_f64.npz")
+    D = int(g["D"][0])
+    probe = g["probe"]
+    assert probe.dtype == np.float64
+    nz = RunningNormalizerOracle(D)
+    for i in range(len(g["a_sizes"])):
+        nz.update(g[f"a_x{i}"])
+        assert nz.mean.dtype == np.float64
+        assert np.array_equal(nz.mean, g[f"a_mean{i}"]) and np.array_equal(nz.var, g[f"a_var{i}"]) and nz.count == g[f"a_count{i}"][0], i
+        assert np.array_equal(nz.normalize(probe), g[f"a_norm{i}"]), i
+    d = yaml.safe_load(str(g["yaml_text"]))
+    ld = RunningNormalizerOracle(D)
+    ld.load_state(d["mean"], d["var"], d["count"], d["clip_range"])
+    assert np.array_equal(ld.mean, g["load_mean"]) and np.array_equal(ld.var, g["load_var"])
+    z = ld.normalize(probe)
+    assert z.dtype == np.float64 and np.array_equal(z, g["b_load_norm"])
+    for i in range(len(g["b_sizes"])):
+        ld.update(g[f"b_x{i}"])
+        assert str(ld.mean.dtype) == str(g[f"b_mean{i}_dtype"]) == "float64"
+        assert np.array_equal(ld.mean, g[f"b_mean{i}"]) and np.array_equal(ld.var, g[f"b_var{i}"]) and ld.count == g[f"b_count{i}"][0], i
+        assert np.array_equal(ld.normalize(probe), g[f"b_norm{i}"]), i
+    ld2 = RunningNormalizerOracle(D)
+    ld2.load_state(d["mean"], d["var"], d["count"], d["clip_range"])
+    ld2.update(g["c_x32"])
+    assert ld2.mean.dtype == np.float32 and np.array_equal(ld2.mean, g["c_mean0"]) and np.array_equal(ld2.var, g["c_var0"])
+    assert np.array_equal(ld2.normalize(probe.astype(np.float32)), g["c_norm0_f32rows"]) and np.array_equal(ld2.normalize(probe), g["c_norm0_f64rows"])
+    ld2.update(g["c_x64"])
+    assert ld2.mean.dtype == np.float64 and np.array_equal(ld2.mean, g["c_mean1"]) and np.array_equal(ld2.var, g["c_var1"]) and ld2.count == g["c_count1"][0]
+    assert np.array_equal(ld2.normalize(probe), g["c_norm1"])
+
+
 # ---------------------------------------------------------------- G10: PER buffer + weighted critic losses
 @pytest.mark.parametrize("tag", ["ddpg", "td3", "sac", "tqc"])
 def test_per_oracle_matches_reference(tag):

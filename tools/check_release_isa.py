@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Build check: every publication through memory is released before the arrival that announces it.
+
+The kernels whose workgroups hand data to each other inside a launch (csrc/meet.h: BatchNorm slab row groups, row-chain
+roles; csrc/gemm_tiled.h: the split-dW ticket; csrc/xchg_ipc.hip: the peer-to-peer gradient exchange) publish with
+write-through (sc1 / sc0 sc1) stores and then arrive at a counter with a global atomic.  On gfx950 a workgroup-scope
+release fence emits NO `s_waitcnt vmcnt(0)`, so the arrival could overtake the stores.  This script
+compiles the translation units to gfx950 assembly (device side only, no GPU needed) and checks, per kernel, that every
+global atomic add that follows write-through stores in the listing is preceded — after the LAST such store — by an
+`s_waitcnt vmcnt(0)`.  Listing order is not control flow, so this is a lint, not a proof; it catches exactly the
+regression the advisor found in the ISA.
+
+usage: tools/check_release_isa.py [--keep DIR]      exit code 0 = every checked kernel passes
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "goal-conditioned-rl-framework_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S"]
+
+# translation unit -> substrings of the (mangled) kernel names that must pass, and must be present
+UNITS = {
+    "bn_slab.hip": ["bn_linear_fwd_slab_kernel", "bn_linear_bwd_slab_kernel"],
+    "rowchain.hip": ["rowchain_split_kernel"],
+    "gemm_mfma.hip": ["gemm_tiled_kernel"],
+    "xchg_ipc.hip": ["xchg_two_shot_kernel"],
+}
+
+STORE_WT = re.compile(r"^\s*(buffer_store|global_store|flat_store)\S*\s.*\bsc1\b")
+ATOMIC = re.compile(r"^\s*(global|flat|buffer)_atomic_(add|or|inc)")
+WAIT0 = re.compile(r"^\s*s_waitcnt\s+.*vmcnt\(0\)")
+
+
+def kernels(asm_text):
+    """yield (name, [instruction lines]) per function of the listing"""
+    name, body = None, []
+    for line in asm_text.splitlines():
+        m = re.match(r"^([A-Za-z_][\w$.]*):\s*(;.*)?$", line)
+        if m and not line.startswith(".L"):
+            if name:
+                yield name, body
+            name, body = m.group(1), []
+        elif name is not None:
+            if re.match(r"^\s*\.end_amdhsa_kernel|^\s*s_endpgm", line):
+                body.append(line)
+            else:
+                body.append(line)
+    if name:
+        yield name, body
+
+
+def check_kernel(body):
+    """(#write-through stores, #atomics after such stores, [problems])"""
+    problems = []
+    last_store = None
+    waited = True
+    n_store = n_atomic = 0
+    for i, line in enumerate(body):
+        if STORE_WT.match(line):
+            last_store, waited = i, False
+            n_store += 1
+        elif WAIT0.match(line):
+            waited = True
+        elif ATOMIC.match(line) and last_store is not None:
+            n_atomic += 1
+            if not waited:
+                problems.append((i, line.strip(), body[last_store].strip()))
+    return n_store, n_atomic, problems
+
+
+def main():
+    keep = None
+    if "--keep" in sys.argv:
+        keep = sys.argv[sys.argv.index("--keep") + 1]
+        os.makedirs(keep, exist_ok=True)
+    bad = 0
+    report = []
+    with tempfile.TemporaryDirectory() as tmp:
+        out_dir = keep or tmp
+        for unit, wanted in UNITS.items():
+            src = os.path.join(CSRC, unit)
+            if not os.path.exists(src):
+                report.append(f"{unit}: MISSING source")
+                bad += 1
+                continue
+            asm = os.path.join(out_dir, unit + ".s")
+            subprocess.run([HIPCC] + FLAGS + ["-x", "hip", src, "-o", asm], check=True, cwd=CSRC)
+            text = open(asm).read()
+            seen = {w: 0 for w in wanted}
+            for name, body in kernels(text):
+                hit = [w for w in wanted if w in name]
+                if not hit:
+                    continue
+                n_store, n_atomic, problems = check_kernel(body)
+                if n_atomic == 0:
+                    continue   # an instantiation without a publication (e.g. the unsplit forms)
+                seen[hit[0]] += 1
+                status = "ok" if not problems else "FAIL"
+                report.append(f"{unit}: {name}: {n_store} write-through stores, {n_atomic} arrivals after them: {status}")
+                for i, atom, store in problems:
+                    report.append(f"    line {i}: `{atom}` follows `{store}` without s_waitcnt vmcnt(0)")
+                bad += len(problems)
+            for w, n in seen.items():
+                if n == 0:
+                    report.append(f"{unit}: no instantiation of {w} with a publication found (pattern changed?)")
+                    bad += 1
+    print("\n".join(report))
+    print("release check:", "PASS" if bad == 0 else f"FAIL ({bad})")
+    return 0 if bad == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
