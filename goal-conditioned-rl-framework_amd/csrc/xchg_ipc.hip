@@ -42,16 +42,25 @@ namespace {
 
 constexpr int kSys = 17;                       // sc0 | sc1 of the raw buffer builtins: system scope (gfx94x / gfx950)
 constexpr long long kFlagStride = 16;          // 64-bit words per flag: one 128-byte line each
+constexpr int kMaxGrid = 1024;                 // workgroups of one rank per exchange
+constexpr int kMaxSeg = 12;                    // segments of one handle (8 critics + actor + log_alpha + spare)
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
-struct XChunk { long long off; int n; int pad; };   // floats from the arena base; n <= kXchgChunk (a multiple of 4 except a net's tail)
+// control block of a rank (IPC-exported; 64-bit words):
+//   ready[src]      at src * kFlagStride                      "src's gradients of exchange e are complete"
+//   epoch           at kXchgMaxWorld * kFlagStride             exchanges this rank has completed (local)
+//   done[src][wg]   at (kXchgMaxWorld + 1) * kFlagStride + src * kMaxGrid + wg     "workgroup wg of src has delivered its chunks of exchange e"
+//   partials        floats, after the flags
+constexpr long long kEpochWord = (long long)kXchgMaxWorld * kFlagStride;
+constexpr long long kDoneWord = (long long)(kXchgMaxWorld + 1) * kFlagStride;
+constexpr long long kFlagWords = kDoneWord + (long long)kXchgMaxWorld * kMaxGrid;
 
 struct XArgs {
   float* arena[kXchgMaxWorld];                 // every rank's gradient arena (own: the local pointer)
-  unsigned long long* ctl[kXchgMaxWorld];      // every rank's control block: ready[W] | done[W] | epoch | ticket (128-byte lines)
+  unsigned long long* ctl[kXchgMaxWorld];      // every rank's control block
   float* parts[kXchgMaxWorld];                 // every rank's partial array
-  const XChunk* chunks;                        // local copy of the chunk table
-  int world, rank, c0, c1;                     // chunks [c0, c1) take part
+  long long seg_off[kMaxSeg]; int seg_n[kMaxSeg]; int seg_c0[kMaxSeg + 1];   // segments: offset / floats / first chunk (seg_c0[nseg] = all chunks)
+  int nseg, world, rank, c0, c1;               // chunks [c0, c1) take part
   unsigned int* status;
 };
 
@@ -67,40 +76,51 @@ __device__ inline __amdgpu_buffer_rsrc_t rsrc_n(const float* p, int nfloats) {
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(nfloats * 4), 0x00020000);
 }
 
+// workgroups rank r runs for an exchange of nch chunks: it owns chunks r, r + W, ... (the host launches exactly this many)
+__host__ __device__ inline int grid_of(int nch, int r, int W) {
+  const int mine = nch > r ? (nch - r + W - 1) / W : 0;
+  return mine < 1 ? 1 : (mine > kMaxGrid ? kMaxGrid : mine);
+}
+
+template <bool SOLO>   // SOLO: a world of one — nobody to wait for, nothing to rewrite: the partials only
 __global__ __launch_bounds__(256) void xchg_two_shot_kernel(XArgs a) {
   __shared__ float red[4];
   __shared__ unsigned int s_ok;
-  const int W = a.world, me = a.rank, tid = threadIdx.x;
+  const int W = SOLO ? 1 : a.world, me = SOLO ? 0 : a.rank, tid = threadIdx.x;
+  constexpr bool solo = SOLO;
   unsigned long long* ctl = a.ctl[me];
-  unsigned long long* ready = ctl;                                   // [src]
-  unsigned long long* done = ctl + (long long)kXchgMaxWorld * kFlagStride;       // [src]
-  unsigned long long* epoch = ctl + 2LL * kXchgMaxWorld * kFlagStride;
-  unsigned long long* ticket = epoch + kFlagStride;
-  // the exchange this launch performs: every workgroup reads the number before it takes its ticket, the workgroup with the last
-  // ticket advances it — after all of them have read it
-  const unsigned long long e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
-  if (blockIdx.x == 0 && tid < W && tid != me)                       // my gradients are complete (stream order): tell every peer
+  // the exchange this launch performs: device state, advanced by workgroup 0 once every workgroup of every rank — this rank's
+  // included, all of which have read it by then — has reported in
+  unsigned long long e = 0;
+  if (!solo) e = __hip_atomic_load(ctl + kEpochWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+  if (!solo && blockIdx.x == 0 && tid < W && tid != me)              // my gradients are complete (stream order): tell every peer
     st_sys(a.ctl[tid] + (long long)me * kFlagStride, e);
   if (tid == 0) s_ok = 1u;
   __syncthreads();
-  if (tid < W && tid != me) {                                        // every peer's gradients are complete
+  if (!solo && tid < W && tid != me) {                               // every peer's gradients are complete
     int spins = 0;
-    while (ld_sys(ready + (long long)tid * kFlagStride) < e && ++spins < kMeetSpinMax) __builtin_amdgcn_s_sleep(2);
+    while (ld_sys(ctl + (long long)tid * kFlagStride) < e && ++spins < kMeetSpinMax) __builtin_amdgcn_s_sleep(2);
     if (spins >= kMeetSpinMax) { s_ok = 0u; if (a.status) __hip_atomic_fetch_or(a.status, (unsigned)MEET_ERR_XCHG_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
-  __syncthreads();
+  if (!solo) __syncthreads();
   const bool ok = s_ok != 0u;
   const int wave = tid >> 6, lane = tid & 63;
   const int boff = 16 * tid;                                         // this lane's four floats of a chunk (byte offset)
   for (int c = a.c0 + me + W * (int)blockIdx.x; c < a.c1; c += W * (int)gridDim.x) {
-    const XChunk ch = a.chunks[c];
+    // chunk c of the handle's table, from the segment list in the kernel arguments (scalar work: no dependent memory access)
+    int sg = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxSeg; ++i) if (i < a.nseg && c >= a.seg_c0[i]) sg = i;
+    const int first = (c - a.seg_c0[sg]) * kXchgChunk;
+    const long long off = a.seg_off[sg] + first;
+    const int n = min(kXchgChunk, a.seg_n[sg] - first);
     // branch-free over the 8 possible peers: a rank beyond the world gets a descriptor of extent 0 — its load returns zeros
     // without touching memory, its store is dropped — so that all W loads are in flight together (a branch per peer made the
     // compiler wait for each load before the next: W serial round trips over the fabric)
     v4u v[kXchgMaxWorld];
 #pragma unroll
     for (int q = 0; q < kXchgMaxWorld; ++q)
-      v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n(a.arena[q < W ? q : 0] + ch.off, q < W ? ch.n : 0), boff, 0, kSys);
+      v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n(a.arena[q < W ? q : 0] + off, q < W ? n : 0), boff, 0, SOLO ? 0 : kSys);
     float s[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -115,40 +135,44 @@ __global__ __launch_bounds__(256) void xchg_two_shot_kernel(XArgs a) {
     const v4u r = {__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3])};
 #pragma unroll
     for (int q = 0; q < kXchgMaxWorld; ++q)
-      __builtin_amdgcn_raw_buffer_store_b128(r, rsrc_n(a.arena[q < W ? q : 0] + ch.off, q < W ? ch.n : 0), boff, 0, kSys);   // (past the chunk: dropped)
+      __builtin_amdgcn_raw_buffer_store_b128(r, rsrc_n(a.arena[q < W ? q : 0] + off, (q < W && !solo) ? n : 0), boff, 0, kSys);   // (past the chunk: dropped)
     // the chunk's sum of squares, in a fixed order: lane's four (zeros past the chunk), wave tree, four waves
     float ss = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (4 * tid + u < ch.n) ss = __fadd_rn(ss, __fmul_rn(s[u], s[u]));
+    for (int u = 0; u < 4; ++u) if (4 * tid + u < n) ss = __fadd_rn(ss, __fmul_rn(s[u], s[u]));
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off, 64));
+    for (int off2 = 32; off2 > 0; off2 >>= 1) ss = __fadd_rn(ss, __shfl_xor(ss, off2, 64));
     __syncthreads();                                                 // (red[] of the previous chunk has been read)
     if (lane == 0) red[wave] = ss;
     __syncthreads();
     if (tid < W) {
       const float tot = __fadd_rn(__fadd_rn(red[0], red[1]), __fadd_rn(red[2], red[3]));
-      __hip_atomic_store(a.parts[tid] + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (solo) a.parts[0][c] = tot;                                  // (the kernel boundary publishes it)
+      else __hip_atomic_store(a.parts[tid] + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  drain_stores();                                                    // every wave: its write-through stores have been acknowledged
+  if (solo) return;
+  drain_stores();                                                    // every wave: its write-through (sc0 sc1) stores have been acknowledged
   __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                    // system scope (the stores above were write-through: ordering only)
-    const unsigned long long t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_ok = (t == gridDim.x - 1) ? 2u : 0u;
-    if (s_ok) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody waits on the ticket: ready for the next launch
+  // this workgroup's chunks are everywhere: say so to every rank, itself included — one 8-byte write-through store per
+  // rank, no atomic (arrivals on one line serialise at a memory round trip each: 272 tickets were most of the launch)
+  if (tid < W) st_sys(a.ctl[tid] + kDoneWord + (long long)me * kMaxGrid + blockIdx.x, e);
+  if (blockIdx.x != 0) return;
+  // workgroup 0 keeps the launch alive until EVERY workgroup of EVERY rank has delivered: the kernel boundary then publishes the
+  // peers' writes to the optimiser launch, and this rank's next backward pass cannot overwrite gradients a peer still reads
+  const int nch = a.c1 - a.c0;
+  bool all = true;
+  for (int q = 0; q < W; ++q) {
+    const int gq = grid_of(nch, q, W);
+    for (int wg = tid; wg < gq; wg += 256) {
+      int spins = 0;
+      while (ld_sys(ctl + kDoneWord + (long long)q * kMaxGrid + wg) < e && ++spins < kMeetSpinMax) __builtin_amdgcn_s_sleep(2);
+      all = all && spins < kMeetSpinMax;
+    }
   }
+  if (!all && a.status) __hip_atomic_fetch_or(a.status, (unsigned)MEET_ERR_XCHG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
-  if (s_ok != 2u) return;
-  // the last workgroup of this rank: everything this rank owns has been delivered everywhere
-  if (tid < W && tid != me) {
-    st_sys(a.ctl[tid] + ((long long)kXchgMaxWorld + me) * kFlagStride, e);
-    int spins = 0;
-    while (ld_sys(done + (long long)tid * kFlagStride) < e && ++spins < kMeetSpinMax) __builtin_amdgcn_s_sleep(2);
-    if (spins >= kMeetSpinMax && a.status) __hip_atomic_fetch_or(a.status, (unsigned)MEET_ERR_XCHG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(ctl + kEpochWord, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -161,9 +185,9 @@ struct gcrl_xchg {
   float* arena = nullptr; long long arena_floats = 0;
   char* ctl = nullptr; size_t ctl_bytes = 0;          // control block + partial array (one hipMalloc, IPC-exported)
   size_t parts_off = 0;
-  XChunk* chunks_dev = nullptr;
-  std::vector<XChunk> chunks;
+  std::vector<long long> seg_off, seg_n;
   std::vector<int> seg_c0;                            // first chunk of segment s; seg_c0[nseg] = total
+  int nchunks() const { return seg_c0.back(); }
   void* peer_arena[kXchgMaxWorld] = {};
   void* peer_ctl[kXchgMaxWorld] = {};
   bool connected = false;
@@ -176,26 +200,25 @@ gcrl_xchg* gcrl_xchg_create(float* arena_dev, int64_t arena_floats, const int64_
                             int world, int device) {
   auto bad = [](const char* m) -> gcrl_xchg* { fail(GCRL_ERR_ARG, "gcrl_xchg_create: %s", m); return nullptr; };
   if (!arena_dev || arena_floats < 1 || !seg_off || !seg_n || nseg < 1) return bad("null / empty argument");
+  if (nseg > kMaxSeg) return bad("at most 12 segments");
   if (world < 1 || world > kXchgMaxWorld || rank < 0 || rank >= world) return bad("1 <= world <= 8 and 0 <= rank < world required (one node, point-to-point xGMI)");
   if (((uintptr_t)arena_dev & 15) != 0) return bad("the arena must be 16-byte aligned");
   gcrl_xchg* x = new gcrl_xchg;
   x->rank = rank; x->world = world; x->device = device;
   x->arena = arena_dev; x->arena_floats = arena_floats;
+  int nch = 0;
   for (int s = 0; s < nseg; ++s) {
-    if (seg_off[s] < 0 || seg_n[s] < 1 || seg_off[s] % 4 != 0 || seg_off[s] + seg_n[s] > arena_floats) { delete x; return bad("segment outside the arena or not 16-byte aligned"); }
-    x->seg_c0.push_back((int)x->chunks.size());
-    for (long long o = 0; o < seg_n[s]; o += kXchgChunk)
-      x->chunks.push_back(XChunk{seg_off[s] + o, (int)std::min<long long>(kXchgChunk, seg_n[s] - o), 0});
+    if (seg_off[s] < 0 || seg_n[s] < 1 || seg_n[s] > 0x7fffffff || seg_off[s] % 4 != 0 || seg_off[s] + seg_n[s] > arena_floats) { delete x; return bad("segment outside the arena or not 16-byte aligned"); }
+    x->seg_off.push_back(seg_off[s]); x->seg_n.push_back(seg_n[s]);
+    x->seg_c0.push_back(nch);
+    nch += (int)((seg_n[s] + kXchgChunk - 1) / kXchgChunk);
   }
-  x->seg_c0.push_back((int)x->chunks.size());
-  const size_t flags = (size_t)(2 * kXchgMaxWorld + 2) * kFlagStride * sizeof(unsigned long long);
+  x->seg_c0.push_back(nch);
+  const size_t flags = (size_t)kFlagWords * sizeof(unsigned long long);
   x->parts_off = flags;
-  x->ctl_bytes = flags + ((x->chunks.size() * sizeof(float) + 255) / 256) * 256;
+  x->ctl_bytes = flags + (((size_t)nch * sizeof(float) + 255) / 256) * 256;
   bool ok = hipSetDevice(device) == hipSuccess && hipMalloc((void**)&x->ctl, x->ctl_bytes) == hipSuccess &&
-            hipMemset(x->ctl, 0, x->ctl_bytes) == hipSuccess &&
-            hipMalloc((void**)&x->chunks_dev, x->chunks.size() * sizeof(XChunk)) == hipSuccess &&
-            hipMemcpy(x->chunks_dev, x->chunks.data(), x->chunks.size() * sizeof(XChunk), hipMemcpyHostToDevice) == hipSuccess &&
-            hipDeviceSynchronize() == hipSuccess;
+            hipMemset(x->ctl, 0, x->ctl_bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { fail(GCRL_ERR_HIP, "gcrl_xchg_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); gcrl_xchg_destroy(x); return nullptr; }
   x->peer_arena[rank] = x->arena;
   x->peer_ctl[rank] = x->ctl;
@@ -212,7 +235,6 @@ void gcrl_xchg_destroy(gcrl_xchg* x) {
     if (x->peer_ctl[q]) (void)hipIpcCloseMemHandle(x->peer_ctl[q]);
   }
   if (x->ctl) (void)hipFree(x->ctl);
-  if (x->chunks_dev) (void)hipFree(x->chunks_dev);
   delete x;
 }
 
@@ -224,7 +246,7 @@ int gcrl_xchg_handles(gcrl_xchg* x, uint8_t* out, int64_t n) {
   GCRL_HIP(hipIpcGetMemHandle(&h[1], x->ctl));
   std::memset(out, 0, (size_t)n);
   std::memcpy(out, h, sizeof(h));
-  const int64_t meta[2] = {(int64_t)x->arena_floats, (int64_t)x->chunks.size()};
+  const int64_t meta[2] = {(int64_t)x->arena_floats, (int64_t)x->nchunks()};
   std::memcpy(out + sizeof(h), meta, sizeof(meta));
   return GCRL_OK;
 }
@@ -239,9 +261,9 @@ int gcrl_xchg_connect(gcrl_xchg* x, const uint8_t* all, int64_t n) {
     int64_t meta[2];
     std::memcpy(h, rec, sizeof(h));
     std::memcpy(meta, rec + sizeof(h), sizeof(meta));
-    if (meta[0] != x->arena_floats || meta[1] != (int64_t)x->chunks.size())
+    if (meta[0] != x->arena_floats || meta[1] != (int64_t)x->nchunks())
       return fail(GCRL_ERR_STATE, "gcrl_xchg_connect: rank %d exchanges a different layout (%lld floats / %lld chunks, here %lld / %zu): the replicas must be built alike",
-                  q, (long long)meta[0], (long long)meta[1], (long long)x->arena_floats, x->chunks.size());
+                  q, (long long)meta[0], (long long)meta[1], (long long)x->arena_floats, (size_t)x->nchunks());
     GCRL_HIP(hipIpcOpenMemHandle(&x->peer_arena[q], h[0], hipIpcMemLazyEnablePeerAccess));
     GCRL_HIP(hipIpcOpenMemHandle(&x->peer_ctl[q], h[1], hipIpcMemLazyEnablePeerAccess));
   }
@@ -279,14 +301,16 @@ int gcrl_xchg_allreduce(gcrl_xchg* x, int seg0, int nseg, void* stream) {
     a.ctl[q] = (unsigned long long*)x->peer_ctl[q];
     a.parts[q] = reinterpret_cast<float*>((char*)x->peer_ctl[q] + x->parts_off);
   }
-  a.chunks = x->chunks_dev;
+  a.nseg = (int)x->seg_off.size();
+  for (int i = 0; i < a.nseg; ++i) { a.seg_off[i] = x->seg_off[i]; a.seg_n[i] = (int)x->seg_n[i]; }
+  for (int i = 0; i <= a.nseg; ++i) a.seg_c0[i] = x->seg_c0[i];
   a.world = x->world; a.rank = x->rank;
   a.c0 = x->seg_c0[seg0]; a.c1 = x->seg_c0[seg0 + nseg];
   a.status = x->status;
-  const int mine = (a.c1 - a.c0 + x->world - 1) / x->world;
-  const int grid = std::max(1, std::min(mine, 1024));
+  const int grid = grid_of(a.c1 - a.c0, x->rank, x->world);
   hipStream_t st = stream == GCRL_STREAM_LEGACY ? (hipStream_t) nullptr : (hipStream_t)stream;
-  hipLaunchKernelGGL(xchg_two_shot_kernel, dim3(grid), dim3(256), 0, st, a);
+  if (x->world == 1) hipLaunchKernelGGL(xchg_two_shot_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(xchg_two_shot_kernel<false>, dim3(grid), dim3(256), 0, st, a);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

@@ -33,6 +33,8 @@ UNITS = {
 
 STORE_WT = re.compile(r"^\s*(buffer_store|global_store|flat_store)\S*\s.*\bsc1\b")
 ATOMIC = re.compile(r"^\s*(global|flat|buffer)_atomic_(add|or|inc)")
+# an 8-byte system-scope store is how xchg_ipc.hip raises its ready / done flags: an arrival as well
+FLAG = re.compile(r"^\s*global_store_dwordx2\s.*\bsc0 sc1\b")
 WAIT0 = re.compile(r"^\s*s_waitcnt\s+.*vmcnt\(0\)")
 
 
@@ -61,7 +63,12 @@ def check_kernel(body):
     waited = True
     n_store = n_atomic = 0
     for i, line in enumerate(body):
-        if STORE_WT.match(line):
+        if FLAG.match(line):
+            if last_store is not None:
+                n_atomic += 1
+                if not waited:
+                    problems.append((i, line.strip(), body[last_store].strip()))
+        elif STORE_WT.match(line):
             last_store, waited = i, False
             n_store += 1
         elif WAIT0.match(line):
