@@ -18,7 +18,6 @@ constexpr int kMaxG = 8;
 constexpr int kMaxInline = 128;    // S limit for host-pointer pushes (values travel as kernargs)
 constexpr int kMaxFut = 2048;      // k_future*(T-1) limit for inline future indices
 constexpr int kMaxEp = 8;          // episodes per flush launch
-constexpr int kStepsPerBlock = 4;
 constexpr int kPayW = 32;          // floats per env of a vector-env step's payload [t | r | d | a(A) | ag(G)]
 
 // ---------------------------------------------------------------- stage one transition
@@ -162,29 +161,44 @@ struct FlushArgs {
   uint8_t fut[kMaxFut];
 };
 
-// grid.x = ceil(maxT / kStepsPerBlock), grid.y = episode.  Each block:
+// grid.x = ceil(rows of the longest episode / 16), grid.y = episode.  A block writes 16 consecutive output rows of its episode
+// (row n of an episode = copy n % (1+k) of step n / (1+k): the original, then its k relabels; the last step has the original
+// only), one row per 16-lane group:
 //   (1) exclusive scan of per-episode output-row counts (one wavefront, cross-lane shifts)
 //       -> first row number of its episode (segment base of the multi-episode flush);
-//   (2) stages its steps' records and the whole achieved-goal column of the episode in LDS;
-//   (3) writes the original row and the k relabelled rows of each of its steps; relabel =
-//       goal slot of s and ns swapped for ag[f] from LDS, reward recomputed, done = 0
-//       (src/buffer.py:151-179).
+//   (2) ONE round of loads into LDS: the records of the (<= 3 at k = 8) steps its rows belong to, the whole achieved-goal column
+//       of the episode, the future picks (and host-computed rewards) of those steps;
+//   (3) every group assembles its row — relabel = goal slot of s and ns swapped for ag[f] from LDS, reward recomputed,
+//       done = 0 (src/buffer.py:151-179) — from independent LDS reads (what a lane's four columns ARE is decided before the
+//       barrier) and stores it as full 16-byte instructions over contiguous bytes.
+// Round 4 (11.5 us per single-episode launch).  By device-clock stamps the round-3 form spent ~3 us in its loads and
+// ~6 us in NINE row iterations per wave: a row is ~300 instructions of index arithmetic, branches and dependent LDS reads, and a
+// lone wave per SIMD issues them at ~5 cycles each — neither the stores nor the loads mattered (removing either changed
+// nothing).  Hence one row per group and no loop: 28 blocks per 442-row episode instead of 13, each re-reading ~2 KB.
 // (kMulti only separates the names in a profile: single-episode launches from a vector-env step's multi-episode ones)
+constexpr int kFlushRows = 16;               // rows per block
 template <bool kMulti>
 __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
-  __shared__ float ag_lds[kMaxT * kMaxG];
-  __shared__ float rec_lds[kStepsPerBlock][160];
+  __shared__ float ag_lds[kMaxT * kMaxG];                              // [step][8]
+  __shared__ __attribute__((aligned(16))) float rec_lds[kFlushRows * 176];   // the staged records of this block's steps, stride RG (<= 176 floats)
+  __shared__ int fut_lds[kFlushRows * 64];             // future pick of (step, rep): k_future <= 64 per step
+  __shared__ float rew_lds[kFlushRows * 64];
   __shared__ long long base_lds;
 
   const int e = blockIdx.y;
   const int T = p.T[e];
-  const int i0 = blockIdx.x * kStepsPerBlock;
-  if (i0 >= T) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = p.k, G = p.G, RG = p.RG, reps = 1 + k;
+  const int total = T + k * (T - 1);
+  const int n0 = blockIdx.x * kFlushRows;
+  if (n0 >= total) return;
+  const int n_hi = min(total - 1, n0 + kFlushRows - 1);
+  const int i_lo = n0 / reps, i_hi = n_hi / reps;        // (uniform)
+  const int nsteps = i_hi - i_lo + 1;                    // <= 16 (k = 0), 3 at k = 8
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   if (wave == 0) {
     long long rows = 0;
-    if (lane < p.nep) rows = (long long)p.T[lane] + (long long)p.k * (p.T[lane] - 1);
+    if (lane < p.nep) rows = (long long)p.T[lane] + (long long)k * (p.T[lane] - 1);
     long long incl = rows;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -194,54 +208,99 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
     if (lane == e) base_lds = incl - rows;
   }
   const float* stg = p.stage[e];
-  for (int t = threadIdx.x; t < T * p.G; t += 256) ag_lds[t] = stg[(t / p.G) * p.RG + p.RW + (t % p.G)];
-  const int nsteps = min(kStepsPerBlock, T - i0);
-  for (int t = threadIdx.x; t < nsteps * p.RG; t += 256) {
-    int li = t / p.RG, c = t - li * p.RG;
-    rec_lds[li][c] = stg[(long long)(i0 + li) * p.RG + c];
+  // everything the rows need, requested together (no divisions in these loops)
+  for (int t = tid; t < T * 8; t += 256) {               // the episode's achieved-goal column, 8 slots per step
+    const int st = t >> 3, q = t & 7;
+    ag_lds[t] = q < G ? stg[(long long)st * RG + p.RW + q] : 0.f;
   }
-  __syncthreads();
-  const long long base = base_lds;
-
-  const int reps = 1 + p.k;
-  for (int job = wave; job < nsteps * reps; job += 4) {
-    const int li = job / reps, rep = job - li * reps;
-    const int i = i0 + li;
-    if (rep > 0 && i >= T - 1) continue;  // last step: no relabels (src/buffer.py:152)
-    const long long g = base + (long long)i * reps + rep;
-    if (g < p.skip) continue;
-    const long long phys = (p.tail + g) % p.cap;
-    int f = 0;
-    const int o_ns = p.SA4, o_r = p.SA4 + p.S4;
-    float rew = rec_lds[li][o_r], done = rec_lds[li][o_r + 1];
-    if (rep > 0) {
-      if (p.rng_mode == GCRL_RNG_CPYTHON_MT) f = (p.fut_ext ? p.fut_ext : p.fut)[p.fut_off[e] + i * p.k + (rep - 1)];
-      else f = i + 1 + (int)gcrl::hash_below(p.seed, p.epi_id[e], (unsigned long long)(i * p.k + rep - 1), (uint32_t)(T - 1 - i));
-      // compute_reward(ag_i, ag_f): d = ||ag_i - ag_f||_2 in fp32, one rounding per op
-      float acc = 0.f;
-      for (int q = 0; q < p.G; ++q) {
-        float df = __fsub_rn(rec_lds[li][p.RW + q], ag_lds[f * p.G + q]);
-        acc = __fadd_rn(acc, __fmul_rn(df, df));
+  {
+    const float4* src = reinterpret_cast<const float4*>(stg + (long long)i_lo * RG);   // (RG is a multiple of 16 floats)
+    float4* dst = reinterpret_cast<float4*>(rec_lds);
+    for (int t = tid; t < nsteps * (RG >> 2); t += 256) dst[t] = src[t];
+  }
+  {
+    const uint8_t* fut = p.fut_ext ? p.fut_ext : p.fut;
+    const int slot0 = p.fut_off[e] + i_lo * k;
+    for (int t = tid; t < nsteps * 64; t += 256) {
+      const int li = t >> 6, rep = t & 63, i = i_lo + li;
+      int f = 0;
+      if (rep < k && i < T - 1) {
+        if (p.rng_mode == GCRL_RNG_CPYTHON_MT) f = fut[slot0 + li * k + rep];
+        else f = i + 1 + (int)gcrl::hash_below(p.seed, p.epi_id[e], (unsigned long long)(i * k + rep), (uint32_t)(T - 1 - i));
+        if (p.rew_ext) rew_lds[t] = p.rew_ext[slot0 + li * k + rep];
       }
-      float dist = sqrtf(acc);
-      rew = (p.reward_kind == GCRL_REWARD_SPARSE) ? ((dist > p.thr) ? -1.0f : -0.0f) : -dist;
-      if (p.rew_ext) rew = p.rew_ext[p.fut_off[e] + i * p.k + (rep - 1)];
-      done = 0.f;
+      fut_lds[t] = f;
     }
-    float* out = p.ring + phys * p.RS;
-    const int gs0 = p.S - p.G;           // goal slot of s
-    const int gs1 = o_ns + p.S - p.G;    // goal slot of ns
-    for (int c = lane; c < p.RS; c += 64) {
-      float v = 0.f;
-      if (c < o_r) {
-        v = rec_lds[li][c];
-        if (rep > 0) {
-          if (c >= gs0 && c < p.S) v = ag_lds[f * p.G + (c - gs0)];
-          else if (c >= gs1 && c < o_ns + p.S) v = ag_lds[f * p.G + (c - gs1)];
-        }
-      } else if (c == o_r) v = rew;
-      else if (c == o_r + 1) v = done;
-      out[c] = v;
+  }
+  // what this lane's four columns of a row are — the same for every row: 0 copy, 1 goal slot of s / ns (component gq), 2 the
+  // reward, 3 the done flag, 4 padding
+  const int grp = tid >> 4, gl = tid & 15;       // 16 groups of 16 lanes: a group owns a row
+  const int o_ns = p.SA4, o_r = p.SA4 + p.S4;
+  const int gs0 = p.S - G, gs1 = o_ns + p.S - G;
+  int kind[3][4], gq[3][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = 64 * j + 4 * gl + u;
+      int kd = 0, q = 0;
+      if (c >= gs0 && c < p.S) { kd = 1; q = c - gs0; }
+      else if (c >= gs1 && c < o_ns + p.S) { kd = 1; q = c - gs1; }
+      else if (c == o_r) kd = 2;
+      else if (c == o_r + 1) kd = 3;
+      else if (c > o_r + 1) kd = 4;
+      kind[j][u] = kd; gq[j][u] = q;
+    }
+  // this group's row
+  const int n = n0 + grp;
+  int li = 0, rep = n - i_lo * reps;
+  while (rep >= reps) { rep -= reps; ++li; }
+  __syncthreads();
+  if (n > n_hi) return;
+  const long long g = base_lds + n;
+  if (g < p.skip) return;                     // fell off a ring smaller than the flush
+  long long phys = p.tail + g;
+  if (phys >= p.cap) phys -= p.cap;
+  if (phys >= p.cap) phys %= p.cap;           // (a ring smaller than the flush)
+  const float* rec = rec_lds + li * RG;
+  const int f = rep > 0 ? fut_lds[li * 64 + rep - 1] : 0;
+  const float* agf = ag_lds + f * 8;
+  // all of the row's LDS reads are independent: issued together, one wait
+  float a_i[kMaxG], a_f[kMaxG];
+#pragma unroll
+  for (int q = 0; q < kMaxG; ++q) { a_i[q] = q < G ? rec[p.RW + q] : 0.f; a_f[q] = agf[q]; }
+  float rew = rec[o_r], done = rec[o_r + 1];
+  const float rew_host = (p.rew_ext && rep > 0) ? rew_lds[li * 64 + rep - 1] : 0.f;
+  if (rep > 0) {
+    // compute_reward(ag_i, ag_f): d = ||ag_i - ag_f||_2 in fp32, one rounding per op
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMaxG; ++q)
+      if (q < G) { const float df = __fsub_rn(a_i[q], a_f[q]); acc = __fadd_rn(acc, __fmul_rn(df, df)); }
+    const float dist = sqrtf(acc);
+    rew = (p.reward_kind == GCRL_REWARD_SPARSE) ? ((dist > p.thr) ? -1.0f : -0.0f) : -dist;
+    if (p.rew_ext) rew = rew_host;
+    done = 0.f;
+  }
+  float* out = p.ring + phys * p.RS;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c4 = 64 * j + 4 * gl;
+    if (c4 < p.RS) {
+      const float4 r4 = *reinterpret_cast<const float4*>(rec + c4);     // (c4 + 3 < RS <= RG)
+      float v[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kd = kind[j][u];
+        float x = v[u];
+        const float gsw = agf[gq[j][u]];                                  // (independent LDS read; gq = 0 where unused)
+        x = (kd == 1 && rep > 0) ? gsw : x;
+        x = kd == 2 ? rew : x;
+        x = kd == 3 ? done : x;
+        x = kd == 4 ? 0.f : x;
+        v[u] = x;
+      }
+      *reinterpret_cast<float4*>(out + c4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -643,7 +702,9 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
     fa.rew_ext = h->rew_dev;
   }
   fa.skip = total > c.capacity ? total - c.capacity : 0;
-  dim3 grid((maxT + kStepsPerBlock - 1) / kStepsPerBlock, nep);
+  int max_rows = 0;
+  for (int e = 0; e < nep; ++e) max_rows = std::max(max_rows, Ts[e] + c.k_future * (Ts[e] - 1));
+  dim3 grid((max_rows + kFlushRows - 1) / kFlushRows, nep);
   if (nep > 1) hipLaunchKernelGGL(her_flush_kernel<true>, grid, dim3(256), 0, st, fa);
   else hipLaunchKernelGGL(her_flush_kernel<false>, grid, dim3(256), 0, st, fa);
   GCRL_HIP(hipGetLastError());
@@ -736,7 +797,7 @@ gcrl_her* gcrl_her_create(const gcrl_her_config* cfg, gcrl_mt* rng) {
   if (cfg->state_dim < 1 || cfg->action_dim < 1 || cfg->action_dim > 16) return bad("state_dim >= 1 and 1 <= action_dim <= 16 required");
   if (cfg->goal_dim < 1 || cfg->goal_dim > kMaxG || cfg->goal_dim > cfg->state_dim) return bad("goal_dim must be 1..8 and <= state_dim");
   if (cfg->capacity < 1 || cfg->capacity >= (1ll << 32)) return bad("capacity must be in [1, 2^32)");
-  if (cfg->nenvs < 1 || cfg->k_future < 0) return bad("nenvs >= 1 and k_future >= 0 required");
+  if (cfg->nenvs < 1 || cfg->k_future < 0 || cfg->k_future > 64) return bad("nenvs >= 1 and 0 <= k_future <= 64 required");
   if (cfg->flush_len < 1 || cfg->flush_len > kMaxT) return bad("flush_len must be 1..64");
   if (2 * cfg->state_dim + cfg->action_dim + 8 + cfg->goal_dim > 160) return bad("record wider than 160 floats");
   int ndev = gcrl_device_count();
