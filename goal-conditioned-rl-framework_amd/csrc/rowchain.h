@@ -210,8 +210,16 @@ __device__ inline void rows_head(const float* xs, int ldx, int K, const float* W
   const bool mine = j < P && p < R * n_out;
   const int r = mine ? p / n_out : 0, o = mine ? p - r * n_out : 0;
   float s = 0.f;
-  if (mine)
-    for (int k = sub; k < K; k += G) s += xs[r * ldx + k] * W[(long long)o * ldw + k];
+  if (mine) {
+    if (((K | (int)ldw) & 3) == 0) {   // 16-byte LDS reads (round 4: the one-float-per-lane loop was 16 dependent rounds of LDS latency)
+      for (int k = 4 * sub; k < K; k += 4 * G) {
+        const v4f x = *(const v4f*)(xs + r * ldx + k), w = *(const v4f*)(W + (long long)o * ldw + k);
+        s += ((x[0] * w[0] + x[1] * w[1]) + x[2] * w[2]) + x[3] * w[3];
+      }
+    } else {
+      for (int k = sub; k < K; k += G) s += xs[r * ldx + k] * W[(long long)o * ldw + k];
+    }
+  }
   for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (mine && sub == 0) {
     const float v = s + (bias ? bias[o] : 0.f);

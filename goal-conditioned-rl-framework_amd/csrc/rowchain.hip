@@ -46,20 +46,36 @@ __device__ inline float* mlp_hidden(const RowNet& net, const float* X0, float* X
   return (float*)in;
 }
 
-// G <- (upstream[r][o] . Whead[o][k]) * act'(h[r][k]) in place over h (LDS), n_up <= 16 head outputs
+// G <- (upstream[r][o] . Whead[o][k]) * act'(h[r][k]) in place over h (LDS), n_up <= 16 head outputs.
+// A thread owns four consecutive k (16-byte LDS accesses; H % 4 == 0): one pass for 4 rows x 256 columns (round 4: the
+// element-per-thread loop was four dependent rounds of LDS reads, 0.8-1.9 us per call by the kernel's own clock stamps).
+// q_out (optional, n_up == 1): ALSO the head's forward value q[r] = sum_k h[r][k] * Whead[k] + q_bias -> q_out[r * 16], formed
+// from the same reads — for callers whose upstream gradient does not depend on it (DDPG's actor phase: d(-mean Q)/dq = -1/B),
+// which saves the separate head pass.  Needs the H / 4 threads of a row inside one wavefront (H = 64, 128, 256).
 template <int RG>
 __device__ inline void head_backward(float* h, int ldl, int H, const float* Wh, int n_up, const float* up /* LDS [R][16] */,
-                                     float* save, int rv) {
+                                     float* save, int rv, float* q_out = nullptr, float q_bias = 0.f) {
   constexpr int R = 4 * RG;
-  for (int i = threadIdx.x; i < R * H; i += kRowThreads) {
-    const int r = i / H, k = i - r * H;
-    float s = 0.f;
-    for (int o = 0; o < n_up; ++o) s += up[r * 16 + o] * Wh[(long long)o * H + k];
-    const float g = s * act_deriv(h[r * ldl + k], MUL_DLEAKY);
-    h[r * ldl + k] = g;
-    if (save && r < rv) save[(long long)r * H + k] = g;
+  const int H4 = H >> 2;
+  for (int i = threadIdx.x; i < R * H4; i += kRowThreads) {
+    const int r = i / H4, k = (i - r * H4) << 2;
+    const v4f hv = *(const v4f*)(h + r * ldl + k);
+    v4f s = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < n_up; ++o) s += up[r * 16 + o] * *(const v4f*)(Wh + (long long)o * H + k);
+    v4f g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = s[q] * act_deriv(hv[q], MUL_DLEAKY);
+    if (q_out) {   // (uniform) the rows of a wave: 64 / H4 of them, H4 lanes each
+      const v4f w = *(const v4f*)(Wh + k);
+      float qs = ((hv[0] * w[0] + hv[1] * w[1]) + hv[2] * w[2]) + hv[3] * w[3];
+      for (int off = H4 >> 1; off > 0; off >>= 1) qs += __shfl_xor(qs, off, 64);
+      if ((i - r * H4) == 0) q_out[r * 16] = qs + q_bias;
+    }
+    *(v4f*)(h + r * ldl + k) = g;
+    if (save && r < rv) *(v4f*)(save + (long long)r * H + k) = g;
   }
 }
+__device__ inline bool head_fusable(int H) { return H == 64 || H == 128 || H == 256; }
 
 // pre-activation gradients of hidden layers L-2..0 from the one of layer L-1 (in G, LDS)
 template <int RG>
@@ -341,6 +357,8 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     seg_store(s_da, hw_da, src_da, A * H);
     if (tid < A) hb[tid] = v_hb;
     if (tid == 32) hb[16] = v_hb;
+    const bool fuse_q = head_fusable(H);   // Q(s, pi(s)) feeds a metric only: its head pass rides in the head's backward pass (below)
+    if (fuse_q && tid < R) sm2[tid * 16] = (tid < rv) ? -1.0f / (float)B : 0.f;   // d(-mean Q)/dq, constant
     __syncthreads();
     // the last actor activation lands in XS and stays there: the critic chain reuses X1 / X2
     float* h = mlp_hidden<RG>(a.actor, X0, X1, X2, ldl, part + R * 16, a.hA, BH, row0, rv, XS);
@@ -350,15 +368,21 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     __syncthreads();
     // critic on [s | pi(s)]
     h = mlp_hidden<RG>(a.critic[0], X0, X1, X2, ldl, part + R * 16, a.hC2, BH, row0, rv);
-    rows_head<RG>(h, ldl, H, hw_c, H, hb + 16, 1, EPI_NONE, sm2);
-    __syncthreads();
-    if (tid < R) {
-      if (tid < rv) a.q2[row0 + tid] = sm2[tid * 16];
-      sm2[tid * 16] = (tid < rv) ? -1.0f / (float)B : 0.f;   // d(-mean Q)/dq
+    if (fuse_q) {
+      head_backward<RG>(h, ldl, H, hw_c, 1, sm2, nullptr, rv, sm3, hb[16]);
+      __syncthreads();
+      if (tid < rv) a.q2[row0 + tid] = sm3[tid * 16];
+    } else {
+      rows_head<RG>(h, ldl, H, hw_c, H, hb + 16, 1, EPI_NONE, sm2);
+      __syncthreads();
+      if (tid < R) {
+        if (tid < rv) a.q2[row0 + tid] = sm2[tid * 16];
+        sm2[tid * 16] = (tid < rv) ? -1.0f / (float)B : 0.f;   // d(-mean Q)/dq
+      }
+      __syncthreads();
+      head_backward<RG>(h, ldl, H, hw_c, 1, sm2, nullptr, rv);
+      __syncthreads();
     }
-    __syncthreads();
-    head_backward<RG>(h, ldl, H, hw_c, 1, sm2, nullptr, rv);
-    __syncthreads();
     float* g0 = grad_chain<RG>(a.critic[0], h, X1, X2, ldl, part + R * 16, a.hC2, nullptr, BH, row0, rv);
     // da[r][j] = g0[r][:] . W0[:, S+j]  (row S+j of the [in][out] copy), then through the tanh
     rows_head<RG>(g0, ldl, H, hw_da, H, nullptr, A, EPI_NONE, sm2);
