@@ -86,6 +86,7 @@ PROTOTYPES = {
     "gcrl_mt_sample_indices": (C.c_int, [_vp, _u32, _u32, _vp]),
     "gcrl_mt_future_indices": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "gcrl_cosine_lr_next": (_f64, [_f64, _f64, _f64, _i64, _i64]),
+    "gcrl_ringbook_sim": (C.c_int, [_i64, _i64, _i64, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "gcrl_her_create": (_vp, [C.POINTER(HerConfig), _vp]),
     "gcrl_her_destroy": (None, [_vp]),
     "gcrl_her_len": (_i64, [_vp]),

@@ -7,6 +7,7 @@
 // Record layout and ring indexing: her_ring.h.
 #include "her_ring.h"
 #include "norm_math.h"
+#include "ring_book.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -618,7 +619,8 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
   std::memset(&fa, 0, sizeof(fa));
   fa.ring = h->ring;
   fa.cap = c.capacity;
-  fa.tail = (h->head + h->len) % c.capacity;
+  gcrl::RingBook book{c.capacity, h->head, h->len};   // deque(maxlen) bookkeeping (ring_book.h)
+  fa.tail = book.tail();
   fa.nep = nep;
   fa.k = c.k_future; fa.S = h->S; fa.A = h->A; fa.G = h->G; fa.SA4 = h->SA4; fa.S4 = h->S4; fa.RW = h->RW; fa.RS = h->RS; fa.RG = h->RG;
   fa.reward_kind = c.reward_kind;
@@ -701,20 +703,16 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
     GCRL_HIP(hipEventRecord(h->rew_ev[rslot], st));
     fa.rew_ext = h->rew_dev;
   }
-  fa.skip = total > c.capacity ? total - c.capacity : 0;
+  fa.skip = book.append(total);   // (head / len of the handle follow once the launch is out)
   int max_rows = 0;
   for (int e = 0; e < nep; ++e) max_rows = std::max(max_rows, Ts[e] + c.k_future * (Ts[e] - 1));
   dim3 grid((max_rows + kFlushRows - 1) / kFlushRows, nep);
   if (nep > 1) hipLaunchKernelGGL(her_flush_kernel<true>, grid, dim3(256), 0, st, fa);
   else hipLaunchKernelGGL(her_flush_kernel<false>, grid, dim3(256), 0, st, fa);
   GCRL_HIP(hipGetLastError());
-  // deque(maxlen) bookkeeping: append `total` rows, the oldest fall off the front
-  int64_t newlen = h->len + total;
-  if (newlen > c.capacity) {
-    h->head = (h->head + (newlen - c.capacity)) % c.capacity;
-    newlen = c.capacity;
-  }
-  h->len = newlen;
+  // deque(maxlen) bookkeeping: `total` rows appended, the oldest fell off the front
+  h->head = book.head;
+  h->len = book.len;
   h->episodes_flushed += nep;
   h->mutation_epoch++;
   *rows_out = total;
@@ -954,8 +952,8 @@ int64_t gcrl_her_append(gcrl_her* h, const float* state, int state_on_device, co
   if ((!state_on_device || !next_on_device) && h->S > kMaxInline)
     return gcrl::fail(GCRL_ERR_ARG, "gcrl_her_append: host-pointer states support state_dim <= %d", kMaxInline);
   hipStream_t st = h->pick(stream);
-  const int64_t cap = h->cfg.capacity;
-  const int64_t phys = (h->head + h->len) % cap;
+  gcrl::RingBook book{h->cfg.capacity, h->head, h->len};
+  const int64_t phys = book.tail();
   StageArgs sa;
   sa.dst = h->ring + (size_t)phys * h->RS;     // a ring record IS the leading RW floats of a staging record
   sa.s_dev = state_on_device ? state : nullptr;
@@ -968,8 +966,8 @@ int64_t gcrl_her_append(gcrl_her* h, const float* state, int state_on_device, co
   if (!next_on_device) std::memcpy(sa.ns_inl, next_state, sizeof(float) * h->S);
   hipLaunchKernelGGL(her_stage_kernel, dim3(1), dim3(64), 0, st, sa);
   GCRL_HIP(hipGetLastError());
-  if (h->len == cap) h->head = (h->head + 1) % cap;   // deque(maxlen): the oldest row falls off
-  else h->len += 1;
+  book.append(1);                              // deque(maxlen): at capacity the oldest row falls off
+  h->head = book.head; h->len = book.len;
   h->mutation_epoch++;
   return 1;
 }

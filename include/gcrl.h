@@ -364,6 +364,12 @@ void gcrl_dp_destroy(gcrl_dp* d);
 int gcrl_dp_world(const gcrl_dp* d);
 int gcrl_dp_allreduce_sum(gcrl_dp* d, float* buf_dev, int64_t n, void* stream); /* in place, fp32 */
 int gcrl_dp_broadcast(gcrl_dp* d, float* buf_dev, int64_t n, int root, void* stream);
+/* Test hook of the replay ring's deque(maxlen) bookkeeping (csrc/ring_book.h; what collections.deque(maxlen=max_len) does for
+ * the reference's buffers, src/buffer.py:95, :8-20).  Host-only: for append i of `appends[0..n)` rows to a ring of `capacity`
+ * rows (initially `len0` rows, head `head0`) reports the physical row its first row goes to and how many of its rows are
+ * overwritten inside the same append; returns the final head / len. */
+int gcrl_ringbook_sim(int64_t capacity, int64_t head0, int64_t len0, const int64_t* appends, int n, int64_t* tail_out, int64_t* skip_out,
+                      int64_t* head_out, int64_t* len_out);
 /* ------------------------------------------------------------------------------------------
  * The gradient exchange INSIDE the engine's launch sequence (csrc/xchg_ipc.hip; round 4).  New design: the reference is
  * single-process, BASELINE.json's north star asks for the all-reduce of actor/critic gradients over xGMI.  One process per GPU of

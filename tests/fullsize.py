@@ -21,7 +21,7 @@ import numpy as np
 import detdata
 from conftest import hparams_from_golden, load_golden
 
-CASES = ["ddpg_pickplace_b256", "cfg2_ddpg_reach_b1024", "cfg3_td3_pickplace_b2048_s1", "cfg3_td3_pickplace_b2048_s2",
+CASES = ["ddpg_pickplace_b256", "cfg1_ddpg_reach_b256", "cfg2_ddpg_reach_b1024", "cfg3_td3_pickplace_b2048_s1", "cfg3_td3_pickplace_b2048_s2",
          "cfg4_tqc_push_b2048", "cfg5_sac_slide_b512"]
 K_REF = 3.0       # fp32 rounding error is one random draw per summation order: allow 3x the reference's own
 RTOL = 1e-5       # north-star tolerance (relative to the quantity's scale)
@@ -59,7 +59,7 @@ class Report:
     """Collects (quantity, error of the implementation vs fp64, the reference's own fp32 error vs fp64, scale)."""
 
     def __init__(self, who: str, case: str):
-        self.who, self.case, self.rows, self.bad = who, case, [], []
+        self.who, self.case, self.rows, self.bad, self.beyond_flat = who, case, [], [], []
         self.flips = self.flips_ref32 = self.kink_units = 0
 
     def check(self, what: str, got, ref32, ref64, mask=None, extra_abs: float = 0.0):
@@ -72,6 +72,11 @@ class Report:
         e_got = float(np.max(np.abs(got - ref64)))
         e_ref = float(np.max(np.abs(ref32 - ref64)))
         ok = e_got <= max(K_REF * e_ref, RTOL * scale) + extra_abs
+        # the north star's flat bound on its own: every quantity of every case meets it today (round 3: worst 7.2e-6), so a
+        # regression may not hide behind the K_REF term.  Kept apart from `ok` so that a report still says which
+        # of the two a quantity missed.
+        if not e_got <= RTOL * scale + extra_abs:
+            self.beyond_flat.append((what, e_got / scale if scale > 0 else e_got, e_ref / scale if scale > 0 else e_ref))
         self.rows.append(dict(case=self.case, who=self.who, quantity=what, scale=scale, err_vs_f64=e_got, ref32_err_vs_f64=e_ref,
                               rel_err=e_got / scale if scale > 0 else 0.0, rel_ref=e_ref / scale if scale > 0 else 0.0,
                               rel_vs_ref32=float(np.max(np.abs(got - ref32))) / scale if scale > 0 else 0.0, ok=bool(ok)))

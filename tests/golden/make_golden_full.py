@@ -49,6 +49,8 @@ import detdata  # noqa: E402
 CASES = {
     # headline: PickAndPlace DDPG, batch 256
     "ddpg_pickplace_b256": dict(kind="DDPG", yaml="config_ddpg_pickplace.yaml", over={}, dims=(23, 4), B=256, step=1, gstep=40),
+    # cfg 1 (BASELINE configs[0], the reference's own CPU-runnable case): Reach, the YAML's H = 64 / L = 3, batch 256
+    "cfg1_ddpg_reach_b256": dict(kind="DDPG", yaml="config_ddpg_reach.yaml", over={}, dims=(10, 3), B=256, step=1, gstep=40),
     # cfg 2: Reach, B=1024, MLP(256,256)
     "cfg2_ddpg_reach_b1024": dict(kind="DDPG", yaml="config_ddpg_reach.yaml", over=dict(hidden_dim=256, layer_count=2),
                                   dims=(10, 3), B=1024, step=1, gstep=40),

@@ -13,7 +13,37 @@ import torch
 
 from conftest import ROOT, load_golden
 
+# tools/asan_host_check.sh: the same tests against csrc's `make asan` build (the host-only translation units under
+# AddressSanitizer + UndefinedBehaviorSanitizer, libgcrl_host_asan.so) — no torch extension, no HIP runtime in that library
+ASAN_LIB = os.environ.get("GCRL_HOST_ASAN_LIB")
+needs_product = pytest.mark.skipif(bool(ASAN_LIB), reason="the sanitizer build holds the host-only translation units")
 
+
+def _prototypes_without_loading():
+    """goal-conditioned-rl-framework_amd/_ffi.py's PROTOTYPES table, taken from its source (importing the module loads the
+    product library)."""
+    src = open(os.path.join(ROOT, "goal-conditioned-rl-framework_amd", "_ffi.py")).read()
+    ns = {"__file__": os.path.join(ROOT, "goal-conditioned-rl-framework_amd", "_ffi.py"), "__name__": "_ffi_head"}
+    exec(compile(src[:src.index("def _load():")], "_ffi.py(head)", "exec"), ns)
+    return ns["PROTOTYPES"]
+
+
+@pytest.fixture(scope="module")
+def lib(request):
+    if not ASAN_LIB:
+        return request.getfixturevalue("gcrl")._ffi.lib
+    l = C.CDLL(ASAN_LIB)
+    bound = 0
+    for name, (res, args) in _prototypes_without_loading().items():
+        if hasattr(l, name):
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+            bound += 1
+    assert bound >= 14, bound      # the Mersenne Twister, the schedule, the error channel, the ring bookkeeping
+    return l
+
+
+@needs_product
 def test_header_symbols_are_all_exported(gcrl):
     hdr = open(os.path.join(ROOT, "include", "gcrl.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
@@ -133,6 +163,33 @@ def test_cosine_schedule_matches_torch(lib, base, eta_min, tmax):
         assert lr == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12, abs=1e-18), e
 
 
+@pytest.mark.parametrize("cap", [1, 7, 100, 443, 1000])
+def test_ring_bookkeeping_is_deque_maxlen(lib, cap):
+    """csrc/ring_book.h — where a flush's rows land and what falls off — against collections.deque(maxlen) (what the reference's
+    buffers are, src/buffer.py:95): appends of 1 row (ReplayBuffer.push), of whole flushes (T + k (T - 1) rows), of more rows
+    than the ring holds (the oldest rows of the SAME flush fall off: the kernel skips them)."""
+    import collections
+    gen = np.random.default_rng(cap)
+    sizes = [int(x) for x in gen.choice([1, 1, 1, 50, 246, 442, 2 * cap + 3], size=60)]
+    dq, serial, where = collections.deque(maxlen=cap), 0, {}
+    tails, skips = (C.c_int64 * len(sizes))(), (C.c_int64 * len(sizes))()
+    head, ln = C.c_int64(), C.c_int64()
+    assert lib.gcrl_ringbook_sim(cap, 0, 0, (C.c_int64 * len(sizes))(*sizes), len(sizes), tails, skips, C.byref(head), C.byref(ln)) == 0
+    for i, n in enumerate(sizes):
+        assert skips[i] == max(0, n - cap)
+        for j in range(n):                       # row j of this append goes to physical row (tail + j) % cap
+            where[serial] = (tails[i] + j) % cap
+            dq.append(serial)
+            serial += 1
+    assert ln.value == len(dq)
+    for logical, s in enumerate(dq):             # logical index j of the deque lives at (head + j) % cap, and holds row s
+        assert where[s] == (head.value + logical) % cap, (logical, s)
+    # argument checks travel through the error channel
+    assert lib.gcrl_ringbook_sim(0, 0, 0, None, 0, None, None, C.byref(head), C.byref(ln)) == -1
+    assert b"gcrl_ringbook_sim" in lib.gcrl_last_error()
+
+
+@needs_product
 def test_device_entry_points_fail_loudly_without_gpu(gcrl, lib):
     if lib.gcrl_device_count() > 0:
         pytest.skip("GPU present")
@@ -144,6 +201,7 @@ def test_device_entry_points_fail_loudly_without_gpu(gcrl, lib):
         gcrl.HERBuffer(100, 50, 1)
 
 
+@needs_product
 def test_bench_spawns_one_process_per_gpu_without_a_launcher():
     """`python bench.py --gpus N` as the driver runs it: N fresh rank processes with RANK / WORLD_SIZE / MASTER_*
     set, rank 0's line relayed, a failing rank turns into a non-zero exit (launch plumbing only: no GPU)."""

@@ -28,13 +28,15 @@ fn = lib.gcrl_debug_rc_stamps
 fn.restype = C.c_int
 assert fn(out) == 0
 st = np.array(list(out), dtype=np.int64).reshape(2, 32)
-names_k = ["start", "prologue", "tactor hidden", "tactor head+act", "tcritic hidden", "tcritic head+y", "critic hidden", "head,loss,head_bwd", "critic dX chain"]
-names_p = ["start", "prologue", "actor hidden", "actor head+act", "critic hidden", "critic head", "head_bwd", "critic dX chain", "da head", "actor head_bwd", "actor dX chain"]
+names_k = {0: "start", 1: "prologue", 2: "target actor hidden", 3: "its head + action", 4: "target critic hidden", 5: "its head + y", 6: "critic hidden",
+           7: "head, loss, head bwd", 8: "critic dX chain"}
+names_p = {0: "start", 1: "prologue", 2: "actor hidden", 3: "actor head + action", 4: "critic hidden", 6: "Q head + head bwd", 7: "critic dX chain",
+           9: "da head, tanh', actor head bwd", 10: "actor dX chain"}
 for role, names in ((0, names_k), (1, names_p)):
     t0 = st[role][0]
     print("role", "K" if role == 0 else "P")
     prev = t0
-    for i, n in enumerate(names):
+    for i in sorted(names):
         t = st[role][i]
-        print(f"  {n:22s} at {(t - t0) / 100:7.2f} us   (+{(t - prev) / 100:5.2f})")
+        print(f"  {names[i]:32s} at {(t - t0) / 100:7.2f} us   (+{(t - prev) / 100:5.2f})")
         prev = t
