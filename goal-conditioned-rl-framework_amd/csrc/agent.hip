@@ -120,6 +120,8 @@ struct gcrl_agent {
   float* pi_buf = nullptr;   // SAC row-chain path: pi(s) [B][Apad] (the layer-per-launch paths keep it in spa's action columns)
   float* act_pinned = nullptr;   // host staging of gcrl_agent_act_host
   char *oa_pinned = nullptr, *oa_dev = nullptr;   // staging of gcrl_agent_observe_act (raw rows, noise, actions)
+  // ... and of its inline form (rowchain.h RowActInline): float64 actions + one flag per workgroup, host-visible
+  char* act_fl_host = nullptr; char* act_fl_dev = nullptr; unsigned long long act_seq = 0;
   size_t oa_bytes = 0;
   // row-block DDPG path (rowchain.h): [in][out] weight copies of actor | target actor | critic 0 |
   // target critic 0, per-layer gradient buffers, TD targets
@@ -1459,6 +1461,7 @@ void gcrl_agent_destroy(gcrl_agent* a) {
   if (a->bn_sync_buf) (void)hipFree(a->bn_sync_buf);
   if (a->act_pinned) (void)hipHostFree(a->act_pinned);
   if (a->oa_pinned) (void)hipHostFree(a->oa_pinned);
+  if (a->act_fl_host) (void)hipHostFree(a->act_fl_host);
   if (a->oa_dev) (void)hipFree(a->oa_dev);
   for (int i = 0; i < gcrl_agent::kProfPairs; ++i) {
     if (a->prof_a[i]) (void)hipEventDestroy(a->prof_a[i]);
@@ -2036,6 +2039,50 @@ int gcrl_agent_observe_act(gcrl_agent* a, gcrl_normalizer* nz_obs, gcrl_normaliz
   // layout: doubles first (alignment): noise [B*A], out [B*A]; then floats: obs, dg, eps
   double* p_noise = (double*)a->oa_pinned; double* p_out = p_noise + d_cnt; float* p_f = (float*)(p_out + d_cnt);
   double* d_noise = (double*)a->oa_dev; double* d_out = d_noise + d_cnt; float* d_f = (float*)(d_out + d_cnt);
+  if (a->rowchain && !a->sac && n * a->S <= kActInlineFloats && n * A <= kActInlineNoise && !std::getenv("GCRL_ACT_STAGED")) {
+    // ONE launch and nothing else (round 4): the raw rows and the noise travel INSIDE the kernel arguments, the float64 actions come
+    // back through host-visible memory followed by a flag per workgroup, and the host waits for the flags — no staged copies, no
+    // stream synchronisation.  (Before: two copies up, the launch, a copy down, hipStreamSynchronize = 30 us per vector step.)
+    if (a->wt_dirty) TRY(rc_rebuild_wt(a, st));
+    constexpr size_t kFlagOff = 2048;
+    if (!a->act_fl_host) {
+      GCRL_HIP(hipHostMalloc((void**)&a->act_fl_host, 4096, hipHostMallocMapped));
+      std::memset(a->act_fl_host, 0, 4096);
+      GCRL_HIP(hipHostGetDevicePointer((void**)&a->act_fl_dev, a->act_fl_host, 0));
+    }
+    RowActInline ri;
+    RowActArgs& ra = ri.base;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.actor = make_rownet(a, a->actor, a->P_actor(), 0);
+    ra.ld_obs = a->S; ra.out = a->dact; ra.ld_out = a->Apad;
+    ra.n = n; ra.S = a->S; ra.A = A; ra.ldl = a->row_ldl;
+    ra.D = D;
+    gcrl::normalizer_view(nz_obs, &ra.nz_mean, &ra.nz_var, nullptr, &ra.nz_clip, &ra.nz_mode);
+    gcrl::normalizer_view(nz_dg, &ra.nzg_mean, &ra.nzg_var, nullptr, &ra.nzg_clip, &ra.nzg_mode);
+    ra.post = mode == 1 ? 1 : (mode == 0 ? 2 : 3);
+    for (int i = 0; i < n; ++i) {
+      std::memcpy(ri.obs_inl + (size_t)i * a->S, obs_host + (size_t)i * D, sizeof(float) * D);
+      std::memcpy(ri.obs_inl + (size_t)i * a->S + D, dg_host + (size_t)i * G, sizeof(float) * G);
+    }
+    ri.with_noise = (noise_host && mode == 1) ? 1 : 0;
+    if (ri.with_noise) std::memcpy(ri.noise_inl, noise_host, sizeof(double) * n * A);
+    ri.out_host = reinterpret_cast<double*>(a->act_fl_dev);
+    ri.flag_host = reinterpret_cast<unsigned long long*>(a->act_fl_dev + kFlagOff);
+    ri.seq = ++a->act_seq;
+    TRY(launch_rowchain_act_inline(st, ri));
+    const int nwg = (n + 3) / 4;
+    volatile unsigned long long* flags = reinterpret_cast<volatile unsigned long long*>(a->act_fl_host + kFlagOff);
+    bool seen = false;
+    for (long spin = 0; spin < 4000000 && !seen; ++spin) {      // (~ms: then the ordinary synchronisation says what happened)
+      seen = true;
+      for (int w = 0; w < nwg; ++w) seen = seen && flags[w] == ri.seq;
+      if (!seen) __builtin_ia32_pause();
+    }
+    if (!seen) GCRL_HIP(hipStreamSynchronize(st));
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    std::memcpy(out_host, a->act_fl_host, sizeof(double) * n * A);
+    return GCRL_OK;
+  }
   if (a->rowchain && !a->sac) {
     // ONE launch: raw [observation | goal] rows up, normalisation in the row-chain act kernel's prologue, select_action's
     // tanh / noise / clip in its epilogue

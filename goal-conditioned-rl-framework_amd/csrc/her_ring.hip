@@ -83,10 +83,10 @@ struct ProcArgs {
   int update, gupdate, n, env0, flush_len, D, S, A, G, SA4, S4, RG;
   int mode, gmode;   // norm_math.h bits: float32 statistics (loaded normalisers), float64 rows (the trainer's observation batches)
 };
-__global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
+__device__ inline void her_process_step_body(const ProcArgs& p, const float* raw, const float* pay) {
   __shared__ double s_mean[128], s_den[128], s_gmean[kMaxG], s_gden[kMaxG];
   const int n = p.n, D = p.D, G = p.G;
-  const float* obs = p.raw; const float* nobs = obs + (size_t)n * D;
+  const float* obs = raw; const float* nobs = obs + (size_t)n * D;
   const float* dg = nobs + (size_t)n * D; const float* ndg = dg + (size_t)n * G;
   int mode = p.mode, gmode = p.gmode;         // as of AFTER this launch's updates (float64 rows leave float64 statistics)
   if (p.update && (mode & gcrl::NORM_ROWS64)) mode &= ~gcrl::NORM_F32;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
   const int o_ns = p.SA4, o_r = p.SA4 + p.S4, RW = o_r + 2, W = RW + G;
   for (int e = threadIdx.x; e < n * W; e += 256) {
     const int i = e / W, c = e - i * W;
-    const float* pw = p.pay + (long long)i * kPayW;
+    const float* pw = pay + (long long)i * kPayW;
     const int t = __float_as_int(pw[0]);
     float v = 0.f;
     auto state_col = [&](const float* o, const float* g, int cc) -> float {
@@ -143,6 +143,12 @@ __global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) {
     p.stage[((long long)(p.env0 + i) * p.flush_len + t) * p.RG + c] = v;
   }
 }
+__global__ __launch_bounds__(256) void her_process_step_kernel(ProcArgs p) { her_process_step_body(p, p.raw, p.pay); }
+// the same with the step's rows and payload INSIDE the kernel arguments (round 4: a vector-env step of a few envs is < 4 KB — no
+// pinned slot, no staged copy, no event: the launch itself carries the data)
+constexpr int kProcInlineFloats = 896;
+struct ProcArgsInline { ProcArgs p; int raw_floats; float data[kProcInlineFloats]; };
+__global__ __launch_bounds__(256) void her_process_step_inline_kernel(ProcArgsInline q) { her_process_step_body(q.p, q.data, q.data + q.raw_floats); }
 
 // ---------------------------------------------------------------- relabel + flush
 struct FlushArgs {
@@ -1032,7 +1038,9 @@ int64_t gcrl_her_process_step_g(gcrl_her* h, gcrl_normalizer* nz_obs, int update
   const int D = obs_dim, G = h->G;
   // ONE upload: raw rows [obs(n*D) | next_obs(n*D) | dg(n*G) | next_dg(n*G)], then the per-env payload [t | r | d | a | ag]
   const size_t raw = (size_t)n * (2 * D + (nz_dg ? 4 : 2) * G), need = raw + (size_t)n * kPayW;
-  if (need > h->ps_floats) {
+  static_assert(sizeof(ProcArgsInline) <= 4096, "kernel arguments are limited to 4 KB");
+  const bool inl = need <= (size_t)kProcInlineFloats && !std::getenv("GCRL_PROC_STAGED");
+  if (!inl && need > h->ps_floats) {
     GCRL_HIP(hipDeviceSynchronize());
     if (h->ps_dev) GCRL_HIP(hipFree(h->ps_dev));
     const size_t want = std::max<size_t>(need, (size_t)h->cfg.nenvs * (2 * D + 4 * G + kPayW));
@@ -1043,10 +1051,14 @@ int64_t gcrl_her_process_step_g(gcrl_her* h, gcrl_normalizer* nz_obs, int update
     }
     h->ps_floats = want;
   }
-  const int slot = h->next_epi_slot;
-  h->next_epi_slot = (slot + 1) % gcrl_her::kSlots;
-  GCRL_HIP(hipEventSynchronize(h->epi_ev[slot]));
-  float* pin = h->ps_pinned[slot];
+  ProcArgsInline qi;
+  int slot = -1;
+  if (!inl) {
+    slot = h->next_epi_slot;
+    h->next_epi_slot = (slot + 1) % gcrl_her::kSlots;
+    GCRL_HIP(hipEventSynchronize(h->epi_ev[slot]));
+  }
+  float* pin = inl ? qi.data : h->ps_pinned[slot];
   std::memcpy(pin, obs_host, sizeof(float) * n * D);
   std::memcpy(pin + (size_t)n * D, next_obs_host, sizeof(float) * n * D);
   std::memcpy(pin + (size_t)2 * n * D, dg_host, sizeof(float) * n * G);
@@ -1068,10 +1080,13 @@ int64_t gcrl_her_process_step_g(gcrl_her* h, gcrl_normalizer* nz_obs, int update
   }
   GCRL_CHECK_ARG(!(nz_dg && h->cfg.reward_kind == GCRL_REWARD_HOST), "gcrl_her_process_step: a goal normaliser together with a host-callback "
                  "compute_reward is not supported by the fused entry (the callback would need the device-normalised goals): use the separate calls");
-  GCRL_HIP(hipMemcpyAsync(h->ps_dev, pin, need * sizeof(float), hipMemcpyHostToDevice, st));
-  GCRL_HIP(hipEventRecord(h->epi_ev[slot], st));
-  ProcArgs pa;
+  if (!inl) {
+    GCRL_HIP(hipMemcpyAsync(h->ps_dev, pin, need * sizeof(float), hipMemcpyHostToDevice, st));
+    GCRL_HIP(hipEventRecord(h->epi_ev[slot], st));
+  }
+  ProcArgs& pa = qi.p;
   std::memset(&pa, 0, sizeof(pa));
+  qi.raw_floats = (int)raw;
   pa.stage = h->stage; pa.raw = h->ps_dev; pa.pay = h->ps_dev + raw;
   const double *mean = nullptr, *var = nullptr;
   gcrl::normalizer_view(nz_obs, &mean, &var, &pa.count, &pa.clip, &pa.mode);
@@ -1085,7 +1100,8 @@ int64_t gcrl_her_process_step_g(gcrl_her* h, gcrl_normalizer* nz_obs, int update
   }
   pa.n = n; pa.env0 = env0; pa.flush_len = h->cfg.flush_len; pa.D = D; pa.S = h->S; pa.A = h->A; pa.G = G;
   pa.SA4 = h->SA4; pa.S4 = h->S4; pa.RG = h->RG;
-  hipLaunchKernelGGL(her_process_step_kernel, dim3(1), dim3(256), 0, st, pa);
+  if (inl) hipLaunchKernelGGL(her_process_step_inline_kernel, dim3(1), dim3(256), 0, st, qi);
+  else hipLaunchKernelGGL(her_process_step_kernel, dim3(1), dim3(256), 0, st, pa);
   GCRL_HIP(hipGetLastError());
   if (pa.update) gcrl::normalizer_updated(nz_obs);
   if (pa.gupdate) gcrl::normalizer_updated(nz_dg);

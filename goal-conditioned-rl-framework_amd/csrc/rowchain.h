@@ -309,6 +309,21 @@ struct RowActArgs {
   int post; const double* noise; double* out64;
 };
 int launch_rowchain_act(hipStream_t st, const RowActArgs& a);
+// The same with the rows (and the exploration noise) travelling INSIDE the kernel arguments and the float64 actions written
+// straight to host-visible (pinned, mapped) memory, followed by one 8-byte flag per workgroup (round 4: one vector-env step of the
+// acting side was two staged copies up, a launch, a copy down and a stream synchronisation — 30 us for a 3 us kernel).  The host
+// waits for the flags instead of synchronising the stream.  n * S <= kActInlineFloats, n * A <= kActInlineNoise.
+constexpr int kActInlineFloats = 640, kActInlineNoise = 96;
+struct RowActInline {
+  RowActArgs base;                       // obs / noise / out64 are ignored: the inline arrays and out_host are used
+  double* out_host;                      // device pointer of the pinned block: [n][A] doubles
+  unsigned long long* flag_host;         // ... and of its flags: flag_host[workgroup] = seq once that workgroup's rows are out
+  unsigned long long seq;
+  int with_noise;
+  float obs_inl[kActInlineFloats];
+  double noise_inl[kActInlineNoise];
+};
+int launch_rowchain_act_inline(hipStream_t st, const RowActInline& a);
 
 // rows per workgroup = 4*rg, rg in {1, 2, 4}
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg);

@@ -598,8 +598,12 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
   }
 }
 
-__global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// `row_at(i)`: element i of the launch's input rows ([n][ld_obs] flattened); `noise_at(t)`: exploration noise of action element t —
+// functors, so that the inline form reads the kernel-argument segment by plain indexed loads (a POINTER into a by-value argument
+// struct made hipcc copy the whole struct into every thread's scratch: 36 us for this kernel, round 4).  SYS: the float64 actions
+// go out as system-scope (write-through) stores, for a host that polls a flag behind them.
+template <bool SYS, typename RowAt, typename NoiseAt>
+__device__ inline void rowchain_act_body(const RowActArgs& a, RowAt row_at, NoiseAt noise_at, bool has_noise, double* out64, float* lds) {
   constexpr int R = 4;
   const int ldl = a.ldl, H = a.actor.H, A = a.A, tid = threadIdx.x;
   float* X0 = lds;
@@ -611,18 +615,33 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a)
   float* hb = hw + A * H;
   const long long row0 = (long long)blockIdx.x * R;
   const int rv = min(R, a.n - (int)row0);
-  const float* rows = a.obs + row0 * a.ld_obs;
   const float* src_h = a.actor.P + a.actor.w[a.actor.L];
-  Staged<2> s_x;
+  const int jp = a.actor.jpad0;
+  constexpr int NX = 2;                        // staged elements per thread: rows of up to 128 floats; wider rows take the loop below
+  float s_x[NX];
   Staged<8> s_h;
-  rows_load<1>(s_x, rows, a.ld_obs, a.S, a.actor.jpad0, rv);
+#pragma unroll
+  for (int u = 0; u < NX; ++u) {
+    const int i = tid + u * kRowThreads, r = i / jp, c = i - r * jp;
+    s_x[u] = (i < R * jp && r < rv && c < a.S) ? row_at((row0 + r) * a.ld_obs + c) : 0.f;
+  }
   seg_load(s_h, src_h, A * H);
   const float v_hb = tid < A ? a.actor.P[a.actor.b[a.actor.L] + tid] : 0.f;
+  // An acting launch is a few workgroups long after the last optimiser launch: every layer's weights come from HBM, one
+  // dependent ~2 us round trip per layer pass.  Touch one float of every 128-byte line of the LATER layers' [in][out] copies now
+  // (fire and forget: the values are only consumed by a never-taken branch at the end), so that their passes find them in L2.
+  float pf = 0.f;
+  {
+    const float* wl = a.actor.Wt + a.actor.wt[a.actor.L > 1 ? 1 : 0];
+    const long long nfl = a.actor.L > 1 ? (long long)(a.actor.L - 1) * H * H : 0;
+    if (nfl <= 64 * 1024)
+      for (long long i = (long long)tid * 32; i < nfl; i += (long long)kRowThreads * 32) pf += wl[i];
+  }
   // fused acting entry: the rows are raw; normalise this thread's elements on their way into LDS
   if (a.nz_mean || a.nzg_mean) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = tid + u * kRowThreads, jp = a.actor.jpad0, r = i / jp, c = i - r * jp;
+    for (int u = 0; u < NX; ++u) {
+      const int i = tid + u * kRowThreads, r = i / jp, c = i - r * jp;
       if (i < R * jp && r < rv && c < a.S) {
         const bool ob = c < a.D;
         const double* m = ob ? a.nz_mean : a.nzg_mean;
@@ -631,12 +650,20 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a)
           const double* v = ob ? a.nz_var : a.nzg_var;
           const double clip = ob ? a.nz_clip : a.nzg_clip;
           const int md = ob ? a.nz_mode : a.nzg_mode;
-          s_x.v[u] = norm_apply(s_x.v[u], m[j], norm_den(v[j], (md & NORM_F32) != 0), clip, norm_apply_f32(md));
+          s_x[u] = norm_apply(s_x[u], m[j], norm_den(v[j], (md & NORM_F32) != 0), clip, norm_apply_f32(md));
         }
       }
     }
   }
-  rows_store<1>(s_x, X0, ldl, rows, a.ld_obs, a.S, a.actor.jpad0, rv);
+#pragma unroll
+  for (int u = 0; u < NX; ++u) {
+    const int i = tid + u * kRowThreads, r = i / jp, c = i - r * jp;
+    if (i < R * jp) X0[r * ldl + c] = s_x[u];
+  }
+  for (int i = tid + NX * kRowThreads; i < R * jp; i += kRowThreads) {   // (rows wider than 128 floats: never with fused normalisation)
+    const int r = i / jp, c = i - r * jp;
+    X0[r * ldl + c] = (r < rv && c < a.S) ? row_at((row0 + r) * a.ld_obs + c) : 0.f;
+  }
   seg_store(s_h, hw, src_h, A * H);
   if (tid < A) hb[tid] = v_hb;
   __syncthreads();
@@ -653,13 +680,30 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a)
         double v = (double)y;
         if (a.post != 3) {
           v = (double)tanhf(y);
-          if (a.post == 1 && a.noise) v += a.noise[t];
+          if (a.post == 1 && has_noise) v += noise_at(t);
           v = fmin(fmax(v, -1.0), 1.0);
         }
-        a.out64[t] = v;
+        if (SYS) __hip_atomic_store(out64 + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else out64[t] = v;
       }
     }
   }
+  if (pf == 1.2345678e-30f && a.post) out64[0] = (double)pf;   // (keeps the prefetch loads alive; never true in practice, harmless if it were)
+}
+
+__global__ __launch_bounds__(kRowThreads) void rowchain_act_kernel(RowActArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  rowchain_act_body<false>(a, [&](long long i) { return a.obs[i]; }, [&](long long t) { return a.noise[t]; }, a.noise != nullptr, a.out64, lds);
+}
+
+// rows and noise inside the kernel arguments, actions and a completion flag per workgroup to host-visible memory (rowchain.h)
+__global__ __launch_bounds__(kRowThreads) void rowchain_act_inline_kernel(RowActInline a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  rowchain_act_body<true>(a.base, [&](long long i) { return a.obs_inl[i]; }, [&](long long t) { return a.noise_inl[t]; }, a.with_noise != 0, a.out_host, lds);
+  // this workgroup's rows are out as write-through stores: drain them, then raise its flag (system scope: the host polls it)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(a.flag_host + blockIdx.x, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Wt[wt[l] + k*H + o] = P[w[l] + o*in_l + k]; layer 0 rows in..jpad0-1 are zero
@@ -751,6 +795,23 @@ int launch_rowchain_act(hipStream_t st, const RowActArgs& a) {
     raised = lds;
   }
   hipLaunchKernelGGL(rowchain_act_kernel, dim3((a.n + 3) / 4), dim3(kRowThreads), lds, st, a);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_rowchain_act_inline(hipStream_t st, const RowActInline& a) {
+  const RowActArgs& b = a.base;
+  GCRL_CHECK_ARG(b.actor.H % 4 == 0 && b.ldl % 4 == 0 && b.A <= 16 && b.n >= 1 && b.post != 0 && a.out_host && a.flag_host, "rowchain act (inline): unsupported shape");
+  GCRL_CHECK_ARG(b.n * b.ld_obs <= kActInlineFloats && b.n * b.A <= kActInlineNoise, "rowchain act (inline): %d rows do not fit the kernel arguments", b.n);
+  GCRL_CHECK_ARG(!(b.nz_mean || b.nzg_mean) || 4 * b.actor.jpad0 <= 2 * kRowThreads, "rowchain act: fused normalisation supports state_dim <= 128");
+  const size_t lds = (size_t)(3 * 4 * b.ldl + 2 * 4 * 4 * kRowChunk + 4 * 16 + b.A * b.actor.H + 32) * sizeof(float);
+  GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain act: %zu bytes of LDS needed", lds);
+  static thread_local size_t raised = 0;
+  if (lds > 64 * 1024 && lds > raised) {
+    GCRL_HIP(hipFuncSetAttribute((const void*)rowchain_act_inline_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = lds;
+  }
+  hipLaunchKernelGGL(rowchain_act_inline_kernel, dim3((b.n + 3) / 4), dim3(kRowThreads), lds, st, a);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

@@ -355,15 +355,26 @@ class _EngineAgent:
             return None
         return (on.handle if obs_normalize else None, gn.handle if g_normalize else None)
 
-    def _rows_dtypes(self, obs_rows, goal_rows, obs_normalize: bool, g_normalize: bool):
+    def _rows_dtypes(self, obs_dtype, goal_dtype, obs_normalize: bool, g_normalize: bool):
         """numpy's type rules decide the reference normaliser's arithmetic: tell the device normalisers which dtype the rows
         have on the caller's side (the trainer's observation batches are float64 arrays, its goal batches float32)."""
         if obs_normalize:
-            self.buffer.obs_normalizer.rows_dtype(np.asarray(obs_rows).dtype)
+            self.buffer.obs_normalizer.rows_dtype(obs_dtype)
         if g_normalize:
-            self.buffer.dg_normalizer.rows_dtype(np.asarray(goal_rows).dtype)
+            self.buffer.dg_normalizer.rows_dtype(goal_dtype)
 
     _ACT_MODE_EXPLORE, _ACT_MODE_EVAL = 1, 0      # DDPG; TD3 overrides eval (raw network output)
+
+    def _staging(self, tag: str, key: tuple, shapes):
+        """Persistent host staging arrays of the fused acting entries (fixed addresses: their ctypes pointers are built once — a
+        fresh numpy array per argument and per call cost more host time than the native call itself, tools/acting_breakdown.py).
+        `shapes()` -> {name: (shape, dtype)} is only called when `key` (the dims) changed."""
+        cache = self.__dict__.setdefault("_stage_cache", {})
+        st = cache.get(tag)
+        if st is None or st[0] != key:
+            arrs = {k: np.empty(shp, dt) for k, (shp, dt) in shapes().items()}
+            st = cache[tag] = (key, arrs, {k: C.c_void_p(v.ctypes.data) for k, v in arrs.items()})
+        return st[1], st[2]
 
     def observe_act(self, observation, desired_goal, eval_action: bool = False, obs_normalize: bool = True,
                     g_normalize: bool = False):
@@ -373,21 +384,27 @@ class _EngineAgent:
         for the Gaussian noise, torch's for SAC / TQC eps).  Falls back to the two separate calls when the normalisers
         are host objects."""
         nz = self._device_normalizers(obs_normalize, g_normalize)
-        obs = np.ascontiguousarray(observation, np.float32)
-        dg = np.ascontiguousarray(desired_goal, np.float32)
-        if nz is None or obs.shape[0] > int(self.config.batch_size):
+        obs_in = observation if isinstance(observation, np.ndarray) else np.asarray(observation)
+        dg_in = desired_goal if isinstance(desired_goal, np.ndarray) else np.asarray(desired_goal)
+        n = obs_in.shape[0]
+        if nz is None or n > int(self.config.batch_size) or obs_in.ndim != 2 or dg_in.ndim != 2:
+            obs, dg = np.ascontiguousarray(obs_in, np.float32), np.ascontiguousarray(dg_in, np.float32)
             return self.select_action(self.normalize_state_batch(obs, dg, obs_normalize, g_normalize), eval_action)
         self.set_eval()
-        self._rows_dtypes(observation, desired_goal, obs_normalize, g_normalize)
-        n = obs.shape[0]
+        self._rows_dtypes(obs_in.dtype, dg_in.dtype, obs_normalize, g_normalize)
         noise, mode = self._act_noise(n, eval_action)
         if mode is None:
             return noise                              # DDPG's epsilon-random action: no network involved
-        out = np.empty((n, self.ac_dim), np.float64)
-        _ffi.check(lib.gcrl_agent_observe_act(self._h, nz[0], nz[1], obs.ctypes.data, obs.shape[1], dg.ctypes.data, dg.shape[1], n,
-                                              noise.ctypes.data if noise is not None else None, mode, out.ctypes.data,
-                                              _ffi.stream_handle()))
-        return out
+        D, G, A = obs_in.shape[1], dg_in.shape[1], self.ac_dim
+        buf, ptr = self._staging("act", (n, D, G, A), lambda: dict(obs=((n, D), np.float32), dg=((n, G), np.float32),
+                                                                    noise=((n, A), np.float64), out=((n, A), np.float64)))
+        np.copyto(buf["obs"], obs_in, casting="unsafe")
+        np.copyto(buf["dg"], dg_in, casting="unsafe")
+        if noise is not None:
+            np.copyto(buf["noise"], noise)
+        _ffi.check(lib.gcrl_agent_observe_act(self._h, nz[0], nz[1], ptr["obs"], D, ptr["dg"], G, n,
+                                              ptr["noise"] if noise is not None else None, mode, ptr["out"], _ffi.stream_handle()))
+        return buf["out"].copy()
 
     def _act_noise(self, n, eval_action):
         """-> (noise or None, mode); DDPG overrides for the epsilon branch."""
@@ -415,23 +432,34 @@ class _EngineAgent:
             s = torch.from_numpy(self.normalize_state_batch(state["observation"], state["desired_goal"], obs_normalize, g_normalize)).float().cuda()
             ns = torch.from_numpy(self.normalize_state_batch(next_obs_raw["observation"], next_obs_raw["desired_goal"], obs_normalize, g_normalize)).float().cuda()
             return buf.push_batch(s, actions, ns, rewards, dones, self.normalize_goal(next_obs_raw["achieved_goal"], g_normalize))
-        f32 = lambda x: np.ascontiguousarray(x, np.float32)
-        self._rows_dtypes(np.result_type(np.asarray(state["observation"]).dtype, np.asarray(next_obs_raw["observation"]).dtype).type(0),
-                          np.result_type(*[np.asarray(g).dtype for g in (state["desired_goal"], next_obs_raw["desired_goal"],
-                                                                         state["achieved_goal"], next_obs_raw["achieved_goal"])]).type(0),
-                          obs_normalize, g_normalize)
-        obs, nobs = f32(state["observation"]), f32(next_obs_raw["observation"])
-        dg, ndg, nag = f32(state["desired_goal"]), f32(next_obs_raw["desired_goal"]), f32(next_obs_raw["achieved_goal"])
-        act, rew = f32(actions), f32(rewards).reshape(-1)
-        dn = np.ascontiguousarray(np.asarray(dones).astype(np.uint8)).reshape(-1)
-        n = obs.shape[0]
-        buf._ensure(obs.shape[1] + dg.shape[1], act.shape[1], nag.shape[1])
+        as_arr = lambda x: x if isinstance(x, np.ndarray) else np.asarray(x)
+        obs_i, nobs_i = as_arr(state["observation"]), as_arr(next_obs_raw["observation"])
+        dg_i, ndg_i, nag_i = as_arr(state["desired_goal"]), as_arr(next_obs_raw["desired_goal"]), as_arr(next_obs_raw["achieved_goal"])
+        ag_i = as_arr(state["achieved_goal"]) if g_normalize else None
+        act_i = as_arr(actions)
+        # np.concatenate's result type, as the reference's update_normalizers forms it (src/agent.py:343-350)
+        odt = obs_i.dtype if obs_i.dtype == nobs_i.dtype else np.result_type(obs_i.dtype, nobs_i.dtype)
+        gdt = dg_i.dtype
+        if g_normalize and not (dg_i.dtype == ndg_i.dtype == ag_i.dtype == nag_i.dtype):
+            gdt = np.result_type(dg_i.dtype, ndg_i.dtype, ag_i.dtype, nag_i.dtype)
+        self._rows_dtypes(odt, gdt, obs_normalize, g_normalize)
+        n, D, G, A = obs_i.shape[0], obs_i.shape[1], dg_i.shape[1], act_i.shape[1]
+        buf._ensure(D + G, A, nag_i.shape[1])
+        f32 = np.float32
+        b, p = self._staging("proc", (n, D, G, A), lambda: dict(obs=((n, D), f32), nobs=((n, D), f32), dg=((n, G), f32), ndg=((n, G), f32),
+                                                                ag=((n, G), f32), nag=((n, G), f32), act=((n, A), f32), rew=((n,), f32),
+                                                                dn=((n,), np.uint8)))
+        cp = np.copyto
+        cp(b["obs"], obs_i, casting="unsafe"); cp(b["nobs"], nobs_i, casting="unsafe"); cp(b["dg"], dg_i, casting="unsafe")
+        cp(b["ndg"], ndg_i, casting="unsafe"); cp(b["nag"], nag_i, casting="unsafe"); cp(b["act"], act_i, casting="unsafe")
+        cp(b["rew"], rewards if (isinstance(rewards, np.ndarray) and rewards.ndim == 1) else np.reshape(rewards, -1), casting="unsafe")
+        cp(b["dn"], dones if (isinstance(dones, np.ndarray) and dones.ndim == 1) else np.reshape(dones, -1), casting="unsafe")
+        if g_normalize:
+            np.copyto(b["ag"], ag_i, casting="unsafe")
         buf.rng.pull()
-        ag0 = f32(state["achieved_goal"]) if g_normalize else None
-        rows = lib.gcrl_her_process_step_g(buf.handle, nz[0], 1 if obs_normalize else 0, nz[1], 1 if g_normalize else 0, obs.ctypes.data,
-                                           nobs.ctypes.data, obs.shape[1], dg.ctypes.data, ndg.ctypes.data,
-                                           ag0.ctypes.data if ag0 is not None else None, nag.ctypes.data, act.ctypes.data, rew.ctypes.data,
-                                           dn.ctypes.data, 0, n, _ffi.stream_handle())
+        rows = lib.gcrl_her_process_step_g(buf.handle, nz[0], 1 if obs_normalize else 0, nz[1], 1 if g_normalize else 0, p["obs"],
+                                           p["nobs"], D, p["dg"], p["ndg"], p["ag"] if g_normalize else None, p["nag"], p["act"], p["rew"],
+                                           p["dn"], 0, n, _ffi.stream_handle())
         buf._check_rows(rows)
         buf.rng.push_back()
         return int(rows)

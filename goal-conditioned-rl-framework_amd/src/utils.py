@@ -198,6 +198,9 @@ class DeviceRunningNormalizer:
         float64 for the trainer's observation batches, float32 for goals and for tensors cast by the caller.  `update` and
         `normalize` call this with their argument's own dtype; the agents' fused entries with the dtype of the arrays they
         were given."""
+        if dtype is getattr(self, "_rows_dt", None):       # (the same dtype object as last time: nothing to do)
+            return
+        self._rows_dt = dtype
         on = 1 if np.dtype(dtype) == np.float64 else 0
         if on != getattr(self, "_rows64", 0):
             self._ffi.check(self._ffi.lib.gcrl_normalizer_set_rows_float64(self._h, on))

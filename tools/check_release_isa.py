@@ -80,6 +80,34 @@ def check_kernel(body):
     return n_store, n_atomic, problems
 
 
+# Second lint: no kernel may copy its arguments (or spill) into per-thread scratch.  Handing a device function a POINTER into a
+# by-value argument struct made hipcc copy the whole 3.7 KB struct to every thread's private memory — a 3 us kernel took 36 us
+# (rowchain_act_inline_kernel, round 4).  `.amdhsa_private_segment_fixed_size` says it all.
+SCRATCH_UNITS = ["her_ring.hip", "ops.hip", "ops_sac.hip", "bn_slab.hip", "rowchain.hip", "agent.hip", "normalizer.hip", "abi_misc.hip",
+                 "gemm_mfma.hip", "xchg_ipc.hip"]
+SCRATCH_ALLOWED = {   # kernel-name substring -> bytes tolerated
+    "rowchain_split_kernelILi4E": 1024, "rowchain_ddpg_kernelILi4E": 1024,   # 16 rows per workgroup: register spills; never selected by default (GCRL_ROW_RG=4)
+    "gemm_tiled_kernel": 16,                                                   # three spilled dwords outside the k-loop
+}
+
+
+def scratch_report(asm_text, unit):
+    bad, lines = 0, []
+    kernel = None
+    for line in asm_text.splitlines():
+        m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", line)
+        if m:
+            kernel = m.group(1)
+        m = re.match(r"\s*\.amdhsa_private_segment_fixed_size\s+(\d+)", line)
+        if m and kernel and int(m.group(1)) > 0:
+            n = int(m.group(1))
+            allowed = max([v for k, v in SCRATCH_ALLOWED.items() if k in kernel] + [0])
+            ok = n <= allowed
+            lines.append(f"{unit}: {kernel}: {n} bytes of scratch per thread: {'tolerated' if ok else 'FAIL'}")
+            bad += 0 if ok else 1
+    return bad, lines
+
+
 def main():
     keep = None
     if "--keep" in sys.argv:
@@ -116,9 +144,18 @@ def main():
                 if n == 0:
                     report.append(f"{unit}: no instantiation of {w} with a publication found (pattern changed?)")
                     bad += 1
+        sbad = 0
+        for unit in SCRATCH_UNITS:
+            asm = os.path.join(out_dir, unit + ".s")
+            if not os.path.exists(asm):
+                subprocess.run([HIPCC] + FLAGS + ["-x", "hip", os.path.join(CSRC, unit), "-o", asm], check=True, cwd=CSRC)
+            b, lines = scratch_report(open(asm).read(), unit)
+            sbad += b
+            report += lines
     print("\n".join(report))
     print("release check:", "PASS" if bad == 0 else f"FAIL ({bad})")
-    return 0 if bad == 0 else 1
+    print("scratch check:", "PASS" if sbad == 0 else f"FAIL ({sbad})")
+    return 0 if bad == 0 and sbad == 0 else 1
 
 
 if __name__ == "__main__":
