@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCRL_HIP_LIB") or os.path.join(_HERE, "libgcrl_hip.so")
 
 STREAM_LEGACY = 1  # GCRL_STREAM_LEGACY
+XCHG_HANDLE_BYTES = 256  # GCRL_XCHG_HANDLE_BYTES
 
 
 class GcrlError(RuntimeError):
@@ -166,6 +167,8 @@ PROTOTYPES = {
     "gcrl_xchg_world": (C.c_int, [_vp]),
     "gcrl_xchg_allreduce": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "gcrl_xchg_reset": (C.c_int, [_vp]),
+    "gcrl_xchg_selftest": (C.c_int, [_vp, _vp]),
+    "gcrl_xchg_read": (C.c_int, [_vp, _i64, _i64, _vp]),
     "gcrl_xchg_get_partials": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
     "gcrl_agent_xchg_create": (_vp, [_vp, C.c_int, C.c_int]),
     "gcrl_agent_set_exchange": (C.c_int, [_vp, _vp]),

@@ -484,6 +484,9 @@ int xchg_launch(gcrl_agent* a, hipStream_t st, int which) {
   const int seg0 = (which & 1) ? 0 : C, nseg = ((which & 1) ? C : 0) + ((which & 2) ? na : 0);
   return gcrl_xchg_allreduce(a->xchg, seg0, nseg, (void*)st);
 }
+// where the optimiser reads a gradient vector: the arena, or — once an exchange over more than one rank has run — the same
+// offset of the exchange's fine-grained receive buffer (xchg_ipc.hip: peers never write into the arena)
+const float* xg(const gcrl_agent* a, const float* p) { return a->xchg ? gcrl_xchg_result(a->xchg) + (p - a->grads) : p; }
 int xchg_parts(gcrl_agent* a, bool critic, const float** p, int* n) { return gcrl_xchg_seg_parts(a->xchg, critic ? 0 : a->C, p, n); }
 
 int adam_common(gcrl_agent* a, AdamArgs& ad);
@@ -644,7 +647,8 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
   const int kind = a->cfg.kind, B = a->B, C = a->C, S = a->S, A = a->A, L = a->L, H = a->H;
   // critic optimiser: global-norm clip + Adam(W) (+ Polyak into the target critics)
   const bool fused = (variant & V_FUSED_NORM) != 0, xc = (variant & V_XCHG) != 0 && !a->xchg_sep_norm;
-  if (!fused && !xc) TRY(launch_sumsq(st, a->G_critic(0), a->critic.numel, a->critic_stride, C, a->norm_partial));
+  const bool xv = (variant & V_XCHG) != 0;   // the gradients the optimiser consumes are the exchanged ones
+  if (!fused && !xc) TRY(launch_sumsq(st, xv ? xg(a, a->G_critic(0)) : a->G_critic(0), a->critic.numel, a->critic_stride, C, a->norm_partial));
   {
     AdamArgs ad;
     std::memset(&ad, 0, sizeof(ad));
@@ -652,7 +656,7 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
     if (fused) { ad.partial = a->parts_c; ad.nparts = a->nparts_c; ad.part_stride = a->nparts_c; }
     if (xc) { TRY(xchg_parts(a, true, &ad.partial, &ad.nparts)); ad.part_stride = ad.nparts; }
     ad.which = 1;
-    ad.p = a->P_critic(0); ad.g = a->G_critic(0);
+    ad.p = a->P_critic(0); ad.g = xv ? xg(a, a->G_critic(0)) : a->G_critic(0);
     ad.m = a->adam_m + a->goff_critic; ad.v = a->adam_v + a->goff_critic;
     ad.target = a->P_tcritic(0);
     ad.n = a->critic.numel; ad.net_stride = a->critic_stride; ad.nets = C;
@@ -864,14 +868,17 @@ int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   if (!(variant & V_ACTOR)) return GCRL_OK;
   const int kind = a->cfg.kind;
   const bool fused = (variant & V_FUSED_NORM) != 0, xc = (variant & V_XCHG) != 0 && !a->xchg_sep_norm;   // (BatchNorm gradients: their launches leave partials too)
-  if (!fused && !xc) TRY(launch_sumsq(st, a->G_actor(), a->actor.numel, 0, 1, a->norm_partial));
+  const bool xv = (variant & V_XCHG) != 0;
+  const float* g_actor = xv ? xg(a, a->G_actor()) : a->G_actor();
+  const float* g_alpha = xv ? xg(a, a->grads + a->goff_alpha) : a->grads + a->goff_alpha;
+  if (!fused && !xc) TRY(launch_sumsq(st, g_actor, a->actor.numel, 0, 1, a->norm_partial));
   AdamArgs ad;
   std::memset(&ad, 0, sizeof(ad));
   adam_common(a, ad);
   if (fused) { ad.partial = a->parts_a; ad.nparts = a->nparts_a; ad.part_stride = a->nparts_a; }
   if (xc) { TRY(xchg_parts(a, false, &ad.partial, &ad.nparts)); ad.part_stride = ad.nparts; }
   ad.which = 0;
-  ad.p = a->P_actor(); ad.g = a->G_actor();
+  ad.p = a->P_actor(); ad.g = g_actor;
   ad.m = a->adam_m + a->goff_actor; ad.v = a->adam_v + a->goff_actor;
   ad.n = a->actor.numel; ad.net_stride = 0; ad.nets = 1;
   for (int c = 0; c < kMaxCritics; ++c) ad.clip[c] = (float)a->cfg.grad_clip;
@@ -883,7 +890,7 @@ int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   if (a->rowchain && !a->sac) rc_adam_extras(a, ad, false);
   const bool alpha_rider = a->sac && a->rowchain;   // the log-alpha step rides on the actor's optimiser launch
   if (alpha_rider) {
-    ad.alpha = AlphaStep{a->P_logalpha(), a->adam_m + a->goff_alpha, a->adam_v + a->goff_alpha, a->alpha_dev, a->grads + a->goff_alpha,
+    ad.alpha = AlphaStep{a->P_logalpha(), a->adam_m + a->goff_alpha, a->adam_v + a->goff_alpha, a->alpha_dev, g_alpha,
                          (float)kBeta2, (float)(1.0 - kBeta1), (float)(1.0 - kBeta2), (float)kAdamEps, a->metrics_dev};
   }
   if (variant & V_ADV) { ad.cur = &a->ctrl()->cur_b; ad.advance = a->ctrl(); }   // the step's last launch (row-block paths only)
@@ -893,7 +900,7 @@ int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
     std::memset(&al, 0, sizeof(al));
     al.cur = a->cur(); al.logp = a->logp; al.B = a->B;
     al.log_alpha = a->P_logalpha(); al.m = a->adam_m + a->goff_alpha; al.v = a->adam_v + a->goff_alpha;
-    al.alpha = a->alpha_dev; al.grad_out = a->grads + a->goff_alpha;
+    al.alpha = a->alpha_dev; al.grad_out = const_cast<float*>(g_alpha);   // (phase 1 of the launch only reads it)
     al.beta2 = (float)kBeta2; al.w1 = (float)(1.0 - kBeta1); al.w2 = (float)(1.0 - kBeta2); al.eps = (float)kAdamEps;
     al.metrics = a->metrics_dev; al.phase = 1;
     TRY(launch_alpha_update(st, al));

@@ -13,8 +13,12 @@
 //   * the block is cut into 1024-float chunks, net by net; chunk c belongs to rank c mod W.  The owner reads the chunk from
 //     EVERY rank's arena (W loads in flight per lane), adds them in RANK ORDER — the same sum whoever computes it, so the
 //     replicas stay bitwise identical — forms the chunk's sum of squares, and writes chunk and partial back into every rank's
-//     arena / partial array IN PLACE (only the owner ever touches a chunk anywhere, so in-place is race-free).  The optimiser
-//     launch that follows reads the reduced gradients and ~N/1024 partials per net: no separate norm launch.
+//     RECEIVE BUFFER / partial array.  The receive buffer (and the control block) is FINE-GRAINED device memory
+//     (hipExtMallocWithFlags): a peer's stores into coarse-grained memory could hide behind stale lines of the local L2, which a
+//     kernel boundary at agent scope does not invalidate for local memory — the arena itself is only ever READ remotely, after the
+//     kernel boundary that follows the owner's backward pass.  The optimiser launch that follows reads the reduced gradients
+//     from the receive buffer and ~N/1024 partials per net: no separate norm launch.  (A world of one: nothing moves, the
+//     optimiser reads the arena, the kernel only forms the partials.)
 //   * ordering by two monotonic 64-bit counters per (rank, source) pair, each on its own 128-byte line of the TARGET's control
 //     block: ready[src] ("src's gradients of exchange e are complete": stream order on src, announced by its first workgroup),
 //     done[src] ("src has delivered every chunk it owns for exchange e").  A rank reads peers only after their `ready`, and the
@@ -56,7 +60,8 @@ constexpr long long kDoneWord = (long long)(kXchgMaxWorld + 1) * kFlagStride;
 constexpr long long kFlagWords = kDoneWord + (long long)kXchgMaxWorld * kMaxGrid;
 
 struct XArgs {
-  float* arena[kXchgMaxWorld];                 // every rank's gradient arena (own: the local pointer)
+  float* arena[kXchgMaxWorld];                 // every rank's gradient arena (own: the local pointer): read only
+  float* recv[kXchgMaxWorld];                  // every rank's receive buffer (fine-grained): the reduced chunks land here
   unsigned long long* ctl[kXchgMaxWorld];      // every rank's control block
   float* parts[kXchgMaxWorld];                 // every rank's partial array
   long long seg_off[kMaxSeg]; int seg_n[kMaxSeg]; int seg_c0[kMaxSeg + 1];   // segments: offset / floats / first chunk (seg_c0[nseg] = all chunks)
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void xchg_two_shot_kernel(XArgs a) {
     const v4u r = {__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3])};
 #pragma unroll
     for (int q = 0; q < kXchgMaxWorld; ++q)
-      __builtin_amdgcn_raw_buffer_store_b128(r, rsrc_n(a.arena[q < W ? q : 0] + off, (q < W && !solo) ? n : 0), boff, 0, kSys);   // (past the chunk: dropped)
+      __builtin_amdgcn_raw_buffer_store_b128(r, rsrc_n(a.recv[q < W ? q : 0] + off, (q < W && !solo) ? n : 0), boff, 0, kSys);   // (past the chunk: dropped)
     // the chunk's sum of squares, in a fixed order: lane's four (zeros past the chunk), wave tree, four waves
     float ss = 0.f;
 #pragma unroll
@@ -183,7 +188,9 @@ using namespace gcrl;
 struct gcrl_xchg {
   int rank = 0, world = 1, device = 0;
   float* arena = nullptr; long long arena_floats = 0;
-  char* ctl = nullptr; size_t ctl_bytes = 0;          // control block + partial array (one hipMalloc, IPC-exported)
+  char* ctl = nullptr; size_t ctl_bytes = 0;          // control block + partial array (fine-grained, IPC-exported)
+  float* recv = nullptr;                              // receive buffer [arena_floats] (fine-grained, IPC-exported; world > 1 only)
+  void* peer_recv[kXchgMaxWorld] = {};
   size_t parts_off = 0;
   std::vector<long long> seg_off, seg_n;
   std::vector<int> seg_c0;                            // first chunk of segment s; seg_c0[nseg] = total
@@ -217,11 +224,21 @@ gcrl_xchg* gcrl_xchg_create(float* arena_dev, int64_t arena_floats, const int64_
   const size_t flags = (size_t)kFlagWords * sizeof(unsigned long long);
   x->parts_off = flags;
   x->ctl_bytes = flags + (((size_t)nch * sizeof(float) + 255) / 256) * 256;
-  bool ok = hipSetDevice(device) == hipSuccess && hipMalloc((void**)&x->ctl, x->ctl_bytes) == hipSuccess &&
-            hipMemset(x->ctl, 0, x->ctl_bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  // fine-grained device memory for everything a PEER writes and this GPU reads (coherent without cache maintenance)
+  auto fine = [](void** p, size_t bytes) {
+    if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return hipMalloc(p, bytes) == hipSuccess;
+  };
+  bool ok = hipSetDevice(device) == hipSuccess && fine((void**)&x->ctl, x->ctl_bytes) &&
+            hipMemset(x->ctl, 0, x->ctl_bytes) == hipSuccess &&
+            (world == 1 || (fine((void**)&x->recv, (size_t)arena_floats * sizeof(float)) &&
+                            hipMemset(x->recv, 0, (size_t)arena_floats * sizeof(float)) == hipSuccess)) &&
+            hipDeviceSynchronize() == hipSuccess;
   if (!ok) { fail(GCRL_ERR_HIP, "gcrl_xchg_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); gcrl_xchg_destroy(x); return nullptr; }
   x->peer_arena[rank] = x->arena;
   x->peer_ctl[rank] = x->ctl;
+  x->peer_recv[rank] = x->recv;
   x->connected = world == 1;
   return x;
 }
@@ -233,17 +250,21 @@ void gcrl_xchg_destroy(gcrl_xchg* x) {
     if (q == x->rank) continue;
     if (x->peer_arena[q]) (void)hipIpcCloseMemHandle(x->peer_arena[q]);
     if (x->peer_ctl[q]) (void)hipIpcCloseMemHandle(x->peer_ctl[q]);
+    if (x->peer_recv[q]) (void)hipIpcCloseMemHandle(x->peer_recv[q]);
   }
   if (x->ctl) (void)hipFree(x->ctl);
+  if (x->recv) (void)hipFree(x->recv);
   delete x;
 }
 
 int gcrl_xchg_handles(gcrl_xchg* x, uint8_t* out, int64_t n) {
   GCRL_CHECK_ARG(x && out && n == GCRL_XCHG_HANDLE_BYTES, "gcrl_xchg_handles: the buffer must hold GCRL_XCHG_HANDLE_BYTES bytes");
-  static_assert(2 * sizeof(hipIpcMemHandle_t) + 2 * sizeof(int64_t) <= GCRL_XCHG_HANDLE_BYTES, "handle record");
-  hipIpcMemHandle_t h[2];
+  static_assert(3 * sizeof(hipIpcMemHandle_t) + 2 * sizeof(int64_t) <= GCRL_XCHG_HANDLE_BYTES, "handle record");
+  hipIpcMemHandle_t h[3];
+  std::memset(h, 0, sizeof(h));
   GCRL_HIP(hipIpcGetMemHandle(&h[0], x->arena));
   GCRL_HIP(hipIpcGetMemHandle(&h[1], x->ctl));
+  if (x->recv) GCRL_HIP(hipIpcGetMemHandle(&h[2], x->recv));
   std::memset(out, 0, (size_t)n);
   std::memcpy(out, h, sizeof(h));
   const int64_t meta[2] = {(int64_t)x->arena_floats, (int64_t)x->nchunks()};
@@ -257,7 +278,7 @@ int gcrl_xchg_connect(gcrl_xchg* x, const uint8_t* all, int64_t n) {
   for (int q = 0; q < x->world; ++q) {
     if (q == x->rank) continue;
     const uint8_t* rec = all + (size_t)q * GCRL_XCHG_HANDLE_BYTES;
-    hipIpcMemHandle_t h[2];
+    hipIpcMemHandle_t h[3];
     int64_t meta[2];
     std::memcpy(h, rec, sizeof(h));
     std::memcpy(meta, rec + sizeof(h), sizeof(meta));
@@ -266,6 +287,7 @@ int gcrl_xchg_connect(gcrl_xchg* x, const uint8_t* all, int64_t n) {
                   q, (long long)meta[0], (long long)meta[1], (long long)x->arena_floats, (size_t)x->nchunks());
     GCRL_HIP(hipIpcOpenMemHandle(&x->peer_arena[q], h[0], hipIpcMemLazyEnablePeerAccess));
     GCRL_HIP(hipIpcOpenMemHandle(&x->peer_ctl[q], h[1], hipIpcMemLazyEnablePeerAccess));
+    GCRL_HIP(hipIpcOpenMemHandle(&x->peer_recv[q], h[2], hipIpcMemLazyEnablePeerAccess));
   }
   x->connected = true;
   return GCRL_OK;
@@ -273,12 +295,23 @@ int gcrl_xchg_connect(gcrl_xchg* x, const uint8_t* all, int64_t n) {
 
 int gcrl_xchg_world(const gcrl_xchg* x) { return x ? x->world : 0; }
 
+// where the reduced gradients are after an exchange: the receive buffer (same layout as the arena) — or the arena itself in a
+// world of one
+const float* gcrl_xchg_result(const gcrl_xchg* x) { return x ? (x->recv ? x->recv : x->arena) : nullptr; }
+
 void gcrl_xchg_set_status(gcrl_xchg* x, unsigned int* status_dev) { if (x) x->status = status_dev; }
 
 int gcrl_xchg_seg_parts(const gcrl_xchg* x, int seg, const float** parts_dev, int* nparts) {
   GCRL_CHECK_ARG(x && seg >= 0 && seg + 1 < (int)x->seg_c0.size() && parts_dev && nparts, "gcrl_xchg_seg_parts: bad segment");
   *parts_dev = reinterpret_cast<const float*>(x->ctl + x->parts_off) + x->seg_c0[seg];
   *nparts = x->seg_c0[seg + 1] - x->seg_c0[seg];
+  return GCRL_OK;
+}
+
+int gcrl_xchg_read(gcrl_xchg* x, int64_t first, int64_t n, float* out_host) {
+  GCRL_CHECK_ARG(x && out_host && first >= 0 && n >= 0 && first + n <= x->arena_floats, "gcrl_xchg_read: range outside the arena");
+  GCRL_HIP(hipDeviceSynchronize());
+  GCRL_HIP(hipMemcpy(out_host, gcrl_xchg_result(x) + first, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   return GCRL_OK;
 }
 
@@ -298,6 +331,7 @@ int gcrl_xchg_allreduce(gcrl_xchg* x, int seg0, int nseg, void* stream) {
   std::memset(&a, 0, sizeof(a));
   for (int q = 0; q < x->world; ++q) {
     a.arena[q] = (float*)x->peer_arena[q];
+    a.recv[q] = (float*)x->peer_recv[q];
     a.ctl[q] = (unsigned long long*)x->peer_ctl[q];
     a.parts[q] = reinterpret_cast<float*>((char*)x->peer_ctl[q] + x->parts_off);
   }
@@ -312,6 +346,47 @@ int gcrl_xchg_allreduce(gcrl_xchg* x, int seg0, int nseg, void* stream) {
   if (x->world == 1) hipLaunchKernelGGL(xchg_two_shot_kernel<true>, dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(xchg_two_shot_kernel<false>, dim3(grid), dim3(256), 0, st, a);
   GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+// Collective self-test (every rank calls it once after gcrl_xchg_connect, before the arena holds anything of value): rank r
+// writes r + 1 + i / 4096 into the first min(2048, n) floats of segment 0, the ranks exchange that segment, and every rank must
+// read back W (W + 1) / 2 + W * (i / 4096).  Catches what the handle exchange cannot see — a peer mapping that faults, peers on
+// different exchange layouts, a rank that never arrives (bounded wait) — so that the host side can fall back to another exchange
+// BEFORE training starts.  Zeroes what it wrote.
+int gcrl_xchg_selftest(gcrl_xchg* x, void* stream) {
+  GCRL_CHECK_ARG(x, "gcrl_xchg_selftest: null handle");
+  if (!x->connected) return fail(GCRL_ERR_STATE, "gcrl_xchg_selftest: not connected");
+  hipStream_t st = stream == GCRL_STREAM_LEGACY ? (hipStream_t) nullptr : (hipStream_t)stream;
+  const int n = (int)std::min<long long>(2048, x->seg_n[0]);
+  std::vector<float> v((size_t)n), got((size_t)n);
+  for (int i = 0; i < n; ++i) v[i] = (float)(x->rank + 1) + (float)i / 4096.0f;
+  float* dst = x->arena + x->seg_off[0];
+  std::vector<float> saved((size_t)n);
+  GCRL_HIP(hipStreamSynchronize(st));
+  GCRL_HIP(hipMemcpy(saved.data(), dst, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  GCRL_HIP(hipMemcpy(dst, v.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  unsigned int* status_keep = x->status;
+  static unsigned int* st_host = nullptr; static unsigned int* st_dev = nullptr;
+  if (!st_host) {
+    GCRL_HIP(hipHostMalloc((void**)&st_host, 64, hipHostMallocMapped));
+    GCRL_HIP(hipHostGetDevicePointer((void**)&st_dev, st_host, 0));
+  }
+  *st_host = 0;
+  x->status = st_dev;
+  const int rc = gcrl_xchg_allreduce(x, 0, 1, stream);
+  x->status = status_keep;
+  if (rc) return rc;
+  GCRL_HIP(hipStreamSynchronize(st));
+  GCRL_HIP(hipMemcpy(got.data(), gcrl_xchg_result(x) + x->seg_off[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  GCRL_HIP(hipMemcpy(dst, saved.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  if (*st_host) return fail(GCRL_ERR_STATE, "gcrl_xchg_selftest: a wait for a peer timed out (status 0x%x)", *st_host);
+  const int W = x->world;
+  for (int i = 0; i < n; ++i) {
+    float want = 0.f;
+    for (int r = 0; r < W; ++r) want += (float)(r + 1) + (float)i / 4096.0f;   // rank order, as the kernel adds
+    if (got[i] != want) return fail(GCRL_ERR_STATE, "gcrl_xchg_selftest: element %d is %.9g, expected %.9g (world %d)", i, (double)got[i], (double)want, W);
+  }
   return GCRL_OK;
 }
 

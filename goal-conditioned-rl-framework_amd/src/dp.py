@@ -132,28 +132,39 @@ class DataParallelUpdater:
         dist.all_gather_object(where, (socket.gethostname(), dev_id), group=group)
         one_host = len({h for h, _ in where}) == 1
         shared_gpu = len(set(where)) < self.world
-        if exchange == "auto":
+        auto = exchange == "auto"
+        if auto:
             exchange = "ipc" if (one_host and self.world <= 8) else ("rccl" if nccl else "python")
         if exchange == "ipc":
             why = ""
             x = lib.gcrl_agent_xchg_create(agent._h, self.rank, self.world) if (one_host and self.world <= 8) else None
-            rec = (C.c_uint8 * 160)()
-            ok = bool(x) and lib.gcrl_xchg_handles(x, rec, 160) == 0
+            rec = (C.c_uint8 * _ffi.XCHG_HANDLE_BYTES)()
+            ok = bool(x) and lib.gcrl_xchg_handles(x, rec, _ffi.XCHG_HANDLE_BYTES) == 0
             if not ok:
                 why = _ffi.last_error() or "the ranks are not on one host / more than 8 ranks"
             recs = [None] * self.world
             dist.all_gather_object(recs, bytes(rec) if ok else b"", group=group)
-            ok = all(len(r) == 160 for r in recs)
+            ok = all(len(r) == _ffi.XCHG_HANDLE_BYTES for r in recs)
             if ok:
-                ok = lib.gcrl_xchg_connect(x, b"".join(recs), 160 * self.world) == 0
+                ok = lib.gcrl_xchg_connect(x, b"".join(recs), _ffi.XCHG_HANDLE_BYTES * self.world) == 0
                 why = why or (_ffi.last_error() if not ok else "")
-            if all_ok(ok):
+            if all_ok(ok):      # a known pattern through the real kernel, before anything depends on it (collective)
+                dist.barrier(group=group)
+                ok = lib.gcrl_xchg_selftest(x, _ffi.stream_handle()) == 0
+                why = why or (_ffi.last_error() if not ok else "")
+                if not all_ok(ok):
+                    ok = False
+                    if x:
+                        lib.gcrl_xchg_reset(x)
+            else:
+                ok = False
+            if ok:
                 self._xchg = x
                 _ffi.check(lib.gcrl_agent_set_exchange(agent._h, x))
             else:
                 if x:
                     lib.gcrl_xchg_destroy(x)
-                if require_native:
+                if require_native and not (auto and nccl):      # (auto over RCCL: the other in-engine exchange is tried next)
                     raise _ffi.GcrlError("gcrl_amd.dp: the in-engine IPC exchange could not be set up on every rank (this rank: " + (why or "ok") +
                                          "); refusing a fallback (require_native)")
                 import warnings

@@ -376,7 +376,8 @@ int gcrl_ringbook_sim(int64_t capacity, int64_t head0, int64_t len0, const int64
  * ONE node (world <= 8); every rank's gradient arena is mapped by every peer through HIP IPC handles and one kernel per exchange
  * performs a two-shot all-reduce peer to peer: the owner of a 1024-float chunk (chunk c: rank c mod world) adds the chunk of
  * every rank in RANK ORDER (bitwise identical replicas), forms its sum of squares, and writes both back to every rank in
- * place — the optimiser launch reads the reduced gradients and the clip norm's partials, no separate norm launch, and the
+ * place (into a fine-grained receive buffer of the arena's layout: gcrl_xchg_read) — the optimiser launch reads the reduced
+ * gradients and the clip norm's partials, no separate norm launch, and the
  * exchange is a plain kernel node: hipGraph replay, control-advance riders and multi-step graphs stay on.
  *   gcrl_xchg_create    over an arena (a hipMalloc base pointer, 16-byte aligned) cut into `nseg` segments (offset / length in
  *                       floats: the nets); every rank must pass the same layout
@@ -392,7 +393,7 @@ int gcrl_ringbook_sim(int64_t capacity, int64_t head0, int64_t len0, const int64
  *                       by 1 / world inside the optimiser launches.  Reference semantics kept: the actor loss goes through the
  *                       STEPPED critic (src/agent.py:1389-1401, :548-639).  NULL detaches.
  * xGMI time is unmeasured (1-GPU boxes); world-size-1 cost: profiles/r04_dp_overhead_world1.json. */
-#define GCRL_XCHG_HANDLE_BYTES 160
+#define GCRL_XCHG_HANDLE_BYTES 256
 typedef struct gcrl_xchg gcrl_xchg;
 gcrl_xchg* gcrl_xchg_create(float* arena_dev, int64_t arena_floats, const int64_t* seg_off, const int64_t* seg_n, int nseg, int rank,
                             int world, int device);
@@ -404,6 +405,12 @@ int gcrl_xchg_allreduce(gcrl_xchg* x, int seg0, int nseg, void* stream);
 /* sums of squares of segment `seg`'s reduced 1024-float chunks as the last exchange left them (what the optimiser launch sums
  * for the clip norm); returns how many (synchronises the device; tests) */
 int gcrl_xchg_get_partials(gcrl_xchg* x, int seg, float* out_host, int n);
+/* the reduced values of [first, first + n) arena floats as the last exchange left them, to the host (synchronises; tests) */
+int gcrl_xchg_read(gcrl_xchg* x, int64_t first, int64_t n, float* out_host);
+/* collective self-test after gcrl_xchg_connect (every rank calls it): exchanges a known pattern through segment 0 and checks
+ * the sum; GCRL_ERR_STATE when a peer's mapping, layout or arrival is wrong — the host side then falls back to another exchange
+ * before training starts (src/dp.py).  Leaves the arena as it found it. */
+int gcrl_xchg_selftest(gcrl_xchg* x, void* stream);
 int gcrl_xchg_reset(gcrl_xchg* x);   /* counters back to zero after a reported failure (call on every rank, ranks synchronised around it) */
 gcrl_xchg* gcrl_agent_xchg_create(gcrl_agent* a, int rank, int world);
 int gcrl_agent_set_exchange(gcrl_agent* a, gcrl_xchg* x);

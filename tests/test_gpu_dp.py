@@ -390,18 +390,26 @@ def _worker_xchg_raw(rank, world, port, out_dir):
     off = (C.c_int64 * len(_XSEGS))(*[o for o, _ in _XSEGS])
     num = (C.c_int64 * len(_XSEGS))(*[n for _, n in _XSEGS])
     x = ffi.check_ptr(lib.gcrl_xchg_create(buf.data_ptr(), buf.numel(), off, num, len(_XSEGS), rank, world, 0), "gcrl_xchg_create")
-    rec = (C.c_uint8 * 160)()
-    ffi.check(lib.gcrl_xchg_handles(x, rec, 160))
+    HB = ffi.XCHG_HANDLE_BYTES
+    rec = (C.c_uint8 * HB)()
+    ffi.check(lib.gcrl_xchg_handles(x, rec, HB))
     recs = [None] * world
     dist.all_gather_object(recs, bytes(rec))
-    ffi.check(lib.gcrl_xchg_connect(x, b"".join(recs), 160 * world))
+    ffi.check(lib.gcrl_xchg_connect(x, b"".join(recs), HB * world))
     dist.barrier()
     st = ffi.stream_handle()
     # exchange 1: segments 0..2; exchange 2: segments 3..4 (a second launch on the same counters); then both again inside a hipGraph
     ffi.check(lib.gcrl_xchg_allreduce(x, 0, 3, st))
     ffi.check(lib.gcrl_xchg_allreduce(x, 3, 2, st))
     torch.cuda.synchronize()
-    first = buf.cpu().numpy().copy()
+
+    def result():       # the reduced values (the fine-grained receive buffer; in a world of one the arena itself)
+        out = np.empty(_XARENA, np.float32)
+        ffi.check(lib.gcrl_xchg_read(x, 0, _XARENA, out.ctypes.data))
+        return out
+
+    first = result()
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), arenas[rank].view(np.uint32))      # the arena is only ever READ by the exchange
     parts = []
     for sgi in range(len(_XSEGS)):
         pb = np.zeros(8, np.float32)
@@ -422,7 +430,7 @@ def _worker_xchg_raw(rank, world, port, out_dir):
             g.replay()
             torch.cuda.synchronize()
             dist.barrier()
-    np.savez(os.path.join(out_dir, f"x{rank}.npz"), first=first, replay=buf.cpu().numpy(), parts=np.concatenate(parts))
+    np.savez(os.path.join(out_dir, f"x{rank}.npz"), first=first, replay=result(), parts=np.concatenate(parts))
     dist.barrier()
     lib.gcrl_xchg_destroy(x)
     dist.destroy_process_group()
@@ -431,19 +439,17 @@ def _worker_xchg_raw(rank, world, port, out_dir):
 @pytest.mark.parametrize("world", [1, 2])
 def test_exchange_kernel_sums_in_rank_order_on_every_rank(gcrl, tmp_path, world):
     """gcrl_xchg_* over a raw arena: every rank ends with the rank-order sum of the segments' floats (ragged segment tails, a
-    one-float segment, bytes outside the segments untouched), two exchanges back to back on the same counters, and three
+    one-float segment) in its receive buffer, its arena untouched, two exchanges back to back on the same counters, and three
     replays of the exchange captured in a hipGraph (the exchange number is device state)."""
     mp.spawn(_worker_xchg_raw, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     arenas, want = _xchg_expected(world)
     for r in range(world):
         got = np.load(tmp_path / f"x{r}.npz")
-        exp = want.copy()
         mask = np.zeros(_XARENA, bool)
         for off, n in _XSEGS:
             mask[off:off + n] = True
-        exp[~mask] = arenas[r][~mask]                      # outside the segments: this rank's own bytes
-        assert np.array_equal(got["first"].view(np.uint32), exp.view(np.uint32)), r
-        assert np.array_equal(got["replay"].view(np.uint32), exp.view(np.uint32)), r
+        for key in ("first", "replay"):                    # inside the segments: the rank-order sum, on every rank
+            assert np.array_equal(got[key][mask].view(np.uint32), want[mask].view(np.uint32)), (r, key)
         # the clip norm's partials: one per 1024-float chunk of every segment, of the REDUCED values, the same on every rank
         wantp = []
         for off, n in _XSEGS:
