@@ -1298,12 +1298,15 @@ int build(gcrl_agent* a) {
       while (S < 8 && phase_tiles * (S * 2) <= 1280 && B / (16 * S * 2) >= 8) S *= 2;
       return S;
     };
-    const bool on = B >= 1024 && B % 32 == 0 && !std::getenv("GCRL_NO_DW_SPLIT");
+    // experiment knob: the split LDS-tiled dW form at any batch size.  Round 4, headline (B = 256), same box: 57.8 us/step with the
+    // 16x16 k-split form, 66.5 (S = 2) / 65.8 (S = 4) with the split tiled form, 74.1 with the unsplit one (GCRL_DW_TILED): stays off
+    const bool anyb = std::getenv("GCRL_DW_SPLIT_ANYB") != nullptr;
+    const bool on = (B >= 1024 || anyb) && B % 32 == 0 && !std::getenv("GCRL_NO_DW_SPLIT");
     // rc_add_dw (DDPG / TD3 on the row-block path: every dW problem of a phase in one launch) at batch >= 2048: TD3 cfg 3
     // 173.8 -> 168.7 us/step (the launch 31.2 -> 27.0 us by rocprofv3 at S = 8, 25.5 at S = 16; element-wise operands — the
     // head's M = 1, the first layer's 27 columns — go through the pipelined k-loop too, in the plain loop they set the launch's
     // length at one memory round trip per k-step).  Not at batch 1024 (DDPG cfg 2: 61.8 -> 67.8 us/step, 8 k-steps per split).
-    const bool chain_dw = a->rowchain && (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3) && B >= 2048;
+    const bool chain_dw = a->rowchain && (c.kind == GCRL_AGENT_DDPG || c.kind == GCRL_AGENT_TD3) && (B >= 2048 || anyb);
     long long tc = 0, ta = 0, big_c = 0;
     for (const Lin& ln : a->critic.lin) { tc += tiles_of(ln); if (ln.out >= 64 && ln.in >= 64) big_c += tiles_of(ln); }
     for (const Lin& ln : a->actor.lin) ta += tiles_of(ln);
