@@ -152,6 +152,7 @@ struct gcrl_agent {
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
   int n_cus = 0;              // compute units of the device (residency checks of the launches whose workgroups meet)
   bool rc_merge = false;      // ... forward and backward part in ONE launch each (part 3; GCRL_NO_RC_MERGE=1: two launches)
+  bool rc_merge_k = false;    // TD3 (split_k): the critic phase's two launches as one, producers / consumers form (meet.h)
   float* rc_bar = nullptr;    // meeting counters of the row blocks [2][nblk][32 words]
   long long rc_bar_words = 0;
   // host-visible status word of the launches whose workgroups wait for each other (meet.h): a timed-out wait sets a bit, the
@@ -1272,6 +1273,14 @@ int build(gcrl_agent* a) {
     // TD3 once the batch fills the chip (cfg 3: 183.5 -> 178.4 us/step; below that the fused launch is the shorter chain)
     a->split_k = a->rowchain && c.kind == GCRL_AGENT_TD3 && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) >= 256 &&
                  !std::getenv("GCRL_NO_SPLIT_TD3");
+    // ... and its two launches (forward | backward) as ONE: the online-critic workgroups go on to their backward chains once the
+    // target roles of their rows have reported in (producers / consumers: no residency requirement, meet.h)
+    a->rc_merge_k = a->split_k && !meet_device_shared() && !std::getenv("GCRL_NO_RC_MERGE");
+    if (a->rc_merge_k && !a->rc_bar_words) {
+      const long long nblk = (B + 4 * a->row_rg - 1) / (4 * a->row_rg);
+      a->rc_bar_words = 2 * nblk * 32;
+      wants.push_back({&a->rc_bar, a->rc_bar_words});
+    }
     a->head_batches = 3;   // (TD3 at batch 2048: the host draws 38 x 2048 indices in ~390 us, more than two 170 us steps)
     if (const char* e = std::getenv("GCRL_HEAD_BATCHES")) a->head_batches = std::max(1, std::min(8, std::atoi(e)));   // experiment knob
     a->dw_batch_off = std::getenv("GCRL_NO_DW_BATCH") != nullptr;
@@ -1872,7 +1881,8 @@ int gcrl_agent_set_meetings(gcrl_agent* a, int on) {
   a->bn_rsplit = (want && a->bn_slab && a->B > 128 && !std::getenv("GCRL_NO_BN_RSPLIT") && bn_slab_row_split(a->B, a->H, 2) > 1) ? 4 : 1;
   a->rc_merge = want && a->rc_bar && a->split_roles && !std::getenv("GCRL_NO_RC_MERGE") && !std::getenv("GCRL_SPLIT_RG") &&
                 rowchain_merge_ok(a->row_rg, a->row_ldl, c.ac_dim, a->H, a->C, a->B);
-  return (a->bn_rsplit > 1 ? 1 : 0) | (a->rc_merge ? 2 : 0);
+  a->rc_merge_k = want && a->rc_bar && a->split_k && !std::getenv("GCRL_NO_RC_MERGE");
+  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k) ? 2 : 0);
 }
 
 int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
@@ -1883,6 +1893,11 @@ int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
   // kept off the chip would cause
   const unsigned long long one = 7;
   float* words = a->rc_merge ? a->rc_bar : (a->bn_rsplit > 1 ? a->bn_bar : nullptr);
+  if (a->rc_merge_k) {   // producers / consumers: a consumer's own launch count far ahead of its producers' counter
+    const unsigned long long far = 1ull << 40;
+    GCRL_HIP(hipMemcpy(a->rc_bar + 4, &far, sizeof(far), hipMemcpyHostToDevice));    // (64-bit word 2 of row block 0's line: critic 0's consumer)
+    return GCRL_OK;
+  }
   GCRL_CHECK_ARG(words, "gcrl_agent_debug_meet_fault: this agent's launches contain no waits (meetings off or not applicable)");
   GCRL_HIP(hipMemcpy(words, &one, sizeof(one), hipMemcpyHostToDevice));
   return GCRL_OK;

@@ -53,6 +53,38 @@ __device__ inline bool meet(unsigned long long* ctr, unsigned int arrivals, bool
   return *s_flag != 0;
 }
 
+// Producers / consumers (round 4, TD3's critic phase at batch 2048: more workgroups than the chip holds at once).  PRODUCER
+// workgroups arrive and never wait; CONSUMER workgroups wait for the `producers` arrivals of THIS launch without arriving
+// themselves — each consumer counts its own launches in a private word (`my_round`; only it ever writes it), so the counter stays
+// a multiple of `producers` between launches.  No consumer waits for another consumer, and the launcher gives every producer a
+// LOWER workgroup index than any consumer: every XCD dispatches its workgroups in index order, so a consumer's producers were
+// dispatched before it on whatever XCD they run and — never waiting — complete.  Deadlock-free without all workgroups being
+// resident at once (the bounded wait and the status word stay all the same).
+__device__ inline void meet_produce(unsigned long long* ctr) {
+  drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline bool meet_consume(const unsigned long long* ctr, unsigned long long* my_round, unsigned int producers, unsigned int* s_flag,
+                                    unsigned int* status, unsigned int err_bit) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long r = __hip_atomic_load(my_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (r + 1ull) * producers;
+    unsigned int ok = 1;
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < kMeetSpinMax) __builtin_amdgcn_s_sleep(4);
+    if (spins >= kMeetSpinMax) {
+      ok = 0;
+      if (status) __hip_atomic_fetch_or(status, err_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(my_round, r + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 // Process-wide switch: GCRL_SHARED_GPU=1 in the environment, or gcrl_set_shared_device(1) — the device is shared with other
 // processes / streams that hold CUs (two ranks on one GPU in the tests, a collective library's kernels), so no launch may

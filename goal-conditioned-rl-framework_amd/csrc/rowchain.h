@@ -272,6 +272,10 @@ struct RowChainArgs {
   // head of each 128-byte line, meet.h), zero-initialised; `status`: host-visible word that takes MEET_ERR_ROWCHAIN on a timed-out wait
   unsigned int* bar;
   unsigned int* status;
+  // phase 0 of part 3 as producers / consumers (meet.h): the target roles only arrive, the online-critic roles only wait for
+  // them (word 4 + 2 * critic of the row block's line: that consumer's own launch count) — admissible WITHOUT all workgroups
+  // being resident at once (TD3 at batch 2048: 1 024 workgroups of 8 rows)
+  int producers_first;
 };
 
 // Twin-critic phases as role-parallel launches (SAC; TD3 at small batches).  In the fused kernel a workgroup

@@ -478,7 +478,10 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
     rows_head<RG>(h, ldl, H, hw_tc, H, hb + 16, 1, EPI_NONE, sm);
     __syncthreads();
     if (tid < rv) st_agent(a.qt + (long long)k * B + row0 + tid, sm[tid * 16]);
-    if (merged) rc_meet(meet, 2 * C, false, &s_flag, a.status);        // (the target roles only report in)
+    if (merged) {                                                    // (the target roles only report in)
+      if (a.producers_first) meet_produce(reinterpret_cast<unsigned long long*>(meet));
+      else rc_meet(meet, 2 * C, false, &s_flag, a.status);
+    }
     return;
   }
   int k2 = role;                                 // the critic whose backward part runs in this workgroup
@@ -495,7 +498,10 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
     __syncthreads();
     if (tid < rv) a.q[(long long)k * B + row0 + tid] = sm[tid * 16];
     if (!merged) return;
-    met = rc_meet(meet, 2 * C, true, &s_flag, a.status);               // both target critics' outputs of these rows are out
+    // both target critics' outputs of these rows are out
+    if (a.producers_first)
+      met = meet_consume(reinterpret_cast<unsigned long long*>(meet), reinterpret_cast<unsigned long long*>(meet) + 2 + k, (unsigned)C, &s_flag, a.status, MEET_ERR_ROWCHAIN);
+    else met = rc_meet(meet, 2 * C, true, &s_flag, a.status);
     k2 = k;
   }
   if (phase == 0) {
@@ -768,7 +774,8 @@ int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int pha
   const int roles = (phase == 0 && part != 2) ? 2 * a.C : a.C;
   // part 3: every workgroup of the launch must be resident at once (rowchain_merge_ok: the kernel's occupancy at this LDS size
   // on a device the process has to itself)
-  GCRL_CHECK_ARG(part != 3 || rowchain_merge_ok(rg, a.ldl, a.A, a.critic[0].H, a.C, a.B), "rowchain split: %d workgroups of %zu bytes of LDS cannot all be resident (or the device is shared)", roles * nblk, lds);
+  GCRL_CHECK_ARG(part != 3 || (phase == 0 && a.producers_first && !meet_device_shared()) || rowchain_merge_ok(rg, a.ldl, a.A, a.critic[0].H, a.C, a.B),
+                 "rowchain split: %d workgroups of %zu bytes of LDS cannot all be resident (or the device is shared)", roles * nblk, lds);
   auto go = [&](auto kern) -> int {
     static thread_local size_t raised = 0;
     if (lds > 64 * 1024 && lds > raised) {
