@@ -275,6 +275,8 @@ def timed_region(agent, dp, w, steps, warmup, step0=1):
             (agent if dp is None else dp).update_many(s0 + done, m)
             done += m
 
+    if dp is not None:
+        dist.barrier()          # the ranks finish filling their rings seconds apart: start the first exchange together
     run(step0, warmup)
     extra = 0
     for m in sorted({min(gstep, steps), steps % gstep} - {0}):

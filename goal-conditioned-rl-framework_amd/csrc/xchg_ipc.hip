@@ -47,6 +47,9 @@ namespace {
 constexpr int kSys = 17;                       // sc0 | sc1 of the raw buffer builtins: system scope (gfx94x / gfx950)
 constexpr long long kFlagStride = 16;          // 64-bit words per flag: one 128-byte line each
 constexpr int kMaxGrid = 1024;                 // workgroups of one rank per exchange
+// Bound of a wait for a PEER (polls of a few us each: about a minute).  Far longer than a wait inside one launch (kMeetSpinMax,
+// ~1 s): ranks reach their first exchange seconds apart (ring fill, graph capture), and a collective library would wait for ever.
+constexpr int kPeerSpinMax = 1 << 24;
 constexpr int kMaxSeg = 12;                    // segments of one handle (8 critics + actor + log_alpha + spare)
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(256) void xchg_two_shot_kernel(XArgs a) {
   __syncthreads();
   if (!solo && tid < W && tid != me) {                               // every peer's gradients are complete
     int spins = 0;
-    while (ld_sys(ctl + (long long)tid * kFlagStride) < e && ++spins < kMeetSpinMax) __builtin_amdgcn_s_sleep(2);
-    if (spins >= kMeetSpinMax) { s_ok = 0u; if (a.status) __hip_atomic_fetch_or(a.status, (unsigned)MEET_ERR_XCHG_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    while (ld_sys(ctl + (long long)tid * kFlagStride) < e && ++spins < kPeerSpinMax) __builtin_amdgcn_s_sleep(8);
+    if (spins >= kPeerSpinMax) { s_ok = 0u; if (a.status) __hip_atomic_fetch_or(a.status, (unsigned)MEET_ERR_XCHG_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
   if (!solo) __syncthreads();
   const bool ok = s_ok != 0u;
@@ -171,8 +174,8 @@ __global__ __launch_bounds__(256) void xchg_two_shot_kernel(XArgs a) {
     const int gq = grid_of(nch, q, W);
     for (int wg = tid; wg < gq; wg += 256) {
       int spins = 0;
-      while (ld_sys(ctl + kDoneWord + (long long)q * kMaxGrid + wg) < e && ++spins < kMeetSpinMax) __builtin_amdgcn_s_sleep(2);
-      all = all && spins < kMeetSpinMax;
+      while (ld_sys(ctl + kDoneWord + (long long)q * kMaxGrid + wg) < e && ++spins < kPeerSpinMax) __builtin_amdgcn_s_sleep(8);
+      all = all && spins < kPeerSpinMax;
     }
   }
   if (!all && a.status) __hip_atomic_fetch_or(a.status, (unsigned)MEET_ERR_XCHG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
