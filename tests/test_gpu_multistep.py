@@ -21,6 +21,16 @@ from oracle.agent_oracle import OracleAgent, make_config
 from oracle.device_rng_oracle import hash_normal
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _oracle_on_one_thread():
+    """The oracle is eager torch on the CPU: its fp32 sums depend on the thread count (the reference itself moves 9.8e-4 between
+    thread counts over a few Adam steps), and a trajectory test must not depend on which test ran before it."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
 S, A = 10, 3
 
 
