@@ -132,6 +132,24 @@ def test_two_ranks_equal_one_big_batch(gcrl, tmp_path, kind, exchange):
         assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
 
 
+def test_three_ranks_through_the_ipc_exchange_equal_one_big_batch(gcrl, tmp_path):
+    """A world that is not a power of two: chunk c of the gradient block belongs to rank c mod 3, the owner adds (g0 + g1) + g2.
+    Three processes on this box's one GPU; DDPG, three injected-batch steps; replicas bitwise identical, parameters those of ONE
+    agent fed the 96-row batch (fp32 summation order apart)."""
+    world, kind = 3, "DDPG"
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), False, "ipc"), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    for k in ("actor", "critic", "target"):
+        assert np.array_equal(r[0][k], r[1][k]) and np.array_equal(r[0][k], r[2][k]), k
+    big = gcrl.DDPG(S, A, _cfg(kind, world * B), None, nenvs=1, gradient_step=4, rng="engine", seed=1)
+    _init_params(big)
+    for step, full in enumerate(_global_batches(world, 3), start=1):
+        big.update(step, batch=tuple(torch.from_numpy(x).cuda() for x in full))
+    for k, v in (("actor", big.actor), ("critic", big.critics[0]), ("target", big.target_critics[0])):
+        err = np.abs(r[0][k].astype(np.float64) - v.flat())
+        assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
+
+
 def _worker_cycle(rank, world, port, out_dir, kind="DDPG", exchange="auto", tag="cycle", sep_norm=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if sep_norm:
@@ -436,7 +454,7 @@ def _worker_xchg_raw(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("world", [1, 2, 3])
 def test_exchange_kernel_sums_in_rank_order_on_every_rank(gcrl, tmp_path, world):
     """gcrl_xchg_* over a raw arena: every rank ends with the rank-order sum of the segments' floats (ragged segment tails, a
     one-float segment) in its receive buffer, its arena untouched, two exchanges back to back on the same counters, and three
