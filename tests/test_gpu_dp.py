@@ -476,3 +476,32 @@ def test_exchange_kernel_sums_in_rank_order_on_every_rank(gcrl, tmp_path, world)
                 wantp.append(float(np.dot(v, v)))
         assert got["parts"].shape == (len(wantp),) and np.allclose(got["parts"], wantp, rtol=2e-6, atol=0), r
         assert np.array_equal(got["parts"], np.load(tmp_path / "x0.npz")["parts"])
+
+
+def test_sync_bn_reconfiguration_grows_its_buffer(gcrl):
+    """gcrl_agent_dp_sync_bn called again with a LARGER world must not keep the buffer sized for the first call (the
+    statistics kernels then wrote 2 * world * blocks * H floats past its end).  World 2 -> 4 -> 1 on one agent, a step after
+    each, with an exchange function that is the identity (the other ranks' slots stay zero: the statistics are those of a batch
+    padded with zero-weight blocks — only finiteness and the absence of a fault are asserted here)."""
+    import ctypes as C
+    from gcrl_amd import _ffi
+    ag = gcrl.SACAgent(S, A, _cfg("SAC", B), None, nenvs=1, gradient_step=2, rng="engine", seed=3)
+    _init_params(ag)
+    calls = []
+
+    def ident(ptr, n, stream, user):
+        calls.append(int(n))
+        return 0
+    cb = _ffi.EXCHANGE_FN(ident)
+    full, eps = _global_batches(1, 3), _global_eps(1, 3)
+    for step, world in enumerate((2, 4, 1), start=1):
+        _ffi.check(_ffi.lib.gcrl_agent_dp_sync_bn(ag._h, world, 0, None, C.cast(cb, C.c_void_p) if world > 1 else None, None))
+        before = len(calls)
+        t = ag.update(step, batch=tuple(torch.from_numpy(x).cuda() for x in full[step - 1]),
+                      eps_next=torch.from_numpy(eps[step - 1][0]), eps_cur=torch.from_numpy(eps[step - 1][1]))
+        assert all(np.isfinite(float(x)) for x in t), (world, [float(x) for x in t])
+        assert (len(calls) > before) == (world > 1)
+        if world > 1:
+            assert max(calls[before:]) >= 2 * world * ((B + 63) // 64) * H      # every rank's slots travel
+    torch.cuda.synchronize()
+    assert np.all(np.isfinite(ag.actor.flat()))
