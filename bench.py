@@ -302,9 +302,9 @@ def timed_region(agent, dp, w, steps, warmup, step0=1):
 
 def pmc_traffic(workload, kernel_substr):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r03_pmc_traffic_<workload>.json, made by tools/pmc_traffic.sh: FETCH_SIZE x 2 + WRITE_SIZE per the
-    guide's gfx950 correction).  bench.py cannot run the counter tool on itself."""
-    for rnd in ("r03", "r02"):
+    (profiles/r0N_pmc_traffic_<workload>.json — the newest round's — made by tools/pmc_traffic.sh: FETCH_SIZE x 2 + WRITE_SIZE per
+    the guide's gfx950 correction).  bench.py cannot run the counter tool on itself."""
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{workload}.json")
         if not os.path.exists(path):
             continue

@@ -262,6 +262,7 @@ struct RowChainArgs {
   long long slot_x, slot_rd;
   int ldx, ldl, B, S, A, Apad;
   int nblk_k, nblk_p;
+  int linear_roles;           // 1 (default): roles in launch order (K's workgroups first); 0: by XCD (GCRL_ROW_XCD_ROLES=1: A/B knob, agent_rowchain.inc)
   float *hC, *gC, *q, *y, *dq;      // K: activations / pre-activation gradients [C][L][B][H], q / dq [C][B], y [B]
   float *hA, *gA, *hC2, *q2, *dz;   // P: ..., critic activations (scratch) [C][L][B][H], Q(s, pi(s)) [C][B], d(pre-tanh) [C][B][Apad]
   float gamma, clamp_lo;

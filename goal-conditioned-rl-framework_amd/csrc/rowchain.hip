@@ -159,14 +159,23 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   float* sm3 = sm2 + R * 16;              // [R][16] reward / done
   float* hw = sm3 + R * 16;               // head weights of the role: [A*H | H | max(A*H, H)], then head biases [16 | 16]
   float* hb = hw + max(max(2 * A + 1, A + 2 * a.C), a.C * (A + 1)) * H;
-  const bool role_k = (int)blockIdx.x < a.nblk_k;
-  const int blk = role_k ? (int)blockIdx.x : (int)blockIdx.x - a.nblk_k;
+  // Which role, which row block.  Workgroup w runs on XCD w % 8 and every XCD has its own L2: with the roles in launch order every
+  // XCD streamed BOTH roles' weights (PMC: 32 MB HBM-side per launch for 3.3 MB of distinct weights).  When both roles have the
+  // same number of row blocks (a multiple of 4) the critic phase K takes XCDs 0-3 and the actor phase P XCDs 4-7: an XCD fetches
+  // one role's networks only.  (A wrong guess about the placement costs speed, never correctness.)
+  bool role_k = (int)blockIdx.x < a.nblk_k;
+  int blk = role_k ? (int)blockIdx.x : (int)blockIdx.x - a.nblk_k;
+  if (a.nblk_k == a.nblk_p && (a.nblk_k & 3) == 0 && !a.linear_roles) {
+    const int xcd = (int)blockIdx.x & 7;
+    role_k = xcd < 4;
+    blk = ((int)blockIdx.x >> 3) * 4 + (xcd & 3);
+  }
   const long long row0 = (long long)blk * R;
   const int rv = min(R, B - (int)row0);
   const long long BH = (long long)B * H;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
-  if (a.clk && tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nblk_k)) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());
+  if (a.clk && tid == 0 && blk == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());
 
   // Everything that does not depend on computed data is requested NOW (inputs, rewards, head
   // weights and biases): each of these was a separate exposed memory round trip (~1 us) in the
