@@ -109,6 +109,11 @@ struct gcrl_agent {
   long long slot_x = 0, slot_rd = 0;
   float *hTA[2] = {}, *hA = nullptr, *hC = nullptr, *hTC = nullptr, *gC = nullptr, *gA[2] = {};
   float *hC2 = nullptr, *gC2 = nullptr, *bn_part = nullptr;
+  // multi-workgroup reductions (td_loss, actor_select_alpha at B >= 1024): [64 nb] + [8 nb] partial sums, then two ticket words on their own lines
+  float* red_scratch = nullptr;
+  float* red_td() const { return red_scratch; }
+  float* red_sel() const { return red_scratch + 64LL * ((B + 255) / 256); }
+  unsigned int* red_ticket(int i) const { return reinterpret_cast<unsigned int*>(red_scratch + 72LL * ((B + 255) / 256) + 32 * i); }
   float *q = nullptr, *qt = nullptr, *q2 = nullptr, *dq = nullptr, *dq2 = nullptr, *dact = nullptr;
   float *zA = nullptr, *xhatA = nullptr, *invstdA = nullptr, *headA = nullptr, *ghead = nullptr, *dh2 = nullptr;
   float *zN = nullptr, *hN = nullptr, *headN = nullptr, *bn_partN = nullptr;   // scratch of the co-scheduled actor.sample(next_state) forward
@@ -147,6 +152,9 @@ struct gcrl_agent {
   float *bn_xchg = nullptr, *bn_bar = nullptr;   // row-group exchange of the slab launches (bn_slab.hip): partials, barrier words
   int bn_rsplit = 1;          // > 1: K >= 128 slab launches split their rows over ceil(B/128) workgroups (GCRL_NO_BN_RSPLIT=1: off)
   int bn_slots = 0;           // sum-of-squares slots of one BatchNorm layer's dgamma | dbeta (16-column slabs)
+  bool red_off = false;       // GCRL_NO_MB_REDUCE=1: single-workgroup td_loss / actor_select_alpha at every batch size
+  bool layer_adv_off = false; // GCRL_NO_LAYER_ADV=1: begin_step launches on the layer-per-launch path as in rounds 1-3
+  bool bn_fused_tiled = true; // GCRL_NO_BN_TILED_STATS=1 turns it off: the LDS-tiled GEMM's epilogue leaves the 64-row BatchNorm partials (no bn_stats launch)
   bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
   bool split_k = false;       // TD3: critic phase as role-parallel launches (agent_rowchain.inc)
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
@@ -414,14 +422,16 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
   }
   for (int l = 0; l < net.L && !slab; ++l) {
     std::vector<GemmDesc> v;
-    bool fused_stats = false;
+    bool fused_stats = false, fused_tiled = false;
     for (int i = 0; i < nf; ++i) {
       const float* X = l == 0 ? f[i].X0 : hbuf(f[i], l - 1);
       GemmDesc d = fwd(X, l == 0 ? a->ldx : H, P, net.lin[l], f[i].z, H, B, EPI_NONE);
       if (l == 0 && f[i].x_slot) { d.slot = a->slot_ptr(); d.a_slot = f[i].x_slot; }
       // BatchNorm statistics out of this GEMM's epilogue when its form allows (16-row partials, at most 32 of them)
       if (i == 0) fused_stats = a->bn_fused && a->bn_sync.world <= 1 && gemm_shape_of(d) == 1 && (B + kBnFusedRows - 1) / kBnFusedRows <= kBnFusedMaxParts;
-      if (fused_stats) d.bn_part = f[i].bn_part;
+      // ... or of the LDS-tiled form's (64-row partials: what bn_stats_kernel would compute from z; TQC's B = 2048, H = 512)
+      if (i == 0) fused_tiled = !fused_stats && a->bn_fused_tiled && a->bn_sync.world <= 1 && gemm_shape_of(d) == 4 && H % 4 == 0;
+      if (fused_stats || fused_tiled) d.bn_part = f[i].bn_part;
       v.push_back(d);
     }
     if (extra && (size_t)l < extra->steps.size()) v.insert(v.end(), extra->steps[l].begin(), extra->steps[l].end());
@@ -431,7 +441,7 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
       pb[i] = BnFwdProb{f[i].z, hbuf(f[i], l), f[i].save ? a->xhatA + (long long)l * BH : nullptr,
                         f[i].save ? a->invstdA + (long long)l * H : nullptr, f[i].bn_part};
     TRY(launch_bn_relu_fwd_multi(st, pb, nf, B, H, P + net.bn_g[l], P + net.bn_b[l], a->bn_rmean + (long long)l * H,
-                                 a->bn_rvar + (long long)l * H, fused_stats ? kBnFusedRows : 64, a->bn_sync.world > 1 ? &a->bn_sync : nullptr));
+                                 a->bn_rvar + (long long)l * H, fused_stats ? kBnFusedRows : 64, a->bn_sync.world > 1 ? &a->bn_sync : nullptr, fused_tiled));
   }
   {
     const int ldh = 2 * a->Apad;
@@ -569,6 +579,8 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
   td.B = B; td.C = C; td.drop = 0;
   td.gamma = (float)a->cfg.gamma;
   td.loss_kind = LOSS_MSE;
+  if (!a->red_off) { td.part = a->red_td(); td.ticket = a->red_ticket(0); }
+  td.refresh = (variant & V_ADV) ? a->ctrl() : nullptr;   // (layer_adv: the step's last optimiser launch reads the copies and advances)
   switch (kind) {
     case GCRL_AGENT_DDPG: td.target_kind = TGT_DDPG; td.clamp_lo = (float)(-1.0 / (1.0 - a->cfg.gamma)); break;
     case GCRL_AGENT_TD3: td.target_kind = TGT_MIN; td.loss_kind = LOSS_SMOOTH_L1; break;
@@ -721,7 +733,8 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
     for (size_t i = 0; i < re.steps.size(); ++i)
       for (const GemmDesc& d : re.steps[i]) c2.add(i, d);
   TRY(c2.run(st));
-  if (re_merged) TRY(launch_mean_metric(st, a->cur(), a->qt, C * B * a->Q, 1.0f, a->metrics_dev, MET_Q));
+  const bool met_rider = re_merged && a->sac && a->Q == 1 && !a->rowchain;   // then the mean rides on the selection launch below
+  if (re_merged && !met_rider) TRY(launch_mean_metric(st, a->cur(), a->qt, C * B * a->Q, 1.0f, a->metrics_dev, MET_Q));
   bool sel_deferred = false;
   ActorSelArgs as_d;
   AlphaArgs al_d;
@@ -748,6 +761,8 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
       sel_deferred = true;   // metrics + log-alpha gradient only on this path: rides on the tanh-Gaussian backward launch below
       as_d = as; al_d = al;
     } else {
+      if (met_rider) { as.mean_x = a->qt; as.mean_n = C * B * a->Q; as.mean_index = MET_Q; }
+      if (!a->red_off) { as.part = a->red_sel(); as.ticket = a->red_ticket(1); }
       TRY(launch_actor_select_alpha(st, as, al));
     }
   }
@@ -889,7 +904,7 @@ int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
     ad.mean_x = a->q2; ad.mean_n = a->B; ad.mean_scale = -1.0f; ad.mean_index = MET_ACTOR_LOSS;
   }
   if (a->rowchain && !a->sac) rc_adam_extras(a, ad, false);
-  const bool alpha_rider = a->sac && a->rowchain;   // the log-alpha step rides on the actor's optimiser launch
+  const bool alpha_rider = a->sac;   // the log-alpha step rides on the actor's optimiser launch (round 4: on every path)
   if (alpha_rider) {
     ad.alpha = AlphaStep{a->P_logalpha(), a->adam_m + a->goff_alpha, a->adam_v + a->goff_alpha, a->alpha_dev, g_alpha,
                          (float)kBeta2, (float)(1.0 - kBeta1), (float)(1.0 - kBeta2), (float)kAdamEps, a->metrics_dev};
@@ -1238,7 +1253,7 @@ int build(gcrl_agent* a) {
       {&a->parts_c, (long long)C * a->nparts_c}, {&a->parts_a, (long long)a->nparts_a},
       {&a->hC2, (long long)C * L * BH}, {&a->gC2, 2 * BH}, {&a->bn_part, 2LL * ((B + 15) / 16) * H},
       {&a->rc_gC, (long long)C * L * BH}, {&a->rc_gA, L * BH}, {&a->ybuf, B}, {&a->pi_buf, (long long)B * a->Apad},
-      {&a->w_in, B}, {&a->td_abs, B},
+      {&a->w_in, B}, {&a->td_abs, B}, {&a->red_scratch, 72LL * ((B + 255) / 256) + 64},
       {&a->bn_bstat, 2LL * 2 * L * H}, {&a->bn_xchg, bn_slab_xchg_floats(H)}, {&a->bn_bar, bn_slab_bar_words(H)}, {&a->zN, BH}, {&a->hN, 2 * BH}, {&a->headN, (long long)B * 2 * a->Apad}, {&a->bn_partN, 2LL * ((B + 15) / 16) * H}};
   // row-block path: plain DDPG nets whose rows fit the 16-byte column ownership
   {
@@ -1284,6 +1299,9 @@ int build(gcrl_agent* a) {
     a->head_batches = 3;   // (TD3 at batch 2048: the host draws 38 x 2048 indices in ~390 us, more than two 170 us steps)
     if (const char* e = std::getenv("GCRL_HEAD_BATCHES")) a->head_batches = std::max(1, std::min(8, std::atoi(e)));   // experiment knob
     a->dw_batch_off = std::getenv("GCRL_NO_DW_BATCH") != nullptr;
+    a->bn_fused_tiled = std::getenv("GCRL_NO_BN_TILED_STATS") == nullptr;
+    a->layer_adv_off = std::getenv("GCRL_NO_LAYER_ADV") != nullptr;
+    a->red_off = std::getenv("GCRL_NO_MB_REDUCE") != nullptr;
     a->bn_fused = std::getenv("GCRL_BN_FUSED") != nullptr;   // measured equal at cfg 5 (204.6 vs 203.6 us/step): off by default
     if (const char* e = std::getenv("GCRL_SPLIT_RG"))   // experiment knob: four digits, rows/4 per workgroup of the four launches
       for (int i = 0; i < 4 && e[i]; ++i) a->split_rg[i] = e[i] - '0';
@@ -1708,7 +1726,11 @@ int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int6
     const int m = std::min(chunk, n - done);
     std::vector<StepPlan> plans;
     const bool ddpg_pipe = a->cfg.kind == GCRL_AGENT_DDPG && a->cfg.pipeline_steps != 0;
-    const int adv = (a->rowchain && !ddpg_pipe) ? V_ADV : 0;   // SAC / TD3 on the row-block path (the call's last step advances into table[m]: never read)
+    // SAC / TD3 on the row-block path (the call's last step advances into table[m]: never read); round 4: also the BatchNorm-actor
+    // agents on the layer-per-launch path (TQC's cfg 4) when every step is an actor step — then the actor's optimiser launch is the
+    // step's last one, and the TD-loss launch refreshes the copies it reads
+    const bool layer_adv = a->sac && !a->rowchain && a->Q == 1 && a->cfg.ac_update_freq == 1 && !a->layer_adv_off;
+    const int adv = ((a->rowchain && !ddpg_pipe) || layer_adv) ? V_ADV : 0;
     const bool pre = ddpg_pipe || adv != 0;                 // these paths start from the uploaded cur: no begin_step launch at all
     TRY(begin_call(a, her, step0 + done, m, nullptr, a->xchg_scale(), st, plans, tickets_out ? tickets_out + done : nullptr,
                    lens_out ? lens_out + done : nullptr, /*defer_rest=*/true, pre));

@@ -48,9 +48,10 @@ struct GemmDesc {
   // sumsq_out[(tile * KSPLIT) + wave]: the global-norm clip needs ||g||, and producing the
   // partials here (fixed slots, fixed order -> deterministic) removes a reduction launch
   float* sumsq_out;
-  // BatchNorm statistics of the result (KSPLIT = 4 form only, launcher-checked): per-column (mean, M2) of each 16-row tile
-  // by a local two-pass, at bn_part[tm*N + n] and bn_part[(tiles_m + tm)*N + n] — the row-block partials bn_relu_apply
-  // merges (ops_sac.hip), so the producing GEMM replaces the bn_stats launch
+  // BatchNorm statistics of the result (launcher-checked: the KSPLIT = 4 form — 16-row tiles — or an unsplit LDS-tiled problem —
+  // 64-row tiles): per-column (mean, M2) of each row tile by a local two-pass, at bn_part[tm*N + n] and
+  // bn_part[(tiles_m + tm)*N + n] — the row-block partials bn_relu_apply merges (ops_sac.hip), so the producing GEMM replaces
+  // the bn_stats launch
   float* bn_part;
   int a_vec, b_vec;  // 16-byte loads legal along k (filled by the launcher)
   int a_rvec, b_rvec;  // 16-byte loads legal along the row index (operand stored k-major)

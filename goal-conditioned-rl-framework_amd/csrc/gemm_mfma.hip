@@ -33,6 +33,7 @@ int launch_shape(hipStream_t st, GemmBatch& gb) {
 //                            sizes; small K just leaves waves idle in the exchange)
 //   <= 8192                : one tile per wave
 //   larger                 : 32x32 per wave
+bool outer_ok(const GemmDesc& d);
 int shape_of(const GemmDesc& d) {
   const long long tiles16 = (long long)((d.M + 15) / 16) * ((d.N + 15) / 16);
   // (tried for long reductions, i.e. dW at batch >= 1024: LDS-tiled 64x64 — 20 tiles per problem each
@@ -56,9 +57,79 @@ int shape_of(const GemmDesc& d) {
   // a single 16-k chunk (head dX with K = 1..4: outer products): nothing to stage, 32x32 wave tiles (12 us vs 17 us
   // LDS-tiled at M=10240, N=512).  K = 25 first layers: the LDS-tiled form again (19 us vs 24 us) since its element-wise
   // fetch went branch-free.
+  if (outer_ok(d) && (long long)d.M * d.N >= (1 << 18)) return 5;   // (small problems: launch-bound either way, the MFMA form stays)
   if (d.K <= 16) return 3;
   const long long tiles64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64);
   return (tiles64 >= 192 || d.K >= 1024) ? 4 : 2;
+}
+
+// Form 5 (round 4): K = 1 — the input gradient of a one-output head, G' = (g w^T) * act'(H): an outer product per problem,
+// no reduction at all.  On the matrix cores (form 3) TQC's five critic heads at B = 2048, H = 512 took 23 us for 42 MB of
+// traffic, twice per step; as a streaming kernel (one 16-byte quad of C per thread and pass, four passes per workgroup, all
+// loads requested first) it is bound by HBM like any copy.  Same value as the MFMA path: one product rounded once (the
+// instruction's padded k contribute exact zeros), then bias, activation and derivative in the same order.
+constexpr int kOuterQuads = 1024;   // quads of C per workgroup
+bool outer_ok(const GemmDesc& d) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  return d.K == 1 && !d.ones_col && !d.sumsq_out && !d.bn_part && d.ksplit <= 1 && d.N % 4 == 0 && d.b_cs == 1 && d.c_rs % 4 == 0 && al(d.B) &&
+         al(d.C) && (!d.bias || al(d.bias)) && (d.mul == MUL_NONE || (d.H && d.h_rs % 4 == 0 && al(d.H))) &&
+         (!d.slot || (d.b_slot % 4 == 0 && d.c_slot % 4 == 0 && d.h_slot % 4 == 0));
+}
+__global__ __launch_bounds__(256) void gemm_outer_kernel(GemmBatch gb) {
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxProb; ++q)
+    if (q < gb.n && (int)blockIdx.x >= gb.d[q].tile0) pi = q;
+  const GemmDesc& d = gb.d[pi];
+  const int nq = d.N >> 2;
+  const long long total = (long long)d.M * nq;
+  const long long sl = d.slot ? (long long)*d.slot : 0;
+  const float* __restrict__ A = d.A + sl * d.a_slot;
+  const float* __restrict__ Bm = d.B + sl * d.b_slot;
+  const float* __restrict__ H = d.H ? d.H + sl * d.h_slot : nullptr;
+  float* __restrict__ C = d.C + sl * d.c_slot;
+  const int epi = d.epi, mul = d.mul;
+  const long long q0 = (long long)((int)blockIdx.x - d.tile0) * kOuterQuads + threadIdx.x;
+  float av[4];
+  v4f bv[4], hv[4], biv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long qi = q0 + 256 * u;
+    const bool in = qi < total;
+    const int m = in ? (int)(qi / nq) : 0, n = in ? (int)(qi % nq) * 4 : 0;
+    av[u] = in ? A[(long long)m * d.a_rs] : 0.f;
+    bv[u] = in ? *(const v4f*)(Bm + n) : (v4f){0.f, 0.f, 0.f, 0.f};
+    biv[u] = (in && d.bias) ? *(const v4f*)(d.bias + n) : (v4f){0.f, 0.f, 0.f, 0.f};
+    hv[u] = (in && mul != MUL_NONE) ? *(const v4f*)(H + (long long)m * d.h_rs + n) : (v4f){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long qi = q0 + 256 * u;
+    if (qi >= total) continue;
+    const int m = (int)(qi / nq), n = (int)(qi % nq) * 4;
+    v4f v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = __fmul_rn(av[u], bv[u][r]);
+      if (d.bias) x += biv[u][r];
+      x = act_apply(x, epi);
+      if (mul != MUL_NONE) x *= act_deriv(hv[u][r], mul);
+      v[r] = x;
+    }
+    *(v4f*)(C + (long long)m * d.c_rs + n) = v;
+  }
+}
+int launch_outer(hipStream_t st, GemmBatch& gb) {
+  int wgs = 0;
+  for (int i = 0; i < gb.n; ++i) {
+    GemmDesc& d = gb.d[i];
+    d.tile0 = wgs;
+    d.ntiles = (int)(((long long)d.M * (d.N >> 2) + kOuterQuads - 1) / kOuterQuads);
+    wgs += d.ntiles;
+  }
+  hipLaunchKernelGGL(gemm_outer_kernel, dim3(wgs), dim3(256), 0, st, gb);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
 }
 
 int launch_tiled(hipStream_t st, GemmBatch& gb) {
@@ -102,16 +173,24 @@ int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape) {
     d.a_rvec = (d.a_rs == 1 && d.a_cs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
     d.b_rvec = (d.b_cs == 1 && d.b_rs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
     shapes[i] = shape ? shape : (d.shape_hint ? d.shape_hint : shape_of(d));
-    GCRL_CHECK_ARG(!d.bn_part || (shapes[i] == 1 && !d.ones_col && d.c_rs >= d.N), "launch_gemm_batch: bn_part needs the k-split 16x16 form");
+    // BatchNorm partials out of the epilogue: the k-split 16x16 form (16-row partials) or the LDS-tiled one (64-row partials, whole
+    // 16-byte column quads only)
+    GCRL_CHECK_ARG(!d.bn_part || (!d.ones_col && d.c_rs >= d.N &&
+                                  (shapes[i] == 1 || (shapes[i] == 4 && d.N % 4 == 0 && d.c_rs % 4 == 0 && ((uintptr_t)d.C & 15) == 0 &&
+                                                      ((uintptr_t)d.bn_part & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
+                                                      d.mul == MUL_NONE && d.ksplit <= 1))),
+                   "launch_gemm_batch: bn_part needs the k-split 16x16 form or an unsplit LDS-tiled problem with aligned quads");
   }
-  for (int s = 1; s <= 4; ++s) {  // one launch per shape present (almost always exactly one)
+  for (int i = 0; i < n; ++i) GCRL_CHECK_ARG(shapes[i] != 5 || outer_ok(descs[i]), "launch_gemm_batch: problem %d is not an aligned K = 1 outer product", i);
+  for (int s = 1; s <= 5; ++s) {  // one launch per shape present (almost always exactly one)
     GemmBatch gb;
     gb.n = 0;
     for (int i = 0; i < n; ++i)
       if (shapes[i] == s) gb.d[gb.n++] = descs[i];
     if (gb.n == 0) continue;
     int rc = s == 1 ? launch_shape<1, 1, 4>(st, gb)
-             : (s == 2 ? launch_shape<1, 1, 1>(st, gb) : (s == 3 ? launch_shape<2, 2, 1>(st, gb) : launch_tiled(st, gb)));
+             : (s == 2 ? launch_shape<1, 1, 1>(st, gb)
+                       : (s == 3 ? launch_shape<2, 2, 1>(st, gb) : (s == 4 ? launch_tiled(st, gb) : launch_outer(st, gb))));
     if (rc) return rc;
   }
   return GCRL_OK;

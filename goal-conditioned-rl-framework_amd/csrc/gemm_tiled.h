@@ -150,6 +150,17 @@ __device__ inline void store_tile(float (&reg)[kNR], float* __restrict__ lds) {
 #define GCRL_STAMP(i) do { } while (0)
 #endif
 
+// sum over the workgroup's 16 row slots for every column quad, in slot order (all threads get the result) — ops_sac.hip's slot_sum
+__device__ inline v4f tiled_slot_sum(v4f v, v4f (*red)[16], int cq, int slot) {
+  __syncthreads();
+  red[slot][cq] = v;
+  __syncthreads();
+  v4f s = red[0][cq];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) s += red[i][cq];
+  return s;
+}
+
 // The bias gradient of a dW problem (column N-1 of G^T [X | 1] = the row sums of the A operand over k) is NOT a synthesised
 // ones column of B any more: for N - 1 = 512 that column cost a ninth tile column — 8 of 72 tiles per problem computing one
 // useful column.  Instead every thread adds up the A fragments it stages anyway (4 adds per k-step), and the tiles of tile
@@ -404,8 +415,10 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
     d.col_out[m0 + threadIdx.x] = dbv;
     ss += dbv * dbv;
   }
+  v4f keep[4];                                  // the finished quads (BatchNorm statistics below)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    keep[i] = (v4f){0.f, 0.f, 0.f, 0.f};
     const int row = er + 16 * i, m = m0 + row;
     if (m >= M || nq >= N) continue;
     const float4 t4 = *reinterpret_cast<const float4*>(tile + row * 64 + ((eq ^ (row & 15)) << 2));
@@ -419,6 +432,7 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
         ss += v[r] * v[r];
       }
       *(v4f*)(C + (long long)m * d.c_rs + nq) = v;      // (non-temporal here: +3 % alone, -0.7 % inside TQC's step — the next layer re-reads it)
+      keep[i] = v;
     } else {
       const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
@@ -432,6 +446,26 @@ __device__ inline void gemm_tiled_body(const GemmDesc& d, int t, float* ldsA, fl
         ss += v * v;
         C[(long long)m * d.c_rs + n] = v;
       }
+    }
+  }
+  if (d.bn_part) {   // (uniform per workgroup; the launcher admits whole-quad tiles only)
+    // BatchNorm1d statistics of the tile's columns over its (up to) 64 rows — the row-block partial bn_stats_kernel (ops_sac.hip)
+    // would form from the stored matrix, by the same sums in the same order (thread = column quad x row slot, rows slot + 16 i;
+    // local two-pass): the actor's forward at B = 2048 loses a 4.4 us launch per hidden layer and a re-read of z
+    v4f (*red)[16] = reinterpret_cast<v4f (*)[16]>(tile);     // (tiled_slot_sum's first barrier: every thread has read its tile quads)
+    const int nr = min(kTB, M - m0);
+    v4f s = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (er + 16 * i < nr) s += keep[i];
+    const v4f mean = tiled_slot_sum(s, red, eq, er) / (float)nr;
+    v4f q = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (er + 16 * i < nr) { const v4f df = keep[i] - mean; q += df * df; }
+    const v4f m2 = tiled_slot_sum(q, red, eq, er);
+    if (er == 0 && nq + 3 < N) {
+      const int tiles_m = (M + kTB - 1) / kTB;
+      *(v4f*)(d.bn_part + (long long)tm * N + nq) = mean;
+      *(v4f*)(d.bn_part + (long long)(tiles_m + tm) * N + nq) = m2;
     }
   }
   GCRL_STAMP(3);

@@ -70,6 +70,11 @@ struct TdLossArgs {
   float* metrics;           // host-mapped records
   int B, C, drop, target_kind, loss_kind;
   float gamma, clamp_lo;
+  // layer-per-launch steps whose last optimiser launch advances the control block (AdamArgs::advance): this launch — before
+  // every optimiser launch of its step — refreshes the copies cur_b / prev_b that launch reads; null otherwise
+  CtrlBlock* refresh;
+  // multi-workgroup form (B >= 1024): 64 * ceil(B/256) floats of partial sums and a zeroed ticket word on its own line; null: one workgroup
+  float* part; unsigned int* ticket;
 };
 int launch_td_loss(hipStream_t st, const TdLossArgs& a);
 
@@ -206,11 +211,12 @@ struct BnSync {
   int (*exchange)(float* dev, long long n, hipStream_t st, void* user) = nullptr;
   void* user = nullptr;
 };
-// rows_per_part: 64 = this launch computes the row-block partials itself (bn_stats launch); 16 = the GEMM that produced z
-// already left them in `scratch` (GemmDesc::bn_part), only the apply launch runs.  scratch: 2 * ceil(B/rows_per_part) * H floats
+// rows_per_part: 64 = this launch computes the row-block partials itself (bn_stats launch) — unless `stats_done`: the LDS-tiled
+// GEMM that produced z left them in `scratch` (GemmDesc::bn_part, 64-row tiles); 16 = the k-split GEMM that produced z left them
+// there; then only the apply launch runs.  scratch: 2 * ceil(B/rows_per_part) * H floats
 int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, int B, int H, const float* gamma,
                              const float* beta, float* running_mean, float* running_var, int rows_per_part = 64,
-                             const BnSync* sync = nullptr);
+                             const BnSync* sync = nullptr, bool stats_done = false);
 constexpr int kBnFusedRows = 16;      // GEMM tile height
 constexpr int kBnFusedMaxParts = 32;  // what bn_relu_apply gathers through LDS
 // eval mode (running statistics): select_action path
@@ -286,6 +292,11 @@ struct ActorSelArgs {
   float* dq;           // [C][B]
   float* metrics;
   int B, C, drop;
+  // rider (launch_actor_select_alpha only): metrics[mean_index] = mean(mean_x[0 .. mean_n)) by a second workgroup — the q_value
+  // metric of the re-evaluated critics (launch_mean_metric's sums), one single-workgroup launch less per step
+  const float* mean_x; int mean_n, mean_index;
+  // multi-workgroup form of launch_actor_select_alpha (B >= 1024): 8 * ceil(B/256) floats of partial sums and a zeroed ticket word; null: one workgroup
+  float* part; unsigned int* ticket;
 };
 int launch_actor_select(hipStream_t st, const ActorSelArgs& a);
 

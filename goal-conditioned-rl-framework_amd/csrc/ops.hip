@@ -6,6 +6,7 @@
 //   optimiser    torch.optim.Adam / AdamW single-tensor path (lerp, addcmul, addcdiv order)
 //   Polyak       tau*p + (1-tau)*p_target  (src/agent.py:1260-1271 etc.)
 #include "ops.h"
+#include "meet.h"
 
 #include <algorithm>
 #include <cmath>
@@ -57,29 +58,57 @@ __global__ void begin_step_kernel(CtrlBlock* cb, int shift) {
 
 // ------------------------------------------------------------------ TD target + loss
 // one block of 256..1024 threads (launch_td_loss): at B = 2048 a 256-thread block walked 8 dependent rounds of ~13 loads
-// each (31 us in TQC's step)
-__global__ __launch_bounds__(1024) void td_loss_kernel(TdLossArgs a) {
+// each (31 us in TQC's step).
+// Round 4: EVERY operand of a thread's (up to) two rows is requested before anything is stored.  The output pointers may alias
+// the inputs as far as the compiler knows, so a row's loads of q[k + 1] used to wait behind its store of dq[k]: five dependent
+// round trips per row, two rows per thread at B = 2048 — 16.6 us for a kernel whose loads fit one round trip.  Same arithmetic
+// in the same order as before (rows in increasing b per thread).
+// One instance per (target kind, loss kind): a single workgroup's kernel runs from a cold instruction cache, and the generic
+// body was 2 845 instructions (22 KB) of which a given agent executes a third.
+constexpr int kTdPartStride = 16;   // floats per wave slot of the multi-workgroup form: kMaxCritics losses, td, q
+static_assert(kMaxCritics + 2 <= kTdPartStride, "td_loss partial slot");
+struct TdRow { float qt[kMaxCritics], q[kMaxCritics], r, d, lp, w; };
+// MB (round 4, B >= 1024 with the agent's scratch): several workgroups of 256 threads, one row per thread.  A single workgroup
+// is bound by its CU's issue rate — ~2 000 wave instructions x 4 cycles x 4 waves per SIMD: 13 of the kernel's 14.6 us at
+// B = 2048 — not by memory.  Every wave leaves the partial sums of the (up to) seven logged quantities at
+// part[(workgroup * 4 + wave) * 16 + q] with agent-scope stores and the workgroup takes a ticket (meet.h's release discipline);
+// the last one adds the partials up in index order — the same result whichever workgroup is last — and writes the metrics.
+// No workgroup waits for another: nothing to time out, safe on a shared device.
+template <int TGT, int LOSS, bool MB>
+__global__ __launch_bounds__(MB ? 256 : 1024) void td_loss_kernel(TdLossArgs a) {
   __shared__ float scratch[16];
   const StepCtrl c = *a.cur;
+  if (a.refresh && blockIdx.x == 0 && threadIdx.x == 0) { a.refresh->cur_b = c; a.refresh->prev_b = a.refresh->prev; }
   const float* __restrict__ r = a.r + (long long)c.batch_slot * a.slot_stride;
   const float* __restrict__ d = a.d + (long long)c.batch_slot * a.slot_stride;
   const float alpha = a.alpha_dev ? *a.alpha_dev : a.alpha_const;
   const int B = a.B, C = a.C;
   const int keep = C - a.drop;
+  const bool ent = TGT == TGT_MIN_ENT || TGT == TGT_TRUNC_ENT;
   float loss[kMaxCritics];
 #pragma unroll
   for (int k = 0; k < kMaxCritics; ++k) loss[k] = 0.f;
   float td = 0.f, qsum = 0.f;
   const float mse_norm = 2.0f / (float)B, l1_norm = 1.0f / (float)B;
 
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    float qt[kMaxCritics];
+  auto fetch = [&](TdRow& w, int b) {
+    const bool in = b < B;
 #pragma unroll
-    for (int k = 0; k < kMaxCritics; ++k) qt[k] = (k < C) ? a.qt[(long long)k * B + b] : INFINITY;
+    for (int k = 0; k < kMaxCritics; ++k) {
+      w.qt[k] = (in && k < C) ? a.qt[(long long)k * B + b] : INFINITY;
+      w.q[k] = (in && k < C) ? a.q[(long long)k * B + b] : 0.f;
+    }
+    w.r = in ? r[b] : 0.f;
+    w.d = in ? d[b] : 0.f;
+    w.lp = (in && ent) ? a.logp_next[b] : 0.f;
+    w.w = (in && a.w) ? a.w[b] : 1.0f;
+  };
+  auto finish = [&](TdRow& w, int b) {
+    float* qt = w.qt;
     float tq;
-    if (a.target_kind == TGT_DDPG) {
+    if (TGT == TGT_DDPG) {
       tq = qt[0];
-    } else if (a.target_kind == TGT_MIN || a.target_kind == TGT_MIN_ENT) {
+    } else if (TGT == TGT_MIN || TGT == TGT_MIN_ENT) {
       tq = fminf(qt[0], qt[1]);
     } else {
       // torch.sort over the critic axis, drop the largest `drop`, mean (src/agent.py:972-974)
@@ -95,21 +124,20 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(TdLossArgs a) {
       for (int k = 0; k < kMaxCritics; ++k) if (k < keep) s = __fadd_rn(s, qt[k]);
       tq = s / (float)keep;
     }
-    if (a.target_kind == TGT_MIN_ENT || a.target_kind == TGT_TRUNC_ENT)
-      tq = __fsub_rn(tq, __fmul_rn(alpha, a.logp_next[b]));
+    if (ent) tq = __fsub_rn(tq, __fmul_rn(alpha, w.lp));
     // y = r + gamma * (1 - d) * tq   (left to right, one rounding per op)
-    float y = __fadd_rn(r[b], __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, d[b])), tq));
-    if (a.target_kind == TGT_DDPG) y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
+    float y = __fadd_rn(w.r, __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, w.d)), tq));
+    if (TGT == TGT_DDPG) y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
     float tdmax = 0.f;
-    const float wb = a.w ? a.w[b] : 1.0f;   // (weights * loss).mean(): every per-sample term scaled before the mean
+    const float wb = w.w;   // (weights * loss).mean(): every per-sample term scaled before the mean
 #pragma unroll
     for (int k = 0; k < kMaxCritics; ++k) {
       if (k < C) {
-        const float qc = a.q[(long long)k * B + b];
+        const float qc = w.q[k];
         const float diff = __fsub_rn(qc, y);
         const float ad = fabsf(diff);
         float g;
-        if (a.loss_kind == LOSS_MSE) {
+        if (LOSS == LOSS_MSE) {
           loss[k] += a.w ? wb * (diff * diff) : diff * diff;
           g = mse_norm * diff;
         } else {
@@ -125,8 +153,57 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(TdLossArgs a) {
     }
     td += tdmax;
     if (a.td_abs) a.td_abs[b] = tdmax;
+  };
+  // software-pipelined over the thread's rows: the next row's operands are in flight while this one is finished (one copy of
+  // the arithmetic in the code)
+  TdRow w;
+  if (MB) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    fetch(w, b);
+    if (b < B) finish(w, b);
+  } else {
+    fetch(w, threadIdx.x);
+#pragma unroll 1
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+      TdRow nx;
+      fetch(nx, b + blockDim.x);
+      finish(w, b);
+      w = nx;
+    }
   }
   float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
+  if (MB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = a.part + ((long long)blockIdx.x * 4 + wave) * kTdPartStride;
+#pragma unroll
+    for (int k = 0; k < kMaxCritics; ++k) {
+      if (k < C) {
+        const float v = wave_sum(loss[k]);
+        if (lane == 0) __hip_atomic_store(mine + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    const float tdw = wave_sum(td), qsw = wave_sum(qsum);
+    if (lane == 0) {
+      __hip_atomic_store(mine + kMaxCritics, tdw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + kMaxCritics + 1, qsw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    drain_stores();
+    __syncthreads();
+    unsigned int* s_ticket = reinterpret_cast<unsigned int*>(scratch);
+    if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_ticket != gridDim.x - 1) return;      // (uniform)
+    if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    const int q = threadIdx.x, np = 4 * gridDim.x;
+    if (q >= kMaxCritics + 2 || (q < kMaxCritics && q >= C)) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < np; ++i) s += __hip_atomic_load(a.part + (long long)i * kTdPartStride + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (q < kMaxCritics) met[MET_CRITIC_LOSS + q] = s / (float)B;
+    else if (q == kMaxCritics) met[MET_TD] = s / (float)B;
+    else met[MET_Q] = s / (float)(B * C);
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < kMaxCritics; ++k) {
     if (k < C) {
@@ -400,7 +477,14 @@ int launch_begin_step(hipStream_t st, CtrlBlock* cb, int shift) {
 
 int launch_td_loss(hipStream_t st, const TdLossArgs& a) {
   GCRL_CHECK_ARG(a.C >= 1 && a.C <= kMaxCritics && a.B >= 1, "td_loss: bad C=%d B=%d", a.C, a.B);
-  hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(reduce_threads(a.B)), 0, st, a);
+  const bool mb = a.part && a.ticket && a.B >= 1024;
+  const dim3 th(mb ? 256 : reduce_threads(a.B)), gr(mb ? (a.B + 255) / 256 : 1);
+#define GCRL_TD(T, L) if (a.target_kind == T && a.loss_kind == L) { if (mb) hipLaunchKernelGGL((td_loss_kernel<T, L, true>), gr, th, 0, st, a); \
+                                                                      else hipLaunchKernelGGL((td_loss_kernel<T, L, false>), gr, th, 0, st, a); } else
+  GCRL_TD(TGT_DDPG, LOSS_MSE) GCRL_TD(TGT_MIN, LOSS_SMOOTH_L1) GCRL_TD(TGT_MIN_ENT, LOSS_MSE) GCRL_TD(TGT_TRUNC_ENT, LOSS_MSE)
+  GCRL_TD(TGT_DDPG, LOSS_SMOOTH_L1) GCRL_TD(TGT_MIN, LOSS_MSE) GCRL_TD(TGT_MIN_ENT, LOSS_SMOOTH_L1) GCRL_TD(TGT_TRUNC_ENT, LOSS_SMOOTH_L1)
+  return fail(GCRL_ERR_ARG, "td_loss: bad target kind %d / loss kind %d", a.target_kind, a.loss_kind);
+#undef GCRL_TD
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

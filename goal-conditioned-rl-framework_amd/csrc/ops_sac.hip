@@ -5,10 +5,12 @@
 //   log-alpha AdamW step                            src/agent.py:532-546, :936-949
 //   wavefront bitonic sort + truncated mean         generalisation of src/agent.py:919-921
 #include "ops.h"
+#include "meet.h"
 #include "gemm_mfma.h"   // v4f
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace gcrl {
 namespace {
@@ -61,7 +63,7 @@ __device__ inline float block_sum_256(float v, float* scratch) {
 // columns over all rows — 128 dependent-latency loads per thread, 2 176 steps/s.)
 constexpr int kBnRows = 64;      // rows per partial
 constexpr int kBnSlots = 16;     // row slots of a block (256 threads / 16 column quads)
-constexpr int kBnMaxPart = 32;   // row-block partials gathered through LDS (B <= 2048); more are read from memory in the merge loop
+constexpr int kBnMaxPart = 32;   // row-block partials a block holds in registers (two per row slot: B <= 2048); more are read in the merge loops
 
 __device__ inline v4f ld4(const float* p) { return *(const v4f*)p; }
 __device__ inline v4f zero4() { return (v4f){0.f, 0.f, 0.f, 0.f}; }
@@ -77,25 +79,20 @@ __device__ inline v4f slot_sum(v4f v, v4f (*red)[16], int cq, int slot) {
   return s;
 }
 
-// the block's slice of two partial arrays [nrb][H] (its 64 columns) -> LDS sp[2][kBnMaxPart][16]; two phases so that
-// the caller's other loads are requested between `gather_request` and `gather_store`
+// Merge of a problem's row-block partials, shared by the 16 row slots of a block (round 4).  Slot s owns partials s, s + 16, ...:
+// the first two are requested straight into registers (with the caller's other loads, before anything waits), the rest —
+// B > 2048, or SyncBN's world x nrb partials — are read in the merge loops.  Rounds 1-3 had every slot gather all partials
+// through LDS and merge them redundantly: 64 dependent LDS reads per thread, 5.8 of the 11.1 us of a B = 2048, H = 512 launch
+// (GCRL_BN_ABL ablation, tools/bn_layer_bench.py).
 struct PartRegs { v4f a[2], b[2]; };
-__device__ inline void gather_request(PartRegs& r, const float* pa, const float* pb, int nrb, int H, int col0) {
+__device__ inline void part_request(PartRegs& r, const float* pa, const float* pb, int nrb, int H, int col, bool ok, int slot) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int it = threadIdx.x + 256 * u, rb = it >> 4, c = col0 + 4 * (it & 15);
-    const bool in = rb < nrb && rb < kBnMaxPart && c < H;
-    r.a[u] = in ? ld4(pa + (long long)rb * H + c) : zero4();
-    r.b[u] = in ? ld4(pb + (long long)rb * H + c) : zero4();
+    const int rb = slot + kBnSlots * u;
+    const bool in = ok && rb < nrb;
+    r.a[u] = in ? ld4(pa + (long long)rb * H + col) : zero4();
+    r.b[u] = in ? ld4(pb + (long long)rb * H + col) : zero4();
   }
-}
-__device__ inline void gather_store(const PartRegs& r, v4f (*sp)[kBnMaxPart][16]) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int it = threadIdx.x + 256 * u, rb = it >> 4;
-    if (rb < kBnMaxPart) { sp[0][rb][it & 15] = r.a[u]; sp[1][rb][it & 15] = r.b[u]; }
-  }
-  __syncthreads();
 }
 
 constexpr int kBnSlabMax = 4;
@@ -141,40 +138,33 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnFwdPair pr, int B, int 
 
 // Merge of a problem's row-block partials (mean_b, M2_b over n_b rows) for one column quad, the same in every block:
 //   mean = sum n_b mean_b / B,   M2 = sum (M2_b + n_b (mean_b - mean)^2)      -> (mean, biased variance)
-// — two short passes over the partials without a division in the loop (Chan's sequential merge, used before, is a
-// serial chain of divisions: ~1 us for 32 partials in every block).
-// sp: the block's LDS copy of the first min(nrb, kBnMaxPart) partials; gm / gq: the arrays in memory for the rest
-// (column quad `col`; only B > 2048).  The LDS loops are unrolled so that their reads are in flight together — as a
-// plain loop every iteration waited out its own LDS latency (17.5 us per launch with 32 partials, measured).
+// — two passes without a division in the loop (Chan's sequential merge is a serial chain of divisions), each a sum over this
+// slot's partials followed by the block's slot sum (fixed order: the result is the same in every block and on every rank).
 // BnSync: nrb = world * nrb_local partials (rank-major), each over the rows of ITS rank's block; Bt = world * B rows in all.
-__device__ inline void bn_merge4(v4f (*sp)[kBnMaxPart][16], int cq, const float* gm, const float* gq, int H, int col, bool ok,
-                                 int nrb, int B, int rpp, v4f* mean_out, v4f* var_out, int world = 1) {
-  const int nl = min(nrb, kBnMaxPart);
+__device__ inline void bn_merge_slots(const PartRegs& r, const float* gm, const float* gq, v4f (*red)[16], int cq, int slot, int H, int col,
+                                      bool ok, int nrb, int B, int rpp, int world, v4f* mean_out, v4f* var_out) {
   const int nrb_l = nrb / world;
-  const int Bl = B;
-  B *= world;
-  auto rows = [&](int rb) { const int r = rb % nrb_l; return (float)(min(Bl, (r + 1) * rpp) - r * rpp); };
+  const float Bt = (float)B * (float)world;
+  auto rows = [&](int rb) { const int q = rb % nrb_l; return (float)(min(B, (q + 1) * rpp) - q * rpp); };
   v4f s = zero4();
-#pragma unroll 8
-  for (int rb = 0; rb < nl; ++rb) s += sp[0][rb][cq] * rows(rb);
-  for (int rb = nl; rb < nrb; ++rb) s += (ok ? ld4(gm + (long long)rb * H + col) : zero4()) * rows(rb);
-  const v4f mean = s / (float)B;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) if (slot + kBnSlots * u < nrb) s += r.a[u] * rows(slot + kBnSlots * u);
+  for (int rb = slot + 2 * kBnSlots; rb < nrb; rb += kBnSlots) s += (ok ? ld4(gm + (long long)rb * H + col) : zero4()) * rows(rb);
+  const v4f mean = slot_sum(s, red, cq, slot) / Bt;
   v4f m2 = zero4();
-#pragma unroll 8
-  for (int rb = 0; rb < nl; ++rb) {
-    const v4f dm = sp[0][rb][cq] - mean;
-    m2 += sp[1][rb][cq] + dm * dm * rows(rb);
-  }
-  for (int rb = nl; rb < nrb; ++rb) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (slot + kBnSlots * u < nrb) { const v4f dm = r.a[u] - mean; m2 += r.b[u] + dm * dm * rows(slot + kBnSlots * u); }
+  for (int rb = slot + 2 * kBnSlots; rb < nrb; rb += kBnSlots) {
     const v4f dm = (ok ? ld4(gm + (long long)rb * H + col) : zero4()) - mean;
     m2 += (ok ? ld4(gq + (long long)rb * H + col) : zero4()) + dm * dm * rows(rb);
   }
-  *mean_out = mean; *var_out = m2 / (float)B;
+  *mean_out = mean; *var_out = slot_sum(m2, red, cq, slot) / Bt;
 }
 
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B, int H, const float* gamma, const float* beta,
                                                             float* rmean, float* rvar) {
-  __shared__ v4f sp[2][kBnMaxPart][16];
+  __shared__ v4f red[kBnSlots][16];
   const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cq;
   const bool ok = col < H;
@@ -183,15 +173,15 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
   const float* __restrict__ z = me.z;
   const float* __restrict__ part_mean = me.scratch;
   const float* __restrict__ part_m2 = me.scratch + (long long)nrb * H;
-  // a block transforms `slabs` slabs of 16 rows (launcher: 1 up to B = 1024, then B/1024): the gather + merge of the
-  // partials is paid once per block, and at B = 2048 it was most of a 19.6 us launch
+  // a block transforms `slabs` slabs of 16 rows (launcher: 1 up to B = 1024, then B/1024): the merge of the partials is paid
+  // once per block
   const int slabs = pr.slabs;
   // request everything first: the partials' slice, the affine pair, this thread's rows
   // the block that updates the running statistics of a two-problem launch also needs problem 1's merged statistics
   const bool second = blockIdx.y == 0 && blockIdx.z == 0 && pr.n > 1;   // (uniform per block)
   PartRegs prg, prg1;
-  gather_request(prg, part_mean, part_m2, nrb, H, blockIdx.x * 64);
-  if (second) gather_request(prg1, pr.p[1].scratch, pr.p[1].scratch + (long long)nrb * H, nrb, H, blockIdx.x * 64);
+  part_request(prg, part_mean, part_m2, nrb, H, col, ok, slot);
+  if (second) part_request(prg1, pr.p[1].scratch, pr.p[1].scratch + (long long)nrb * H, nrb, H, col, ok, slot);
   const v4f g = ok ? ld4(gamma + col) : zero4(), bt = ok ? ld4(beta + col) : zero4();
   v4f v[kBnSlabMax];
 #pragma unroll
@@ -201,9 +191,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
   }
   v4f rm0 = zero4(), rv0 = zero4();
   if (blockIdx.y == 0 && blockIdx.z == 0 && slot == 0 && ok) { rm0 = ld4(rmean + col); rv0 = ld4(rvar + col); }
-  gather_store(prg, sp);
   v4f mean, var;
-  bn_merge4(sp, cq, part_mean, part_m2, H, col, ok, nrb, B, rpp, &mean, &var, pr.world);   // biased variance: what normalises the batch
+  bn_merge_slots(prg, part_mean, part_m2, red, cq, slot, H, col, ok, nrb, B, rpp, pr.world, &mean, &var);   // biased variance: what normalises the batch
   v4f invstd;
 #pragma unroll
   for (int q = 0; q < 4; ++q) invstd[q] = 1.0f / sqrtf(var[q] + kBnEps);
@@ -229,12 +218,10 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(BnFwdPair pr, int B,
     v4f rm = (1.0f - kBnMomentum) * rm0 + kBnMomentum * mean;
     v4f rv = (1.0f - kBnMomentum) * rv0 + kBnMomentum * (var * ub);
     if (second) {
-      __syncthreads();   // every thread is done with problem 0's partials
-      gather_store(prg1, sp);
       const float* pm1 = pr.p[1].scratch;
       const float* pq1 = pm1 + (long long)nrb * H;
       v4f m1, v1;
-      bn_merge4(sp, cq, pm1, pq1, H, col, ok, nrb, B, rpp, &m1, &v1, pr.world);
+      bn_merge_slots(prg1, pm1, pq1, red, cq, slot, H, col, ok, nrb, B, rpp, pr.world, &m1, &v1);
       rm = (1.0f - kBnMomentum) * rm + kBnMomentum * m1;
       rv = (1.0f - kBnMomentum) * rv + kBnMomentum * (v1 * ub);
     }
@@ -314,13 +301,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ part_dyx, int B, int H,
                                                                 float* __restrict__ dz, float* dgamma, float* dbeta,
                                                                 float* sumsq_out, int slabs, int world, int rank) {
-  __shared__ v4f sp[2][kBnMaxPart][16];
+  __shared__ v4f red[kBnSlots][16];
   const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cq;
   const bool ok = col < H;
   const int nrb_l = (B + kBnRows - 1) / kBnRows, nrb = nrb_l * world;   // (BnSync: every rank's partials, rank-major)
   PartRegs prg;
-  gather_request(prg, part_dy, part_dyx, nrb, H, blockIdx.x * 64);
+  part_request(prg, part_dy, part_dyx, nrb, H, col, ok, slot);
   const v4f g = ok ? ld4(gamma + col) : zero4(), bt = ok ? ld4(beta + col) : zero4(), is = ok ? ld4(invstd + col) : zero4();
   v4f vd[kBnSlabMax], vd2[kBnSlabMax], vx[kBnSlabMax];
 #pragma unroll
@@ -332,21 +319,23 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
     vd2[sl] = (in && dh2) ? ld4(dh2 + idx) : zero4();
     vx[sl] = in ? ld4(xhat + idx) : zero4();
   }
-  gather_store(prg, sp);
+  // this slot's partials (s, s + 16, ...), then the block's slot sums (the forward's merge, above)
   v4f sum_dy = zero4(), sum_dyx = zero4();
   v4f own_dy = zero4(), own_dyx = zero4();      // this rank's share: what dgamma | dbeta hold (the gradient exchange sums the ranks')
-  const int nl = min(nrb, kBnMaxPart);
-#pragma unroll 8
-  for (int rb = 0; rb < nl; ++rb) {
-    const v4f a1 = sp[0][rb][cq], a2 = sp[1][rb][cq];
-    sum_dy += a1; sum_dyx += a2;
-    if (rb / nrb_l == rank) { own_dy += a1; own_dyx += a2; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rb = slot + kBnSlots * u;
+    sum_dy += prg.a[u]; sum_dyx += prg.b[u];     // (zeros past nrb)
+    if (rb < nrb && rb / nrb_l == rank) { own_dy += prg.a[u]; own_dyx += prg.b[u]; }
   }
-  for (int rb = nl; rb < nrb; ++rb) {
+  for (int rb = slot + 2 * kBnSlots; rb < nrb; rb += kBnSlots) {
     const v4f a1 = ok ? ld4(part_dy + (long long)rb * H + col) : zero4(), a2 = ok ? ld4(part_dyx + (long long)rb * H + col) : zero4();
     sum_dy += a1; sum_dyx += a2;
     if (rb / nrb_l == rank) { own_dy += a1; own_dyx += a2; }
   }
+  sum_dy = slot_sum(sum_dy, red, cq, slot);
+  sum_dyx = slot_sum(sum_dyx, red, cq, slot);
+  if (world > 1) { own_dy = slot_sum(own_dy, red, cq, slot); own_dyx = slot_sum(own_dyx, red, cq, slot); }
   const v4f k = g * is;
   const float Bt = (float)B * (float)world;
   const v4f m1 = sum_dy / Bt, m2 = sum_dyx / Bt;
@@ -431,16 +420,23 @@ __global__ void tanh_gauss_fwd2_kernel(TanhGaussArgs a0, TanhGaussArgs a1) {
   else tanh_gauss_fwd_body(a1);
 }
 
-__device__ inline void actor_select_body(const ActorSelArgs& a, float* scratch) {
-  const StepCtrl c = *a.cur;
+// (round 4: every operand of a thread's (up to) two rows is requested before any store — the compiler must assume dq aliases
+// q / logp, and each row's later loads used to wait behind its first stores; ops.hip td_loss_kernel has the numbers)
+struct SelRow { float q[kMaxCritics], lp; };
+// the thread's share of sum_b (alpha * logp_b - sel_b); mb: row blockIdx.x * 256 + threadIdx.x only (multi-workgroup form)
+__device__ inline float actor_select_acc(const ActorSelArgs& a, bool mb) {
   const float alpha = a.alpha_dev ? *a.alpha_dev : a.alpha_const;
   const int B = a.B, C = a.C, keep = a.C - a.drop;
   const float gb = -1.0f / (float)B;
   float acc = 0.f;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    float q[kMaxCritics];
+  auto fetch = [&](SelRow& w, int b) {
+    const bool in = b < B;
 #pragma unroll
-    for (int k = 0; k < kMaxCritics; ++k) q[k] = (k < C) ? a.q[(long long)k * B + b] : INFINITY;
+    for (int k = 0; k < kMaxCritics; ++k) w.q[k] = (in && k < C) ? a.q[(long long)k * B + b] : INFINITY;
+    w.lp = in ? a.logp[b] : 0.f;
+  };
+  auto finish = [&](SelRow& w, int b) {
+    float* q = w.q;
     float sel;
     if (C == 2 && a.drop == 0) {
       // torch.min(q1, q2): gradient to the smaller, split on ties
@@ -473,10 +469,29 @@ __device__ inline void actor_select_body(const ActorSelArgs& a, float* scratch) 
       for (int k = 0; k < kMaxCritics; ++k) if (k < keep) s = __fadd_rn(s, q[k]);
       sel = s / (float)keep;
     }
-    acc += __fsub_rn(__fmul_rn(alpha, a.logp[b]), sel);
+    acc += __fsub_rn(__fmul_rn(alpha, w.lp), sel);
+  };
+  if (mb) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    SelRow w;
+    fetch(w, b);
+    if (b < B) finish(w, b);
+    return acc;
   }
-  acc = block_sum(acc, scratch);
-  if (threadIdx.x == 0) a.metrics[(long long)c.metrics_slot * kMetricFloats + MET_ACTOR_LOSS] = acc / (float)B;
+  for (int b0 = threadIdx.x; b0 < B; b0 += 2 * blockDim.x) {
+    const int b1 = b0 + blockDim.x;
+    SelRow w0, w1;
+    fetch(w0, b0);
+    fetch(w1, b1);
+    finish(w0, b0);
+    if (b1 < B) finish(w1, b1);
+  }
+  return acc;
+}
+__device__ inline void actor_select_body(const ActorSelArgs& a, float* scratch) {
+  const StepCtrl c = *a.cur;
+  const float acc = block_sum(actor_select_acc(a, false), scratch);
+  if (threadIdx.x == 0) a.metrics[(long long)c.metrics_slot * kMetricFloats + MET_ACTOR_LOSS] = acc / (float)a.B;
 }
 
 __global__ __launch_bounds__(1024) void actor_select_kernel(ActorSelArgs a) {
@@ -537,9 +552,63 @@ __global__ __launch_bounds__(1024) void alpha_update_kernel(AlphaArgs a) {
 // actor-loss selection and the log-alpha gradient (both single-block passes over logp) in one launch
 __global__ __launch_bounds__(1024) void actor_select_alpha_kernel(ActorSelArgs s, AlphaArgs al) {
   __shared__ float scratch[16];
+  if (blockIdx.x == 1) {   // the rider: ops.hip mean_metric_kernel's sums
+    float m = 0.f;
+#pragma unroll 8
+    for (int i = threadIdx.x; i < s.mean_n; i += blockDim.x) m += s.mean_x[i];
+    m = block_sum(m, scratch);
+    if (threadIdx.x == 0) s.metrics[(long long)s.cur->metrics_slot * kMetricFloats + s.mean_index] = m / (float)s.mean_n;
+    return;
+  }
   actor_select_body(s, scratch);
   __syncthreads();
   alpha_body(al, scratch);
+}
+
+// Multi-workgroup form of the same launch (round 4, B >= 1024 with the agent's scratch; ops.hip td_loss_kernel<.., MB> has the
+// reasoning: one workgroup is bound by its CU's issue rate).  Workgroups of 256 threads, one row per thread; every wave leaves
+// its partial of the two sums (actor loss terms; logp + target entropy) at part[(workgroup * 4 + wave) * 2 + {0, 1}], the last
+// workgroup to arrive adds them up in index order and finishes both results.  Workgroup gridDim.x - 1 is the q_value rider when
+// there is one (it takes no ticket).
+__global__ __launch_bounds__(256) void actor_select_alpha_mb_kernel(ActorSelArgs s, AlphaArgs al) {
+  __shared__ float scratch[16];
+  const int nb = (s.B + 255) / 256;
+  if ((int)blockIdx.x >= nb) {   // the rider
+    float m = 0.f;
+#pragma unroll 8
+    for (int i = threadIdx.x; i < s.mean_n; i += 256) m += s.mean_x[i];
+    m = block_sum_256(m, scratch);
+    if (threadIdx.x == 0) s.metrics[(long long)s.cur->metrics_slot * kMetricFloats + s.mean_index] = m / (float)s.mean_n;
+    return;
+  }
+  const StepCtrl c = *s.cur;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const float lp = (c.do_alpha && b < al.B) ? al.logp[b] + al.target_entropy : 0.f;
+  const float acc = wave_sum(actor_select_acc(s, true));
+  const float lps = wave_sum(lp);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    float* mine = s.part + ((long long)blockIdx.x * 4 + wave) * 2;
+    __hip_atomic_store(mine, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + 1, lps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  drain_stores();
+  __syncthreads();
+  unsigned int* s_ticket = reinterpret_cast<unsigned int*>(scratch);
+  if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(s.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*s_ticket != (unsigned)(nb - 1)) return;   // (uniform)
+  if (threadIdx.x == 0) __hip_atomic_store(s.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  if (threadIdx.x > 1) return;
+  float t = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < 4 * nb; ++i) t += __hip_atomic_load(s.part + (long long)i * 2 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* met = s.metrics + (long long)c.metrics_slot * kMetricFloats;
+  if (threadIdx.x == 0) { met[MET_ACTOR_LOSS] = t / (float)s.B; return; }
+  if (!c.do_alpha) { met[MET_ALPHA_LOSS] = 0.f; met[MET_ALPHA] = *al.alpha; return; }   // `gradient_step <= alpha_min_steps: return 0.0`
+  const float mean_x = t / (float)al.B;
+  met[MET_ALPHA_LOSS] = -(*al.log_alpha * mean_x);
+  *al.grad_out = -mean_x;
 }
 
 // row-block SAC: the selection kernel's outputs are metrics and the log-alpha gradient only (the row-block launch forms
@@ -698,7 +767,7 @@ int launch_quantile_actor(hipStream_t st, const QuantileActorArgs& a) {
 }
 
 static inline unsigned reduce_threads(long long n) { return (unsigned)std::min<long long>(1024, std::max<long long>(256, (n + 63) / 64 * 64)); }
-static inline int bn_slabs(int B) { return std::min(kBnSlabMax, std::max(1, B / 1024)); }
+static inline int bn_slabs(int B) { static const char* e = getenv("GCRL_BN_SLABS"); if (e) return atoi(e); return std::min(kBnSlabMax, std::max(1, B / 1024)); }
 static inline bool bn_aligned(const void* p) { return ((unsigned long long)p & 15ull) == 0; }
 
 int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float* gamma,
@@ -709,7 +778,7 @@ int launch_bn_relu_fwd(hipStream_t st, const float* z, int B, int H, const float
 }
 
 int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, int B, int H, const float* gamma,
-                             const float* beta, float* rmean, float* rvar, int rows_per_part, const BnSync* sync) {
+                             const float* beta, float* rmean, float* rvar, int rows_per_part, const BnSync* sync, bool stats_done) {
   GCRL_CHECK_ARG(nprob == 1 || nprob == 2, "bn_relu_fwd_multi: 1 or 2 problems");
   const int world = (sync && sync->world > 1) ? sync->world : 1;
   GCRL_CHECK_ARG(world == 1 || (rows_per_part == kBnRows && sync->exchange && world < kBnSlots && sync->rank >= 0 && sync->rank < world),
@@ -726,7 +795,8 @@ int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, 
   pr.p[1] = nprob > 1 ? probs[1] : probs[0];
   pr.rpp = rows_per_part;
   pr.world = world; pr.rank = world > 1 ? sync->rank : 0;
-  if (rows_per_part == kBnRows) {
+  GCRL_CHECK_ARG(!stats_done || (rows_per_part == kBnRows && world == 1), "bn_relu_fwd_multi: partials from the tiled GEMM are 64-row ones of one rank");
+  if (rows_per_part == kBnRows && !stats_done) {
     hipLaunchKernelGGL(bn_stats_kernel, dim3((H + 63) / 64, nrb, nprob), dim3(256), 0, st, pr, B, H);
     GCRL_HIP(hipGetLastError());
   }
@@ -798,7 +868,12 @@ int launch_actor_select(hipStream_t st, const ActorSelArgs& a) {
 
 int launch_actor_select_alpha(hipStream_t st, const ActorSelArgs& a, const AlphaArgs& al) {
   GCRL_CHECK_ARG(a.C >= 1 && a.C <= kMaxCritics && a.drop >= 0 && a.drop < a.C, "actor_select: bad C=%d drop=%d", a.C, a.drop);
-  hipLaunchKernelGGL(actor_select_alpha_kernel, dim3(1), dim3(reduce_threads(a.B)), 0, st, a, al);
+  if (a.part && a.ticket && a.B >= 1024 && al.phase == 0 && al.B == a.B) {
+    hipLaunchKernelGGL(actor_select_alpha_mb_kernel, dim3((a.B + 255) / 256 + (a.mean_x ? 1 : 0)), dim3(256), 0, st, a, al);
+    GCRL_HIP(hipGetLastError());
+    return GCRL_OK;
+  }
+  hipLaunchKernelGGL(actor_select_alpha_kernel, dim3(a.mean_x ? 2 : 1), dim3(reduce_threads(a.B)), 0, st, a, al);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

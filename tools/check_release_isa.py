@@ -29,6 +29,8 @@ UNITS = {
     "rowchain.hip": ["rowchain_split_kernel"],
     "gemm_mfma.hip": ["gemm_tiled_kernel"],
     "xchg_ipc.hip": ["xchg_two_shot_kernel"],
+    "ops.hip": ["td_loss_kernelILi3ELi0ELb1"],
+    "ops_sac.hip": ["actor_select_alpha_mb_kernel"],
 }
 
 STORE_WT = re.compile(r"^\s*(buffer_store|global_store|flat_store)\S*\s.*\bsc1\b")

@@ -1,11 +1,16 @@
-"""Idle gaps between consecutive kernels of the last `n` kernels of a rocprofv3 kernel trace (the bench's timed region)."""
+"""Idle gaps between consecutive kernels of the last `n` kernels of a rocprofv3 kernel trace (the bench's timed region);
+an optional third argument names a kernel: the window then ends at its last launch."""
 import csv
 import glob
 import sys
 
 d, n = sys.argv[1], int(sys.argv[2])
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
-rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))[-n:]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+if len(sys.argv) > 3:
+    last = max(i for i, r in enumerate(rows) if sys.argv[3] in r["Kernel_Name"])
+    rows = rows[:last + 1]
+rows = rows[-n:]
 t0 = int(rows[0]["Start_Timestamp"])
 prev_end = None
 busy = 0
