@@ -63,7 +63,7 @@ int gcrl_sort_truncate_mean(const float* in_dev, int64_t rows, int width, int dr
 int gcrl_gemm_f32(const float* a, int64_t a_rs, int64_t a_cs, const float* b, int64_t b_rs, int64_t b_cs,
                   float* c, int64_t c_rs, const float* bias, int M, int N, int K, int act, int shape,
                   void* stream) {
-  GCRL_CHECK_ARG(act >= 0 && act <= 3 && shape >= 0 && shape <= 4, "gcrl_gemm_f32: bad act/shape");
+  GCRL_CHECK_ARG(act >= 0 && act <= 3 && shape >= 0 && shape <= 5, "gcrl_gemm_f32: bad act/shape");
   gcrl::GemmDesc d;
   std::memset(&d, 0, sizeof(d));
   d.A = a; d.a_rs = a_rs; d.a_cs = a_cs;

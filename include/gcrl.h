@@ -523,7 +523,8 @@ int gcrl_sort_truncate_mean(const float* in_dev, int64_t rows, int width, int dr
  * problem: C[M,N] = act(A.B + bias) with element strides (A(m,k) = A[m*a_rs + k*a_cs],
  * B(k,n) = B[k*b_rs + n*b_cs], C row stride c_rs); act: 0 none, 1 LeakyReLU(0.01), 2 ReLU,
  * 3 tanh.  shape: 0 auto, 1 = 16x16 tile per workgroup with K split over its 4 waves,
- * 2 = 16x16 per wave, 3 = 32x32 per wave, 4 = LDS-tiled 64x64 per workgroup (tests sweep all). */
+ * 2 = 16x16 per wave, 3 = 32x32 per wave, 4 = LDS-tiled 64x64 per workgroup, 5 = K == 1 only: the outer product as a
+ * streaming kernel (16-byte aligned B / C / bias, N and c_rs multiples of 4, b_cs == 1; else GCRL_ERR_ARG) — tests sweep all. */
 int gcrl_gemm_f32(const float* a_dev, int64_t a_rs, int64_t a_cs, const float* b_dev, int64_t b_rs,
                   int64_t b_cs, float* c_dev, int64_t c_rs, const float* bias_dev, int M, int N,
                   int K, int act, int shape, void* stream);

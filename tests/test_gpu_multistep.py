@@ -121,6 +121,38 @@ def test_update_many_is_bitwise_at_the_benchmarked_sizes(gcrl, kind, H, L, B):
     assert all(np.isfinite(v) for t in t_one for v in t)
 
 
+def test_round4_layer_path_forms_change_nothing_but_metric_roundings(gcrl, monkeypatch):
+    """TQC at BASELINE cfg 4's shape with round 4's layer-per-launch forms (BatchNorm partials out of the tiled GEMM's epilogue,
+    multi-workgroup td_loss / actor_select_alpha, control advance riding the actor's optimiser launch) against the same agent
+    with the three knobs that restore round 3's launches: every parameter, running statistic and alpha bitwise equal — the
+    fused partials are the sums bn_stats_kernel forms, in its order; the reductions feed logged numbers only — and the logged
+    numbers equal to rounding."""
+    kind, H, L, B, gstep = "TQC", 512, 3, 2048, 4
+    cfg = _cfg(kind, H, L, B, max_len=20000)
+
+    def build():
+        ag = _cls(gcrl, kind)(S, A, cfg, None, nenvs=2, gradient_step=gstep, rng="engine", seed=33)
+        gen = np.random.default_rng(5)
+        ep = 0
+        while len(ag.buffer) < B + 500:
+            for st in her_oracle.synthetic_episode(gen, 50, S, A):
+                ag.push_her(ep % 2, *st)
+            ep += 1
+        return ag
+
+    new = build()
+    for k in ("GCRL_NO_BN_TILED_STATS", "GCRL_NO_LAYER_ADV", "GCRL_NO_MB_REDUCE"):
+        monkeypatch.setenv(k, "1")
+    old = build()
+    t_new = [tuple(float(x) for x in t) for t in new.update_many(1, 9)]
+    t_old = [tuple(float(x) for x in t) for t in old.update_many(1, 9)]
+    for x, y in zip(_state(new), _state(old)):
+        assert np.array_equal(x, y)
+    for a, b in zip(t_new, t_old):
+        assert len(a) == len(b) and np.allclose(a, b, rtol=2e-6, atol=1e-7), (a, b)
+    assert all(np.isfinite(v) for t in t_new for v in t)
+
+
 def _engine_noise(seed, stream, step_index, B, n_cols):
     """What the engine draws for the step planned `step_index`-th since the agent was created (csrc/agent.hip plan_step:
     counter base += 16 * B per step; csrc/ops.h hash_normal(seed + stream, base + b * A + j)): TD3 smoothing noise is stream 0,

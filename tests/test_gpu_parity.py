@@ -65,6 +65,28 @@ def test_gemm_forms_against_fp64(lib, M, N, K, shape):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("M,N", [(2048, 512), (1024, 256), (77, 36), (5, 4)])
+def test_gemm_outer_form_equals_the_mfma_form(lib, M, N):
+    """K = 1 (the input gradient of a one-output head): the streaming form (5) writes what the matrix-core form (3) writes,
+    with and without bias / activation; a misaligned problem is refused."""
+    gen = torch.Generator().manual_seed(M + N)
+    g = torch.randn(M, 1, generator=gen).cuda()
+    w = torch.randn(1, N, generator=gen).cuda()
+    b = torch.randn(N, generator=gen).cuda()
+    for act, bias in ((0, None), (1, b.data_ptr()), (3, b.data_ptr())):
+        out = [torch.full((M, N), float("nan"), device="cuda") for _ in range(2)]
+        for o, shape in zip(out, (3, 5)):
+            assert lib.gcrl_gemm_f32(g.data_ptr(), 1, 1, w.data_ptr(), N, 1, o.data_ptr(), N, bias, M, N, 1, act, shape, 1) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], out[1])          # (-0 == +0: the MFMA path adds its padded k, exact zeros)
+        ref = g.double() @ w.double() + (b.double() if bias else 0)
+        ref = torch.nn.functional.leaky_relu(ref, 0.01) if act == 1 else (torch.tanh(ref) if act == 3 else ref)
+        assert vec_close(out[1].cpu().numpy(), ref.cpu().numpy(), rtol=2e-6)
+    o = torch.empty(M, N + 1, device="cuda")
+    assert lib.gcrl_gemm_f32(g.data_ptr(), 1, 1, w.data_ptr(), N, 1, o.data_ptr(), N + 1, None, M, N, 1, 0, 5, 1) != 0   # c_rs % 4 != 0
+    assert lib.gcrl_gemm_f32(g.data_ptr(), 1, 1, w.data_ptr(), N, 1, o.data_ptr(), N, None, M, N, 2, 0, 5, 1) != 0       # K != 1
+
+
 def test_gemm_asymmetric_identity(lib):
     """A = I with an asymmetric B catches a transposed C write (guide §3)."""
     n = 48
