@@ -163,6 +163,10 @@ struct gcrl_agent {
   bool rc_merge_k = false;    // TD3 (split_k): the critic phase's two launches as one, producers / consumers form (meet.h)
   float* rc_bar = nullptr;    // meeting counters of the row blocks [2][nblk][32 words]
   long long rc_bar_words = 0;
+  // weight-slice form of the DDPG launch (rowtile.hip): a 16 x 16 tile of every layer per workgroup, hand-offs inside the launch
+  bool rowtile = false, rowtile_can = false;
+  float *rt_xT = nullptr, *rt_gP = nullptr, *rt_qpart = nullptr, *rt_ctr = nullptr, *rt_xid = nullptr;
+  long long rt_ctr_words = 0;   // 64-bit words
   // host-visible status word of the launches whose workgroups wait for each other (meet.h): a timed-out wait sets a bit, the
   // next host synchronisation of this handle returns GCRL_ERR_STATE, zeroes the counters and clears it (meet_check below)
   unsigned int *status_host = nullptr, *status_dev = nullptr;
@@ -1155,6 +1159,7 @@ int meet_check(gcrl_agent* a) {
   (void)hipDeviceSynchronize();
   if (a->bn_bar) (void)hipMemset(a->bn_bar, 0, (size_t)bn_slab_bar_words(a->H) * sizeof(unsigned int));
   if (a->rc_bar && a->rc_bar_words) (void)hipMemset(a->rc_bar, 0, (size_t)a->rc_bar_words * sizeof(unsigned int));
+  if (a->rt_ctr && a->rt_ctr_words) (void)hipMemset(a->rt_ctr, 0, (size_t)a->rt_ctr_words * sizeof(unsigned long long));
   if (bits & (MEET_ERR_XCHG_READY | MEET_ERR_XCHG_DONE)) {
     (void)hipDeviceSynchronize();
     __atomic_store_n(a->status_host, 0u, __ATOMIC_RELEASE);
@@ -1173,6 +1178,13 @@ int bytes_alloc(float** p, long long n) {
   GCRL_HIP(hipMalloc((void**)p, (size_t)n * sizeof(float)));
   GCRL_HIP(hipMemset(*p, 0, (size_t)n * sizeof(float)));
   return GCRL_OK;
+}
+
+// the weight-slice DDPG launch (rowtile.hip): GCRL_ROWTILE=1 turns it on, GCRL_NO_ROWTILE=1 off (the default until its full-size
+// parity and speed are recorded)
+bool rowtile_enabled() {
+  if (std::getenv("GCRL_NO_ROWTILE")) return false;
+  return std::getenv("GCRL_ROWTILE") != nullptr;
 }
 
 int build(gcrl_agent* a) {
@@ -1295,6 +1307,15 @@ int build(gcrl_agent* a) {
       const long long nblk = (B + 4 * a->row_rg - 1) / (4 * a->row_rg);
       a->rc_bar_words = 2 * nblk * 32;
       wants.push_back({&a->rc_bar, a->rc_bar_words});
+    }
+    // DDPG, one critic: the weight-slice launch (rowtile.hip) when all its 3 * (B/16) * (H/16) workgroups are resident at once
+    a->rowtile_can = a->rowchain && c.kind == GCRL_AGENT_DDPG && C == 1 && rowtile_shape_ok(B, H, L, S, A, C);
+    a->rowtile = a->rowtile_can && rowtile_enabled() && rowtile_ok(B, H, L, S, A, C);
+    if (a->rowtile_can) {
+      a->rt_ctr_words = rowtile_ctr_words(B, L);
+      wants.push_back({&a->rt_xT, 2LL * L * BH}); wants.push_back({&a->rt_gP, (long long)L * BH});
+      wants.push_back({&a->rt_qpart, rowtile_part_floats(B, H)}); wants.push_back({&a->rt_ctr, 2 * a->rt_ctr_words});
+      wants.push_back({&a->rt_xid, 3LL * (B / 16) * 32});
     }
     a->head_batches = 3;   // (TD3 at batch 2048: the host draws 38 x 2048 indices in ~390 us, more than two 170 us steps)
     if (const char* e = std::getenv("GCRL_HEAD_BATCHES")) a->head_batches = std::max(1, std::min(8, std::atoi(e)));   // experiment knob
@@ -1904,7 +1925,8 @@ int gcrl_agent_set_meetings(gcrl_agent* a, int on) {
   a->rc_merge = want && a->rc_bar && a->split_roles && !std::getenv("GCRL_NO_RC_MERGE") && !std::getenv("GCRL_SPLIT_RG") &&
                 rowchain_merge_ok(a->row_rg, a->row_ldl, c.ac_dim, a->H, a->C, a->B);
   a->rc_merge_k = want && a->rc_bar && a->split_k && !std::getenv("GCRL_NO_RC_MERGE");
-  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k) ? 2 : 0);
+  a->rowtile = want && a->rowtile_can && rowtile_enabled() && rowtile_ok(a->B, a->H, a->L, a->S, a->A, a->C);
+  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k) ? 2 : 0) | (a->rowtile ? 4 : 0);
 }
 
 int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
@@ -1915,6 +1937,10 @@ int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
   // kept off the chip would cause
   const unsigned long long one = 7;
   float* words = a->rc_merge ? a->rc_bar : (a->bn_rsplit > 1 ? a->bn_bar : nullptr);
+  if (a->rowtile) {   // the actor-phase role's first hand-off counter of row block 0 (stage 1): +7 of 16 arrivals
+    GCRL_HIP(hipMemcpy(a->rt_ctr + 2 * 16, &one, sizeof(one), hipMemcpyHostToDevice));
+    return GCRL_OK;
+  }
   if (a->rc_merge_k) {   // producers / consumers: a consumer's own launch count far ahead of its producers' counter
     const unsigned long long far = 1ull << 40;
     GCRL_HIP(hipMemcpy(a->rc_bar + 4, &far, sizeof(far), hipMemcpyHostToDevice));    // (64-bit word 2 of row block 0's line: critic 0's consumer)

@@ -330,6 +330,26 @@ struct RowActInline {
 };
 int launch_rowchain_act_inline(hipStream_t st, const RowActInline& a);
 
+// Weight-slice form of the DDPG launch (rowtile.hip): a workgroup owns the 16 x 16 tile (row block, column block) of every
+// layer of its role's chain; the H / 16 workgroups of a row block hand the layer outputs to each other inside the launch.
+struct RowTileArgs {
+  RowChainArgs rc;            // networks, batch arrays, outputs (nblk_k / nblk_p != 0: which phases run)
+  float* xT;                  // target networks' activations [2L][B][H] (hand-off only)
+  float* gP;                  // actor phase: the critic's pre-activation gradients [L][B][H] (hand-off only)
+  float* qpart;               // scalar-head partials [3][B/16][H/16][16]: Q' (target role), q (online critic), Q(s, pi(s))
+  unsigned long long* ctr;    // arrival counters [3 roles][B/16][2 + 4L stages][16 words]: one 128-byte line each, zero-initialised
+  unsigned int* xid;          // [3 roles][B/16][32]: the XCD of each workgroup of a row block (+1)
+  unsigned int* status;       // host-visible word: MEET_ERR_ROWCHAIN on a timed-out wait
+  int force_sc1;              // never the plain-store form (GCRL_ROWTILE_SC1=1)
+  // filled by the launcher
+  int roles[3], nroles, nstage, w16, ldsx, kperx, force_linear, role_mask;
+};
+bool rowtile_shape_ok(int B, int H, int L, int S, int A, int C);
+bool rowtile_ok(int B, int H, int L, int S, int A, int C);   // ... and all 3 * (B/16) * (H/16) workgroups resident at once, device not shared
+long long rowtile_ctr_words(int B, int L);                   // 64-bit words
+long long rowtile_part_floats(int B, int H);
+int launch_rowtile_ddpg(hipStream_t st, RowTileArgs t);
+
 // rows per workgroup = 4*rg, rg in {1, 2, 4}
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg);
 size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C);

@@ -1,0 +1,11 @@
+#!/bin/bash
+# the weight-slice (16 x 16 tile per workgroup) form of a dependent chain of layer passes, measured (tools/microbench_rowtile.hip)
+set -e
+out=$GRAFT_REPO_ROOT/gpurun_out/${1:-rowtile}
+mkdir -p $out
+cd $GRAFT_REPO_ROOT
+for B in 256 128; do
+  echo "== B=$B H=256 NL=10" >> $out/microbench.txt
+  timeout -k 10 150 ./tools/microbench_rowtile $B 256 10 >> $out/microbench.txt
+done
+cat $out/microbench.txt
