@@ -161,11 +161,13 @@ struct gcrl_agent {
   int n_cus = 0;              // compute units of the device (residency checks of the launches whose workgroups meet)
   bool rc_merge = false;      // ... forward and backward part in ONE launch each (part 3; GCRL_NO_RC_MERGE=1: two launches)
   bool rc_merge_k = false;    // TD3 (split_k): the critic phase's two launches as one, producers / consumers form (meet.h)
+  bool ddpg_ksplit = false, ddpg_ksplit_can = false;   // DDPG: the critic phase as two roles of the fused launch (rowchain.hip, k_split)
   float* rc_bar = nullptr;    // meeting counters of the row blocks [2][nblk][32 words]
   long long rc_bar_words = 0;
   // weight-slice form of the DDPG launch (rowtile.hip): a 16 x 16 tile of every layer per workgroup, hand-offs inside the launch
   bool rowtile = false, rowtile_can = false;
-  float *rt_xT = nullptr, *rt_gP = nullptr, *rt_qpart = nullptr, *rt_ctr = nullptr, *rt_xid = nullptr;
+  float *rt_xb = nullptr, *rt_qpart = nullptr, *rt_ctr = nullptr, *rt_xid = nullptr;
+  long long rt_xb_floats = 0, rt_part_floats = 0;
   long long rt_ctr_words = 0;   // 64-bit words
   // host-visible status word of the launches whose workgroups wait for each other (meet.h): a timed-out wait sets a bit, the
   // next host synchronisation of this handle returns GCRL_ERR_STATE, zeroes the counters and clears it (meet_check below)
@@ -1152,6 +1154,7 @@ int end_call(gcrl_agent* a, hipStream_t st) {
 // Called after every host synchronisation of the handle: the error surfaces ONCE, the meeting counters are zeroed (a
 // timed-out round may have left them off a multiple of the arrival count) and the next launch works again.  The reference
 // raises on any failed step (src/agent.py:659-699).
+int rowtile_reset(gcrl_agent* a);
 int meet_check(gcrl_agent* a) {
   if (!a->status_host) return GCRL_OK;
   const unsigned int bits = __atomic_load_n(a->status_host, __ATOMIC_ACQUIRE);
@@ -1159,7 +1162,7 @@ int meet_check(gcrl_agent* a) {
   (void)hipDeviceSynchronize();
   if (a->bn_bar) (void)hipMemset(a->bn_bar, 0, (size_t)bn_slab_bar_words(a->H) * sizeof(unsigned int));
   if (a->rc_bar && a->rc_bar_words) (void)hipMemset(a->rc_bar, 0, (size_t)a->rc_bar_words * sizeof(unsigned int));
-  if (a->rt_ctr && a->rt_ctr_words) (void)hipMemset(a->rt_ctr, 0, (size_t)a->rt_ctr_words * sizeof(unsigned long long));
+  (void)rowtile_reset(a);
   if (bits & (MEET_ERR_XCHG_READY | MEET_ERR_XCHG_DONE)) {
     (void)hipDeviceSynchronize();
     __atomic_store_n(a->status_host, 0u, __ATOMIC_RELEASE);
@@ -1172,6 +1175,14 @@ int meet_check(gcrl_agent* a) {
   return fail(GCRL_ERR_STATE, "a wait between workgroups inside a launch timed out (status 0x%x:%s%s); the affected step's statistics / gradients are NaN. "
                               "The device is probably shared with other work: set GCRL_SHARED_GPU=1 (or gcrl_set_shared_device) to use the launch forms without such waits",
               bits, (bits & MEET_ERR_BN_SLAB) ? " BatchNorm slab row groups" : "", (bits & MEET_ERR_ROWCHAIN) ? " row-chain roles" : "");
+}
+
+// the weight-slice launch's hand-off words: "not written yet" everywhere, counters at zero (creation; after a timed-out wait)
+int rowtile_reset(gcrl_agent* a) {
+  if (a->rt_ctr && a->rt_ctr_words) GCRL_HIP(hipMemset(a->rt_ctr, 0, (size_t)a->rt_ctr_words * sizeof(unsigned long long)));
+  if (a->rt_xb && a->rt_xb_floats) GCRL_HIP(hipMemset(a->rt_xb, 0xFF, (size_t)a->rt_xb_floats * sizeof(float)));
+  if (a->rt_qpart && a->rt_part_floats) GCRL_HIP(hipMemset(a->rt_qpart, 0xFF, (size_t)a->rt_part_floats * sizeof(float)));
+  return GCRL_OK;
 }
 
 int bytes_alloc(float** p, long long n) {
@@ -1313,9 +1324,18 @@ int build(gcrl_agent* a) {
     a->rowtile = a->rowtile_can && rowtile_enabled() && rowtile_ok(B, H, L, S, A, C);
     if (a->rowtile_can) {
       a->rt_ctr_words = rowtile_ctr_words(B, L);
-      wants.push_back({&a->rt_xT, 2LL * L * BH}); wants.push_back({&a->rt_gP, (long long)L * BH});
-      wants.push_back({&a->rt_qpart, rowtile_part_floats(B, H)}); wants.push_back({&a->rt_ctr, 2 * a->rt_ctr_words});
+      a->rt_xb_floats = rowtile_xb_floats(B, H, L); a->rt_part_floats = rowtile_part_floats(B, H);
+      wants.push_back({&a->rt_xb, a->rt_xb_floats});
+      wants.push_back({&a->rt_qpart, a->rt_part_floats}); wants.push_back({&a->rt_ctr, 2 * a->rt_ctr_words});
       wants.push_back({&a->rt_xid, 3LL * (B / 16) * 32});
+    }
+    // DDPG: target chain and online critic of the critic phase in their own workgroups of the fused launch while all three roles'
+    // workgroups fit the chip at once (one per CU)
+    {
+      const long long nblk = (B + 4 * a->row_rg - 1) / (4 * a->row_rg);
+      a->ddpg_ksplit_can = a->rowchain && c.kind == GCRL_AGENT_DDPG && C == 1 && 3 * nblk <= std::max(a->n_cus, 1);
+      a->ddpg_ksplit = a->ddpg_ksplit_can && !meet_device_shared() && !std::getenv("GCRL_NO_DDPG_KSPLIT");
+      if (a->ddpg_ksplit_can && !a->rc_bar_words) { a->rc_bar_words = 2 * nblk * 32; wants.push_back({&a->rc_bar, a->rc_bar_words}); }
     }
     a->head_batches = 3;   // (TD3 at batch 2048: the host draws 38 x 2048 indices in ~390 us, more than two 170 us steps)
     if (const char* e = std::getenv("GCRL_HEAD_BATCHES")) a->head_batches = std::max(1, std::min(8, std::atoi(e)));   // experiment knob
@@ -1383,6 +1403,7 @@ int build(gcrl_agent* a) {
   TRY(bytes_alloc(&a->work, total));
   long long used = 0;
   for (auto& w : wants) { *w.first = a->work + used; used += align_up(w.second, 64); }
+  TRY(rowtile_reset(a));
 
   // upload block + pinned mirrors, metrics, events
   a->upload_bytes = sizeof(UploadBlock) + (size_t)kMaxStepsPerCall * B * sizeof(uint32_t);
@@ -1925,8 +1946,9 @@ int gcrl_agent_set_meetings(gcrl_agent* a, int on) {
   a->rc_merge = want && a->rc_bar && a->split_roles && !std::getenv("GCRL_NO_RC_MERGE") && !std::getenv("GCRL_SPLIT_RG") &&
                 rowchain_merge_ok(a->row_rg, a->row_ldl, c.ac_dim, a->H, a->C, a->B);
   a->rc_merge_k = want && a->rc_bar && a->split_k && !std::getenv("GCRL_NO_RC_MERGE");
+  a->ddpg_ksplit = want && a->ddpg_ksplit_can && a->rc_bar && !std::getenv("GCRL_NO_DDPG_KSPLIT");
   a->rowtile = want && a->rowtile_can && rowtile_enabled() && rowtile_ok(a->B, a->H, a->L, a->S, a->A, a->C);
-  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k) ? 2 : 0) | (a->rowtile ? 4 : 0);
+  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k || a->ddpg_ksplit) ? 2 : 0) | (a->rowtile ? 4 : 0);
 }
 
 int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
@@ -1937,11 +1959,11 @@ int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
   // kept off the chip would cause
   const unsigned long long one = 7;
   float* words = a->rc_merge ? a->rc_bar : (a->bn_rsplit > 1 ? a->bn_bar : nullptr);
-  if (a->rowtile) {   // the actor-phase role's first hand-off counter of row block 0 (stage 1): +7 of 16 arrivals
-    GCRL_HIP(hipMemcpy(a->rt_ctr + 2 * 16, &one, sizeof(one), hipMemcpyHostToDevice));
+  if (a->rowtile) {   // the first-arrival counter of the actor-phase role's row block 0: +7 of its H / 16 arrivals
+    GCRL_HIP(hipMemcpy(a->rt_ctr, &one, sizeof(one), hipMemcpyHostToDevice));
     return GCRL_OK;
   }
-  if (a->rc_merge_k) {   // producers / consumers: a consumer's own launch count far ahead of its producers' counter
+  if (a->rc_merge_k || (a->ddpg_ksplit && !a->rowtile)) {   // producers / consumers: a consumer's own launch count far ahead of its producers' counter
     const unsigned long long far = 1ull << 40;
     GCRL_HIP(hipMemcpy(a->rc_bar + 4, &far, sizeof(far), hipMemcpyHostToDevice));    // (64-bit word 2 of row block 0's line: critic 0's consumer)
     return GCRL_OK;

@@ -277,6 +277,8 @@ struct RowChainArgs {
   // them (word 4 + 2 * critic of the row block's line: that consumer's own launch count) — admissible WITHOUT all workgroups
   // being resident at once (TD3 at batch 2048: 1 024 workgroups of 8 rows)
   int producers_first;
+  // DDPG (rowchain_ddpg_kernel): the critic phase as the two roles above inside the fused launch (needs bar, qt, producers_first)
+  int k_split;
 };
 
 // Twin-critic phases as role-parallel launches (SAC; TD3 at small batches).  In the fused kernel a workgroup
@@ -334,19 +336,19 @@ int launch_rowchain_act_inline(hipStream_t st, const RowActInline& a);
 // layer of its role's chain; the H / 16 workgroups of a row block hand the layer outputs to each other inside the launch.
 struct RowTileArgs {
   RowChainArgs rc;            // networks, batch arrays, outputs (nblk_k / nblk_p != 0: which phases run)
-  float* xT;                  // target networks' activations [2L][B][H] (hand-off only)
-  float* gP;                  // actor phase: the critic's pre-activation gradients [L][B][H] (hand-off only)
-  float* qpart;               // scalar-head partials [3][B/16][H/16][16]: Q' (target role), q (online critic), Q(s, pi(s))
-  unsigned long long* ctr;    // arrival counters [3 roles][B/16][2 + 4L stages][16 words]: one 128-byte line each, zero-initialised
-  unsigned int* xid;          // [3 roles][B/16][32]: the XCD of each workgroup of a row block (+1)
+  float* xb;                  // hand-off tile stages [2 roles][4L][B][H], every word 0xFFFFFFFF ("not written yet") between launches
+  float* qpart;               // scalar-head partials [3][B/16][H/16][16]: Q' (target chain), q (online critic), Q(s, pi(s)); same convention
+  unsigned long long* ctr;    // first-arrival counters [2 roles][B/16][16 words]: one 128-byte line each, zero-initialised, monotonic
+  unsigned int* xid;          // [2 roles][B/16][32]: the XCD of each workgroup of a row block (+1)
   unsigned int* status;       // host-visible word: MEET_ERR_ROWCHAIN on a timed-out wait
   int force_sc1;              // never the plain-store form (GCRL_ROWTILE_SC1=1)
   // filled by the launcher
-  int roles[3], nroles, nstage, w16, ldsx, kperx, force_linear, role_mask;
+  int roles[3], nroles, nstage, w16, ldsx, kperx, force_linear, role_mask, sleep_first, sleep_poll;
 };
 bool rowtile_shape_ok(int B, int H, int L, int S, int A, int C);
 bool rowtile_ok(int B, int H, int L, int S, int A, int C);   // ... and all 3 * (B/16) * (H/16) workgroups resident at once, device not shared
 long long rowtile_ctr_words(int B, int L);                   // 64-bit words
+long long rowtile_xb_floats(int B, int H, int L);
 long long rowtile_part_floats(int B, int H);
 int launch_rowtile_ddpg(hipStream_t st, RowTileArgs t);
 

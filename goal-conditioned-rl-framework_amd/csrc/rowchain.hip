@@ -145,8 +145,24 @@ __device__ inline void stage(float* dst, const float* src, int n) {
 }
 
 template <int RG>
+__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid);
+
+template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // k_split (round 4, DDPG): the critic phase K as TWO roles in this launch — its target chain (target actor -> target critic -> Q')
+  // and its online critic's forward are independent, so K's critical path shrinks from 11 layer passes to 6 + 2 (the split kernel's
+  // phase 0, part 3, producers / consumers form: workgroups [0, nblk_k) the target role, [nblk_k, 2 nblk_k) the online critic, which
+  // waits for its rows' Q' only) and the launch is bounded by the actor phase's 10 passes instead.  Same per-row arithmetic.
+  if (a.k_split && a.nblk_k) {
+    if ((int)blockIdx.x < 2 * a.nblk_k) {
+      if (a.clk && threadIdx.x == 0 && blockIdx.x == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());
+      rowchain_split_body<RG>(a, 0, 3, (int)blockIdx.x);
+      if (a.clk && threadIdx.x == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
+      return;
+    }
+  }
+  const int kblocks = (a.k_split && a.nblk_k) ? 2 * a.nblk_k : a.nblk_k;
   constexpr int R = 4 * RG;
   const int ldl = a.ldl, H = a.critic[0].H, S = a.S, A = a.A, B = a.B;
   float* X0 = lds;
@@ -163,9 +179,9 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   // XCD streamed BOTH roles' weights (PMC: 32 MB HBM-side per launch for 3.3 MB of distinct weights).  When both roles have the
   // same number of row blocks (a multiple of 4) the critic phase K takes XCDs 0-3 and the actor phase P XCDs 4-7: an XCD fetches
   // one role's networks only.  (A wrong guess about the placement costs speed, never correctness.)
-  bool role_k = (int)blockIdx.x < a.nblk_k;
-  int blk = role_k ? (int)blockIdx.x : (int)blockIdx.x - a.nblk_k;
-  if (a.nblk_k == a.nblk_p && (a.nblk_k & 3) == 0 && !a.linear_roles) {
+  bool role_k = (int)blockIdx.x < kblocks;
+  int blk = role_k ? (int)blockIdx.x : (int)blockIdx.x - kblocks;
+  if (a.nblk_k == a.nblk_p && (a.nblk_k & 3) == 0 && !a.linear_roles && !a.k_split) {
     const int xcd = (int)blockIdx.x & 7;
     role_k = xcd < 4;
     blk = ((int)blockIdx.x >> 3) * 4 + (xcd & 3);
@@ -421,7 +437,7 @@ __device__ inline void st_agent(float* p, float v) { __hip_atomic_store(p, v, __
 __device__ inline float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int RG>
-__global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArgs a, int phase, int part) {
+__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int R = 4 * RG;
   const int ldl = a.ldl, H = a.critic[0].H, S = a.S, A = a.A, B = a.B, C = a.C;
@@ -436,8 +452,8 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
   float* hw = sm3 + R * 16;
   float* hb = hw + max(max(2 * A + 1, A + 2 * C), C * (A + 1)) * H;
   const int nblk = (B + R - 1) / R;
-  const int role = (int)blockIdx.x / nblk;
-  const int blk = (int)blockIdx.x - role * nblk;
+  const int role = bid / nblk;
+  const int blk = bid - role * nblk;
   const long long row0 = (long long)blk * R;
   const int rv = min(R, B - (int)row0);
   const long long BH = (long long)B * H;
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
   __shared__ unsigned int s_flag;
   unsigned int* meet = merged ? a.bar + ((long long)phase * nblk + blk) * 32 : nullptr;
   bool met = true;
-  if (phase == 0 && part != 2 && blockIdx.x == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
+  if (phase == 0 && part != 2 && bid == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
 
   if (phase == 0 && part != 2 && role < C) {
     // ---- target critic `role` on [ns | a'] (a' given: SAC; else the target actor runs first: TD3)
@@ -613,6 +629,11 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
   }
 }
 
+template <int RG>
+__global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArgs a, int phase, int part) {
+  rowchain_split_body<RG>(a, phase, part, (int)blockIdx.x);
+}
+
 // `row_at(i)`: element i of the launch's input rows ([n][ld_obs] flattened); `noise_at(t)`: exploration noise of action element t —
 // functors, so that the inline form reads the kernel-argument segment by plain indexed loads (a POINTER into a by-value argument
 // struct made hipcc copy the whole struct into every thread's scratch: 36 us for this kernel, round 4).  SYS: the float64 actions
@@ -755,7 +776,8 @@ int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
                  "rowchain: unsupported shape (H=%d, A=%d, C=%d)", a.critic[0].H, a.A, a.C);
   const size_t lds = rowchain_lds_bytes(rg, a.ldl, a.A, a.critic[0].H, a.C);
   GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain: %zu bytes of LDS needed", lds);
-  const int grid = a.nblk_k + a.nblk_p;
+  GCRL_CHECK_ARG(!a.k_split || (a.bar && a.qt && a.producers_first && a.C == 1), "rowchain: the two-role critic phase needs its meeting counters");
+  const int grid = (a.k_split ? 2 : 1) * a.nblk_k + a.nblk_p;
   if (grid < 1) return GCRL_OK;
   auto go = [&](auto kern) -> int {
     static thread_local size_t raised = 0;

@@ -46,8 +46,11 @@ __device__ inline unsigned int xcc_id() { return __builtin_amdgcn_s_getreg((3 <<
 
 // development: -DGCRL_RT_STAMPS leaves device-clock stamps of workgroup (row block 0, column block 0) of each role (tools/rt_stamps.py)
 #ifdef GCRL_RT_STAMPS
+#ifndef GCRL_RT_STAMPS_MASK
+#define GCRL_RT_STAMPS_MASK 3   // which launches: 3 = both roles in one launch, 1 = actor phase alone, 2 = critic phase alone
+#endif
 __device__ unsigned long long g_rt_stamps[3][64];   // [role][stamp] (third row unused)
-#define RT_STAMP(i) do { if (threadIdx.x == 0 && c.rb == 0 && c.cb == GCRL_RT_STAMPS && t.role_mask == 3) g_rt_stamps[role][i] = wall_clock64(); } while (0)
+#define RT_STAMP(i) do { if (threadIdx.x == 0 && c.rb == 0 && c.cb == GCRL_RT_STAMPS && t.role_mask == GCRL_RT_STAMPS_MASK) g_rt_stamps[role][i] = wall_clock64(); } while (0)
 #else
 #define RT_STAMP(i) do { } while (0)
 #endif
@@ -58,6 +61,10 @@ __device__ unsigned long long g_rt_stamps[3][64];   // [role][stamp] (third row 
 #endif
 #define RT_STAMPR() RT_STAMPW()
 #define RT_STAMPA() RT_STAMPW()
+
+// "not written yet": the hand-off buffers hold this word until their tile arrives (a NaN pattern no arithmetic produces:
+// hardware NaNs are 0x7FC00000 / 0xFFC00000)
+constexpr unsigned int kSent = 0xFFFFFFFFu;
 
 struct TileCtx {
   int rb, cb, wave, lane, li, lg, ncb;
@@ -123,15 +130,18 @@ __device__ inline void load_bh(float (&bw)[4][4], const TileCtx& c, const float*
   }
 }
 // A operand from a handed-off [B][H] buffer: rows rb*16 + li, k = kb + 16 t + 4 lg .. + 3 (sc1: past the CU's L1)
-__device__ inline void load_a(v4f (&af)[4], const TileCtx& c, const float* X, long long nfloats, int H, int kper) {
+__device__ inline bool load_a(v4f (&af)[4], const TileCtx& c, const float* X, long long nfloats, int H, int kper) {
   const __amdgpu_buffer_rsrc_t rs = bounded_rsrc(X, nfloats);
   const int kb = c.wave * kper, nt = kper >> 4;
+  bool missing = false;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     v4u v = {0u, 0u, 0u, 0u};
     if (t < nt) v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((c.rb * 16 + c.li) * H + kb + 16 * t + 4 * c.lg) * 4, 0, kSc1);
+    missing = missing || v[0] == kSent || v[1] == kSent || v[2] == kSent || v[3] == kSent;
     af[t] = (v4f){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
   }
+  return missing;
 }
 // A operand from the workgroup's staged input rows (LDS [16][ldsx], zero padded to a multiple of 16 columns)
 __device__ inline void load_a_lds(v4f (&af)[4], const TileCtx& c, const float* xs, int ldsx, int J16, int kper) {
@@ -171,14 +181,27 @@ __device__ inline v4f tile_reduce(const TileCtx& c, float* part, int& pb, v4f ac
 
 // sum over the row block's H / 16 column-block partials of a scalar head, [cb][16 rows] floats, in a fixed order (the same in
 // every workgroup of the row block): lane -> row lane >> 2; its four lanes take four column blocks each
-__device__ inline float sum_partials(const TileCtx& c, const float* qp, long long nfloats, int base) {
+__device__ inline float sum_partials(TileCtx& c, const float* qp, long long nfloats, int base) {
   const __amdgpu_buffer_rsrc_t rs = bounded_rsrc(qp, nfloats);
   const int row = c.lane >> 2, j = c.lane & 3;
   float v[4];   // (H <= 256: at most 16 column blocks; every load requested before the first is used)
+  for (int spins = 0;; ++spins) {
+    bool missing = false;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int cbi = 4 * i + j;
-    v[i] = cbi < c.ncb ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (base + cbi * 16 + row) * 4, 0, kSc1)) : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int cbi = 4 * i + j;
+      const unsigned int w = cbi < c.ncb ? __builtin_amdgcn_raw_buffer_load_b32(rs, (base + cbi * 16 + row) * 4, 0, kSc1) : 0u;
+      missing = missing || w == kSent;
+      v[i] = __uint_as_float(w);
+    }
+    if (c.failed || !__any(missing)) break;
+    if (spins >= kMeetSpinMax) {
+      if (c.lane == 0 && c.status) __hip_atomic_fetch_or(c.status, MEET_ERR_ROWCHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      c.failed = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
   }
   float s = 0.f;
 #pragma unroll
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
   TileCtx c;
   c.lane = tid & 63; c.li = c.lane & 15; c.lg = c.lane >> 4; c.ncb = ncb;
   c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  c.plain = false; c.failed = false; c.status = t.status;
+  c.plain = false; c.failed = false; c.status = t.status; c.target = 0;
   // role and tile.  A row block's workgroups sit on one XCD when the dispatcher deals workgroups round-robin over the 8 XCDs
   // (always the two-role order, whichever roles run: a tile's workgroup index — and with it its XCD — is then the same in
   // every launch of the handle; workgroups of a role that does not run exit at once)
@@ -227,24 +250,63 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
   float* hd = xs2 + 16 * ldsx;             // [16][16] a head's result
   float* as_ = hd + 256;                   // [16][16] tanh(actor head) (P)
   float* own = as_ + 256;                  // [2L][256] own tiles (wave 0; lane-private 16-byte slots)
-  __shared__ unsigned long long s_round;
+  __shared__ unsigned int s_plain;
   int pb = 0;
   int sidx = 4;
   (void)sidx;
   if (a.clk && tid == 0 && c.rb == 0 && c.cb == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());
-
-  const StepCtrl sc = role == ROLE_P ? *a.cur_p : *a.cur_k;
   RT_STAMP(0);
-  // counters of this (role, row block): [stage][16 u64]
-  unsigned long long* ctr = t.ctr + ((long long)(role * nrb + c.rb) * t.nstage) * 16;
-  auto stage_ctr = [&](int s) { return ctr + (long long)s * 16; };
-  // first arrival: publishes this workgroup's XCD and names the round of every counter of the row block
+
+  const int kperx = t.kperx, kperh = H >> 2;
+  const int orow = c.lane >> 2, ocol = c.cb * 16 + 4 * (c.lane & 3);   // wave 0: own tile element group
+  const int ooff = (row0 + orow) * H + ocol;
+  // hand-off buffers of this role: tile stages [4L][B][H]; partials [3 kinds][B/16][H/16][16]
+  float* xb = t.xb + (long long)role * 4 * L * BH;
+  auto X = [&](int stage) { return xb + (long long)stage * BH; };
+  const long long qn = 3LL * nrb * ncb * 16;
+  const int qbase_t = (0 * nrb + c.rb) * ncb * 16, qbase_o = (1 * nrb + c.rb) * ncb * 16, qbase_p = (2 * nrb + c.rb) * ncb * 16;
+  const v4f sent4 = {__uint_as_float(kSent), __uint_as_float(kSent), __uint_as_float(kSent), __uint_as_float(kSent)};
+
+  // first-layer weights: requested before anything that depends on the step's control block
+  float bw[4][4], bw2[4][4];
+  v4f af[4], af2[4];
+  v4f bias = {0.f, 0.f, 0.f, 0.f}, bias2 = {0.f, 0.f, 0.f, 0.f};
+  v4f acc, acc2 = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f}, v2 = {0.f, 0.f, 0.f, 0.f};
+  const RowNet& cr = a.critic[0];
+  {
+    const RowNet& n0 = role == ROLE_P ? a.actor : a.tactor;
+    load_b(bw, c, n0.Wt + n0.wt[0], H, n0.jpad0, kperx);
+    if (c.wave == 0) bias = *(const v4f*)(n0.P + n0.b[0] + ocol);
+    if (role == ROLE_K) {
+      load_b(bw2, c, cr.Wt + cr.wt[0], H, cr.jpad0, kperx);
+      if (c.wave == 0) bias2 = *(const v4f*)(cr.P + cr.b[0] + ocol);
+    }
+  }
+  const StepCtrl sc = role == ROLE_P ? *a.cur_p : *a.cur_k;
+  // Which store form?  Wave 1 publishes this workgroup's XCD with its arrival at the row block's counter (monotonic: the value the
+  // add returns names the round) and, after layer 0, reads the row block's H / 16 words: all on one XCD -> plain stores.
+  unsigned long long* ctr = t.ctr + (long long)(role * nrb + c.rb) * 16;
   unsigned int* xid = t.xid + (long long)(role * nrb + c.rb) * 32;
-  unsigned long long t0 = 0;
-  if (tid == 0) {
+  if (tid == 64) {
     __hip_atomic_store(xid + c.cb, xcc_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     drain_stores();
-    t0 = __hip_atomic_fetch_add(stage_ctr(0), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.target = (t0 / (unsigned long long)ncb + 1ull) * (unsigned long long)ncb;
+  }
+  c.target = __shfl(c.target, 0, 64);   // (wave 1: lane 0's value; other waves: 0, unused)
+  if (tid == 0) s_plain = 0u;
+  // last launch's leftovers -> "not written yet": the final tile stage of the chain (nobody could tell when its readers were
+  // done) and the scalar-head partials.  Their readers of THIS launch come several hand-offs later, each of which needs a tile
+  // of this workgroup that it stores after these resets have been acknowledged (the waits for its loads below).
+  if (c.wave == 0) {
+    tile_store(c, X(3 * L + 1), BH, ooff, sent4);   // (write-through: the store form is not decided yet)
+    if ((c.lane & 3) == 0) {
+      if (role == ROLE_P) tile_store1(c, t.qpart, qn, qbase_p + c.cb * 16 + orow, __uint_as_float(kSent), true);
+      else {
+        tile_store1(c, t.qpart, qn, qbase_t + c.cb * 16 + orow, __uint_as_float(kSent), true);
+        tile_store1(c, t.qpart, qn, qbase_o + c.cb * 16 + orow, __uint_as_float(kSent), true);
+      }
+    }
   }
   // input rows -> LDS (zero padded): P: s;  K: s' and [s | a]
   {
@@ -257,13 +319,6 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
       if (role == ROLE_K) xs2[r * ldsx + cc] = cc < S + A ? rows2[(long long)r * a.ldx + cc] : 0.f;
     }
   }
-  const int kperx = t.kperx, kperh = H >> 2;
-  const int orow = c.lane >> 2, ocol = c.cb * 16 + 4 * (c.lane & 3);   // wave 0: own tile element group
-  const int ooff = (row0 + orow) * H + ocol;
-  float bw[4][4], bw2[4][4];
-  v4f af[4], af2[4];
-  v4f bias = {0.f, 0.f, 0.f, 0.f}, bias2 = {0.f, 0.f, 0.f, 0.f};
-  v4f acc, acc2, v, v2 = {0.f, 0.f, 0.f, 0.f};
 
   auto fwd_epi = [&](v4f x, v4f b) {
     x += b;
@@ -277,13 +332,34 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
     return x;
   };
   auto own_at = [&](int i) { return (v4f*)(own + i * 256 + 4 * c.lane); };
-  // ONE wave polls (twelve polling waves per CU slowed every hand-off of the CU's other workgroups); the others sleep in the barrier
-  auto wait_all = [&](int s1, int s2) {
-    if (c.wave == 0) {
-      tile_wait(c, stage_ctr(s1));
-      if (s2 >= 0) tile_wait(c, stage_ctr(s2));
+  auto save = [&](float* buf, v4f x) { *(v4f*)(buf + ooff) = x; };   // for the dW launch: a plain store, visible at the kernel boundary
+  // The hand-off: the DATA is the flag.  Every wave loads its fragments of the row block's tiles (sc1: past the CU's L1) until none
+  // of its words is the "not written yet" pattern; the workgroup votes and repeats together.  Once a set of stages has arrived,
+  // every workgroup of the row block has stored its tiles of that set — which it did AFTER reading the previous set — so the
+  // previous set's own tiles go back to "not written yet" for the next launch.
+  // (No workgroup vote per poll: a wave polls for itself — tools/microbench_rowtile.hip: 1.79 vs 2.13 us per layer — and the
+  // reset of the previous set waits for the barrier of the partial-sum exchange, behind which every wave has its fragments.)
+  float* prev1 = nullptr; float* prev2 = nullptr;      // the set consumed before the current one
+  float* cur1 = nullptr; float* cur2 = nullptr;
+  bool need1 = false, need2 = false;
+  auto consume_begin = [&](float* X1, float* X2) {     // first poll: requested BEFORE the caller's weight loads
+    for (int i = 0; i < t.sleep_first; ++i) __builtin_amdgcn_s_sleep(1);
+    cur1 = X1; cur2 = X2;
+    need1 = __any(load_a(af, c, X1, BH, H, kperh));
+    need2 = X2 ? __any(load_a(af2, c, X2, BH, H, kperh)) : false;
+  };
+  auto consume_end = [&]() {
+    for (int spins = 0; (need1 || need2) && !c.failed; ++spins) {
+      if (spins >= kMeetSpinMax) {
+        if (c.lane == 0 && c.status) __hip_atomic_fetch_or(c.status, MEET_ERR_ROWCHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        c.failed = true;
+        break;
+      }
+      for (int i = 0; i < t.sleep_poll; ++i) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      if (need1) need1 = __any(load_a(af, c, cur1, BH, H, kperh));
+      if (need2) need2 = __any(load_a(af2, c, cur2, BH, H, kperh));
     }
-    __syncthreads();
     RT_STAMPW();
   };
   // the four waves' partial tiles of ONE or TWO chains meet in LDS (one barrier); wave 0 gets the sums
@@ -293,6 +369,11 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
     if (two) *(v4f*)(p + 1024 + c.wave * 256 + c.li * 16 + 4 * c.lg) = acc2;
     __syncthreads();
     if (c.wave == 0) {
+      c.plain = s_plain != 0;   // (wave 1's decision, once it is made: the stores before it go write-through)
+      if (cur1 != prev1 || cur2 != prev2) {   // a new set has been consumed by every wave: the one before it goes back to "not written yet"
+        if (prev1) tile_store(c, prev1, BH, ooff, sent4);
+        if (prev2) tile_store(c, prev2, BH, ooff, sent4);
+      }
       v = *(const v4f*)(p + 4 * c.lane);
 #pragma unroll
       for (int w = 1; w < 4; ++w) v += *(const v4f*)(p + w * 256 + 4 * c.lane);
@@ -302,93 +383,110 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
         for (int w = 1; w < 4; ++w) v2 += *(const v4f*)(p + 1024 + w * 256 + 4 * c.lane);
       }
     }
+    prev1 = cur1; prev2 = cur2;
     pb ^= 1;
     RT_STAMPR();
   };
-  // wave 0 decides the store form once the row block's workgroups have all made their first arrival
+  // wave 1, after layer 0: the row block's first arrivals are in (bounded wait) -> one XCD?  Wave 0 reads the answer behind the
+  // next barrier.
   auto decide_plain = [&]() {
-    if (c.wave != 0) return;
-    tile_wait(c, stage_ctr(0));
+    if (c.wave != 1) return;
+    tile_wait(c, ctr);
     const unsigned int mine = c.lane < ncb ? __hip_atomic_load(xid + c.lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const unsigned int first = __shfl(mine, 0, 64);
     const bool same = c.lane >= ncb || (mine == first && mine == xcc_id() + 1u);
-    c.plain = !t.force_sc1 && !c.failed && __all(same);
+    const bool plain = !t.force_sc1 && !c.failed && __all(same);
+    if (c.lane == 0) s_plain = plain ? 1u : 0u;
   };
-  // hidden layers l_beg .. l_end-1 of `net` on the handed-off activations in hbuf[l-1]; own tiles kept at own[own0 + l]
-  auto hidden_rest = [&](const RowNet& net, float* hbuf, int stage0, int own0, int l_beg, int l_end) {
+  // hidden layers l_beg .. l_end-1 of `net`: layer l reads stage st0 + l - 1 and hands its tile on as stage st0 + l; own tiles kept
+  // at own[own0 + l]; sv: where the dW launch finds the layer's output ([L][B][H]) or null
+  auto hidden_rest = [&](const RowNet& net, int st0, float* sv, int own0, int l_beg, int l_end) {
     for (int l = l_beg; l < l_end; ++l) {
+      consume_begin(X(st0 + l - 1), nullptr);
       load_b(bw, c, net.Wt + net.wt[l], H, H, kperh);
       if (c.wave == 0) bias = *(const v4f*)(net.P + net.b[l] + ocol);
-      wait_all(stage0 + l - 1, -1);
-      load_a(af, c, hbuf + (long long)(l - 1) * BH, BH, H, kperh);
+      consume_end();
       acc = tile_mma(bw, af, kperh);
       reduce(false);
       if (c.wave == 0) {
         v = fwd_epi(v, bias);
         *own_at(own0 + l) = v;
-        tile_store(c, hbuf + (long long)l * BH, BH, ooff, v);
-        tile_arrive(c, stage_ctr(stage0 + l)); RT_STAMPA();
+        tile_store(c, X(st0 + l), BH, ooff, v);
+        if (sv) save(sv + (long long)l * BH, v);
+        RT_STAMPA();
       }
     }
   };
-  // input-gradient chain: g[l-1] = (g[l] . W[l]) * act'(h[l-1]) for l = L-1 .. 1 (own tiles of h at own[own0 + l - 1])
-  auto grad_rest = [&](const RowNet& net, float* gbuf, int stage0, int own0) {
+  // input-gradient chain: g[l-1] = (g[l] . W[l]) * act'(h[l-1]) for l = L-1 .. 1 (own tiles of h at own[own0 + l - 1]); stage
+  // st0 + l holds g[l]
+  auto grad_rest = [&](const RowNet& net, int st0, float* sv, int own0) {
     for (int l = L - 1; l >= 1; --l) {
+      consume_begin(X(st0 + l), nullptr);
       load_b(bw, c, net.P + net.w[l], H, H, kperh);
-      wait_all(stage0 + l, -1);
-      load_a(af, c, gbuf + (long long)l * BH, BH, H, kperh);
+      consume_end();
       acc = tile_mma(bw, af, kperh);
       reduce(false);
       if (c.wave == 0) {
         v = bwd_epi(v, *own_at(own0 + l - 1));
-        tile_store(c, gbuf + (long long)(l - 1) * BH, BH, ooff, v);
-        if (l > 1) { tile_arrive(c, stage_ctr(stage0 + l - 1)); RT_STAMPA(); }
+        if (l > 1) tile_store(c, X(st0 + l - 1), BH, ooff, v);
+        if (sv) save(sv + (long long)(l - 1) * BH, v);
+        RT_STAMPA();
       }
     }
   };
-  // a head on the handed-off activations of layer L-1: out[row][o] -> wave 0's v (lane: row, outputs 4 (lane & 3) .. + 3)
-  auto head_on = [&](const float* W, int n_out, const float* hbuf_last, int stage) {
+  // a head on a handed-off stage: out[row][o] -> wave 0's v (lane: row, outputs 4 (lane & 3) .. + 3)
+  auto head_on = [&](const float* W, int n_out, int stage) {
+    consume_begin(X(stage), nullptr);
     load_bh(bw, c, W, H, n_out, H, kperh);
-    wait_all(stage, -1);
-    load_a(af, c, hbuf_last, BH, H, kperh);
+    consume_end();
     acc = tile_mma(bw, af, kperh);
     reduce(false);
   };
-  // partial of a scalar head over this tile's 16 columns -> qp[cb][row] (consumed by workgroups of the SAME role and row block)
-  auto head_partial = [&](v4f h, const float* Wh, float* qp, long long qn, int base) {
+  // partial of a scalar head over this tile's 16 columns -> qp[cb][row] (read by workgroups of the SAME role and row block)
+  auto head_partial = [&](v4f h, const float* Wh, int base) {
     const v4f w = *(const v4f*)(Wh + ocol);
     float s = ((h[0] * w[0] + h[1] * w[1]) + h[2] * w[2]) + h[3] * w[3];
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if ((c.lane & 3) == 0) tile_store1(c, qp, qn, base + c.cb * 16 + orow, s, false);
+    if ((c.lane & 3) == 0) tile_store1(c, t.qpart, qn, base + c.cb * 16 + orow, s, false);
   };
-  const long long qn = 3LL * nrb * ncb * 16;
-  const int qbase_t = (0 * nrb + c.rb) * ncb * 16, qbase_o = (1 * nrb + c.rb) * ncb * 16, qbase_p = (2 * nrb + c.rb) * ncb * 16;
 
   if (role == ROLE_P) {
-    // stages: 1 + l: hA[l];  1 + L + l: hC2[l];  1 + 2L + l: critic gradient gP[l];  1 + 3L + l: gA[l]
-    const RowNet& cr = a.critic[0];
-    load_b(bw, c, a.actor.Wt + a.actor.wt[0], H, a.actor.jpad0, kperx);
-    bias = *(const v4f*)(a.actor.P + a.actor.b[0] + ocol);
+    // tile stages: l: hA[l];  L + l: critic activations;  2L + l: critic gradients;  3L + l: gA[l]
     __syncthreads();
     load_a_lds(af, c, xs, ldsx, t.w16, kperx);
     acc = tile_mma(bw, af, kperx);
     RT_STAMP(1);
-    if (tid == 0) s_round = t0 / (unsigned long long)ncb;
     reduce(false);
-    c.target = (s_round + 1ull) * (unsigned long long)ncb;
     if (c.wave == 0) {
       v = fwd_epi(v, bias);
       *own_at(0) = v;
-      tile_store(c, a.hA, BH, ooff, v);   // (write-through: the store form is not decided yet)
-      tile_arrive(c, stage_ctr(1)); RT_STAMPA();
+      tile_store(c, X(0), BH, ooff, v);   // (write-through: the store form is not decided yet)
+      save(a.hA, v);
+      RT_STAMPA();
     }
     decide_plain();
-    hidden_rest(a.actor, a.hA, 1, 0, 1, L);
+    // layer 1
+    {
+      consume_begin(X(0), nullptr);
+      load_b(bw, c, a.actor.Wt + a.actor.wt[1], H, H, kperh);
+      if (c.wave == 0) bias = *(const v4f*)(a.actor.P + a.actor.b[1] + ocol);
+      consume_end();
+      acc = tile_mma(bw, af, kperh);
+      reduce(false);
+      if (c.wave == 0) {
+        v = fwd_epi(v, bias);
+        *own_at(1) = v;
+        tile_store(c, X(1), BH, ooff, v);
+        save(a.hA + BH, v);
+        RT_STAMPA();
+      }
+    }
+    hidden_rest(a.actor, 0, a.hA, 0, 2, L);
     // actor head -> a = tanh(.) -> critic layer 0 on [s | a]
     load_b(bw2, c, cr.Wt + cr.wt[0], H, cr.jpad0, kperx);
     const v4f bias_c0 = *(const v4f*)(cr.P + cr.b[0] + ocol);
-    head_on(a.actor.P + a.actor.w[L], A, a.hA + (long long)(L - 1) * BH, 1 + L - 1);
+    head_on(a.actor.P + a.actor.w[L], A, L - 1);
     if (c.wave == 0) {
       const int o0 = 4 * (c.lane & 3);
 #pragma unroll
@@ -406,47 +504,48 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
     if (c.wave == 0) {
       v = fwd_epi(v, bias_c0);
       *own_at(L) = v;
-      tile_store(c, a.hC2, BH, ooff, v);
-      tile_arrive(c, stage_ctr(1 + L)); RT_STAMPA();
+      tile_store(c, X(L), BH, ooff, v);
+      RT_STAMPA();
     }
-    hidden_rest(cr, a.hC2, 1 + L, L, 1, L - 1);
+    hidden_rest(cr, L, nullptr, L, 1, L - 1);
     // last critic layer: its tile stays here — Q(s, pi(s)) partial (a metric), then the head's backward: upstream -1/B
+    consume_begin(X(L + L - 2), nullptr);
     load_b(bw, c, cr.Wt + cr.wt[L - 1], H, H, kperh);
     if (c.wave == 0) bias = *(const v4f*)(cr.P + cr.b[L - 1] + ocol);
-    wait_all(1 + L + L - 2, -1);
-    load_a(af, c, a.hC2 + (long long)(L - 2) * BH, BH, H, kperh);
+    consume_end();
     acc = tile_mma(bw, af, kperh);
     reduce(false);
     if (c.wave == 0) {
       v = fwd_epi(v, bias);
       const float* Wh = cr.P + cr.w[L];
-      head_partial(v, Wh, t.qpart, qn, qbase_p);
+      head_partial(v, Wh, qbase_p);
       const v4f w = *(const v4f*)(Wh + ocol);
       const float gb = -1.0f / (float)B;
       v4f g;
 #pragma unroll
       for (int q = 0; q < 4; ++q) g[q] = (0.f + gb * w[q]) * act_deriv(v[q], MUL_DLEAKY);
-      tile_store(c, t.gP + (long long)(L - 1) * BH, BH, ooff, g);
-      tile_arrive(c, stage_ctr(1 + 2 * L + L - 1)); RT_STAMPA();
+      tile_store(c, X(2 * L + L - 1), BH, ooff, g);
+      RT_STAMPA();
     }
-    // critic input-gradient chain; column block 0 also finishes Q(s, pi(s)) (every partial of the row block is in by the first wait)
+    // critic input-gradient chain; column block 0 also finishes Q(s, pi(s))
     for (int l = L - 1; l >= 1; --l) {
+      consume_begin(X(2 * L + l), nullptr);
       load_b(bw, c, cr.P + cr.w[l], H, H, kperh);
-      wait_all(1 + 2 * L + l, -1);
-      load_a(af, c, t.gP + (long long)l * BH, BH, H, kperh);
-      float q2v = 0.f;
-      if (l == L - 1 && c.cb == 0 && c.wave == 0) q2v = sum_partials(c, t.qpart, qn, qbase_p);
+      consume_end();
       acc = tile_mma(bw, af, kperh);
       reduce(false);
       if (c.wave == 0) {
-        if (l == L - 1 && c.cb == 0 && (c.lane & 3) == 0) a.q2[row0 + orow] = q2v + cr.P[cr.b[L]];
         v = bwd_epi(v, *own_at(L + l - 1));
-        tile_store(c, t.gP + (long long)(l - 1) * BH, BH, ooff, v);
-        tile_arrive(c, stage_ctr(1 + 2 * L + l - 1)); RT_STAMPA();
+        tile_store(c, X(2 * L + l - 1), BH, ooff, v);
+        RT_STAMPA();
+        if (l == L - 1 && c.cb == 0) {
+          const float q2v = sum_partials(c, t.qpart, qn, qbase_p);
+          if ((c.lane & 3) == 0) a.q2[row0 + orow] = q2v + cr.P[cr.b[L]];
+        }
       }
     }
     // action gradient da = g0 . W0[:, S + o] (rows S.. of the [in][out] copy), through the tanh, then the actor head's backward
-    head_on(cr.Wt + cr.wt[0] + (long long)S * H, A, t.gP, 1 + 2 * L);
+    head_on(cr.Wt + cr.wt[0] + (long long)S * H, A, 2 * L);
     if (c.wave == 0) {
       const int o0 = 4 * (c.lane & 3);
 #pragma unroll
@@ -463,58 +562,45 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
       v4f s = {0.f, 0.f, 0.f, 0.f};
       for (int o = 0; o < A; ++o) s += hd[orow * 16 + o] * *(const v4f*)(Wh + (long long)o * H + ocol);
       v = bwd_epi(s, *own_at(L - 1));
-      tile_store(c, a.gA + (long long)(L - 1) * BH, BH, ooff, v);
-      tile_arrive(c, stage_ctr(1 + 3 * L + L - 1)); RT_STAMPA();
+      tile_store(c, X(3 * L + L - 1), BH, ooff, v);
+      save(a.gA + (long long)(L - 1) * BH, v);
+      RT_STAMPA();
     }
-    grad_rest(a.actor, a.gA, 1 + 3 * L, 0);
+    grad_rest(a.actor, 3 * L, a.gA, 0);
   } else {
     // K: the target chain (target actor -> a' -> target critic -> partials of Q') and the online critic's forward are independent:
     // their layers go through the hand-off cycle TOGETHER (two tiles per cycle) while both have layers left.
-    // stages: 1 + l: target actor xT[l];  1 + L + l: target critic xT[L + l];  1 + 2L: partials of Q';
-    //         KO0 + l: hC[l] (l = L-1: with the partials of q);  KO0 + L + l: gC[l]
-    const int KO0 = 2 + 2 * L;
-    const RowNet& cr = a.critic[0];
+    // tile stages: l: target actor, L + l: target critic (l < L - 1);  2L + l: hC[l] (l < L - 1);  3L + l: gC[l]
     const RowNet& tc = a.tcritic[0];
     float rr = 0.f, dd = 0.f;
     if (c.wave == 0) {
       rr = a.rbuf[(long long)sc.batch_slot * a.slot_rd + row0 + orow];
       dd = a.dbuf[(long long)sc.batch_slot * a.slot_rd + row0 + orow];
     }
-    load_b(bw, c, a.tactor.Wt + a.tactor.wt[0], H, a.tactor.jpad0, kperx);
-    load_b(bw2, c, cr.Wt + cr.wt[0], H, cr.jpad0, kperx);
-    bias = *(const v4f*)(a.tactor.P + a.tactor.b[0] + ocol);
-    bias2 = *(const v4f*)(cr.P + cr.b[0] + ocol);
     __syncthreads();
     load_a_lds(af, c, xs, ldsx, t.w16, kperx);
     load_a_lds(af2, c, xs2, ldsx, t.w16, kperx);
     acc = tile_mma(bw, af, kperx);
     acc2 = tile_mma(bw2, af2, kperx);
     RT_STAMP(1);
-    if (tid == 0) s_round = t0 / (unsigned long long)ncb;
     reduce(true);
-    c.target = (s_round + 1ull) * (unsigned long long)ncb;
     const float* Whc = cr.P + cr.w[L];
     if (c.wave == 0) {
       v = fwd_epi(v, bias);
       v2 = fwd_epi(v2, bias2);
       *own_at(0) = v2;
-      tile_store(c, t.xT, BH, ooff, v);   // (write-through: the store form is not decided yet)
-      tile_store(c, a.hC, BH, ooff, v2);
-      drain_stores();
-      if (c.lane == 0) {
-        __hip_atomic_fetch_add(stage_ctr(1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(stage_ctr(KO0), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      tile_store(c, X(0), BH, ooff, v);   // (write-through: the store form is not decided yet)
+      tile_store(c, X(2 * L), BH, ooff, v2);
+      save(a.hC, v2);
       RT_STAMPA();
     }
     decide_plain();
     for (int l = 1; l < L; ++l) {
+      consume_begin(X(l - 1), X(2 * L + l - 1));
       load_b(bw, c, a.tactor.Wt + a.tactor.wt[l], H, H, kperh);
       load_b(bw2, c, cr.Wt + cr.wt[l], H, H, kperh);
       if (c.wave == 0) { bias = *(const v4f*)(a.tactor.P + a.tactor.b[l] + ocol); bias2 = *(const v4f*)(cr.P + cr.b[l] + ocol); }
-      wait_all(1 + l - 1, KO0 + l - 1);
-      load_a(af, c, t.xT + (long long)(l - 1) * BH, BH, H, kperh);
-      load_a(af2, c, a.hC + (long long)(l - 1) * BH, BH, H, kperh);
+      consume_end();
       acc = tile_mma(bw, af, kperh);
       acc2 = tile_mma(bw2, af2, kperh);
       reduce(true);
@@ -522,14 +608,10 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
         v = fwd_epi(v, bias);
         v2 = fwd_epi(v2, bias2);
         *own_at(l) = v2;
-        tile_store(c, t.xT + (long long)l * BH, BH, ooff, v);
-        tile_store(c, a.hC + (long long)l * BH, BH, ooff, v2);
-        if (l == L - 1) head_partial(v2, Whc, t.qpart, qn, qbase_o);
-        drain_stores();
-        if (c.lane == 0) {
-          __hip_atomic_fetch_add(stage_ctr(1 + l), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_fetch_add(stage_ctr(KO0 + l), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        tile_store(c, X(l), BH, ooff, v);
+        if (l < L - 1) tile_store(c, X(2 * L + l), BH, ooff, v2);
+        else head_partial(v2, Whc, qbase_o);
+        save(a.hC + (long long)l * BH, v2);
         RT_STAMPA();
       }
     }
@@ -538,7 +620,7 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
     // target actor head -> a' = tanh(.) -> target critic layer 0 on [s' | a']
     load_b(bw2, c, tc.Wt + tc.wt[0], H, tc.jpad0, kperx);
     const v4f bias_c0 = *(const v4f*)(tc.P + tc.b[0] + ocol);
-    head_on(a.tactor.P + a.tactor.w[L], A, t.xT + (long long)(L - 1) * BH, 1 + L - 1);
+    head_on(a.tactor.P + a.tactor.w[L], A, L - 1);
     if (c.wave == 0) {
       const int o0 = 4 * (c.lane & 3);
 #pragma unroll
@@ -549,26 +631,23 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
     load_a_lds(af, c, xs, ldsx, t.w16, kperx);
     acc = tile_mma(bw2, af, kperx);
     reduce(false);
-    float* tcb = t.xT + (long long)L * BH;
     if (c.wave == 0) {
       v = fwd_epi(v, bias_c0);
-      tile_store(c, tcb, BH, ooff, v);
-      tile_arrive(c, stage_ctr(1 + L)); RT_STAMPA();
+      tile_store(c, X(L), BH, ooff, v);
+      RT_STAMPA();
     }
-    hidden_rest(tc, tcb, 1 + L, L, 1, L - 1);
+    hidden_rest(tc, L, nullptr, L, 1, L - 1);
+    consume_begin(X(L + L - 2), nullptr);
     load_b(bw, c, tc.Wt + tc.wt[L - 1], H, H, kperh);
     if (c.wave == 0) bias = *(const v4f*)(tc.P + tc.b[L - 1] + ocol);
-    wait_all(1 + L + L - 2, -1);
-    load_a(af, c, tcb + (long long)(L - 2) * BH, BH, H, kperh);
+    consume_end();
     acc = tile_mma(bw, af, kperh);
     reduce(false);
     if (c.wave == 0) {
       v = fwd_epi(v, bias);
-      head_partial(v, tc.P + tc.w[L], t.qpart, qn, qbase_t);
-      tile_arrive(c, stage_ctr(1 + 2 * L)); RT_STAMPA();
+      head_partial(v, tc.P + tc.w[L], qbase_t);
+      RT_STAMPA();
       // q of the rows, Q' of the rows, TD target, loss gradient (src/agent.py:1311-1317)
-      tile_wait(c, stage_ctr(KO0 + L - 1));
-      tile_wait(c, stage_ctr(1 + 2 * L));
       const float qv = sum_partials(c, t.qpart, qn, qbase_o) + cr.P[cr.b[L]];
       const float tq = sum_partials(c, t.qpart, qn, qbase_t) + tc.P[tc.b[L]];
       float y = __fadd_rn(rr, __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, dd)), tq));
@@ -580,10 +659,11 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
       v4f gt;
 #pragma unroll
       for (int q = 0; q < 4; ++q) gt[q] = (0.f + g * w[q]) * act_deriv(h3[q], MUL_DLEAKY);
-      tile_store(c, a.gC + (long long)(L - 1) * BH, BH, ooff, gt);
-      tile_arrive(c, stage_ctr(KO0 + L + L - 1)); RT_STAMPA();
+      tile_store(c, X(3 * L + L - 1), BH, ooff, gt);
+      save(a.gC + (long long)(L - 1) * BH, gt);
+      RT_STAMPA();
     }
-    grad_rest(cr, a.gC, KO0 + L, 0);
+    grad_rest(cr, 3 * L, a.gC, 0);
   }
   if (a.clk && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
@@ -610,14 +690,15 @@ bool rowtile_ok(int B, int H, int L, int S, int A, int C) {
   return 2LL * (B / 16) * (H / 16) <= meet_capacity((const void*)rowtile_ddpg_kernel, kTileThreads, lds);
 }
 
-long long rowtile_ctr_words(int B, int L) { return 3LL * (B / 16) * (2 + 4 * L) * 16; }   // 64-bit words
+long long rowtile_ctr_words(int B, int L) { return 2LL * (B / 16) * 16; }   // 64-bit words: one 128-byte line per (role, row block)
+long long rowtile_xb_floats(int B, int H, int L) { return 2LL * 4 * L * B * H; }
 long long rowtile_part_floats(int B, int H) { return 3LL * (B / 16) * (H / 16) * 16; }
 
 int launch_rowtile_ddpg(hipStream_t st, RowTileArgs t) {
   const RowChainArgs& a = t.rc;
   const int H = a.critic[0].H, L = a.critic[0].L;
   GCRL_CHECK_ARG(rowtile_shape_ok(a.B, H, L, a.S, a.A, a.C) && a.actor.L == L && a.actor.H == H && a.target_kind == TGT_DDPG &&
-                     a.loss_kind == LOSS_MSE && !a.given_next && !a.p_critic_only && t.xT && t.gP && t.qpart && t.ctr && t.xid,
+                     a.loss_kind == LOSS_MSE && !a.given_next && !a.p_critic_only && t.xb && t.qpart && t.ctr && t.xid,
                  "rowtile: unsupported configuration (B=%d H=%d L=%d A=%d C=%d)", a.B, H, L, a.A, a.C);
   t.nroles = 0; t.role_mask = 0;
   static const int dbg_roles = std::getenv("GCRL_RT_ROLES") ? std::atoi(std::getenv("GCRL_RT_ROLES")) : 3;   // timing experiments only (wrong results): 1 = P, 2 = K
@@ -626,6 +707,9 @@ int launch_rowtile_ddpg(hipStream_t st, RowTileArgs t) {
   if (t.nroles == 0) return GCRL_OK;
   static const bool lin = std::getenv("GCRL_RT_LINEAR") != nullptr;   // experiment: never the XCD-aligned workgroup order
   t.force_linear = lin ? 1 : 0;
+  static const int sl_first = std::getenv("GCRL_RT_SLEEP_FIRST") ? std::atoi(std::getenv("GCRL_RT_SLEEP_FIRST")) : 0;   // experiment knobs (64-clock units)
+  static const int sl_poll = std::getenv("GCRL_RT_SLEEP_POLL") ? std::atoi(std::getenv("GCRL_RT_SLEEP_POLL")) : 1;
+  t.sleep_first = sl_first; t.sleep_poll = sl_poll;
   t.nstage = 2 + 4 * L;
   t.w16 = (a.S + a.A + 15) & ~15;
   t.ldsx = t.w16 + 4;

@@ -32,7 +32,7 @@ __device__ inline __amdgpu_buffer_rsrc_t rsrc_of(const void* p, long long bytes)
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
-// MODE 0: sentinel, 1: counter, 2: no exchange.  LD_AUX / ST_AUX: cache-policy bits of the exchange loads / stores (16 = sc1:
+// MODE 0: sentinel, 1: counter, 2: no exchange, 3: sentinel with a workgroup vote (__syncthreads_or) per poll iteration.  LD_AUX / ST_AUX: cache-policy bits of the exchange loads / stores (16 = sc1:
 // agent scope; 1 = sc0).  WAVES: waves per workgroup (k split WAVES ways).
 template <int MODE, int XCD, int LD_AUX, int ST_AUX, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void tile_chain(const float* X0, int B, int H, const float* Wt, const float* bias, int NL, float* Y,
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_chain(const float* X0, int B,
   const int nt = kper >> 4;              // 16-k groups per wave
   // own tile, as wave 0 writes it: lane -> row lane >> 2, columns 4 * (lane & 3) .. + 3
   const int orow = rb * 16 + (lane >> 2), ocol = cb * 16 + 4 * (lane & 3);
-  if (MODE == 0 && wave == 0 && NL >= 2) {
+  if ((MODE == 0 || MODE == 3) && wave == 0 && NL >= 2) {
     // last launch's final exchange tile (input of layer NL - 1): nobody could tell when its readers were done
     const v4u s = {kSent, kSent, kSent, kSent};
     __builtin_amdgcn_raw_buffer_store_b128(s, rsrc_of(xb + (long long)(NL - 1) * BH, BH * 4), (orow * H + ocol) * 4, 0, ST_AUX);
@@ -92,12 +92,13 @@ __global__ __launch_bounds__(64 * WAVES) void tile_chain(const float* X0, int B,
           if (l == 0) a[t] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff + 64 * t, 0, 0);
           else a[t] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff + 64 * t, 0, LD_AUX);
         }
-      if (MODE != 0 || l == 0) break;
+      if ((MODE != 0 && MODE != 3) || l == 0) break;
       bool bad = false;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         if (t < nt) bad = bad || a[t][0] == kSent || a[t][1] == kSent || a[t][2] == kSent || a[t][3] == kSent;
-      if (!__any(bad)) break;
+      if (MODE == 3) { if (!__syncthreads_or(__any(bad) ? 1 : 0)) break; }
+      else if (!__any(bad)) break;
       if (++spins >= kSpinMax) { if (lane == 0) atomicOr(fail, 2u); break; }
       __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_chain(const float* X0, int B,
     *(v4f*)(&part[l & 1][wave][li * 16 + 4 * lg]) = acc0 + acc1;
     __syncthreads();
     if (wave == 0) {
-      if (MODE == 0 && l >= 2) {
+      if ((MODE == 0 || MODE == 3) && l >= 2) {
         // ALL waves' inputs of layer l have arrived (the barrier): every workgroup of the row block is past its reads of layer l - 1's input
         const v4u s = {kSent, kSent, kSent, kSent};
         __builtin_amdgcn_raw_buffer_store_b128(s, rsrc_of(xb + (long long)(l - 1) * BH, BH * 4), (orow * H + ocol) * 4, 0, ST_AUX);
@@ -179,7 +180,8 @@ int main(int argc, char** argv) {
                   {"tile_nox      xcd=1          4 waves", 3}, {"tile_sentinel xcd=1 sc0/plain 4 waves (same-XCD L2 only)", 4},
                   {"tile_sentinel xcd=1 sc1/sc1 8 waves", 5}, {"tile_sentinel xcd=1 sys/sys 4 waves", 6},
                   {"tile_sentinel xcd=1 sc1 loads / PLAIN stores (same-XCD L2; placement-dependent)", 7},
-                  {"tile_counter  xcd=1 sc1 loads / PLAIN stores (placement-dependent)", 8}};
+                  {"tile_counter  xcd=1 sc1 loads / PLAIN stores (placement-dependent)", 8},
+                  {"tile_sentinel + workgroup vote per poll, xcd=1 sc1 loads / PLAIN stores", 9}};
   for (const V& v : vs) {
     unsigned long long round = 0;
     CK(hipMemset(dCtr, 0, nctr * 8));
@@ -196,6 +198,7 @@ int main(int argc, char** argv) {
         case 5: hipLaunchKernelGGL((tile_chain<0, 1, 16, 16, 8>), dim3(grid), dim3(512), 0, st, dX, B, H, dW, db, NL, dY, dXb, dCtr, round, dFail); break;
         case 7: hipLaunchKernelGGL((tile_chain<0, 1, 16, 0, 4>), dim3(grid), dim3(256), 0, st, dX, B, H, dW, db, NL, dY, dXb, dCtr, round, dFail); break;
         case 8: hipLaunchKernelGGL((tile_chain<1, 1, 16, 0, 4>), dim3(grid), dim3(256), 0, st, dX, B, H, dW, db, NL, dY, dXb, dCtr, round, dFail); break;
+        case 9: hipLaunchKernelGGL((tile_chain<3, 1, 16, 0, 4>), dim3(grid), dim3(256), 0, st, dX, B, H, dW, db, NL, dY, dXb, dCtr, round, dFail); break;
         case 6: hipLaunchKernelGGL((tile_chain<0, 1, 17, 17, 4>), dim3(grid), dim3(256), 0, st, dX, B, H, dW, db, NL, dY, dXb, dCtr, round, dFail); break;
       }
       ++round;

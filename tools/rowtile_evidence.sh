@@ -4,8 +4,9 @@ set -e
 out=$GRAFT_REPO_ROOT/gpurun_out/${1:-rowtile}
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
+./tools/xcc_census > $out/microbench.txt
 for B in 256 128; do
   echo "== B=$B H=256 NL=10" >> $out/microbench.txt
-  timeout -k 10 150 ./tools/microbench_rowtile $B 256 10 >> $out/microbench.txt
+  timeout -k 10 200 ./tools/microbench_rowtile $B 256 10 >> $out/microbench.txt
 done
 cat $out/microbench.txt
