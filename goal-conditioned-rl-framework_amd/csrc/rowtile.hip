@@ -1,34 +1,40 @@
-// rowtile.hip — the DDPG critic phase (K) and actor phase (P) of rowchain.hip in WEIGHT-SLICE form (round 4).
+// rowtile.hip — the DDPG critic phase (K) and actor phase (P) of rowchain.hip in WEIGHT-SLICE form (round 4; opt-in: GCRL_ROWTILE=1).
 //
 // rowchain_ddpg_kernel gives every 4 batch rows a workgroup that streams each layer's WHOLE weight matrix (256 KB at
 // H = 256) through one CU: a layer pass is bound by that CU's vector-memory path (2.85 us measured, 1.7 us at the L1's
 // 64 B/clk), ten dependent passes per phase, half the chip idle at B = 256.  Here a workgroup owns the 16 x 16 output
 // tile (row block rb, column block cb) of EVERY layer of its role's chain: per layer it reads its 16 columns of the weight
-// matrix (16 KB, independent of computed data: requested before the wait) and its row block's 16 x H activations (16 KB)
-// and issues 16 MFMAs per wave (v_mfma_f32_16x16x4_f32, k split over the four waves, partial sums through LDS).  The price
-// is a hand-off per layer between the H / 16 workgroups of a row block — the saved activations / gradients the dW launch
-// needs anyway ARE the exchanged bytes.  tools/microbench_rowtile.hip (profiles/r04_rowtile_microbench.txt): 1.8-2.2 us per
-// layer against 2.85.
+// matrix (16 KB, independent of computed data) and its row block's 16 x H activations (16 KB) and issues 16 MFMAs per wave
+// (v_mfma_f32_16x16x4_f32, k split over the four waves, partial sums through LDS).  The price is a hand-off per layer between
+// the H / 16 workgroups of a row block.  tools/microbench_rowtile.hip (profiles/r04_rowtile_microbench.txt): 1.8-2.2 us per
+// layer of a bare chain against 2.85; inside the engine (heads, two roles, saves) 2.7-2.9 us per hand-off cycle: the step is
+// 55.4 us against 56.3 with the row-chain launch — measured, and left opt-in.
 //
 // Roles (src/agent.py:1288-1317; the arithmetic per row is rowchain.hip's, the summation order inside a dot product is not):
-//   P   actor phase: actor forward (saved) -> a = tanh(head) -> critic forward on [s | a] -> q2 partials, constant
+//   P   actor phase: actor forward (saved) -> a = tanh(head) -> critic forward on [s | a] -> partials of Q(s, pi(s)), constant
 //       upstream -1/B -> critic input-gradient chain -> action gradient, tanh' -> actor gradient chain (saved)
-//   KT  target chain: target actor -> a' -> target critic -> partials of Q'(s', a')
-//   KO  online critic on [s | a] (saved) -> q; waits for KT's partials of its rows -> y, dq -> gradient chain (saved)
+//   K   critic phase: the target chain (target actor -> a' -> target critic -> partials of Q') and the online critic's forward
+//       on [s | a] (saved) are independent — their layers share the hand-off cycle, two tiles per cycle — then y, dq and the
+//       online critic's gradient chain (saved)
 // Small heads (N <= 16 outputs) are computed REDUNDANTLY by every workgroup of a row block from the row block's full
 // activations (one more group of MFMAs on the fragments it has loaded anyway) — no extra hand-off.
 //
-// Hand-off protocol (meet.h; MI355X guide, inter-workgroup visibility): the tile leaves wave 0 as ONE 16-byte store per
-// lane, the wave drains its stores (s_waitcnt vmcnt(0)) and one lane adds to the stage's monotonic counter (one 128-byte
-// line per (role, stage, row block)); a consumer wave polls that counter with agent-scope loads, then loads its fragments
-// with sc1 loads (they bypass the CU's L1).  The round of a counter is told by the value the workgroup's FIRST arrival of
-// the launch returned (every counter of a row block advances by exactly H / 16 per launch).  A wait is bounded; a timed-out
-// wait sets MEET_ERR_ROWCHAIN in the host-visible status word (the next synchronising call returns GCRL_ERR_STATE).
-// Stores: agent-scope write-through (sc1) unless the workgroups of the row block found each other on ONE XCD (each
-// publishes its XCC_ID at the first arrival; all read the same H / 16 words, so all decide alike): then plain stores —
-// the XCD's L2 is the point of coherence for its own CUs, and sc1 loads are served from it — 1.8 instead of 2.2 us per
-// layer.  The launch order puts a row block's workgroups on one XCD (workgroup w runs on XCD w % 8); a different placement
-// costs speed, never correctness.  All workgroups of the launch must be resident at once (rowtile_ok).
+// Hand-off: THE DATA IS THE FLAG.  Every word of a hand-off buffer is 0xFFFFFFFF ("not written yet": a NaN pattern no fp32
+// arithmetic produces) between launches.  The tile leaves wave 0 as ONE 16-byte store per lane — no drain, no counter —
+// and a consumer wave simply loads its fragments (sc1: past the CU's L1) until none of their words is that pattern.
+// Once a workgroup holds ALL tiles of a stage, every workgroup of the row block has stored its tile of that stage, which it
+// did after reading the stage before: so the workgroup puts its own tile of the PREVIOUS stage back to "not written yet",
+// ready for the next launch (hipGraph replays included).  The last stage of a chain and the scalar-head partials are put back
+// at the start of the next launch: their readers come several hand-offs later.  A poll is bounded; a timed-out poll sets
+// MEET_ERR_ROWCHAIN in the host-visible status word: the next synchronising call returns GCRL_ERR_STATE and re-initialises
+// every hand-off word (agent.hip: rowtile_reset).
+// Stores: agent-scope write-through (sc1) unless the workgroups of the row block found each other on ONE XCD (wave 1
+// publishes the workgroup's XCC_ID behind a drained store with its arrival at the row block's monotonic counter, whose
+// returned value names the round; all read the same H / 16 words, so all decide alike): then plain stores — the XCD's L2 is
+// the point of coherence for its own CUs and serves the sc1 loads — 1.8 instead of 2.2 us per layer of a bare chain.  The
+// launch order puts a row block's workgroups on one XCD (workgroup w runs on XCD w % 8, tools/xcc_census.hip) and keeps a
+// tile's workgroup index the same in every launch; a different placement costs speed, never correctness.  Nothing crosses
+// roles.  All workgroups of the launch must be resident at once (rowtile_ok).
 #include "rowchain.h"
 #include "meet.h"
 
@@ -74,24 +80,25 @@ struct TileCtx {
   bool failed;
 };
 
+// a timed-out wait: the host-visible status word (behind this wave's stores: tools/check_release_isa.py reads every atomic that
+// follows write-through stores as an arrival)
+__device__ inline void report_timeout(const TileCtx& c) {
+  drain_stores();
+  if (c.lane == 0 && c.status) __hip_atomic_fetch_or(c.status, MEET_ERR_ROWCHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // a wave waits for the stage's arrivals (every lane polls the same word: one request)
 __device__ inline void tile_wait(TileCtx& c, const unsigned long long* ctr) {
   if (c.failed) return;
   int spins = 0;
   while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.target) {
     if (++spins >= kMeetSpinMax) {
-      if (c.lane == 0 && c.status) __hip_atomic_fetch_or(c.status, MEET_ERR_ROWCHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      report_timeout(c);
       c.failed = true;
       break;
     }
     __builtin_amdgcn_s_sleep(2);
   }
-}
-
-// wave 0, after its stores of the stage: drained, then one arrival
-__device__ inline void tile_arrive(const TileCtx& c, unsigned long long* ctr) {
-  drain_stores();
-  if (c.lane == 0) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ inline void tile_store(const TileCtx& c, float* buf, long long nfloats, int off_floats, v4f v) {
@@ -196,7 +203,7 @@ __device__ inline float sum_partials(TileCtx& c, const float* qp, long long nflo
     }
     if (c.failed || !__any(missing)) break;
     if (spins >= kMeetSpinMax) {
-      if (c.lane == 0 && c.status) __hip_atomic_fetch_or(c.status, MEET_ERR_ROWCHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      report_timeout(c);
       c.failed = true;
       break;
     }
@@ -283,8 +290,9 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
     }
   }
   const StepCtrl sc = role == ROLE_P ? *a.cur_p : *a.cur_k;
-  // Which store form?  Wave 1 publishes this workgroup's XCD with its arrival at the row block's counter (monotonic: the value the
-  // add returns names the round) and, after layer 0, reads the row block's H / 16 words: all on one XCD -> plain stores.
+  // Which store form?  Wave 1 publishes this workgroup's XCD (a drained write-through store) and arrives at the row block's counter
+  // (monotonic: the value the add returns names the round); after layer 0 it waits for the row block's arrivals (bounded) and
+  // reads the H / 16 words: all on one XCD -> plain stores.
   unsigned long long* ctr = t.ctr + (long long)(role * nrb + c.rb) * 16;
   unsigned int* xid = t.xid + (long long)(role * nrb + c.rb) * 32;
   if (tid == 64) {
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
   auto consume_end = [&]() {
     for (int spins = 0; (need1 || need2) && !c.failed; ++spins) {
       if (spins >= kMeetSpinMax) {
-        if (c.lane == 0 && c.status) __hip_atomic_fetch_or(c.status, MEET_ERR_ROWCHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        report_timeout(c);
         c.failed = true;
         break;
       }

@@ -202,11 +202,12 @@ def test_sampled_noisy_updates_track_oracle(gcrl, kind):
     print(f"sampled noisy updates [{kind}]: worst relative tuple error {worst:.2e}")
 
 
-@pytest.mark.parametrize("kind,H,L,B", [("SAC", 256, 3, 512), ("TD3", 256, 3, 2048)])
+@pytest.mark.parametrize("kind,H,L,B", [("SAC", 256, 3, 512), ("TD3", 256, 3, 2048), ("DDPG", 256, 3, 256)])
 def test_failed_meeting_inside_a_launch_is_reported_and_the_handle_recovers(gcrl, tmp_path, kind, H, L, B):
     """SAC at batch 512: the BatchNorm slab launches split their rows over four workgroups that wait for each other inside the
     launch, and so do the role workgroups of the twin-critic row chains (csrc/meet.h).  TD3 at batch 2048: the critic phase's
-    online-critic workgroups wait for the target roles of their rows (producers / consumers: 1 024 workgroups, not all resident).  A wait that times out used to leave NaN
+    online-critic workgroups wait for the target roles of their rows (producers / consumers: 1 024 workgroups, not all resident);
+    DDPG at batch 256 (round 4): the same two roles inside the fused launch (k_split).  A wait that times out used to leave NaN
     statistics / gradients and nothing else: now the status word makes the next synchronising call fail ONCE with
     GCRL_ERR_STATE — the reference raises on any failed step (src/agent.py:659-699) — and the handle works again afterwards.
     The fault is injected by knocking one meeting counter off its multiple-of-arrivals state (gcrl_agent_debug_meet_fault)."""

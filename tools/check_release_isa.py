@@ -2,7 +2,7 @@
 """Build check: every publication through memory is released before the arrival that announces it.
 
 The kernels whose workgroups hand data to each other inside a launch (csrc/meet.h: BatchNorm slab row groups, row-chain
-roles; csrc/gemm_tiled.h: the split-dW ticket; csrc/xchg_ipc.hip: the peer-to-peer gradient exchange) publish with
+roles, also inside the fused DDPG launch; csrc/rowtile.hip: the first arrival of the weight-slice launch; csrc/gemm_tiled.h: the split-dW ticket; csrc/xchg_ipc.hip: the peer-to-peer gradient exchange) publish with
 write-through (sc1 / sc0 sc1) stores and then arrive at a counter with a global atomic.  On gfx950 a workgroup-scope
 release fence emits NO `s_waitcnt vmcnt(0)`, so the arrival could overtake the stores.  This script
 compiles the translation units to gfx950 assembly (device side only, no GPU needed) and checks, per kernel, that every
@@ -26,7 +26,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--c
 # translation unit -> substrings of the (mangled) kernel names that must pass, and must be present
 UNITS = {
     "bn_slab.hip": ["bn_linear_fwd_slab_kernel", "bn_linear_bwd_slab_kernel"],
-    "rowchain.hip": ["rowchain_split_kernel"],
+    "rowchain.hip": ["rowchain_split_kernel", "rowchain_ddpg_kernel"],
+    "rowtile.hip": ["rowtile_ddpg_kernel"],
     "gemm_mfma.hip": ["gemm_tiled_kernel"],
     "xchg_ipc.hip": ["xchg_two_shot_kernel"],
     "ops.hip": ["td_loss_kernelILi3ELi0ELb1"],
