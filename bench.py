@@ -300,6 +300,21 @@ def timed_region(agent, dp, w, steps, warmup, step0=1):
     return elapsed, s0 + steps, extra, run
 
 
+def _meeting_forms(agent):
+    try:
+        m = int(agent.meetings())
+    except Exception:
+        return None
+    names = []
+    if m & 1:
+        names.append("BatchNorm slab row groups")
+    if m & 2:
+        names.append("row-chain roles (DDPG: the critic phase as two roles of the fused launch)")
+    if m & 4:
+        names.append("weight-slice DDPG launch (GCRL_ROWTILE=1)")
+    return names
+
+
 def pmc_traffic(workload, kernel_substr):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/r0N_pmc_traffic_<workload>.json — the newest round's — made by tools/pmc_traffic.sh: FETCH_SIZE x 2 + WRITE_SIZE per
@@ -525,6 +540,8 @@ def main():
                        "state_dim": w["S"], "action_dim": w["A"], "hidden": w["H"], "layers": w["L"], "k_future": w["k"],
                        "gradient_step": gstep, "parallelism": f"dp{world}" if world > 1 else "single",
                        "hip_graph": not args.no_graph,
+                       # launch forms with in-kernel waits that are ACTIVE (csrc/meet.h; gcrl_agent_set_meetings' mask)
+                       "in_kernel_meetings": _meeting_forms(agent),
                        "rng": "cpython-mt19937 (host) indices" if args.rng == "engine" else "counter-hash indices (in-kernel HER picks)",
                        "reward": "built-in sparse goal-distance reward (panda-gym absent: the only parity-unpinned seam, DESIGN.md §2)"},
             "value_semantics": ("one agent.update(step) on a batch of %d rows per second" % w["B"]) if world == 1 else

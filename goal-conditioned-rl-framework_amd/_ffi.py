@@ -174,6 +174,7 @@ PROTOTYPES = {
     "gcrl_agent_set_exchange": (C.c_int, [_vp, _vp]),
     "gcrl_set_shared_device": (C.c_int, [C.c_int]),
     "gcrl_agent_set_meetings": (C.c_int, [_vp, C.c_int]),
+    "gcrl_agent_get_meetings": (C.c_int, [_vp]),
     "gcrl_agent_debug_meet_fault": (C.c_int, [_vp]),
     "gcrl_hash_normal_fill": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, _vp, _vp]),
     "gcrl_event_create": (_vp, []),

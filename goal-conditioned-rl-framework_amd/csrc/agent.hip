@@ -1981,6 +1981,11 @@ int gcrl_agent_set_meetings(gcrl_agent* a, int on) {
   return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k || a->ddpg_ksplit) ? 2 : 0) | (a->rowtile ? 4 : 0);
 }
 
+int gcrl_agent_get_meetings(gcrl_agent* a) {
+  GCRL_CHECK_ARG(a, "gcrl_agent_get_meetings: null handle");
+  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k || a->ddpg_ksplit) ? 2 : 0) | (a->rowtile ? 4 : 0);
+}
+
 int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
   GCRL_CHECK_ARG(a, "gcrl_agent_debug_meet_fault: null handle");
   GCRL_HIP(hipDeviceSynchronize());

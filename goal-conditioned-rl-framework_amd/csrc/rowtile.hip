@@ -102,7 +102,8 @@ __device__ inline void tile_wait(TileCtx& c, const unsigned long long* ctr) {
 }
 
 __device__ inline void tile_store(const TileCtx& c, float* buf, long long nfloats, int off_floats, v4f v) {
-  const v4u o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  v4u o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  if (c.failed && o[0] != kSent) o = (v4u){0x7FC00000u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u};   // after a timed-out wait: NaN, not a plausible number
   const __amdgpu_buffer_rsrc_t rs = bounded_rsrc(buf, nfloats);
   if (c.plain) __builtin_amdgcn_raw_buffer_store_b128(o, rs, off_floats * 4, 0, 0);
   else __builtin_amdgcn_raw_buffer_store_b128(o, rs, off_floats * 4, 0, kSc1);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
   float* hd = xs2 + 16 * ldsx;             // [16][16] a head's result
   float* as_ = hd + 256;                   // [16][16] tanh(actor head) (P)
   float* own = as_ + 256;                  // [2L][256] own tiles (wave 0; lane-private 16-byte slots)
-  __shared__ unsigned int s_plain;
+  __shared__ unsigned int s_plain, s_fail;
   int pb = 0;
   int sidx = 4;
   (void)sidx;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
     c.target = (t0 / (unsigned long long)ncb + 1ull) * (unsigned long long)ncb;
   }
   c.target = __shfl(c.target, 0, 64);   // (wave 1: lane 0's value; other waves: 0, unused)
-  if (tid == 0) s_plain = 0u;
+  if (tid == 0) { s_plain = 0u; s_fail = 0u; }
   // last launch's leftovers -> "not written yet": the final tile stage of the chain (nobody could tell when its readers were
   // done) and the scalar-head partials.  Their readers of THIS launch come several hand-offs later, each of which needs a tile
   // of this workgroup that it stores after these resets have been acknowledged (the waits for its loads below).
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
     return x;
   };
   auto own_at = [&](int i) { return (v4f*)(own + i * 256 + 4 * c.lane); };
-  auto save = [&](float* buf, v4f x) { *(v4f*)(buf + ooff) = x; };   // for the dW launch: a plain store, visible at the kernel boundary
+  auto save = [&](float* buf, v4f x) {
+    if (c.failed) x = (v4f){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+    *(v4f*)(buf + ooff) = x;
+  };   // for the dW launch: a plain store, visible at the kernel boundary
   // The hand-off: the DATA is the flag.  Every wave loads its fragments of the row block's tiles (sc1: past the CU's L1) until none
   // of its words is the "not written yet" pattern; the workgroup votes and repeats together.  Once a set of stages has arrived,
   // every workgroup of the row block has stored its tiles of that set — which it did AFTER reading the previous set — so the
@@ -361,6 +365,7 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
       if (spins >= kMeetSpinMax) {
         report_timeout(c);
         c.failed = true;
+        if (c.lane == 0) s_fail = 1u;   // (wave 0 poisons what this workgroup hands on and saves: a timed-out step must not pass for a result)
         break;
       }
       for (int i = 0; i < t.sleep_poll; ++i) __builtin_amdgcn_s_sleep(1);
@@ -378,6 +383,7 @@ __global__ __launch_bounds__(kTileThreads) void rowtile_ddpg_kernel(RowTileArgs 
     __syncthreads();
     if (c.wave == 0) {
       c.plain = s_plain != 0;   // (wave 1's decision, once it is made: the stores before it go write-through)
+      if (s_fail) c.failed = true;
       if (cur1 != prev1 || cur2 != prev2) {   // a new set has been consumed by every wave: the one before it goes back to "not written yet"
         if (prev1) tile_store(c, prev1, BH, ooff, sent4);
         if (prev2) tile_store(c, prev2, BH, ooff, sent4);

@@ -208,6 +208,11 @@ class _EngineAgent:
         shared with other processes or streams (`gcrl_set_shared_device` / GCRL_SHARED_GPU=1 do it process-wide)."""
         return _ffi.check(lib.gcrl_agent_set_meetings(self._h, 1 if on else 0))
 
+    def meetings(self) -> int:
+        """Bit mask of the launch forms with in-kernel waits that are active on this handle (1 BatchNorm slab row groups, 2 row-chain
+        roles, 4 the opt-in weight-slice DDPG launch); changes nothing."""
+        return _ffi.check(lib.gcrl_agent_get_meetings(self._h))
+
     # ------------------------------------------------------------------ update
     def _metrics(self, ticket: int, n: int):
         vals = self._metric_cache.get(ticket)

@@ -435,13 +435,16 @@ int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_
  *                               shared with other processes / streams that hold CUs (several ranks on one GPU, another
  *                               library's collectives) — handles created afterwards use the launch forms without waits;
  *   gcrl_agent_set_meetings     switches an existing handle (0: off; 1: on where admissible); captured graphs are dropped;
- *                               returns a bit mask of the forms now active (1 slab row groups, 2 merged row-chain phases);
+ *                               returns a bit mask of the forms now active (1 slab row groups, 2 row-chain roles: merged phases,
+ *                               DDPG's two-role critic phase; 4 the opt-in weight-slice DDPG launch, GCRL_ROWTILE=1);
+ *   gcrl_agent_get_meetings     the same mask, changing nothing;
  *   a wait that times out (~1 s) poisons that launch's statistics / gradients with NaN AND is reported: the next call that
  *   synchronises the handle (gcrl_agent_metrics, _get, _save_state) returns GCRL_ERR_STATE once, after which the handle works
  *   again — the reference raises on any failed step (src/agent.py:659-699);
  *   gcrl_agent_debug_meet_fault injects such a failure into the handle's next launch (tests). */
 int gcrl_set_shared_device(int shared);
 int gcrl_agent_set_meetings(gcrl_agent* a, int on);
+int gcrl_agent_get_meetings(gcrl_agent* a);
 int gcrl_agent_debug_meet_fault(gcrl_agent* a);
 /* device pointer of a named vector (parameters / grads), for zero-copy interop */
 int gcrl_agent_dev_ptr(gcrl_agent* a, const char* name, float** ptr_dev_out, int64_t* numel_out);
