@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for e in "GCRL_DW_SLEEP=1" "GCRL_DW_SLEEP=4" "GCRL_DW_SLEEP=16" "GCRL_NO_DW_INLINE=1"; do
-echo "$e: $(env $e timeout -k 10 100 python bench.py --no-cpu-baseline --no-profiler --steps 3000 --warmup 300 2>&1 | tail -1 | cut -c1-200 | grep -o '"ms_per_step": [0-9.]*\|Error.*')"
-done
-bash tools/prof_bench.sh dwinline 2>&1 | grep -E "rowchain|adam_pair|gemm_batch" | cut -c1-150
+mkdir -p gpurun_out/full2
+timeout -k 10 1100 python -m pytest tests -m gpu -q > gpurun_out/full2/default.txt 2>&1; echo "rc=$?"; tail -6 gpurun_out/full2/default.txt | cut -c1-250
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
