@@ -1340,7 +1340,8 @@ int build(gcrl_agent* a) {
     // workgroups fit the chip at once (one per CU)
     {
       const long long nblk = (B + 4 * a->row_rg - 1) / (4 * a->row_rg);
-      a->ddpg_ksplit_can = a->rowchain && c.kind == GCRL_AGENT_DDPG && C == 1 && 3 * nblk <= std::max(a->n_cus, 1);
+      static const int per_cu = std::getenv("GCRL_DDPG_KSPLIT_PER_CU") ? std::atoi(std::getenv("GCRL_DDPG_KSPLIT_PER_CU")) : 1;   // experiment knob
+      a->ddpg_ksplit_can = a->rowchain && c.kind == GCRL_AGENT_DDPG && C == 1 && 3 * nblk <= per_cu * std::max(a->n_cus, 1);
       a->ddpg_ksplit = a->ddpg_ksplit_can && !meet_device_shared() && !std::getenv("GCRL_NO_DDPG_KSPLIT");
       if (a->ddpg_ksplit_can && !a->rc_bar_words) { a->rc_bar_words = 2 * nblk * 32; wants.push_back({&a->rc_bar, a->rc_bar_words}); }
     }

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/full2
-timeout -k 10 1100 python -m pytest tests -m gpu -q > gpurun_out/full2/default.txt 2>&1; echo "rc=$?"; tail -6 gpurun_out/full2/default.txt | cut -c1-250
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+for r in 1 2; do
+for e in "X=1" "GCRL_DDPG_KSPLIT_PER_CU=2"; do
+echo "cfg2 $e: $(env $e timeout -k 10 100 python bench.py --workload ddpg_reach_b1024 --no-cpu-baseline --no-profiler --steps 2000 --warmup 200 2>&1 | tail -1 | cut -c1-200 | grep -o '"ms_per_step": [0-9.]*\|Error.*')"
+done; done
