@@ -161,12 +161,6 @@ struct gcrl_agent {
   int n_cus = 0;              // compute units of the device (residency checks of the launches whose workgroups meet)
   bool rc_merge = false;      // ... forward and backward part in ONE launch each (part 3; GCRL_NO_RC_MERGE=1: two launches)
   bool rc_merge_k = false;    // TD3 (split_k): the critic phase's two launches as one, producers / consumers form (meet.h)
-  // DDPG: the phases' dW | db problems in consumer workgroups of the fused row-chain launch (rowchain.h: dw_inline).  Six prepared
-  // batches in device memory: [critic | actor reading `cur` | actor reading `prev`] x [Σg² partials out of the epilogue | not]
-  bool dw_inline = false, dw_inline_can = false;
-  GemmBatch* dwb_dev = nullptr;
-  int dwb_blocks[6] = {0, 0, 0, 0, 0, 0};
-  float *dw_done = nullptr, *dw_round = nullptr;
   bool ddpg_ksplit = false, ddpg_ksplit_can = false;   // DDPG: the critic phase as two roles of the fused launch (rowchain.hip, k_split)
   float* rc_bar = nullptr;    // meeting counters of the row blocks [2][nblk][32 words]
   long long rc_bar_words = 0;
@@ -1169,7 +1163,6 @@ int meet_check(gcrl_agent* a) {
   if (a->bn_bar) (void)hipMemset(a->bn_bar, 0, (size_t)bn_slab_bar_words(a->H) * sizeof(unsigned int));
   if (a->rc_bar && a->rc_bar_words) (void)hipMemset(a->rc_bar, 0, (size_t)a->rc_bar_words * sizeof(unsigned int));
   (void)rowtile_reset(a);
-  if (a->dw_done) { (void)hipMemset(a->dw_done, 0, 64 * sizeof(float)); (void)hipMemset(a->dw_round, 0, 2 * 8192 * sizeof(float)); }
   if (bits & (MEET_ERR_XCHG_READY | MEET_ERR_XCHG_DONE)) {
     (void)hipDeviceSynchronize();
     __atomic_store_n(a->status_host, 0u, __ATOMIC_RELEASE);
@@ -1345,13 +1338,6 @@ int build(gcrl_agent* a) {
       a->ddpg_ksplit = a->ddpg_ksplit_can && !meet_device_shared() && !std::getenv("GCRL_NO_DDPG_KSPLIT");
       if (a->ddpg_ksplit_can && !a->rc_bar_words) { a->rc_bar_words = 2 * nblk * 32; wants.push_back({&a->rc_bar, a->rc_bar_words}); }
     }
-    // DDPG at a latency-bound batch: the dW problems CAN ride in the row-chain launch as consumer workgroups (the critic's start when
-    // the critic phase's chains are done, ~8 us before the actor phase's; one launch boundary less).  Measured (round 4, headline):
-    // the launch grows from 37.7 to 55.4 us where the dW launch it replaces takes 7.2 — 66.6 vs 57.0 us/step (61.9 with the ~1 200
-    // waiting workgroups polling every 7 us instead of every 0.4): OFF unless GCRL_DW_INLINE=1.
-    a->dw_inline_can = a->ddpg_ksplit_can && c.kind == GCRL_AGENT_DDPG && B <= 512;
-    a->dw_inline = a->dw_inline_can && a->ddpg_ksplit && std::getenv("GCRL_DW_INLINE") != nullptr;
-    if (a->dw_inline_can) { wants.push_back({&a->dw_done, 64}); wants.push_back({&a->dw_round, 2 * 8192}); }
     a->head_batches = 3;   // (TD3 at batch 2048: the host draws 38 x 2048 indices in ~390 us, more than two 170 us steps)
     if (const char* e = std::getenv("GCRL_HEAD_BATCHES")) a->head_batches = std::max(1, std::min(8, std::atoi(e)));   // experiment knob
     a->dw_batch_off = std::getenv("GCRL_NO_DW_BATCH") != nullptr;
@@ -1448,21 +1434,6 @@ int build(gcrl_agent* a) {
   TRY(launch_fill(a->stream, a->dq2, (long long)C * B * a->Q, -1.0f / (float)B));
   TRY(launch_fill(a->stream, a->alpha_dev, 1, 1.0f));  // exp(log_alpha = 0)
   GCRL_HIP(hipStreamSynchronize(a->stream));
-
-  if (a->dw_inline_can) {
-    GCRL_HIP(hipMalloc((void**)&a->dwb_dev, 6 * sizeof(GemmBatch)));
-    const PipeCtx kc{a->cur(), &a->ctrl()->cur.batch_slot}, pc{a->prev(), &a->ctrl()->prev.batch_slot};
-    for (int v = 0; v < 6; ++v) {
-      Launches ls;
-      rc_add_dw(a, ls, v >= 4 ? pc : kc, v < 2, (v & 1) == 0);
-      GemmBatch gb;
-      std::memset(&gb, 0, sizeof(gb));
-      const int rc = (ls.steps.size() == 1 && ls.steps[0].size() <= (size_t)kMaxProb)
-                         ? prepare_gemm_batch_ksplit(ls.steps[0].data(), (int)ls.steps[0].size(), &gb, &a->dwb_blocks[v]) : GCRL_ERR_ARG;
-      if (rc != GCRL_OK || a->dwb_blocks[v] > 4096) { a->dw_inline_can = a->dw_inline = false; last_error().clear(); break; }
-      GCRL_HIP(hipMemcpy(a->dwb_dev + v, &gb, sizeof(gb), hipMemcpyHostToDevice));
-    }
-  }
 
   // names
   auto reg = [&](const std::string& k, float* p, long long n) { a->names[k] = {p, n}; };
@@ -1977,7 +1948,6 @@ int gcrl_agent_set_meetings(gcrl_agent* a, int on) {
                 rowchain_merge_ok(a->row_rg, a->row_ldl, c.ac_dim, a->H, a->C, a->B);
   a->rc_merge_k = want && a->rc_bar && a->split_k && !std::getenv("GCRL_NO_RC_MERGE");
   a->ddpg_ksplit = want && a->ddpg_ksplit_can && a->rc_bar && !std::getenv("GCRL_NO_DDPG_KSPLIT");
-  a->dw_inline = a->ddpg_ksplit && a->dw_inline_can && std::getenv("GCRL_DW_INLINE") != nullptr;
   a->rowtile = want && a->rowtile_can && rowtile_enabled() && rowtile_ok(a->B, a->H, a->L, a->S, a->A, a->C);
   return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k || a->ddpg_ksplit) ? 2 : 0) | (a->rowtile ? 4 : 0);
 }

@@ -133,10 +133,8 @@ __device__ inline int xcd_tile_of(int w, int G) {
   return w < (per << 3) ? (w & 7) * per + (w >> 3) : w;
 }
 
-// `block` of `nblocks`: the workgroup's index among those that run this batch (the kernel below: blockIdx.x of gridDim.x; the
-// DDPG row-chain launch runs a phase's dW problems in workgroups of its own grid, rowchain.hip)
 template <int TM, int TN, int KSPLIT>
-__device__ __forceinline__ void gemm_batch_body(const GemmBatch& gb, int block, int nblocks) {
+__global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
   static_assert(KSPLIT == 1 || (TM == 1 && TN == 1), "k-split only for single 16x16 tiles");
   constexpr int NACC = (TM * TN >= 4) ? 1 : (TM * TN == 2 ? 2 : 4);
   // wave-tile forms: the MFMAs run with the operand roles swapped, so the accumulator holds the TRANSPOSED tile —
@@ -146,7 +144,7 @@ __device__ __forceinline__ void gemm_batch_body(const GemmBatch& gb, int block, 
   constexpr bool TR = KSPLIT == 1;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bid = xcd_tile_of(block, nblocks);
+  const int bid = xcd_tile_of((int)blockIdx.x, (int)gridDim.x);
   const int wtile = (KSPLIT == 4) ? bid : bid * 4 + wave;
   int pi = 0;
 #pragma unroll
@@ -437,18 +435,10 @@ __device__ __forceinline__ void gemm_batch_body(const GemmBatch& gb, int block, 
   }
 }
 
-template <int TM, int TN, int KSPLIT>
-__global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
-  gemm_batch_body<TM, TN, KSPLIT>(gb, (int)blockIdx.x, (int)gridDim.x);
-}
-
 // 1: one 16x16 tile per workgroup with K split over its waves (the form that can produce bn_part), 2-4: larger forms
 int gemm_shape_of(const GemmDesc& d);
 
 // Launch `n` problems in one grid.  shape: 0 = auto.
 int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape = 0);
-// The same problems as ONE batch of the k-split 16x16 form, filled in (fragment forms, tile ranges) but not launched: for a caller
-// that runs gemm_batch_body<1, 1, 4> in workgroups of its own kernel.  Fails unless every problem's shape rule picks that form.
-int prepare_gemm_batch_ksplit(GemmDesc* descs, int n, GemmBatch* out, int* blocks);
 
 }  // namespace gcrl

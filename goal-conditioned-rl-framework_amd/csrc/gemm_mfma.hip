@@ -161,29 +161,6 @@ int launch_tiled(hipStream_t st, GemmBatch& gb) {
 
 int gemm_shape_of(const GemmDesc& d) { return shape_of(d); }
 
-int prepare_gemm_batch_ksplit(GemmDesc* descs, int n, GemmBatch* out, int* blocks) {
-  GCRL_CHECK_ARG(n >= 1 && n <= kMaxProb && out && blocks, "prepare_gemm_batch_ksplit: %d problems (max %d)", n, kMaxProb);
-  int tiles = 0;
-  out->n = n;
-  for (int i = 0; i < n; ++i) {
-    GemmDesc& d = descs[i];
-    GCRL_CHECK_ARG(d.M >= 1 && d.N >= 1 && d.K >= 1 && d.A && d.B && d.C, "prepare_gemm_batch_ksplit: bad problem %d (M=%d N=%d K=%d)", i, d.M, d.N, d.K);
-    GCRL_CHECK_ARG(!d.ones_col || (d.N >= 2 && d.col_out), "prepare_gemm_batch_ksplit: ones_col needs N >= 2 and col_out");
-    GCRL_CHECK_ARG((d.shape_hint ? d.shape_hint : shape_of(d)) == 1 && !d.bn_part, "prepare_gemm_batch_ksplit: problem %d is not a k-split 16x16 problem", i);
-    d.a_vec = (d.a_cs == 1 && d.a_rs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
-    d.b_vec = (d.b_rs == 1 && d.b_cs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
-    d.a_rvec = (d.a_rs == 1 && d.a_cs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
-    d.b_rvec = (d.b_cs == 1 && d.b_rs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
-    d.tiles_n = (d.N + 15) / 16;
-    d.ntiles = ((d.M + 15) / 16) * d.tiles_n;
-    d.tile0 = tiles;
-    tiles += d.ntiles;
-    out->d[i] = d;
-  }
-  *blocks = tiles;
-  return GCRL_OK;
-}
-
 int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape) {
   GCRL_CHECK_ARG(n >= 1 && n <= kMaxProb, "launch_gemm_batch: %d problems (max %d)", n, kMaxProb);
   int shapes[kMaxProb];

@@ -89,17 +89,6 @@ __device__ inline void rows_matmul_wave(const float* xs, int ldx, __amdgpu_buffe
   }
 }
 
-// a saved activation / gradient row segment for the dW GEMMs: plain, or write-through (sc1) when the dW problems run in consumer
-// workgroups of the SAME launch (rowchain_ddpg_kernel, dw_inline: they read it behind a drained arrival, meet.h)
-__device__ inline void save4(float* base, long long off_floats, v4f v, bool wt) {
-  if (wt) {
-    const v4u o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-    __builtin_amdgcn_raw_buffer_store_b128(o, wave_uniform_rsrc(base), (int)(off_floats * 4), 0, 16);
-  } else {
-    *(v4f*)(base + off_floats) = v;
-  }
-}
-
 // y = act(x . M + bias) [* act'(hprev)] for the block's rows; all kRowThreads threads call it.
 //   part   LDS scratch 2 x [4 waves][4*RG][kRowChunk] (two buffers, `pbuf` picks one)
 //   ys     LDS output [4*RG][ldy]   (must not alias xs)
@@ -114,7 +103,7 @@ template <int RG>
 __device__ inline void rows_linear(const float* xs, int ldx, int J, const float* M, int ldm, int N, const float* bias,
                                    int epi, float* part, float* ys, int ldy, float* save, long long ld_save,
                                    int rows_valid, const float* mulH = nullptr, long long ld_mul = 0, int mul = MUL_NONE,
-                                   bool chained = false, int pbuf = 0, bool save_wt = false) {
+                                   bool chained = false, int pbuf = 0) {
   constexpr int R = 4 * RG;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -157,7 +146,7 @@ __device__ inline void rows_linear(const float* xs, int ldx, int J, const float*
           if (mul != MUL_NONE) v[q] *= act_deriv(eh[it][q], mul);
         }
         *(v4f*)(ys + r * ldy + cc) = v;
-        if (save && r < rows_valid) save4(save, (long long)r * ld_save + cc, v, save_wt);
+        if (save && r < rows_valid) *(v4f*)(save + (long long)r * ld_save + cc) = v;
       }
     }
     return;
@@ -195,7 +184,7 @@ __device__ inline void rows_linear(const float* xs, int ldx, int J, const float*
           if (mul != MUL_NONE) v[q] *= act_deriv(hm[rr][q], mul);
         }
         *(v4f*)(ys + r * ldy + c) = v;
-        if (save && r < rows_valid) save4(save, (long long)r * ld_save + c, v, save_wt);
+        if (save && r < rows_valid) *(v4f*)(save + (long long)r * ld_save + c) = v;
       }
     }
     __syncthreads();
@@ -290,16 +279,6 @@ struct RowChainArgs {
   int producers_first;
   // DDPG (rowchain_ddpg_kernel): the critic phase as the two roles above inside the fused launch (needs bar, qt, producers_first)
   int k_split;
-  // DDPG (rowchain_ddpg_kernel): the phases' dW | db problems in CONSUMER workgroups of the same launch (gemm_batch_body<1, 1, 4>;
-  // workgroups after the chains': dw_k_blocks for the critic's problems, then dw_p_blocks for the actor's).  The chain workgroups
-  // store what those problems read write-through and arrive at dw_done[0] (critic phase) / dw_done[16] (actor phase) when done
-  // (meet_produce); a consumer waits for its phase's arrivals of THIS launch (its own launch count in dw_round[workgroup]).
-  // Producers have the lower workgroup indices: deadlock-free without residency (meet.h).
-  int dw_inline;
-  const GemmBatch* dw_k; const GemmBatch* dw_p;   // device memory
-  int dw_k_blocks, dw_p_blocks, dw_sleep;   // dw_sleep: poll period of a waiting consumer in units of 16 x 64 clocks
-  unsigned long long* dw_done;    // [32] zero-initialised
-  unsigned long long* dw_round;   // [dw_k_blocks + dw_p_blocks] zero-initialised
 };
 
 // Twin-critic phases as role-parallel launches (SAC; TD3 at small batches).  In the fused kernel a workgroup

@@ -26,16 +26,11 @@ __device__ inline void load_rows(float* X, int ldl, const float* src, long long 
   }
 }
 
-__device__ inline void st_maybe_wt(float* p, float v, bool wt) {
-  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-
 // hidden layers 0..L-1 of `net` on the rows in X0 (jpad0 columns, zero padded); returns the LDS
 // buffer holding the last hidden activation.  save: [L][B][H] global, row r0 of the block.
 template <int RG>
 __device__ inline float* mlp_hidden(const RowNet& net, const float* X0, float* X1, float* X2, int ldl, float* part,
-                                    float* save, long long BH, long long row0, int rv, float* last_out = nullptr, bool save_wt = false) {
+                                    float* save, long long BH, long long row0, int rv, float* last_out = nullptr) {
   const float* in = X0;
   float* out = X1;
   const bool chained = RG == 1 && net.H <= kRowChunk;   // one barrier per layer (rows_linear); measured slower at 8 rows
@@ -43,7 +38,7 @@ __device__ inline float* mlp_hidden(const RowNet& net, const float* X0, float* X
     if (last_out && l == net.L - 1) out = last_out;   // e.g. kept aside while the ping-pong buffers are reused
     rows_linear<RG>(in, ldl, l == 0 ? net.jpad0 : net.H, net.Wt + net.wt[l], net.H, net.H, net.P + net.b[l], EPI_LEAKY,
                     part, out, ldl, save ? save + l * BH + row0 * net.H : nullptr, net.H, rv, nullptr, 0, MUL_NONE,
-                    chained, l & 1, save_wt);
+                    chained, l & 1);
     in = out;
     out = (out == X1) ? X2 : X1;
   }
@@ -59,7 +54,7 @@ __device__ inline float* mlp_hidden(const RowNet& net, const float* X0, float* X
 // which saves the separate head pass.  Needs the H / 4 threads of a row inside one wavefront (H = 64, 128, 256).
 template <int RG>
 __device__ inline void head_backward(float* h, int ldl, int H, const float* Wh, int n_up, const float* up /* LDS [R][16] */,
-                                     float* save, int rv, float* q_out = nullptr, float q_bias = 0.f, bool save_wt = false) {
+                                     float* save, int rv, float* q_out = nullptr, float q_bias = 0.f) {
   constexpr int R = 4 * RG;
   const int H4 = H >> 2;
   for (int i = threadIdx.x; i < R * H4; i += kRowThreads) {
@@ -77,7 +72,7 @@ __device__ inline void head_backward(float* h, int ldl, int H, const float* Wh, 
       if ((i - r * H4) == 0) q_out[r * 16] = qs + q_bias;
     }
     *(v4f*)(h + r * ldl + k) = g;
-    if (save && r < rv) save4(save, (long long)r * H + k, g, save_wt);
+    if (save && r < rv) *(v4f*)(save + (long long)r * H + k) = g;
   }
 }
 __device__ inline bool head_fusable(int H) { return H == 64 || H == 128 || H == 256; }
@@ -85,14 +80,14 @@ __device__ inline bool head_fusable(int H) { return H == 64 || H == 128 || H == 
 // pre-activation gradients of hidden layers L-2..0 from the one of layer L-1 (in G, LDS)
 template <int RG>
 __device__ inline float* grad_chain(const RowNet& net, float* G, float* X1, float* X2, int ldl, float* part,
-                                    const float* hsaved, float* gsave, long long BH, long long row0, int rv, bool save_wt = false) {
+                                    const float* hsaved, float* gsave, long long BH, long long row0, int rv) {
   float* in = G;
   const bool chained = RG == 1 && net.H <= kRowChunk;
   for (int l = net.L - 1; l >= 1; --l) {
     float* out = (in == X1) ? X2 : X1;
     rows_linear<RG>(in, ldl, net.H, net.P + net.w[l], net.H, net.H, nullptr, EPI_NONE, part, out, ldl,
                     gsave ? gsave + (l - 1) * BH + row0 * net.H : nullptr, net.H, rv,
-                    hsaved + (l - 1) * BH + row0 * net.H, net.H, MUL_DLEAKY, chained, l & 1, save_wt);
+                    hsaved + (l - 1) * BH + row0 * net.H, net.H, MUL_DLEAKY, chained, l & 1);
     in = out;
   }
   if (chained) __syncthreads();
@@ -168,36 +163,6 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     }
   }
   const int kblocks = (a.k_split && a.nblk_k) ? 2 * a.nblk_k : a.nblk_k;
-  // dw_inline: the workgroups behind the chains' run the phases' dW | db problems once their phase's chains have arrived
-  if (a.dw_inline && (int)blockIdx.x >= kblocks + a.nblk_p) {
-    const int b = (int)blockIdx.x - kblocks - a.nblk_p;
-    const bool crit = b < a.dw_k_blocks;
-    __shared__ unsigned int s_dw_flag;
-    // (the wait of meet_consume with a longer sleep: up to ~600 consumers poll for ~30 us next to the chains)
-    if (threadIdx.x == 0) {
-      unsigned long long* my = a.dw_round + (crit ? b : 4096 + (b - a.dw_k_blocks));   // (a role's consumers count THEIR launches)
-      const unsigned long long* ctr = a.dw_done + (crit ? 0 : 16);
-      const unsigned long long r = *my;
-      const unsigned long long target = (r + 1ull) * (unsigned long long)(crit ? a.nblk_k : a.nblk_p);
-      unsigned int ok = 1;
-      int spins = 0;
-      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++spins >= kMeetSpinMax) {
-          ok = 0;
-          if (a.status) __hip_atomic_fetch_or(a.status, MEET_ERR_ROWCHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          break;
-        }
-        for (int i = 0; i < a.dw_sleep; ++i) __builtin_amdgcn_s_sleep(16);
-      }
-      *my = r + 1ull;
-      s_dw_flag = ok;
-    }
-    __syncthreads();
-    (void)s_dw_flag;   // (a timed-out wait is reported through the status word; the tiles are computed all the same)
-    if (crit) gemm_batch_body<1, 1, 4>(*a.dw_k, b, a.dw_k_blocks);
-    else gemm_batch_body<1, 1, 4>(*a.dw_p, b - a.dw_k_blocks, a.dw_p_blocks);
-    return;
-  }
   constexpr int R = 4 * RG;
   const int ldl = a.ldl, H = a.critic[0].H, S = a.S, A = a.A, B = a.B;
   float* X0 = lds;
@@ -225,7 +190,6 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
   const int rv = min(R, B - (int)row0);
   const long long BH = (long long)B * H;
   const int tid = threadIdx.x;
-  const bool wt = a.dw_inline != 0;   // saves for dW problems that run in this launch: write-through (rowchain.h)
   if (blockIdx.x == 0 && tid == 0) { a.cb->cur_b = a.cb->cur; a.cb->prev_b = a.cb->prev; }
   if (a.clk && tid == 0 && blk == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());
 
@@ -316,7 +280,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     }
     // online critic(s) on [s | a]: forward (activations saved), loss gradient, input-gradient chain
     for (int k = 0; k < C; ++k) {
-      h = mlp_hidden<RG>(a.critic[k], XS, X1, X2, ldl, part + R * 16, a.hC + (long long)k * a.critic[k].L * BH, BH, row0, rv, nullptr, wt);
+      h = mlp_hidden<RG>(a.critic[k], XS, X1, X2, ldl, part + R * 16, a.hC + (long long)k * a.critic[k].L * BH, BH, row0, rv);
       rows_head<RG>(h, ldl, H, hw_c + k * H, H, hb + 18 + k, 1, EPI_NONE, sm);
       __syncthreads();
       if (tid < R) {
@@ -328,15 +292,14 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
         else { const float n1 = 1.0f / (float)B; g = (diff < -1.0f) ? -n1 : (diff > 1.0f ? n1 : n1 * diff); }   // smooth-L1
         if (r >= rv) g = 0.f;
         sm2[r * 16] = g;
-        if (r < rv) { a.q[(long long)k * B + row0 + r] = q; st_maybe_wt(a.dq + (long long)k * B + row0 + r, g, wt); }
+        if (r < rv) { a.q[(long long)k * B + row0 + r] = q; a.dq[(long long)k * B + row0 + r] = g; }
       }
       __syncthreads();
       float* gsave = a.gC + (long long)k * a.critic[k].L * BH;
-      head_backward<RG>(h, ldl, H, hw_c + k * H, 1, sm2, gsave + (a.critic[k].L - 1) * BH + row0 * H, rv, nullptr, 0.f, wt);
+      head_backward<RG>(h, ldl, H, hw_c + k * H, 1, sm2, gsave + (a.critic[k].L - 1) * BH + row0 * H, rv);
       __syncthreads();
-      grad_chain<RG>(a.critic[k], h, X1, X2, ldl, part + R * 16, a.hC + (long long)k * a.critic[k].L * BH, gsave, BH, row0, rv, wt);
+      grad_chain<RG>(a.critic[k], h, X1, X2, ldl, part + R * 16, a.hC + (long long)k * a.critic[k].L * BH, gsave, BH, row0, rv);
     }
-    if (wt) meet_produce(a.dw_done);   // the critic's dW workgroups of this launch may start
   } else if (a.p_critic_only) {
     const StepCtrl c = *a.cur_p;
     const int C = a.C;
@@ -423,7 +386,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
     if (fuse_q && tid < R) sm2[tid * 16] = (tid < rv) ? -1.0f / (float)B : 0.f;   // d(-mean Q)/dq, constant
     __syncthreads();
     // the last actor activation lands in XS and stays there: the critic chain reuses X1 / X2
-    float* h = mlp_hidden<RG>(a.actor, X0, X1, X2, ldl, part + R * 16, a.hA, BH, row0, rv, XS, wt);
+    float* h = mlp_hidden<RG>(a.actor, X0, X1, X2, ldl, part + R * 16, a.hA, BH, row0, rv, XS);
     rows_head<RG>(h, ldl, H, hw_a, H, hb, A, EPI_TANH, sm);
     __syncthreads();
     if (tid < R * A) { const int r = tid / A, o = tid - r * A; X0[r * ldl + S + o] = sm[r * 16 + o]; }
@@ -454,13 +417,12 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs
       const float act = sm[r * 16 + o];
       const float g = sm2[r * 16 + o] * act_deriv(act, MUL_DTANH);
       sm2[r * 16 + o] = g;
-      if (r < rv) st_maybe_wt(a.dz + (row0 + r) * a.Apad + o, g, wt);
+      if (r < rv) a.dz[(row0 + r) * a.Apad + o] = g;
     }
     __syncthreads();
-    head_backward<RG>(XS, ldl, H, hw_a, A, sm2, a.gA + (a.actor.L - 1) * BH + row0 * H, rv, nullptr, 0.f, wt);
+    head_backward<RG>(XS, ldl, H, hw_a, A, sm2, a.gA + (a.actor.L - 1) * BH + row0 * H, rv);
     __syncthreads();
-    grad_chain<RG>(a.actor, XS, X1, X2, ldl, part + R * 16, a.hA, a.gA, BH, row0, rv, wt);
-    if (wt) meet_produce(a.dw_done + 16);   // the actor's dW workgroups of this launch may start
+    grad_chain<RG>(a.actor, XS, X1, X2, ldl, part + R * 16, a.hA, a.gA, BH, row0, rv);
   }
   if (a.clk && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
@@ -497,7 +459,6 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
   const long long BH = (long long)B * H;
   const int tid = threadIdx.x;
   const StepCtrl c = phase == 0 ? *a.cur_k : *a.cur_p;
-  const bool wt = a.dw_inline != 0;              // saves for dW problems that run in this launch: write-through
   const bool merged = part == 3;                 // parts 1 and 2 in this launch (rowchain.h)
   __shared__ unsigned int s_flag;
   unsigned int* meet = merged ? a.bar + ((long long)phase * nblk + blk) * 32 : nullptr;
@@ -557,7 +518,7 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
     stage(hw, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
     if (tid == 0) hb[18] = a.critic[k].P[a.critic[k].b[a.critic[k].L]];
     __syncthreads();
-    float* h = mlp_hidden<RG>(a.critic[k], XS, X1, X2, ldl, part_ + R * 16, a.hC + (long long)k * a.critic[k].L * BH, BH, row0, rv, nullptr, wt);
+    float* h = mlp_hidden<RG>(a.critic[k], XS, X1, X2, ldl, part_ + R * 16, a.hC + (long long)k * a.critic[k].L * BH, BH, row0, rv);
     rows_head<RG>(h, ldl, H, hw, H, hb + 18, 1, EPI_NONE, sm);
     __syncthreads();
     if (tid < rv) a.q[(long long)k * B + row0 + tid] = sm[tid * 16];
@@ -595,16 +556,15 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
         else { const float n1 = 1.0f / (float)B; g = (diff < -1.0f) ? -n1 : (diff > 1.0f ? n1 : n1 * diff); }
         if (!met) g = __builtin_nanf("");          // a timed-out meeting must not pass for a result
         if (k == 0) a.y[row0 + r] = y;
-        st_maybe_wt(a.dq + (long long)k * B + row0 + r, g, wt);
+        a.dq[(long long)k * B + row0 + r] = g;
       }
       sm2[r * 16] = g;
     }
     __syncthreads();
     float* gsave = a.gC + (long long)k * L * BH;
-    head_backward<RG>(XS, ldl, H, hw, 1, sm2, gsave + (L - 1) * BH + row0 * H, rv, nullptr, 0.f, wt);
+    head_backward<RG>(XS, ldl, H, hw, 1, sm2, gsave + (L - 1) * BH + row0 * H, rv);
     __syncthreads();
-    grad_chain<RG>(a.critic[k], XS, X1, X2, ldl, part_ + R * 16, hs, gsave, BH, row0, rv, wt);
-    if (wt) meet_produce(a.dw_done);   // (DDPG's fused launch: the critic's dW workgroups may start)
+    grad_chain<RG>(a.critic[k], XS, X1, X2, ldl, part_ + R * 16, hs, gsave, BH, row0, rv);
     return;
   }
   if (part != 2) {
@@ -817,10 +777,7 @@ int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
   const size_t lds = rowchain_lds_bytes(rg, a.ldl, a.A, a.critic[0].H, a.C);
   GCRL_CHECK_ARG(lds <= 160 * 1024, "rowchain: %zu bytes of LDS needed", lds);
   GCRL_CHECK_ARG(!a.k_split || (a.bar && a.qt && a.producers_first && a.C == 1), "rowchain: the two-role critic phase needs its meeting counters");
-  GCRL_CHECK_ARG(!a.dw_inline || (a.dw_done && a.dw_round && (a.dw_k_blocks == 0 || a.dw_k) && (a.dw_p_blocks == 0 || a.dw_p) &&
-                                  (a.dw_k_blocks == 0) == (a.nblk_k == 0) && (a.dw_p_blocks == 0) == (a.nblk_p == 0)),
-                 "rowchain: the dW consumer workgroups need their batches and counters");
-  const int grid = (a.k_split ? 2 : 1) * a.nblk_k + a.nblk_p + (a.dw_inline ? a.dw_k_blocks + a.dw_p_blocks : 0);
+  const int grid = (a.k_split ? 2 : 1) * a.nblk_k + a.nblk_p;
   if (grid < 1) return GCRL_OK;
   auto go = [&](auto kern) -> int {
     static thread_local size_t raised = 0;

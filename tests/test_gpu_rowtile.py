@@ -92,16 +92,3 @@ def test_weight_slice_hand_off_that_never_arrives_is_reported(gcrl, monkeypatch,
     assert all(np.isfinite(after)), after
     more = [tuple(float(x) for x in tt) for tt in ag.update_many(4, 40)]
     assert np.all(np.isfinite(np.array(more)))
-
-
-def test_dw_problems_inside_the_row_chain_launch_change_nothing(gcrl, monkeypatch):
-    """GCRL_DW_INLINE=1 (an experiment that lost: DESIGN.md section 4): the phases' dW | db problems as consumer workgroups of the
-    row-chain launch — write-through saves, a drained arrival per chain workgroup, the same GEMM body.  The arithmetic is the dW
-    launch's: 90 pipelined steps bitwise equal to the default schedule."""
-    monkeypatch.delenv("GCRL_ROWTILE", raising=False)
-    ref = _run_many(_ddpg_for_schedules(gcrl, 64, 3, 2, B=64))
-    monkeypatch.setenv("GCRL_DW_INLINE", "1")
-    ag = _ddpg_for_schedules(gcrl, 64, 3, 2, B=64)
-    if not (ag.set_meetings(True) & 2):
-        pytest.skip("launch forms with in-kernel waits are not admissible on this device")
-    assert _run_many(ag) == ref
