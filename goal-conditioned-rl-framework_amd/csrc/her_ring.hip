@@ -152,9 +152,13 @@ __global__ __launch_bounds__(256) void her_process_step_inline_kernel(ProcArgsIn
 
 // ---------------------------------------------------------------- relabel + flush
 struct FlushArgs {
+  // the first 16 dwords are preloaded into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16 for this translation
+  // unit, Makefile): what the first round of loads of a single-episode launch needs — episode 0's staging pointer and length, the
+  // record geometry — so that those loads do not wait for a kernel-argument fetch first
   float* ring;
+  const float* stage0; int T0, k, G, RG, RW, nep;
   long long cap, tail, skip;  // rows whose running number is < skip fell off a too-small ring
-  int nep, k, S, A, G, SA4, S4, RW, RS, RG;
+  int S, A, SA4, S4, RS;
   int reward_kind;
   float thr;
   int rng_mode;
@@ -192,8 +196,8 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
   __shared__ float rew_lds[kFlushRows * 64];
   __shared__ long long base_lds;
 
-  const int e = blockIdx.y;
-  const int T = p.T[e];
+  const int e = kMulti ? blockIdx.y : 0;
+  const int T = kMulti ? p.T[e] : p.T0;
   const int k = p.k, G = p.G, RG = p.RG, reps = 1 + k;
   const int total = T + k * (T - 1);
   const int n0 = blockIdx.x * kFlushRows;
@@ -205,7 +209,8 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
 
   if (wave == 0) {
     long long rows = 0;
-    if (lane < p.nep) rows = (long long)p.T[lane] + (long long)k * (p.T[lane] - 1);
+    if (kMulti) { if (lane < p.nep) rows = (long long)p.T[lane] + (long long)k * (p.T[lane] - 1); }
+    else if (lane == 0) rows = (long long)T + (long long)k * (T - 1);
     long long incl = rows;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void her_flush_kernel(FlushArgs p) {
     }
     if (lane == e) base_lds = incl - rows;
   }
-  const float* stg = p.stage[e];
+  const float* stg = kMulti ? p.stage[e] : p.stage0;
   // everything the rows need, requested together (no divisions in these loops)
   for (int t = tid; t < T * 8; t += 256) {               // the episode's achieved-goal column, 8 slots per step
     const int st = t >> 3, q = t & 7;
@@ -656,6 +661,7 @@ int launch_flush(gcrl_her* h, int nep, const int* envs, const int* Ts, const uin
     const int T = Ts[e];
     fa.stage[e] = h->stage + ((size_t)envs[e] * c.flush_len) * h->RG;
     fa.T[e] = T;
+    if (e == 0) { fa.stage0 = fa.stage[0]; fa.T0 = T; }
     fa.epi_id[e] = h->episodes_flushed + e;
     fa.fut_off[e] = fut_used;
     const int nf = c.k_future * (T - 1);
