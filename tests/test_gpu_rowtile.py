@@ -92,3 +92,22 @@ def test_weight_slice_hand_off_that_never_arrives_is_reported(gcrl, monkeypatch,
     assert all(np.isfinite(after)), after
     more = [tuple(float(x) for x in tt) for tt in ag.update_many(4, 40)]
     assert np.all(np.isfinite(np.array(more)))
+
+
+@pytest.mark.parametrize("H,L,B", [(64, 3, 64), (256, 3, 256)])
+def test_two_role_critic_phase_is_bitwise_the_one_role_launch(gcrl, monkeypatch, H, L, B):
+    """DDPG's critic phase as two roles of the fused row-chain launch (target chain | online critic, producers / consumers:
+    csrc/rowchain.hip k_split, the default) against the launch that walks a row block through both (GCRL_NO_DDPG_KSPLIT=1): the
+    same per-row arithmetic in the same order — 90 pipelined steps, every tuple and every parameter bitwise equal."""
+    monkeypatch.delenv("GCRL_ROWTILE", raising=False)
+    monkeypatch.setenv("GCRL_NO_DDPG_KSPLIT", "1")
+    a_one = _ddpg_for_schedules(gcrl, H, L, 2, B=B)
+    assert not (a_one.meetings() & 2)
+    one = _run_many(a_one)
+    monkeypatch.delenv("GCRL_NO_DDPG_KSPLIT")
+    a_two = _ddpg_for_schedules(gcrl, H, L, 2, B=B)
+    if not (a_two.meetings() & 2):
+        pytest.skip("launch forms with in-kernel waits are not admissible on this device")
+    assert _run_many(a_two) == one
+    for v1, v2 in [(a_one.actor, a_two.actor), (a_one.critic, a_two.critic), (a_one.target_critic, a_two.target_critic)]:
+        assert np.array_equal(v1.flat(), v2.flat())
