@@ -27,6 +27,7 @@
 #include <string>
 #include <vector>
 
+#include "dw_adam.h"
 #include "gemm_mfma.h"
 #include "her_ring.h"
 #include "meet.h"
@@ -162,6 +163,11 @@ struct gcrl_agent {
   bool rc_merge = false;      // ... forward and backward part in ONE launch each (part 3; GCRL_NO_RC_MERGE=1: two launches)
   bool rc_merge_k = false;    // TD3 (split_k): the critic phase's two launches as one, producers / consumers form (meet.h)
   bool ddpg_ksplit = false, ddpg_ksplit_can = false;   // DDPG: the critic phase as two roles of the fused launch (rowchain.hip, k_split)
+  // the dW | db GEMMs, the clip and the optimiser step of the row-chain DDPG step as ONE launch (dw_adam.hip; GCRL_NO_OPT_FUSE=1: the
+  // two launches): per net [critic 0 | actor] two arrays of of_stride 64-bit norm slots and a launch count on its own line
+  bool opt_fuse = false, opt_fuse_can = false;
+  float *of_slots = nullptr, *of_seq = nullptr;
+  long long of_stride = 0;
   float* rc_bar = nullptr;    // meeting counters of the row blocks [2][nblk][32 words]
   long long rc_bar_words = 0;
   // weight-slice form of the DDPG launch (rowtile.hip): a 16 x 16 tile of every layer per workgroup, hand-offs inside the launch
@@ -1155,6 +1161,7 @@ int end_call(gcrl_agent* a, hipStream_t st) {
 // timed-out round may have left them off a multiple of the arrival count) and the next launch works again.  The reference
 // raises on any failed step (src/agent.py:659-699).
 int rowtile_reset(gcrl_agent* a);
+int optfuse_reset(gcrl_agent* a);
 int meet_check(gcrl_agent* a) {
   if (!a->status_host) return GCRL_OK;
   const unsigned int bits = __atomic_load_n(a->status_host, __ATOMIC_ACQUIRE);
@@ -1163,6 +1170,7 @@ int meet_check(gcrl_agent* a) {
   if (a->bn_bar) (void)hipMemset(a->bn_bar, 0, (size_t)bn_slab_bar_words(a->H) * sizeof(unsigned int));
   if (a->rc_bar && a->rc_bar_words) (void)hipMemset(a->rc_bar, 0, (size_t)a->rc_bar_words * sizeof(unsigned int));
   (void)rowtile_reset(a);
+  (void)optfuse_reset(a);
   if (bits & (MEET_ERR_XCHG_READY | MEET_ERR_XCHG_DONE)) {
     (void)hipDeviceSynchronize();
     __atomic_store_n(a->status_host, 0u, __ATOMIC_RELEASE);
@@ -1172,9 +1180,18 @@ int meet_check(gcrl_agent* a) {
   }
   (void)hipDeviceSynchronize();
   __atomic_store_n(a->status_host, 0u, __ATOMIC_RELEASE);
-  return fail(GCRL_ERR_STATE, "a wait between workgroups inside a launch timed out (status 0x%x:%s%s); the affected step's statistics / gradients are NaN. "
+  return fail(GCRL_ERR_STATE, "a wait between workgroups inside a launch timed out (status 0x%x:%s%s%s); the affected step's statistics / gradients are NaN. "
                               "The device is probably shared with other work: set GCRL_SHARED_GPU=1 (or gcrl_set_shared_device) to use the launch forms without such waits",
-              bits, (bits & MEET_ERR_BN_SLAB) ? " BatchNorm slab row groups" : "", (bits & MEET_ERR_ROWCHAIN) ? " row-chain roles" : "");
+              bits, (bits & MEET_ERR_BN_SLAB) ? " BatchNorm slab row groups" : "", (bits & MEET_ERR_ROWCHAIN) ? " row-chain roles" : "",
+              (bits & MEET_ERR_DW_ADAM) ? " gradient-norm slots of the fused optimiser launch" : "");
+}
+
+// the fused optimiser launch's norm slots: "not written yet" everywhere, launch counts at zero (creation; after a timed-out wait)
+int optfuse_reset(gcrl_agent* a) {
+  if (!a->of_slots) return GCRL_OK;
+  GCRL_HIP(hipMemset(a->of_slots, 0xFF, (size_t)(a->C + 1) * 2 * a->of_stride * sizeof(unsigned long long)));
+  GCRL_HIP(hipMemset(a->of_seq, 0, (size_t)(a->C + 1) * 32 * sizeof(unsigned int)));
+  return GCRL_OK;
 }
 
 // the weight-slice launch's hand-off words: "not written yet" everywhere, counters at zero (creation; after a timed-out wait)
@@ -1338,6 +1355,30 @@ int build(gcrl_agent* a) {
       a->ddpg_ksplit = a->ddpg_ksplit_can && !meet_device_shared() && !std::getenv("GCRL_NO_DDPG_KSPLIT");
       if (a->ddpg_ksplit_can && !a->rc_bar_words) { a->rc_bar_words = 2 * nblk * 32; wants.push_back({&a->rc_bar, a->rc_bar_words}); }
     }
+    // DDPG: dW | db + clip + optimiser as one launch whose workgroups (one per 16x16 gradient tile of both nets) are all resident
+    // at once; every problem on the k-split 16x16 form the two-launch path uses for it (same bits either way)
+    {
+      auto tiles16 = [&](const NetSpec& net, bool* form1) {
+        long long t = 0;
+        for (const Lin& ln : net.lin) {
+          GemmDesc d = bwd_dw(a->grads, 1, a->grads, 1, a->grads, ln, B);
+          if (gemm_shape_of(d) != 1) *form1 = false;
+          t += (long long)((ln.out + 15) / 16) * ((ln.in + 1 + 15) / 16);
+        }
+        return t;
+      };
+      bool form1 = true;
+      const long long tc = tiles16(a->critic, &form1), ta = tiles16(a->actor, &form1);
+      const long long cap = dw_adam_capacity();
+      a->of_stride = align_up(std::max(tc, ta), 32);
+      a->opt_fuse_can = a->rowchain && c.kind == GCRL_AGENT_DDPG && C == 1 && L + 1 <= kFusedMaxLayers && form1 && B < 2048 &&
+                        std::max(tc, ta) <= 256LL * kFusedMaxSlotsPerThread && 2 * std::max(tc, ta) <= cap;
+      a->opt_fuse = a->opt_fuse_can && !meet_device_shared() && !std::getenv("GCRL_NO_OPT_FUSE");
+      if (a->opt_fuse_can) {
+        wants.push_back({&a->of_slots, (long long)(C + 1) * 2 * a->of_stride * 2});
+        wants.push_back({&a->of_seq, (long long)(C + 1) * 32});
+      }
+    }
     a->head_batches = 3;   // (TD3 at batch 2048: the host draws 38 x 2048 indices in ~390 us, more than two 170 us steps)
     if (const char* e = std::getenv("GCRL_HEAD_BATCHES")) a->head_batches = std::max(1, std::min(8, std::atoi(e)));   // experiment knob
     a->dw_batch_off = std::getenv("GCRL_NO_DW_BATCH") != nullptr;
@@ -1405,6 +1446,7 @@ int build(gcrl_agent* a) {
   long long used = 0;
   for (auto& w : wants) { *w.first = a->work + used; used += align_up(w.second, 64); }
   TRY(rowtile_reset(a));
+  TRY(optfuse_reset(a));
 
   // upload block + pinned mirrors, metrics, events
   a->upload_bytes = sizeof(UploadBlock) + (size_t)kMaxStepsPerCall * B * sizeof(uint32_t);
@@ -1949,12 +1991,13 @@ int gcrl_agent_set_meetings(gcrl_agent* a, int on) {
   a->rc_merge_k = want && a->rc_bar && a->split_k && !std::getenv("GCRL_NO_RC_MERGE");
   a->ddpg_ksplit = want && a->ddpg_ksplit_can && a->rc_bar && !std::getenv("GCRL_NO_DDPG_KSPLIT");
   a->rowtile = want && a->rowtile_can && rowtile_enabled() && rowtile_ok(a->B, a->H, a->L, a->S, a->A, a->C);
-  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k || a->ddpg_ksplit) ? 2 : 0) | (a->rowtile ? 4 : 0);
+  a->opt_fuse = want && a->opt_fuse_can && !std::getenv("GCRL_NO_OPT_FUSE");
+  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k || a->ddpg_ksplit) ? 2 : 0) | (a->rowtile ? 4 : 0) | (a->opt_fuse ? 8 : 0);
 }
 
 int gcrl_agent_get_meetings(gcrl_agent* a) {
   GCRL_CHECK_ARG(a, "gcrl_agent_get_meetings: null handle");
-  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k || a->ddpg_ksplit) ? 2 : 0) | (a->rowtile ? 4 : 0);
+  return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k || a->ddpg_ksplit) ? 2 : 0) | (a->rowtile ? 4 : 0) | (a->opt_fuse ? 8 : 0);
 }
 
 int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
@@ -1972,6 +2015,11 @@ int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
   if (a->rc_merge_k || (a->ddpg_ksplit && !a->rowtile)) {   // producers / consumers: a consumer's own launch count far ahead of its producers' counter
     const unsigned long long far = 1ull << 40;
     GCRL_HIP(hipMemcpy(a->rc_bar + 4, &far, sizeof(far), hipMemcpyHostToDevice));    // (64-bit word 2 of row block 0's line: critic 0's consumer)
+    return GCRL_OK;
+  }
+  if (a->opt_fuse) {   // the fused optimiser launch: one workgroup's norm slot never arrives (once)
+    const unsigned int on = 1;
+    GCRL_HIP(hipMemcpy(reinterpret_cast<unsigned int*>(a->of_seq) + 1, &on, sizeof(on), hipMemcpyHostToDevice));   // (critic 0's fault word)
     return GCRL_OK;
   }
   GCRL_CHECK_ARG(words, "gcrl_agent_debug_meet_fault: this agent's launches contain no waits (meetings off or not applicable)");

@@ -133,8 +133,14 @@ __device__ inline int xcd_tile_of(int w, int G) {
   return w < (per << 3) ? (w & 7) * per + (w >> 3) : w;
 }
 
+// One (16*TM)x(16*TN) tile `t` of problem `d` by the calling wave (KSPLIT = 1) / workgroup (KSPLIT = 4): the whole body of
+// gemm_batch_kernel up to and including the result stores and the BatchNorm partials.  Returns false for waves / workgroups
+// beyond the problem's tiles (KSPLIT = 4: after the workgroup barrier of the partial-sum exchange, which every wave reaches).
+// ss_out: this lane's sum of squares of the values it stored; x_out (KSPLIT = 4 only): the finished value of this lane's element
+// (row m0 + 4*(lane>>4) + wave, column n0 + (lane&15) of the tile), 0 outside the problem.  The fused dW + optimiser launch
+// (dw_adam.hip) calls the SAME body, so a gradient element is the same bits whichever launch form produced it.
 template <int TM, int TN, int KSPLIT>
-__global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
+__device__ __forceinline__ bool gemm_batch_tile(const GemmDesc& d, const int t, float& x_out, float& ss_out) {
   static_assert(KSPLIT == 1 || (TM == 1 && TN == 1), "k-split only for single 16x16 tiles");
   constexpr int NACC = (TM * TN >= 4) ? 1 : (TM * TN == 2 ? 2 : 4);
   // wave-tile forms: the MFMAs run with the operand roles swapped, so the accumulator holds the TRANSPOSED tile —
@@ -144,16 +150,9 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
   constexpr bool TR = KSPLIT == 1;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bid = xcd_tile_of((int)blockIdx.x, (int)gridDim.x);
-  const int wtile = (KSPLIT == 4) ? bid : bid * 4 + wave;
-  int pi = 0;
-#pragma unroll
-  for (int q = 1; q < kMaxProb; ++q)
-    if (q < gb.n && wtile >= gb.d[q].tile0) pi = q;
-  const GemmDesc& d = gb.d[pi];
-  const int t = wtile - d.tile0;
   const bool active = t < d.ntiles;
-  if (KSPLIT == 1 && !active) return;
+  x_out = 0.f; ss_out = 0.f;
+  if (KSPLIT == 1 && !active) return false;
 
   const int M = d.M, N = d.N, K = d.K;
   const int tn = active ? t % d.tiles_n : 0, tm = active ? t / d.tiles_n : 0;
@@ -377,11 +376,12 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[0][0][0][r];
     __syncthreads();
-    if (!active) return;
+    if (!active) return false;
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += red[w][wave][lane];
     const float x = finish(v, m0 + 4 * lg + wave, n0 + li, pre_b[0][0], pre_h[0][0][0]);
+    x_out = x;
     if (d.bn_part) {   // (uniform per workgroup: one problem, one tile)
       __shared__ float cs[2][4][16];
       const int rows = min(16, M - m0), n = n0 + li;
@@ -428,6 +428,24 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
         }
       }
   }
+  ss_out = ss;
+  return true;
+}
+
+template <int TM, int TN, int KSPLIT>
+__global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bid = xcd_tile_of((int)blockIdx.x, (int)gridDim.x);
+  const int wtile = (KSPLIT == 4) ? bid : bid * 4 + wave;
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxProb; ++q)
+    if (q < gb.n && wtile >= gb.d[q].tile0) pi = q;
+  const GemmDesc& d = gb.d[pi];
+  const int t = wtile - d.tile0;
+  float x, ss;
+  if (!gemm_batch_tile<TM, TN, KSPLIT>(d, t, x, ss)) return;
   if (d.sumsq_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);

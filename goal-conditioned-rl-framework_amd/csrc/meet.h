@@ -24,7 +24,7 @@ namespace gcrl {
 
 constexpr int kMeetSpinMax = 1 << 20;
 // bits of the status word
-enum { MEET_ERR_BN_SLAB = 1, MEET_ERR_ROWCHAIN = 2, MEET_ERR_XCHG_READY = 4, MEET_ERR_XCHG_DONE = 8 };
+enum { MEET_ERR_BN_SLAB = 1, MEET_ERR_ROWCHAIN = 2, MEET_ERR_XCHG_READY = 4, MEET_ERR_XCHG_DONE = 8, MEET_ERR_DW_ADAM = 16 };
 
 // this wave's global stores (agent- or system-scope write-through ones in particular) have been acknowledged
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -187,6 +187,39 @@ int launch_adam(hipStream_t st, const AdamArgs& a);
 int launch_adam_pair(hipStream_t st, const AdamArgs& a0, const AdamArgs& a1);  // two single-net steps, one launch
 int launch_polyak(hipStream_t st, const float* p, float* target, long long n, double tau);
 
+// ---- dw_adam.hip: weight gradients + global-norm clip + Adam(W) (+ Polyak, [in][out] copies, metrics, control advance) of up
+// to two plain MLPs in ONE launch (round 5).  The reference's sequence is backward -> clip_grad_norm_ -> optimizer.step()
+// (src/agent.py:1326-1333 critic, :1288-1300 actor); nothing but the global norm stands between a gradient element and its
+// parameter's step.  A workgroup owns one 16x16 tile of one layer's dW | db problem (gemm_mfma.h: the SAME tile body as the
+// batched GEMM launch, K split over its four waves), requests its tile's p / m / v / target first, publishes the tile's sum of
+// squares into its own slot, re-loads every slot of its net until none is the "not written yet" pattern — the data is the flag,
+// no atomics — sums them in slot order (the order adam_kernel sums the GEMM launch's partials: results are the same bits as the
+// two-launch form), and steps the elements it still holds.  Every workgroup of the launch must be resident at once (launcher
+// checks, dw_adam_capacity); a wait is bounded and reported (meet.h).
+constexpr int kFusedMaxLayers = 5;      // dW problems per net (hidden layers + head)
+constexpr int kFusedMaxSlotsPerThread = 4;   // a net has at most 256 * this many tiles
+struct GemmDesc;
+struct DwAdamLayer {
+  long long pw, pb;      // offsets of the layer's weight [out][in] and bias [out] inside the net's parameter vector
+  long long wt_dst;      // offset of the weight's [in][out] copy inside wt (hidden layers); < 0: none
+  int slot0, pad;        // the layer's first norm slot (adam_kernel's order: by layer, then by tile)
+};
+struct DwAdamNetArgs {
+  int nl, ntiles;        // dW problems; 16x16 tiles of all of them = workgroups = norm slots
+  DwAdamLayer lay[kFusedMaxLayers];
+  const StepCtrl* cur; int which;   // as AdamArgs (the control block's copy: this launch may advance the original)
+  float *p, *m, *v, *target;        // the net's parameter vector, Adam moments, Polyak destination (null: none)
+  float *wt, *wt_target;            // [in][out] copies of the net / of the Polyak destination
+  float clip; int polyak; int metric_index;
+  // per-tile sums of squares as fp64 bit patterns, two arrays of slot_stride words used by alternate launches of this net
+  // (`seq` counts them); all-ones = "not written yet": a workgroup writes its slot of this launch's array and puts its slot of
+  // the other array back
+  unsigned long long* slots; int slot_stride; unsigned int* seq;
+  const float* mean_x; int mean_n; float mean_scale; int mean_index;           // riders, as AdamArgs
+  const float* td_q; const float* td_y; int td_n, td_C, td_loss_kind;
+};
+long long dw_adam_capacity();   // workgroups of the launch resident at once on the current device (0: shared device / query failed)
+
 // ---- SAC / TQC pieces (ops_sac.hip) -------------------------------------------------------
 // nn.BatchNorm1d in training mode followed by ReLU (src/model.py:106-108): z [B,H] -> h [B,H];
 // saves xhat [B,H] and invstd [H] when `xhat` is non-null; updates running_mean/var

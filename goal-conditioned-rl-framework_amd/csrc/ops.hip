@@ -6,6 +6,7 @@
 //   optimiser    torch.optim.Adam / AdamW single-tensor path (lerp, addcmul, addcdiv order)
 //   Polyak       tau*p + (1-tau)*p_target  (src/agent.py:1260-1271 etc.)
 #include "ops.h"
+#include "adam_math.h"
 #include "meet.h"
 
 #include <algorithm>
@@ -15,17 +16,7 @@
 namespace gcrl {
 namespace {
 
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-__device__ inline double wave_sum_d(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-// sum over a 256-thread block; result valid in thread 0.  `scratch` holds 4 floats.
+// (wave_sum, wave_sum_d, block_sum_256: adam_math.h)
 // sum over a block of up to 1024 threads (whole waves); result valid in every thread.  `scratch` holds 16 floats.
 // Waves beyond the data contribute exact zeros, so the result does not depend on the block size chosen for small B.
 __device__ inline float block_sum(float v, float* scratch) {
@@ -37,14 +28,6 @@ __device__ inline float block_sum(float v, float* scratch) {
   float s = scratch[0];
   for (int w = 1; w < nw; ++w) s += scratch[w];
   return s;
-}
-__device__ inline float block_sum_256(float v, float* scratch) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) scratch[wave] = v;
-  __syncthreads();
-  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
 __global__ void begin_step_kernel(CtrlBlock* cb, int shift) {
@@ -279,10 +262,7 @@ __global__ __launch_bounds__(256) void sumsq2_kernel(const float* g0, long long 
 __device__ inline void adam_body(const AdamArgs& a, const int net) {
   __shared__ float s_coef;
   const StepCtrl c = *a.cur;
-  float step_size, bc2s, decay;
-  if (a.which == 0) { step_size = c.step_size_actor; bc2s = c.bc2s_actor; decay = c.decay_actor; }
-  else if (a.which == 1) { step_size = c.step_size_critic; bc2s = c.bc2s_critic; decay = c.decay_critic; }
-  else { step_size = c.step_size_alpha; bc2s = c.bc2s_alpha; decay = c.decay_alpha; }
+  const AdamStepScalars sc = adam_scalars(c, a.which);
   const float gscale = c.grad_scale;
   const long long base = (long long)net * a.net_stride;
   float* __restrict__ p = a.p + base;
@@ -338,75 +318,26 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
     __syncthreads();
     if (threadIdx.x == 0) {
       s = dred[0] + dred[1] + dred[2] + dred[3];
-      const float norm = gscale * (float)sqrt(s);
-      const float clip = a.clip[net];
-      float coef = 1.0f;
-      if (clip >= 0.f) coef = fminf(clip / (norm + 1e-6f), 1.0f);
-      s_coef = coef;
+      float post;
+      s_coef = clip_coef(s, gscale, a.clip[net], &post);
       if (blockIdx.x == 0 && a.metrics)
-        a.metrics[(long long)c.metrics_slot * kMetricFloats + a.metric_index + net] = norm * coef;
+        a.metrics[(long long)c.metrics_slot * kMetricFloats + a.metric_index + net] = post;
     }
   }
   __syncthreads();
-  if (a.mean_x && blockIdx.x == 0 && net == 0) {
-    __shared__ float scratch[4];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < a.mean_n; i += 256) s += a.mean_x[i];
-    s = block_sum_256(s, scratch);
-    if (threadIdx.x == 0)
-      a.metrics[(long long)c.metrics_slot * kMetricFloats + a.mean_index] = a.mean_scale * (s / (float)a.mean_n);
-  }
-  if (a.td_q && blockIdx.x == 0 && net == 0) {
-    // same sums, in the same order, as td_loss_kernel forms
-    __shared__ float scratch[4];
-    const int C = a.td_C;
-    float loss[2] = {0.f, 0.f}, td = 0.f, qs = 0.f;
-    for (int i = threadIdx.x; i < a.td_n; i += 256) {
-      const float y = a.td_y[i];
-      float tdmax = 0.f;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if (k < C) {
-          const float q = a.td_q[(long long)k * a.td_n + i];
-          const float diff = __fsub_rn(q, y);
-          const float ad = fabsf(diff);
-          if (a.td_loss_kind == LOSS_MSE) loss[k] += diff * diff;
-          else loss[k] += (ad < 1.0f) ? 0.5f * diff * diff : ad - 0.5f;
-          tdmax = fmaxf(tdmax, ad);
-          qs += q;
-        }
-      }
-      td += tdmax;
-    }
-    float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k < C) {
-        const float s = block_sum_256(loss[k], scratch);
-        if (threadIdx.x == 0) met[MET_CRITIC_LOSS + k] = s / (float)a.td_n;
-      }
-    }
-    td = block_sum_256(td, scratch);
-    qs = block_sum_256(qs, scratch);
-    if (threadIdx.x == 0) {
-      met[MET_TD] = td / (float)a.td_n;
-      met[MET_Q] = qs / (float)(a.td_n * C);
-    }
-  }
+  if (a.mean_x && blockIdx.x == 0 && net == 0)
+    rider_mean_metric(a.mean_x, a.mean_n, a.mean_scale, a.metrics + (long long)c.metrics_slot * kMetricFloats + a.mean_index);
+  if (a.td_q && blockIdx.x == 0 && net == 0)
+    rider_td_metrics(a.td_q, a.td_y, a.td_n, a.td_C, a.td_loss_kind, a.metrics + (long long)c.metrics_slot * kMetricFloats);
   const float gmul = gscale * s_coef;
   const float w1 = a.w1, w2 = a.w2, one_m_tau = a.one_m_tau;
   const bool pk = tp && a.polyak;
   // one element: torch's single-tensor Adam(W) op order; returns the new parameter, *ti the new target
   auto step_vals = [&](long long i, float g_raw, float pi, float mi, float v_old, float t_old, float* ti) -> float {
-    const float gi = __fmul_rn(g_raw, gmul);
-    if (decay != 1.0f) pi = __fmul_rn(pi, decay);
-    mi = __fadd_rn(mi, __fmul_rn(w1, __fsub_rn(gi, mi)));
-    const float vi = __fadd_rn(__fmul_rn(v_old, a.beta2), __fmul_rn(__fmul_rn(w2, gi), gi));
-    const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), bc2s), a.eps);
-    pi = __fadd_rn(pi, __fdiv_rn(__fmul_rn(-step_size, mi), denom));
-    p[i] = pi; m[i] = mi; v[i] = vi;
-    if (pk) { *ti = __fadd_rn(__fmul_rn(a.tau, pi), __fmul_rn(one_m_tau, t_old)); tp[i] = *ti; }
-    return pi;
+    const AdamElem e = adam_elem(g_raw, pi, mi, v_old, gmul, sc, a.beta2, w1, w2, a.eps);
+    p[i] = e.p; m[i] = e.m; v[i] = e.v;
+    if (pk) { *ti = polyak_elem(a.tau, e.p, one_m_tau, t_old); tp[i] = *ti; }
+    return e.p;
   };
   if (a.n_seg == 0) {
     float ti;
@@ -437,11 +368,7 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
 
 __device__ inline void advance_ctrl(const AdamArgs& a) {
   if (a.advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    CtrlBlock* cb = a.advance;
-    const int c = cb->cursor;
-    cb->prev = cb->cur;
-    cb->cur = cb->table[c];
-    cb->cursor = c + 1;
+    ctrl_advance(a.advance);
   }
 }
 

@@ -210,7 +210,7 @@ class _EngineAgent:
 
     def meetings(self) -> int:
         """Bit mask of the launch forms with in-kernel waits that are active on this handle (1 BatchNorm slab row groups, 2 row-chain
-        roles, 4 the opt-in weight-slice DDPG launch); changes nothing."""
+        roles, 4 the opt-in weight-slice DDPG launch, 8 the fused dW + optimiser launch of the row-chain DDPG step); changes nothing."""
         return _ffi.check(lib.gcrl_agent_get_meetings(self._h))
 
     # ------------------------------------------------------------------ update

@@ -1,0 +1,120 @@
+"""GPU (-m gpu): the weight-gradient GEMMs, the global-norm clip and the optimiser step of the row-chain DDPG step as ONE launch
+(csrc/dw_adam.hip, round 5) against the two launches it replaces (GCRL_NO_OPT_FUSE=1: batched dW | db GEMMs, then Adam).
+
+The reference's sequence is backward -> clip_grad_norm_ -> optimizer.step() (src/agent.py:1326-1333 critic, :1288-1300 actor):
+only the global norm stands between a gradient element and its parameter's step.  A workgroup of the fused launch keeps its
+16 x 16 gradient tile in registers, publishes the tile's sum of squares into its own slot (the data is the flag), waits until every
+slot of its net is there, adds them up in the order the optimiser launch adds the GEMM launch's partials, and steps its elements.
+What has to hold: the same BITS as the two-launch form — tuples, parameters, targets, Adam moments, the stored gradients — over
+K-only, merged and P-only launches, Polyak steps and graph replays; the reference's full-size fixtures; and a slot that never
+arrives is an error at the next synchronising call (src/agent.py:659-699: the reference raises on any failed step), after which
+the handle works again."""
+import numpy as np
+import pytest
+
+from fullsize import Case, Report, compare
+from test_gpu_full_size import build, run
+from test_gpu_parity import _ddpg_for_schedules, _run_many
+
+pytestmark = pytest.mark.gpu
+
+
+def _agent(gcrl, monkeypatch, fused, H, L, B, **kw):
+    monkeypatch.delenv("GCRL_ROWTILE", raising=False)
+    if fused:
+        monkeypatch.delenv("GCRL_NO_OPT_FUSE", raising=False)
+    else:
+        monkeypatch.setenv("GCRL_NO_OPT_FUSE", "1")
+    ag = _ddpg_for_schedules(gcrl, H, L, 2, B=B, **kw)
+    active = ag.meetings()
+    if fused and not (active & 8):
+        pytest.skip("the fused optimiser launch is not admissible on this device (shared GPU, or too few CUs for its workgroups)")
+    assert fused or not (active & 8)
+    return ag
+
+
+def _everything(ag):
+    out = [v.flat() for v in (ag.actor, ag.critic, ag.target_actor, ag.target_critic)]
+    for name in ("grad:actor", "grad:critic_0", "adam_m:actor", "adam_v:actor", "adam_m:critic_0", "adam_v:critic_0"):
+        out.append(ag.actor._get(name))
+    return out
+
+
+@pytest.mark.parametrize("H,L,B,S,A", [(256, 3, 256, 23, 4), (64, 3, 64, 10, 3), (128, 2, 40, 9, 2), (72, 4, 50, 12, 5)])
+def test_fused_optimiser_launch_is_bitwise_the_two_launch_form(gcrl, monkeypatch, H, L, B, S, A):
+    """90 pipelined steps at the headline's shape (S 23, A 4, H 256, L 3, B 256) and three others (ragged tiles: 40 rows, 72 and
+    9 + 2 columns): every tuple, parameter, target, Adam moment and stored gradient bitwise equal to the two-launch form."""
+    two = _agent(gcrl, monkeypatch, False, H, L, B, S=S, A=A)
+    ref = _run_many(two)
+    one = _agent(gcrl, monkeypatch, True, H, L, B, S=S, A=A)
+    got = _run_many(one)
+    assert len(got) == len(ref) == 90
+    for i, (x, y) in enumerate(zip(ref, got)):
+        assert x == y, (i + 1, x, y)
+    for i, (x, y) in enumerate(zip(_everything(two), _everything(one))):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), i
+    assert np.all(np.isfinite(np.array(got)))
+
+
+def test_fused_optimiser_update_equals_update_many(gcrl, monkeypatch):
+    """update() per step (K-only then P-only fused launches) and the pipelined update_many (the paired launch) are the same
+    arithmetic: bitwise equal tuples and parameters over 90 steps, eager and replayed from graphs."""
+    a_seq, a_pipe = _agent(gcrl, monkeypatch, True, 64, 3, 64), _agent(gcrl, monkeypatch, True, 64, 3, 64)
+    a_eager = _agent(gcrl, monkeypatch, True, 64, 3, 64, use_graph=False)
+    seq = [tuple(float(x) for x in a_seq.update(s)) for s in range(1, 91)]
+    assert seq == _run_many(a_pipe) == _run_many(a_eager)
+    for x, y, z in zip(_everything(a_seq), _everything(a_pipe), _everything(a_eager)):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
+@pytest.mark.parametrize("name", ["ddpg_pickplace_b256", "cfg1_ddpg_reach_b256", "cfg2_ddpg_reach_b1024"])
+def test_fused_optimiser_launch_matches_the_reference_at_full_size(gcrl, monkeypatch, name):
+    """The headline shape, BASELINE cfg 1 and cfg 2 against the fixtures captured from the reference
+    (tests/golden/make_golden_full.py): the criterion of tests/test_gpu_full_size.py, and the flat 1e-5."""
+    monkeypatch.delenv("GCRL_NO_OPT_FUSE", raising=False)
+    c = Case(name)
+    ag, views = build(gcrl, c)
+    if not (ag.meetings() & 8):
+        pytest.skip("the fused optimiser launch is not admissible on this device")
+    rep = Report("hip/fused_optimiser", name)
+    compare(c, rep, *run(c, ag, views))
+    print(rep.summary())
+    assert not rep.bad, rep.bad[:8]
+    assert not rep.beyond_flat, rep.beyond_flat[:8]
+
+
+def test_norm_slot_that_never_arrives_is_reported(gcrl, monkeypatch, tmp_path):
+    """gcrl_agent_debug_meet_fault makes one workgroup of the next fused launch keep its norm slot to itself — what a workgroup
+    held off the chip would cause: every workgroup of the critic's net waits (bounded), the step is poisoned, the status word
+    turns the next synchronising call into GCRL_ERR_STATE once; the slots are re-initialised and the next steps are finite."""
+    from gcrl_amd import _ffi
+    monkeypatch.setenv("GCRL_NO_DDPG_KSPLIT", "1")   # (so that the fused optimiser launch is the only launch with a wait)
+    ag = _agent(gcrl, monkeypatch, True, 256, 3, 256, S=23, A=4)
+    assert ag.meetings() == 8
+    good = [float(x) for x in ag.update(1)]
+    assert all(np.isfinite(good))
+    ag.save_state(str(tmp_path / "ckpt"))
+    _ffi.check(_ffi.lib.gcrl_agent_debug_meet_fault(ag._h))
+    t = ag.update(2)
+    with pytest.raises(_ffi.GcrlError, match="timed out"):
+        [float(x) for x in t]
+    ag.load_state(str(tmp_path / "ckpt"))   # (back to the last checkpoint, as a trainer would)
+    after = [float(x) for x in ag.update(3)]
+    assert all(np.isfinite(after)), after
+    more = [tuple(float(x) for x in tt) for tt in ag.update_many(4, 40)]
+    assert np.all(np.isfinite(np.array(more)))
+
+
+def test_meetings_switch_selects_the_two_launch_form(gcrl, monkeypatch):
+    """gcrl_agent_set_meetings(0) — what DataParallelUpdater does for ranks that share a device — takes the fused launch out (it
+    contains a wait); back on, the agent continues on the fused form: one trajectory, bitwise, whichever form ran each step."""
+    a, b = _agent(gcrl, monkeypatch, True, 64, 3, 64), _agent(gcrl, monkeypatch, True, 64, 3, 64)
+    ref = [tuple(float(x) for x in t) for t in a.update_many(1, 30)]
+    got = [tuple(float(x) for x in t) for t in b.update_many(1, 10)]
+    assert not (b.set_meetings(False) & 8)
+    got += [tuple(float(x) for x in t) for t in b.update_many(11, 10)]
+    assert b.set_meetings(True) & 8
+    got += [tuple(float(x) for x in t) for t in b.update_many(21, 10)]
+    assert got == ref
+    for x, y in zip(_everything(a), _everything(b)):
+        assert np.array_equal(x, y)

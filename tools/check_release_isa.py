@@ -87,7 +87,7 @@ def check_kernel(body):
 # by-value argument struct made hipcc copy the whole 3.7 KB struct to every thread's private memory — a 3 us kernel took 36 us
 # (rowchain_act_inline_kernel, round 4).  `.amdhsa_private_segment_fixed_size` says it all.
 SCRATCH_UNITS = ["her_ring.hip", "ops.hip", "ops_sac.hip", "bn_slab.hip", "rowchain.hip", "agent.hip", "normalizer.hip", "abi_misc.hip",
-                 "gemm_mfma.hip", "xchg_ipc.hip"]
+                 "gemm_mfma.hip", "xchg_ipc.hip", "dw_adam.hip"]
 SCRATCH_ALLOWED = {   # kernel-name substring -> bytes tolerated
     "rowchain_split_kernelILi4E": 1024, "rowchain_ddpg_kernelILi4E": 1024,   # 16 rows per workgroup: register spills; never selected by default (GCRL_ROW_RG=4)
     "gemm_tiled_kernel": 16,                                                   # three spilled dwords outside the k-loop
@@ -108,6 +108,25 @@ def scratch_report(asm_text, unit):
             ok = n <= allowed
             lines.append(f"{unit}: {kernel}: {n} bytes of scratch per thread: {'tolerated' if ok else 'FAIL'}")
             bad += 0 if ok else 1
+    return bad, lines
+
+
+# Third lint (round 5): the fused dW + optimiser launch (dw_adam.hip) hands a workgroup's sum of squares to every other workgroup as
+# ONE 8-byte word that is its own flag — no arrival follows it, so there is nothing to release — but the word must leave as a
+# write-through store and every poll of it must bypass the L1: a plain store or load here would be a silent stale read.
+def slot_report(asm_text):
+    bad, lines = 0, []
+    for name, body in kernels(asm_text):
+        if "dw_adam_kernel" not in name:
+            continue
+        st = [l for l in body if re.match(r"^\s*global_store_dwordx2\s.*\bsc1\b", l)]
+        ld = [l for l in body if re.match(r"^\s*global_load_dwordx2\s.*\bsc1\b", l)]
+        ok = len(st) >= 1 and len(ld) >= 1
+        lines.append(f"dw_adam.hip: {name}: {len(st)} write-through slot store(s), {len(ld)} L1-bypassing slot loads: {'ok' if ok else 'FAIL'}")
+        bad += 0 if ok else 1
+    if not lines:
+        lines.append("dw_adam.hip: dw_adam_kernel not found (pattern changed?)")
+        bad += 1
     return bad, lines
 
 
@@ -155,6 +174,9 @@ def main():
             b, lines = scratch_report(open(asm).read(), unit)
             sbad += b
             report += lines
+        b3, lines = slot_report(open(os.path.join(out_dir, "dw_adam.hip.s")).read())
+        report += lines
+        sbad += b3
     print("\n".join(report))
     print("release check:", "PASS" if bad == 0 else f"FAIL ({bad})")
     print("scratch check:", "PASS" if sbad == 0 else f"FAIL ({sbad})")
