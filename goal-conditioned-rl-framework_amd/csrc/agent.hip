@@ -1370,7 +1370,7 @@ int build(gcrl_agent* a) {
       bool form1 = true;
       const long long tc = tiles16(a->critic, &form1), ta = tiles16(a->actor, &form1);
       const long long cap = dw_adam_capacity();
-      a->of_stride = align_up(std::max(tc, ta), 32);
+      a->of_stride = align_up(std::max(tc, ta) + 8, 32);   // (the last eight words of an array: the leaders' result words)
       a->opt_fuse_can = a->rowchain && c.kind == GCRL_AGENT_DDPG && C == 1 && L + 1 <= kFusedMaxLayers && form1 && B < 2048 &&
                         std::max(tc, ta) <= 256LL * kFusedMaxSlotsPerThread && 2 * std::max(tc, ta) <= cap;
       a->opt_fuse = a->opt_fuse_can && !meet_device_shared() && !std::getenv("GCRL_NO_OPT_FUSE");

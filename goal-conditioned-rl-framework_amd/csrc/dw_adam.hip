@@ -12,17 +12,38 @@
 namespace gcrl {
 namespace {
 
-constexpr unsigned long long kSlotEmpty = ~0ull;   // a negative quiet NaN with every payload bit set: never a sum of squares
+constexpr unsigned long long kSlotEmpty = ~0ull;
+constexpr int kLeaderMinTiles = 64;   // a negative quiet NaN with every payload bit set: never a sum of squares
 
-__global__ __launch_bounds__(256) void dw_adam_kernel(DwAdamArgs a) {
+// development build (-DGCRL_OF_STAMPS, tools/of_stamps.sh): thread 0 of every workgroup leaves the constant-rate clock (100 MHz) at
+// its section boundaries in a.stamps[(net * 2048 + workgroup) * 8 + k]
+#ifdef GCRL_OF_STAMPS
+#define OF_STAMP(k) of_t[k] = wall_clock64()
+#else
+#define OF_STAMP(k) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256, 5) void dw_adam_kernel(DwAdamArgs a) {
+#ifdef GCRL_OF_STAMPS
+  unsigned long long of_t[5];
+#endif
+  OF_STAMP(0);
   __shared__ float s_ss[4];
   __shared__ double dred[4];
   __shared__ float s_coef;
   __shared__ float tile_p[16][17], tile_t[16][17];
   const DwAdamNet& na = a.net[blockIdx.y];
   const DwAdamNetArgs& o = na.o;
-  const int bid = (int)blockIdx.x;
-  if (bid >= o.ntiles) return;   // (a paired launch is sized for the larger net; uniform per workgroup, before any barrier)
+  if ((int)blockIdx.x >= o.ntiles) return;   // (a paired launch is sized for the larger net; uniform per workgroup, before any barrier)
+  // XCD-aware workgroup -> tile order (gemm_mfma.h xcd_tile_of, here for the 2-D grid: workgroup (x, y) runs on XCD
+  // (x + y * gridDim.x) % 8): an XCD takes a contiguous range of the net's tiles — whole tile rows of a layer, i.e. that layer's
+  // activations enter ONE L2 instead of eight.  A wrong guess about the placement costs speed, never correctness.
+  const unsigned long long t_start = wall_clock64();
+  int bid = (int)blockIdx.x;
+  {
+    const int per = o.ntiles >> 3;
+    if (bid < (per << 3)) bid = ((bid + (int)(blockIdx.y * gridDim.x)) & 7) * per + (bid >> 3);
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
@@ -56,6 +77,7 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(DwAdamArgs a) {
   }
 
   float x, ss;
+  OF_STAMP(1);
   gemm_batch_tile<1, 1, 4>(d, t, x, ss);   // (t < d.ntiles by construction; the gradient element is also stored: get("grad:...") reads it)
 
   // the tile's sum of squares in the order adam_kernel adds up the batched launch's four per-wave partials of a tile
@@ -70,48 +92,80 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(DwAdamArgs a) {
     __hip_atomic_store(mine + slot, (unsigned long long)__double_as_longlong(dt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
     o.slots[(long long)((seq & 1u) ^ 1u) * o.slot_stride + slot] = kSlotEmpty;   // nobody reads the other array in this launch; the kernel boundary publishes it
   }
+  OF_STAMP(2);
   // riders of the net's first workgroup, while the other workgroups' slots arrive
   float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
   if (bid == 0) {
     if (o.mean_x) rider_mean_metric(o.mean_x, o.mean_n, o.mean_scale, met + o.mean_index);
     if (o.td_q) rider_td_metrics(o.td_q, o.td_y, o.td_n, o.td_C, o.td_loss_kind, met);
   }
-  // ||g||: every workgroup sums the same slots in the same order (thread t: slots t, t + 256, ...), in fp64
+  // ||g||: the net's slots summed in ONE order (thread t: slots t, t + 256, ...; then lanes, then waves), in fp64.  Nets of
+  // >= kLeaderMinTiles tiles: only the first eight workgroups of the net — one per XCD under round-robin dispatch — sweep the
+  // slots; each leaves the sum in a result word (again its own flag), and every other workgroup polls the ONE word of the leader
+  // that shares its XCD.  With every workgroup sweeping every slot the early finishers kept ~5 MB of slot loads per round in
+  // flight in front of the operand loads of the workgroups still working (measured: the last tile done at 10-15 us instead of
+  // 7.5); a leader's sweep is 37 lines.  Smaller nets: every workgroup sweeps (a few KB in all).
   {
-    unsigned long long w[kFusedMaxSlotsPerThread];
+    const bool lead_mode = a.leaders && o.ntiles >= kLeaderMinTiles;
+    const bool sweeper = !lead_mode || blockIdx.x < 8;
+    const int xc = ((int)blockIdx.x + (int)(blockIdx.y * gridDim.x)) & 7;
+    unsigned long long* res = mine + (o.slot_stride - 8);
     bool ok = true;
-    int spins = 0;
-    for (;;) {
-      bool all = true;
+    double s = 0.0;
+    if (sweeper) {
+      // a lane re-loads only the slots it has not seen yet
+      unsigned long long w[kFusedMaxSlotsPerThread];
+      int spins = 0;
+      for (int i = 0; i < a.poll_first_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+      for (int i = 0; i < 4096 && (long long)(wall_clock64() - t_start) < (long long)a.poll_gate; ++i) __builtin_amdgcn_s_sleep(2);
 #pragma unroll
       for (int u = 0; u < kFusedMaxSlotsPerThread; ++u) {
         const int i = (int)threadIdx.x + 256 * u;
         w[u] = i < o.ntiles ? __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        all = all && w[u] != kSlotEmpty;
       }
-      if (all) break;
-      if (++spins >= kMeetSpinMax) { ok = false; break; }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    double s = 0.0;
+      for (;;) {
+        bool all = true;
 #pragma unroll
-    for (int u = 0; u < kFusedMaxSlotsPerThread; ++u)
-      if ((int)threadIdx.x + 256 * u < o.ntiles) s += __longlong_as_double((long long)w[u]);
-    if (!ok) {   // a slot never arrived: the step is poisoned and the host learns it (meet.h)
-      s = __longlong_as_double(0x7ff8000000000000ll);
-      if (a.status) __hip_atomic_fetch_or(a.status, (unsigned int)MEET_ERR_DW_ADAM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int u = 0; u < kFusedMaxSlotsPerThread; ++u) all = all && w[u] != kSlotEmpty;
+        if (all) break;
+        if (++spins >= kMeetSpinMax) { ok = false; break; }
+        for (int i = 0; i < a.poll_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int u = 0; u < kFusedMaxSlotsPerThread; ++u)
+          if (w[u] == kSlotEmpty) w[u] = __hip_atomic_load(mine + (int)threadIdx.x + 256 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < kFusedMaxSlotsPerThread; ++u)
+        if ((int)threadIdx.x + 256 * u < o.ntiles) s += __longlong_as_double((long long)w[u]);
+      if (!ok) s = __longlong_as_double(0x7ff8000000000000ll);   // a slot never arrived: the step is poisoned (and reported below)
+      s = wave_sum_d(s);
+      if (lane == 0) dred[wave] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        s = dred[0] + dred[1] + dred[2] + dred[3];
+        if (lead_mode) {
+          __hip_atomic_store(res + xc, (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+          o.slots[(long long)((seq & 1u) ^ 1u) * o.slot_stride + (o.slot_stride - 8) + xc] = kSlotEmpty;
+        }
+      }
+    } else if (threadIdx.x == 0) {
+      unsigned long long w = __hip_atomic_load(res + xc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spins = 0; w == kSlotEmpty; ) {
+        if (++spins >= kMeetSpinMax) { ok = false; w = 0x7ff8000000000000ull; break; }
+        for (int i = 0; i < a.poll_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+        w = __hip_atomic_load(res + xc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s = __longlong_as_double((long long)w);
     }
-    s = wave_sum_d(s);
-    if (lane == 0) dred[wave] = s;
-    __syncthreads();
+    if (!ok && a.status) __hip_atomic_fetch_or(a.status, (unsigned int)MEET_ERR_DW_ADAM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host learns it (meet.h)
     if (threadIdx.x == 0) {
-      s = dred[0] + dred[1] + dred[2] + dred[3];
       float post;
       s_coef = clip_coef(s, c.grad_scale, o.clip, &post);
       if (bid == 0 && a.metrics) met[o.metric_index] = post;
     }
   }
   __syncthreads();
+  OF_STAMP(3);
   const float gmul = c.grad_scale * s_coef;
   float p_new = 0.f, t_new = 0.f;
   if (my_i >= 0) {
@@ -132,6 +186,11 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(DwAdamArgs a) {
       if (pk && o.wt_target) o.wt_target[at] = tile_t[tx][ty];
     }
   }
+  OF_STAMP(4);
+#ifdef GCRL_OF_STAMPS
+  if (a.stamps && threadIdx.x == 0)
+    for (int k = 0; k < 5; ++k) a.stamps[((long long)blockIdx.y * 2048 + blockIdx.x) * 8 + k] = of_t[k];
+#endif
   if (bid == 0 && threadIdx.x == 0) {
     o.seq[1] = 0u;
     o.seq[0] = seq + 1u;   // every workgroup of this launch read it before it published, and this workgroup has seen every slot
@@ -166,7 +225,7 @@ int launch_dw_adam(hipStream_t st, DwAdamArgs& a) {
       tiles += d.ntiles;
     }
     n.o.ntiles = tiles;
-    GCRL_CHECK_ARG(tiles <= 256 * kFusedMaxSlotsPerThread && tiles <= n.o.slot_stride, "dw_adam: net %d has %d tiles (slots: %d)", i, tiles, n.o.slot_stride);
+    GCRL_CHECK_ARG(tiles <= 256 * kFusedMaxSlotsPerThread && tiles + 8 <= n.o.slot_stride, "dw_adam: net %d has %d tiles (slots: %d)", i, tiles, n.o.slot_stride);
     widest = std::max(widest, tiles);
   }
   // (the residency of widest * nnets workgroups is the caller's admission check — dw_adam_capacity — made once per agent)
