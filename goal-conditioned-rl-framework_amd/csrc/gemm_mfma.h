@@ -216,6 +216,16 @@ __device__ __forceinline__ bool gemm_batch_tile(const GemmDesc& d, const int t, 
   for (int i = 0; i < TM; ++i) aoff[i] = (int)((ap[i] - A) * 4);
 #pragma unroll
   for (int j = 0; j < TN; ++j) boff[j] = (int)((bp[j] - Bm) * 4);
+  // The ones column (B(k, N-1) := 1, the bias gradient of a dW | db problem) without a select on the loaded value: its lanes
+  // request an offset past the descriptor's range (the hardware returns 0, no traffic) and OR the bits of 1.0f into what comes
+  // back.  `ones ? 1 : loaded` invited the compiler to branch around the loads — and, in the fused optimiser launch (round 5), to
+  // drain every load in flight (s_waitcnt vmcnt(0)) at each such branch: one memory round trip per 16-k chunk.
+  unsigned int bor[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bor[j] = bone[j] ? 0x3f800000u : 0u;
+    if (bone[j]) boff[j] = (int)0x80000000u;   // (+ any k offset below 2 GiB stays at or above the range of every descriptor used here)
+  }
 
   // epilogue operands (bias, saved activations) are fetched BEFORE the k-loop so their latency
   // overlaps the fragment loads instead of adding a memory round trip after the last MFMA
@@ -305,9 +315,12 @@ __device__ __forceinline__ bool gemm_batch_tile(const GemmDesc& d, const int t, 
               for (int q = 0; q < 4; ++q) b[u][j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, o + q * brs4, 0, 0));
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[u][j][q] = bone[j] ? 1.f : b[u][j][q];
+            for (int q = 0; q < 4; ++q) b[u][j][q] = __uint_as_float(__float_as_uint(b[u][j][q]) | bor[j]);
           }
         }
+        // (every load of the group is requested before its first MFMA: in the fused optimiser launch the scheduler sank the last
+        // loads of a chunk below the first MFMAs and waited for each of them on its own — four round trips instead of one)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u)
           if (u < nvalid) mfma_chunk(a[u], b[u]);
@@ -339,9 +352,9 @@ __device__ __forceinline__ bool gemm_batch_tile(const GemmDesc& d, const int t, 
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int off = (kb + q < K) ? boff[j] + (int)((long long)(kb + q) * b_rs * 4) : kPast;
-          const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tb, off, 0, 0));
-          b[j][q] = bone[j] ? ((kb + q < K) ? 1.f : 0.f) : v;
+          const int off = (kb + q < K && !bone[j]) ? boff[j] + (int)((long long)(kb + q) * b_rs * 4) : kPast;
+          const unsigned int v = __builtin_amdgcn_raw_buffer_load_b32(tb, off, 0, 0);
+          b[j][q] = __uint_as_float(v | ((kb + q < K) ? bor[j] : 0u));
         }
       mfma_chunk(a, b);
     }
