@@ -552,6 +552,7 @@ int enqueue_phase0(gcrl_agent* a, hipStream_t st, int variant) {
     if (a->sac) TRY(sac_actor_forwards(a, st, variant, (variant & V_ACTOR) != 0, nullptr));
     const PipeCtx kc{a->cur(), a->slot_ptr()};
     TRY(rc_launch_chain(a, st, kc, kc, 1, (variant & V_NOISE) ? a->noise_in : nullptr));
+    if (of_phase_critics(a, variant)) return of_launch_critics(a, st, variant);   // dW | db + clip + optimiser step of every critic: one launch (dw_adam.hip)
     Launches dw;
     rc_add_dw(a, dw, kc, true, (variant & V_FUSED_NORM) != 0);
     TRY(dw.run(st));
@@ -674,7 +675,7 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
   const bool fused = (variant & V_FUSED_NORM) != 0, xc = (variant & V_XCHG) != 0 && !a->xchg_sep_norm;
   const bool xv = (variant & V_XCHG) != 0;   // the gradients the optimiser consumes are the exchanged ones
   if (!fused && !xc) TRY(launch_sumsq(st, xv ? xg(a, a->G_critic(0)) : a->G_critic(0), a->critic.numel, a->critic_stride, C, a->norm_partial));
-  {
+  if (!(a->rowchain && of_phase_critics(a, variant))) {   // (else: the critics were stepped by phase 0's last launch)
     AdamArgs ad;
     std::memset(&ad, 0, sizeof(ad));
     adam_common(a, ad);
@@ -719,6 +720,7 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
     // row-block form of the actor phase: actor, stepped critic 0, both input-gradient chains; then dW|db
     const PipeCtx pc{a->cur(), a->slot_ptr()};
     TRY(rc_launch_chain(a, st, pc, pc, 2));
+    if (of_phase_actor(a, variant)) return of_launch_actor(a, st, variant);   // ... and the actor's (phase 2 then has nothing to do)
     Launches dw;
     rc_add_dw(a, dw, pc, false, (variant & V_FUSED_NORM) != 0);
     return dw.run(st);
@@ -894,6 +896,7 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
 // ---------------------------------------------------------------- phase 2
 int enqueue_phase2(gcrl_agent* a, hipStream_t st, int variant) {
   if (!(variant & V_ACTOR)) return GCRL_OK;
+  if (a->rowchain && of_phase_actor(a, variant)) return GCRL_OK;   // stepped by phase 1's last launch
   const int kind = a->cfg.kind;
   const bool fused = (variant & V_FUSED_NORM) != 0, xc = (variant & V_XCHG) != 0 && !a->xchg_sep_norm;   // (BatchNorm gradients: their launches leave partials too)
   const bool xv = (variant & V_XCHG) != 0;
@@ -1371,7 +1374,9 @@ int build(gcrl_agent* a) {
       const long long tc = tiles16(a->critic, &form1), ta = tiles16(a->actor, &form1);
       const long long cap = dw_adam_capacity();
       a->of_stride = align_up(std::max(tc, ta) + 8, 32);   // (the last eight words of an array: the leaders' result words)
-      a->opt_fuse_can = a->rowchain && c.kind == GCRL_AGENT_DDPG && C == 1 && L + 1 <= kFusedMaxLayers && form1 && B < 2048 &&
+      // DDPG: critic | actor in one launch of the overlapped step; TD3 / SAC: the C critics in one launch (TD3: then the actor alone)
+      const bool kind_ok = (c.kind == GCRL_AGENT_DDPG && C == 1) || ((c.kind == GCRL_AGENT_TD3 || c.kind == GCRL_AGENT_SAC) && C == 2);
+      a->opt_fuse_can = a->rowchain && kind_ok && L + 1 <= kFusedMaxLayers && form1 && B < 2048 &&
                         std::max(tc, ta) <= 256LL * kFusedMaxSlotsPerThread && 2 * std::max(tc, ta) <= cap;
       a->opt_fuse = a->opt_fuse_can && !meet_device_shared() && !std::getenv("GCRL_NO_OPT_FUSE");
       if (a->opt_fuse_can) {

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "kernarg.h"
 
 namespace gcrl {
 
@@ -75,8 +76,25 @@ constexpr int kTicketStride = 32;                // tickets 128 bytes apart
 
 struct GemmBatch {
   int n;
+  int tile0[kMaxProb];   // d[q].tile0 once more, next to n: the problem lookup's ONE scalar load (filled by the launchers)
+  int pad[3];
   GemmDesc d[kMaxProb];
 };
+
+// the workgroup's / wave's problem: the last one whose first tile is not beyond `tile` (branch-free over the header's table)
+__device__ __forceinline__ int gemm_problem_of(const GemmBatch& gb, int tile) {
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxProb; ++q) pi += (q < gb.n && tile >= gb.tile0[q]) ? 1 : 0;
+  return pi;
+}
+// every field the tile bodies read in front of (or at) their first operand request, in registers NOW (kernarg.h)
+__device__ __forceinline__ void gemm_pin(const GemmDesc& d) {
+  // ONE asm statement: volatile asms are not reordered among themselves, so a pin per field would be a round trip per field
+  asm volatile("" ::"s"(d.A), "s"(d.B), "s"(d.C), "s"(d.bias), "s"(d.H), "s"(d.col_out), "s"(d.a_rs), "s"(d.a_cs), "s"(d.b_rs), "s"(d.b_cs),
+               "s"(d.c_rs), "s"(d.h_rs), "s"(d.M), "s"(d.N), "s"(d.K), "s"(d.epi), "s"(d.mul), "s"(d.ones_col), "s"(d.slot), "s"(d.a_slot),
+               "s"(d.b_slot), "s"(d.c_slot), "s"(d.h_slot), "s"(d.a_vec), "s"(d.b_vec), "s"(d.tile0), "s"(d.tiles_n), "s"(d.ntiles));
+}
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -451,11 +469,9 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmBatch gb) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = xcd_tile_of((int)blockIdx.x, (int)gridDim.x);
   const int wtile = (KSPLIT == 4) ? bid : bid * 4 + wave;
-  int pi = 0;
-#pragma unroll
-  for (int q = 1; q < kMaxProb; ++q)
-    if (q < gb.n && wtile >= gb.d[q].tile0) pi = q;
+  const int pi = gemm_problem_of(gb, wtile);
   const GemmDesc& d = gb.d[pi];
+  gemm_pin(d);
   const int t = wtile - d.tile0;
   float x, ss;
   if (!gemm_batch_tile<TM, TN, KSPLIT>(d, t, x, ss)) return;

@@ -20,6 +20,7 @@ int launch_shape(hipStream_t st, GemmBatch& gb) {
     if (KSPLIT == 1) tiles = (tiles + 3) & ~3;  // a workgroup's 4 waves stay inside one problem
   }
   const int grid = (KSPLIT == 4) ? tiles : (tiles + 3) / 4;
+  for (int i = 0; i < kMaxProb; ++i) gb.tile0[i] = i < gb.n ? gb.d[i].tile0 : 0x7fffffff;
   hipLaunchKernelGGL((gemm_batch_kernel<TM, TN, KSPLIT>), dim3(grid), dim3(256), 0, st, gb);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
@@ -76,11 +77,9 @@ bool outer_ok(const GemmDesc& d) {
          (!d.slot || (d.b_slot % 4 == 0 && d.c_slot % 4 == 0 && d.h_slot % 4 == 0));
 }
 __global__ __launch_bounds__(256) void gemm_outer_kernel(GemmBatch gb) {
-  int pi = 0;
-#pragma unroll
-  for (int q = 1; q < kMaxProb; ++q)
-    if (q < gb.n && (int)blockIdx.x >= gb.d[q].tile0) pi = q;
+  const int pi = gemm_problem_of(gb, (int)blockIdx.x);
   const GemmDesc& d = gb.d[pi];
+  gemm_pin(d);
   const int nq = d.N >> 2;
   const long long total = (long long)d.M * nq;
   const long long sl = d.slot ? (long long)*d.slot : 0;
@@ -127,6 +126,7 @@ int launch_outer(hipStream_t st, GemmBatch& gb) {
     d.ntiles = (int)(((long long)d.M * (d.N >> 2) + kOuterQuads - 1) / kOuterQuads);
     wgs += d.ntiles;
   }
+  for (int i = 0; i < kMaxProb; ++i) gb.tile0[i] = i < gb.n ? gb.d[i].tile0 : 0x7fffffff;
   hipLaunchKernelGGL(gemm_outer_kernel, dim3(wgs), dim3(256), 0, st, gb);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
@@ -153,6 +153,7 @@ int launch_tiled(hipStream_t st, GemmBatch& gb) {
     d.tile0 = tiles;
     tiles += d.ntiles;
   }
+  for (int i = 0; i < kMaxProb; ++i) gb.tile0[i] = i < gb.n ? gb.d[i].tile0 : 0x7fffffff;
   hipLaunchKernelGGL(gemm_tiled_kernel, dim3(tiles), dim3(256), 0, st, gb);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;

@@ -481,11 +481,10 @@ __global__ __launch_bounds__(256, 5) void gemm_tiled_kernel(GemmBatch gb) {   //
   float* ldsA = lds;
   float* ldsB = lds + 2 * kTB * kLDT;
   const int tile = xcd_tile_of((int)blockIdx.x, (int)gridDim.x);   // an XCD owns whole tile rows: each A panel enters ONE L2 (gemm_mfma.h)
-  int pi = 0;
-#pragma unroll
-  for (int q = 1; q < kMaxProb; ++q)
-    if (q < gb.n && tile >= gb.d[q].tile0) pi = q;
+  const int pi = gemm_problem_of(gb, tile);
   const GemmDesc& d = gb.d[pi];
+  gemm_pin(d);   // (the record in registers after ONE scalar round trip instead of fourteen dependent ones: kernarg.h)
+  asm volatile("" ::"s"(d.a_rvec), "s"(d.b_rvec), "s"(d.ksplit), "s"(d.kpart), "s"(d.kticket), "s"(d.sumsq_out), "s"(d.bn_part));
   const int t = tile - d.tile0;
   if (t >= d.ntiles) return;
   // fetch modes are per problem and wave-uniform: 3 x 3 straight-line instances

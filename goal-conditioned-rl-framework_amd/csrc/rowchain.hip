@@ -150,6 +150,7 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
 template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  kernarg_warm<sizeof(RowChainArgs)>();
   // k_split (round 4, DDPG): the critic phase K as TWO roles in this launch — its target chain (target actor -> target critic -> Q')
   // and its online critic's forward are independent, so K's critical path shrinks from 11 layer passes to 6 + 2 (the split kernel's
   // phase 0, part 3, producers / consumers form: workgroups [0, nblk_k) the target role, [nblk_k, 2 nblk_k) the online critic, which
@@ -631,6 +632,7 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
 
 template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArgs a, int phase, int part) {
+  kernarg_warm<sizeof(RowChainArgs) + 8>();
   rowchain_split_body<RG>(a, phase, part, (int)blockIdx.x);
 }
 

@@ -121,6 +121,60 @@ def test_update_many_is_bitwise_at_the_benchmarked_sizes(gcrl, kind, H, L, B):
     assert all(np.isfinite(v) for t in t_one for v in t)
 
 
+def _headline_ddpg(gcrl, orc=None, seed=1898, **kw):
+    """bench.py's headline call: DDPG, PickAndPlace dims (S 23, A 4), H 256, L 3, B 256, k_future 8, gradient_step 40."""
+    Sh, Ah, B = 23, 4, 256
+    cfg = make_config("DDPG", hidden_dim=256, layer_count=3, batch_size=B, max_len=20000, grad_clip=10.0, tau=0.05, k_future=8)
+    ag = gcrl.DDPG(Sh, Ah, cfg, None, nenvs=2, gradient_step=40, rng="engine", seed=seed, **kw)
+    gen = np.random.default_rng(7)
+    for ep in range(6):
+        for st in her_oracle.synthetic_episode(gen, 50, Sh, Ah):
+            ag.push_her(ep % 2, *st)
+            if orc is not None:
+                orc.push_her(ep % 2, *st)
+    return ag, cfg
+
+
+def test_the_benchmarked_ddpg_call_is_bitwise_repeated_update(gcrl):
+    """the call bench.py times — pipelined `update_many` at S 23 / A 4 / H 256 / B 256 / gradient_step 40 — was pinned only
+    by transitivity (a sequential `update()` at these dims against the reference; pipelined == sequential at S 10 / A 3).  Here:
+    update_many(1, 40) + update_many(41, 40) (a trainer cycle each: K-only, 39 merged launches — the fused dW + optimiser launch
+    among them — P-only, the step-40 / step-80 Polyak updates inside the overlapped schedule, the deferred draw) against 80 x
+    update(): every tuple, parameter, target and Adam moment bitwise (reference: src/agent.py:1378-1404, trainer loop
+    src/env.py:384-385)."""
+    one, _ = _headline_ddpg(gcrl)
+    many, _ = _headline_ddpg(gcrl)
+    t_one = [tuple(float(x) for x in one.update(step)) for step in range(1, 81)]
+    t_many = [tuple(float(x) for x in t) for t in many.update_many(1, 40)] + [tuple(float(x) for x in t) for t in many.update_many(41, 40)]
+    for step, (a, b) in enumerate(zip(t_one, t_many), start=1):
+        assert a == b, (step, a, b)
+    for x, y in zip(_state(one), _state(many)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    for name in ("adam_m:actor", "adam_v:actor", "adam_m:critic_0", "adam_v:critic_0"):
+        assert np.array_equal(one.actor._get(name), many.actor._get(name)), name
+    assert all(np.isfinite(v) for t in t_one for v in t)
+
+
+def test_the_benchmarked_ddpg_call_tracks_the_oracle(gcrl):
+    """... and five sampled steps of that call against OracleAgent fed the same pushes and the same MT index stream: the first
+    step (same parameters on both sides) at the north star's 1e-5, the following ones as a trajectory (Adam amplifies an fp32
+    rounding of a ~0 gradient into a full lr-sized step of that weight)."""
+    Sh, Ah, seed = 23, 4, 1898
+    cfg = make_config("DDPG", hidden_dim=256, layer_count=3, batch_size=256, max_len=20000, grad_clip=10.0, tau=0.05, k_future=8)
+    orc = OracleAgent("DDPG", Sh, Ah, cfg, nenvs=2, gradient_step=40, rng=random.Random(seed))
+    ag, _ = _headline_ddpg(gcrl, orc=orc, seed=seed)
+    ag.actor.set_flat(orc.flat_params(orc.actor))
+    ag.critic.set_flat(orc.flat_params(orc.critics[0]))
+    ag.update_target_network()
+    orc.hard_update()
+    outs = ag.update_many(1, 5)
+    for k, info in enumerate(outs):
+        got = np.array([float(x) for x in info])
+        want = np.array([float(np.asarray(x)) for x in orc.update(k + 1)])
+        tol = 1e-5 if k == 0 else 2e-3
+        assert np.allclose(got, want, rtol=tol, atol=tol * 1e-1), (k + 1, got, want)
+
+
 def test_round4_layer_path_forms_change_nothing_but_metric_roundings(gcrl, monkeypatch):
     """TQC at BASELINE cfg 4's shape with round 4's layer-per-launch forms (BatchNorm partials out of the tiled GEMM's epilogue,
     multi-workgroup td_loss / actor_select_alpha, control advance riding the actor's optimiser launch) against the same agent

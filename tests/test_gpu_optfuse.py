@@ -118,3 +118,41 @@ def test_meetings_switch_selects_the_two_launch_form(gcrl, monkeypatch):
     assert got == ref
     for x, y in zip(_everything(a), _everything(b)):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("kind,H,L,B", [("TD3", 64, 3, 300), ("SAC", 64, 3, 130), ("SAC", 256, 3, 512), ("TD3", 128, 2, 40)])
+def test_fused_optimiser_launch_for_twin_critics_is_bitwise_the_two_launch_form(gcrl, monkeypatch, kind, H, L, B):
+    """TD3 / SAC on the row-chain path: both critics' dW | db + clip + AdamW (+ Polyak; TD3's critic_1 unclipped, src/agent.py:201)
+    as one launch at the end of the critic phase, TD3's actor likewise — 39 steps of update_many (multi-step graphs, SAC's
+    step % gradient_step Polyak, TD3's delayed actor, the alpha branch switching on) against GCRL_NO_OPT_FUSE=1: tuples and every
+    parameter, target, BatchNorm statistic bitwise."""
+    import test_gpu_multistep as ms
+    cfg = ms._cfg(kind, H, L, B, max_len=20000 if B > 200 else 4000)
+
+    def build():
+        ag = ms._cls(gcrl, kind)(ms.S, ms.A, cfg, None, nenvs=2, gradient_step=5, rng="engine", seed=21)
+        gen = np.random.default_rng(3)
+        ep = 0
+        while len(ag.buffer) < B + 300:
+            for st in ms.her_oracle.synthetic_episode(gen, 50, ms.S, ms.A):
+                ag.push_her(ep % 2, *st)
+            ep += 1
+        return ag
+
+    monkeypatch.setenv("GCRL_NO_OPT_FUSE", "1")
+    two = build()
+    assert not (two.meetings() & 8)
+    monkeypatch.delenv("GCRL_NO_OPT_FUSE")
+    one = build()
+    if not (one.meetings() & 8):
+        pytest.skip("the fused optimiser launch is not admissible on this device")
+    chunks = [(1, 19), (20, 1), (21, 8), (29, 11)]
+    t_two, t_one = [], []
+    for s0, n in chunks:
+        t_two += [tuple(float(x) for x in t) for t in two.update_many(s0, n)]
+        t_one += [tuple(float(x) for x in t) for t in one.update_many(s0, n)]
+    for step, (x, y) in enumerate(zip(t_two, t_one), start=1):
+        assert x == y, (kind, step, x, y)
+    for x, y in zip(ms._state(two), ms._state(one)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert all(np.isfinite(v) for t in t_one for v in t)
