@@ -312,6 +312,8 @@ def _meeting_forms(agent):
         names.append("row-chain roles (DDPG: the critic phase as two roles of the fused launch)")
     if m & 4:
         names.append("weight-slice DDPG launch (GCRL_ROWTILE=1)")
+    if m & 8:
+        names.append("fused dW + clip + optimiser launch (csrc/dw_adam.hip: norm slots swept inside the launch)")
     return names
 
 
@@ -319,7 +321,7 @@ def pmc_traffic(workload, kernel_substr):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/r0N_pmc_traffic_<workload>.json — the newest round's — made by tools/pmc_traffic.sh: FETCH_SIZE x 2 + WRITE_SIZE per
     the guide's gfx950 correction).  bench.py cannot run the counter tool on itself."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{workload}.json")
         if not os.path.exists(path):
             continue
@@ -332,6 +334,7 @@ def pmc_traffic(workload, kernel_substr):
 KERNELS = {   # short name -> substring of the profiler's kernel name
     "gather_main": "her_gather_update_kernel<false", "gather_head": "her_gather_update_kernel<true",
     "flush_single": "her_flush_kernel<false>", "flush_multi": "her_flush_kernel<true>", "rowchain": "rowchain_ddpg_kernel",
+    "dw_adam": "dw_adam_kernel", "dw_gemm": "gemm_batch_kernel<1, 1, 4>", "adam_pair": "adam_pair_kernel",
 }
 
 
@@ -552,6 +555,7 @@ def main():
             "warmup_extra_steps": extra_warm,
             "roofline_gather": {"kernel": "her_gather_update_kernel<false> (a trainer cycle's main gather)", "bound": "hbm", "achieved": achieved,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                "traffic_source": (g_pmc or {}).get("source"),
                                 "avg_launch_us": use_us, "rows_per_launch": rows_per_launch,
                                 "algorithmic_bytes_per_row": alg_bytes_per_row, "timing": clock,
                                 "hip_event_us": ev_us, "hip_event_launches": launches.value,
@@ -569,6 +573,7 @@ def main():
         }
         if dp is not None:
             out["dp_exchange"] = dp.exchange
+            out["dp_exchange_reason"] = getattr(dp, "exchange_reason", "")
         # HER relabel + flush kernel: per episode read T*(2S+A+2+G)*4 B of staging, write (T + k(T-1)) rows of R bytes
         T, G = 50, 3
         ep_bytes = T * (2 * w["S"] + w["A"] + 2 + G) * 4 + (T + w["k"] * (T - 1)) * R
@@ -597,6 +602,7 @@ def main():
                 "kernel": "rowchain_ddpg_kernel", "bound": "mfma", "achieved": fl_ / (r_us * 1e-6) / 1e12,
                 "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl_ / (r_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF,
                 "traffic": r_pmc["hbm_bytes_per_launch_corrected"] if r_pmc else None,
+                "traffic_source": (r_pmc or {}).get("source"),
                 "l2_to_cu_read_requests_per_launch": r_pmc.get("TCP_TCC_READ_REQ_sum") if r_pmc else None,
                 "avg_launch_us": r_us, "algorithmic_flops_per_launch": fl_,
                 "timing": "rocprofv3 kernel duration (child run of this command)" if "rowchain" in ks else "HIP-event pair (profiler unavailable)",
@@ -604,6 +610,19 @@ def main():
                 "hip_event_us": rc[1], "hip_event_launches": rc[0], "device_clock_us": rc[2],
                 "share_of_step_time": r_us / (1e6 * elapsed / args.steps),
                 "note": "latency-bound chain (10 dependent 256-wide layer passes per phase, 128 of 256 CUs at B=256), see DESIGN.md §4"}
+            if "dw_adam" in ks:
+                # the step's other launch (round 5): every dW | db GEMM, the global-norm clip, Adam, Polyak, weight copies, metrics
+                S_, A_, H_, L_ = w["S"], w["A"], w["H"], w["L"]
+                n_par = (S_ * H_ + (L_ - 1) * H_ * H_ + H_ * A_ + L_ * H_ + A_) + ((S_ + A_) * H_ + (L_ - 1) * H_ * H_ + H_ + L_ * H_ + 1)   # actor + critic, weights and biases
+                o_us = ks["dw_adam"]["avg_us"]
+                out["optimiser_launch"] = {
+                    "kernel": "dw_adam_kernel (dW | db of both nets + clip + Adam + Polyak + [in][out] copies + metrics + control advance)",
+                    "bound": "latency (one cold operand round trip, two hand-offs through memory inside the launch)",
+                    "avg_launch_us": o_us, "profiler": ks["dw_adam"],
+                    "algorithmic_flops_per_launch": 2 * w["B"] * n_par, "achieved_tflops": 2 * w["B"] * n_par / (o_us * 1e-6) / 1e12,
+                    "algorithmic_bytes_per_launch": 28 * n_par + 2 * 4 * w["B"] * (w["H"] * 2 * w["L"]),
+                    "replaces": "gemm_batch_kernel<1,1,4> (7.2 us) + adam_pair_kernel (8.8 us): profiles/r04_kernel_stats_ddpg_pickplace_b256.csv",
+                    "share_of_step_time": o_us / (1e6 * elapsed / args.steps)}
         else:
             # many-kernel steps (TD3 / SAC / TQC): the step as a whole against the MFMA roofline, not one kernel
             tf = flops_per_step(w) * args.steps / elapsed / 1e12

@@ -5,6 +5,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <map>
+#include <string>
+
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "common.h"
 #include "gemm_mfma.h"
@@ -24,6 +31,41 @@ bool meet_device_shared() {
   return g_shared == 1;
 }
 void meet_set_device_shared(bool on) { g_shared = on ? 1 : 0; }
+
+// Is another PROCESS using this device through this library?  (the launch forms with in-kernel waits were switched off
+// for ranks that share a GPU only under DataParallelUpdater; anyone else had to set GCRL_SHARED_GPU by hand.)  Every process that
+// creates a handle on a device holds a SHARED advisory lock on a per-device presence file (named after the PCI bus id); whoever
+// cannot convert it into an exclusive lock — non-blocking — is not alone, and from then on counts the device as shared.  Probed
+// at handle creation and every few update calls (two system calls), so the process that was there first notices a later arrival
+// too.  Not seen: a process with another /tmp, or another library on the same GPU (GCRL_SHARED_GPU=1 remains for those).
+// GCRL_NO_DEVICE_LOCK=1 switches the probe off.
+bool meet_probe_device(int device) {
+  static std::map<int, int> fds;
+  static const bool off = std::getenv("GCRL_NO_DEVICE_LOCK") != nullptr;
+  if (off) return false;
+  auto it = fds.find(device);
+  if (it == fds.end()) {
+    char bus[32] = {0};
+    int fd = -2;
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) == hipSuccess && bus[0]) {
+      for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.') *c = '_';
+      std::string path = std::string(std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp") + "/gcrl_amd_gpu_" + bus + ".lock";
+      fd = ::open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+      if (fd >= 0) { (void)::fchmod(fd, 0666); (void)::flock(fd, LOCK_SH); } else fd = -2;
+    } else {
+      (void)hipGetLastError();
+    }
+    it = fds.emplace(device, fd).first;
+  }
+  if (it->second < 0) return false;
+  if (::flock(it->second, LOCK_EX | LOCK_NB) == 0) {   // alone: back to the shared lock every process holds
+    (void)::flock(it->second, LOCK_SH);
+    return false;
+  }
+  (void)::flock(it->second, LOCK_SH);   // (a failed conversion drops the old lock on Linux: take it again)
+  g_shared = 1;
+  return true;
+}
 
 long long meet_capacity(const void* kernel, int threads, size_t lds_bytes) {
   if (meet_device_shared()) return 0;

@@ -1177,8 +1177,9 @@ int meet_check(gcrl_agent* a) {
   if (bits & (MEET_ERR_XCHG_READY | MEET_ERR_XCHG_DONE)) {
     (void)hipDeviceSynchronize();
     __atomic_store_n(a->status_host, 0u, __ATOMIC_RELEASE);
-    return fail(GCRL_ERR_STATE, "the in-engine gradient exchange timed out waiting for a peer (status 0x%x:%s%s): a rank is missing, late by more than ~1 s, or enqueued "
-                                "a different exchange sequence; this step's gradients are NaN on this rank.  Re-synchronise the ranks and call gcrl_xchg_reset on each",
+    return fail(GCRL_ERR_STATE, "the in-engine gradient exchange timed out waiting for a peer (status 0x%x:%s%s): a rank is missing, late by more than the bounded wait (2^24 polls: "
+                                "about a minute), or enqueued a different exchange sequence; this step's gradients are NaN on this rank.  Re-synchronise the ranks and call "
+                                "gcrl_xchg_reset on each (Python: DataParallelUpdater.recover(), collective), then reload the last checkpoint",
                 bits, (bits & MEET_ERR_XCHG_READY) ? " peers' gradients not ready" : "", (bits & MEET_ERR_XCHG_DONE) ? " peers' chunks not delivered" : "");
   }
   (void)hipDeviceSynchronize();
@@ -1221,6 +1222,7 @@ bool rowtile_enabled() {
 int build(gcrl_agent* a) {
   const gcrl_agent_config& c = a->cfg;
   GCRL_HIP(hipSetDevice(c.device));
+  (void)meet_probe_device(c.device);   // another process of this library on the device: no launch form with an in-kernel wait (meet.h)
   GCRL_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
   GCRL_HIP(hipStreamCreateWithFlags(&a->cap_stream, hipStreamNonBlocking));
   const int S = a->S, A = a->A, H = a->H, L = a->L, B = a->B, C = a->C;
@@ -1810,6 +1812,8 @@ int gcrl_agent_update(gcrl_agent* a, gcrl_her* her, int64_t step, const gcrl_upd
 int gcrl_agent_update_n(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, int64_t* tickets_out, int32_t* lens_out, void* stream) {
   GCRL_CHECK_ARG(a && her, "gcrl_agent_update_n: null handle");
   GCRL_CHECK_ARG(n >= 1, "gcrl_agent_update_n: n must be >= 1");
+  // a process that arrived on this device after the handle was built: its kernels hold CUs, so no more waits inside launches
+  if ((a->calls & 31) == 0 && !meet_device_shared()) { const int rc = gcrl_agent_get_meetings(a); if (rc < 0) return rc; }   // (probes, and switches the forms off)
   hipStream_t st = a->pick(stream);
   const int chunk = std::min(kMaxStepsPerCall, a->Mmax);
   for (int done = 0; done < n; done += chunk) {
@@ -2002,6 +2006,10 @@ int gcrl_agent_set_meetings(gcrl_agent* a, int on) {
 
 int gcrl_agent_get_meetings(gcrl_agent* a) {
   GCRL_CHECK_ARG(a, "gcrl_agent_get_meetings: null handle");
+  if (!meet_device_shared() && meet_probe_device(a->cfg.device)) {   // (someone arrived since: the forms go off now)
+    const int rc = gcrl_agent_set_meetings(a, 0);
+    if (rc < 0) return rc;
+  }
   return (a->bn_rsplit > 1 ? 1 : 0) | ((a->rc_merge || a->rc_merge_k || a->ddpg_ksplit) ? 2 : 0) | (a->rowtile ? 4 : 0) | (a->opt_fuse ? 8 : 0);
 }
 

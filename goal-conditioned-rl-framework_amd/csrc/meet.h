@@ -91,6 +91,8 @@ __device__ inline bool meet_consume(const unsigned long long* ctr, unsigned long
 // contain a wait for another workgroup of itself.
 bool meet_device_shared();
 void meet_set_device_shared(bool on);
+// another process holds the per-device presence lock of this library (abi_misc.hip): counts the device as shared from then on
+bool meet_probe_device(int device);
 // workgroups of `kernel` (block threads, dynamic LDS bytes) that are resident at once on the current device, with the
 // headroom the occupancy query needs (it over-reports: 5 where 4 are resident at 32 KB of LDS); 0 when the
 // device is shared or the query fails

@@ -228,17 +228,20 @@ gcrl_xchg* gcrl_xchg_create(float* arena_dev, int64_t arena_floats, const int64_
   x->parts_off = flags;
   x->ctl_bytes = flags + (((size_t)nch * sizeof(float) + 255) / 256) * 256;
   // fine-grained device memory for everything a PEER writes and this GPU reads (coherent without cache maintenance)
-  auto fine = [](void** p, size_t bytes) {
+  // (NO fallback to coarse-grained memory once there is a peer — a peer's store could then hide behind a stale line of
+  // this GPU's L2, i.e. stale reduced gradients or spurious timeouts, with nothing to warn about it.  The caller falls back to
+  // another exchange when creation fails: src/dp.py.  A world of one has no peer and may take what it gets.)
+  auto fine = [world](void** p, size_t bytes) {
     if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) return true;
     (void)hipGetLastError();
-    return hipMalloc(p, bytes) == hipSuccess;
+    return world == 1 && hipMalloc(p, bytes) == hipSuccess;
   };
   bool ok = hipSetDevice(device) == hipSuccess && fine((void**)&x->ctl, x->ctl_bytes) &&
             hipMemset(x->ctl, 0, x->ctl_bytes) == hipSuccess &&
             (world == 1 || (fine((void**)&x->recv, (size_t)arena_floats * sizeof(float)) &&
                             hipMemset(x->recv, 0, (size_t)arena_floats * sizeof(float)) == hipSuccess)) &&
             hipDeviceSynchronize() == hipSuccess;
-  if (!ok) { fail(GCRL_ERR_HIP, "gcrl_xchg_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); gcrl_xchg_destroy(x); return nullptr; }
+  if (!ok) { fail(GCRL_ERR_HIP, "gcrl_xchg_create: device allocation failed (fine-grained device memory is required for the buffers peers write): %s", hipGetErrorString(hipGetLastError())); gcrl_xchg_destroy(x); return nullptr; }
   x->peer_arena[rank] = x->arena;
   x->peer_ctl[rank] = x->ctl;
   x->peer_recv[rank] = x->recv;
@@ -262,7 +265,7 @@ void gcrl_xchg_destroy(gcrl_xchg* x) {
 
 int gcrl_xchg_handles(gcrl_xchg* x, uint8_t* out, int64_t n) {
   GCRL_CHECK_ARG(x && out && n == GCRL_XCHG_HANDLE_BYTES, "gcrl_xchg_handles: the buffer must hold GCRL_XCHG_HANDLE_BYTES bytes");
-  static_assert(3 * sizeof(hipIpcMemHandle_t) + 2 * sizeof(int64_t) <= GCRL_XCHG_HANDLE_BYTES, "handle record");
+  static_assert(3 * sizeof(hipIpcMemHandle_t) + 2 * sizeof(int64_t) + 32 <= GCRL_XCHG_HANDLE_BYTES, "handle record");
   hipIpcMemHandle_t h[3];
   std::memset(h, 0, sizeof(h));
   GCRL_HIP(hipIpcGetMemHandle(&h[0], x->arena));
@@ -272,6 +275,10 @@ int gcrl_xchg_handles(gcrl_xchg* x, uint8_t* out, int64_t n) {
   std::memcpy(out, h, sizeof(h));
   const int64_t meta[2] = {(int64_t)x->arena_floats, (int64_t)x->nchunks()};
   std::memcpy(out + sizeof(h), meta, sizeof(meta));
+  // the owner's PCI bus id: a peer on ANOTHER device asks hipDeviceCanAccessPeer before it maps anything (gcrl_xchg_connect)
+  char bus[32] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), x->device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+  std::memcpy(out + sizeof(h) + sizeof(meta), bus, sizeof(bus));
   return GCRL_OK;
 }
 
@@ -288,6 +295,19 @@ int gcrl_xchg_connect(gcrl_xchg* x, const uint8_t* all, int64_t n) {
     if (meta[0] != x->arena_floats || meta[1] != (int64_t)x->nchunks())
       return fail(GCRL_ERR_STATE, "gcrl_xchg_connect: rank %d exchanges a different layout (%lld floats / %lld chunks, here %lld / %zu): the replicas must be built alike",
                   q, (long long)meta[0], (long long)meta[1], (long long)x->arena_floats, (size_t)x->nchunks());
+    // a peer on another device of this process's view: peer access must be possible at all — a clear error here (the caller falls
+    // back to RCCL) instead of a fault or a hang in the first exchange
+    char bus[32];
+    std::memcpy(bus, rec + sizeof(h) + sizeof(meta), sizeof(bus));
+    bus[31] = 0;
+    int pdev = -1;
+    if (bus[0] && hipDeviceGetByPCIBusId(&pdev, bus) == hipSuccess && pdev >= 0 && pdev != x->device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, x->device, pdev) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+      if (!can) return fail(GCRL_ERR_STATE, "gcrl_xchg_connect: device %d cannot access the memory of rank %d's device %d (%s): no peer-to-peer exchange on this node", x->device, q, pdev, bus);
+    } else {
+      (void)hipGetLastError();   // (the peer's device is not visible to this process, or it is this device: the mapping below decides)
+    }
     GCRL_HIP(hipIpcOpenMemHandle(&x->peer_arena[q], h[0], hipIpcMemLazyEnablePeerAccess));
     GCRL_HIP(hipIpcOpenMemHandle(&x->peer_ctl[q], h[1], hipIpcMemLazyEnablePeerAccess));
     GCRL_HIP(hipIpcOpenMemHandle(&x->peer_recv[q], h[2], hipIpcMemLazyEnablePeerAccess));
@@ -352,45 +372,65 @@ int gcrl_xchg_allreduce(gcrl_xchg* x, int seg0, int nseg, void* stream) {
   return GCRL_OK;
 }
 
-// Collective self-test (every rank calls it once after gcrl_xchg_connect, before the arena holds anything of value): rank r
-// writes r + 1 + i / 4096 into the first min(2048, n) floats of segment 0, the ranks exchange that segment, and every rank must
-// read back W (W + 1) / 2 + W * (i / 4096).  Catches what the handle exchange cannot see — a peer mapping that faults, peers on
-// different exchange layouts, a rank that never arrives (bounded wait) — so that the host side can fall back to another exchange
-// BEFORE training starts.  Zeroes what it wrote.
+// Collective self-test (every rank calls it once after gcrl_xchg_connect, before the arena holds anything of value).  THREE rounds
+// over the SAME addresses with a different pattern each — rank r writes (r + 1) * (round + 1) + i / 4096 into the first
+// min(2048, n) floats of segment 0 (and, in the middle round, of segment 1 as well: another grid, other chunk owners) — and every
+// rank must read back the rank-order sum.  The first round catches what the handle exchange cannot see (a peer mapping that
+// faults, peers on different layouts, a rank that never arrives: bounded wait); the later ones what a first touch cannot (ADVICE
+// r4): a stale line of the arena or of the receive buffer in a reader's caches when the same addresses are read again, an epoch or
+// done flag that does not survive re-use.  The host side falls back to another exchange BEFORE training starts when any rank
+// fails.  Restores what it overwrote.
 int gcrl_xchg_selftest(gcrl_xchg* x, void* stream) {
   GCRL_CHECK_ARG(x, "gcrl_xchg_selftest: null handle");
   if (!x->connected) return fail(GCRL_ERR_STATE, "gcrl_xchg_selftest: not connected");
   hipStream_t st = stream == GCRL_STREAM_LEGACY ? (hipStream_t) nullptr : (hipStream_t)stream;
-  const int n = (int)std::min<long long>(2048, x->seg_n[0]);
-  std::vector<float> v((size_t)n), got((size_t)n);
-  for (int i = 0; i < n; ++i) v[i] = (float)(x->rank + 1) + (float)i / 4096.0f;
-  float* dst = x->arena + x->seg_off[0];
-  std::vector<float> saved((size_t)n);
-  GCRL_HIP(hipStreamSynchronize(st));
-  GCRL_HIP(hipMemcpy(saved.data(), dst, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-  GCRL_HIP(hipMemcpy(dst, v.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  const int nseg_all = (int)x->seg_n.size();
   unsigned int* status_keep = x->status;
   static unsigned int* st_host = nullptr; static unsigned int* st_dev = nullptr;
   if (!st_host) {
     GCRL_HIP(hipHostMalloc((void**)&st_host, 64, hipHostMallocMapped));
     GCRL_HIP(hipHostGetDevicePointer((void**)&st_dev, st_host, 0));
   }
-  *st_host = 0;
-  x->status = st_dev;
-  const int rc = gcrl_xchg_allreduce(x, 0, 1, stream);
-  x->status = status_keep;
-  if (rc) return rc;
-  GCRL_HIP(hipStreamSynchronize(st));
-  GCRL_HIP(hipMemcpy(got.data(), gcrl_xchg_result(x) + x->seg_off[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-  GCRL_HIP(hipMemcpy(dst, saved.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-  if (*st_host) return fail(GCRL_ERR_STATE, "gcrl_xchg_selftest: a wait for a peer timed out (status 0x%x)", *st_host);
   const int W = x->world;
-  for (int i = 0; i < n; ++i) {
-    float want = 0.f;
-    for (int r = 0; r < W; ++r) want += (float)(r + 1) + (float)i / 4096.0f;   // rank order, as the kernel adds
-    if (got[i] != want) return fail(GCRL_ERR_STATE, "gcrl_xchg_selftest: element %d is %.9g, expected %.9g (world %d)", i, (double)got[i], (double)want, W);
+  std::vector<std::vector<float>> saved((size_t)std::min(2, nseg_all));
+  GCRL_HIP(hipStreamSynchronize(st));
+  for (size_t sg = 0; sg < saved.size(); ++sg) {
+    saved[sg].resize((size_t)std::min<long long>(2048, x->seg_n[sg]));
+    GCRL_HIP(hipMemcpy(saved[sg].data(), x->arena + x->seg_off[sg], saved[sg].size() * sizeof(float), hipMemcpyDeviceToHost));
   }
-  return GCRL_OK;
+  int rc = GCRL_OK;
+  for (int round = 0; round < 3 && rc == GCRL_OK; ++round) {
+    const int nsegs = (round == 1) ? (int)saved.size() : 1;
+    auto value = [&](int r, int sg, int i) { return (float)((r + 1) * (round + 1)) + (float)i / 4096.0f + (float)(16 * sg); };
+    for (int sg = 0; sg < nsegs; ++sg) {
+      std::vector<float> v(saved[sg].size());
+      for (size_t i = 0; i < v.size(); ++i) v[i] = value(x->rank, sg, (int)i);
+      GCRL_HIP(hipMemcpy(x->arena + x->seg_off[sg], v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *st_host = 0;
+    x->status = st_dev;
+    rc = gcrl_xchg_allreduce(x, 0, nsegs, stream);
+    x->status = status_keep;
+    if (rc) break;
+    GCRL_HIP(hipStreamSynchronize(st));
+    if (*st_host) { rc = fail(GCRL_ERR_STATE, "gcrl_xchg_selftest: a wait for a peer timed out in round %d (status 0x%x)", round, *st_host); break; }
+    for (int sg = 0; sg < nsegs && rc == GCRL_OK; ++sg) {
+      std::vector<float> got(saved[sg].size());
+      GCRL_HIP(hipMemcpy(got.data(), gcrl_xchg_result(x) + x->seg_off[sg], got.size() * sizeof(float), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < got.size(); ++i) {
+        float want = 0.f;
+        for (int r = 0; r < W; ++r) want += value(r, sg, (int)i);   // rank order, as the kernel adds
+        if (got[i] != want) {
+          rc = fail(GCRL_ERR_STATE, "gcrl_xchg_selftest: round %d, segment %d, element %zu is %.9g, expected %.9g (world %d)%s", round, sg, i, (double)got[i],
+                    (double)want, W, round ? ": a re-read of the same addresses returned stale data" : "");
+          break;
+        }
+      }
+    }
+  }
+  for (size_t sg = 0; sg < saved.size(); ++sg)
+    (void)hipMemcpy(x->arena + x->seg_off[sg], saved[sg].data(), saved[sg].size() * sizeof(float), hipMemcpyHostToDevice);
+  return rc;
 }
 
 // after a timed-out exchange (status word): every rank's counters back to a common state.  Collective in spirit: the caller

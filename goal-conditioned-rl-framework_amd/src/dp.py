@@ -133,8 +133,18 @@ class DataParallelUpdater:
         one_host = len({h for h, _ in where}) == 1
         shared_gpu = len(set(where)) < self.world
         auto = exchange == "auto"
+        self.exchange_reason = "asked for" if not auto else ""
         if auto:
-            exchange = "ipc" if (one_host and self.world <= 8) else ("rccl" if nccl else "python")
+            # Under the nccl backend `auto` takes the library collective: the peer-to-peer exchange has only ever run
+            # with its ranks on ONE device (1-GPU boxes) — opt in with exchange="ipc" / GCRL_DP_EXCHANGE=ipc; its three-round
+            # self-test then decides, and a failure falls back to RCCL on every rank together.  Under gloo (CPU rendezvous, ranks
+            # sharing a GPU: the tests) the peer-to-peer exchange is the in-engine path there is.
+            if nccl:
+                exchange, self.exchange_reason = "rccl", "auto: nccl backend (the IPC exchange is opt-in until validated across devices)"
+            elif one_host and self.world <= 8:
+                exchange, self.exchange_reason = "ipc", "auto: one host, gloo backend"
+            else:
+                exchange, self.exchange_reason = "python", "auto: several hosts without the nccl backend"
         if exchange == "ipc":
             why = ""
             x = lib.gcrl_agent_xchg_create(agent._h, self.rank, self.world) if (one_host and self.world <= 8) else None
@@ -164,12 +174,13 @@ class DataParallelUpdater:
             else:
                 if x:
                     lib.gcrl_xchg_destroy(x)
-                if require_native and not (auto and nccl):      # (auto over RCCL: the other in-engine exchange is tried next)
+                if require_native and not nccl:      # (over RCCL the other in-engine exchange is tried next)
                     raise _ffi.GcrlError("gcrl_amd.dp: the in-engine IPC exchange could not be set up on every rank (this rank: " + (why or "ok") +
                                          "); refusing a fallback (require_native)")
                 import warnings
                 warnings.warn("gcrl_amd.dp: in-engine IPC exchange unavailable (" + (why or "another rank failed") + "); falling back")
                 exchange = "rccl" if nccl else "python"
+                self.exchange_reason = "fallback from ipc: " + (why or "another rank failed")
         if exchange == "rccl" and nccl:
             # the librccl PyTorch itself uses (two RCCL / HIP runtime copies in one process do not mix)
             path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
@@ -236,6 +247,16 @@ class DataParallelUpdater:
         h, self._native = getattr(self, "_native", None), None
         if h:
             self._ffi.lib.gcrl_dp_destroy(h)
+
+    def recover(self):
+        """COLLECTIVE: after a timed-out exchange (`GcrlError: ... exchange timed out waiting for a peer`) every rank calls this —
+        barrier, counters of the peer-to-peer exchange back to their common initial state (gcrl_xchg_reset), barrier.  The step
+        that timed out took NaN gradients: reload the last checkpoint (`agent.load_state`) on every rank afterwards, as a trainer
+        would after any failed step (reference: src/agent.py:659-699 raises and stops).  A no-op for the RCCL / Python exchanges."""
+        dist.barrier(group=self.group)
+        if self._xchg:
+            self._ffi.check(self._ffi.lib.gcrl_xchg_reset(self._xchg))
+        dist.barrier(group=self.group)
 
     def _allreduce_block(self, i: int, st):
         if self._native:

@@ -206,9 +206,23 @@ class DeviceRunningNormalizer:
             self._ffi.check(self._ffi.lib.gcrl_normalizer_set_rows_float64(self._h, on))
             self._rows64 = on
 
+    def _check_float32_valued(self, x):
+        """The float64-rows regime restates numpy's float64 ARITHMETIC, but the rows travel to the device as float32: exact for
+        panda-gym's observations (float32 values in a float64 array, reference src/utils.py:156), silently different for an
+        environment that emits genuine float64 values.  Checked on the first float64 batch of every normaliser, warned
+        about once."""
+        if x.dtype == np.float64 and not getattr(self, "_f64_checked", False):
+            self._f64_checked = True
+            if not np.array_equal(x.astype(np.float32).astype(np.float64), x):
+                import warnings
+                warnings.warn("gcrl_amd: float64 observations that are not float32-valued: the device normaliser rounds rows to float32 before its "
+                              "float64 arithmetic, so statistics and normalised values differ from the reference's in the last float32 bits "
+                              "(INTEGRATION.md, rows_dtype)")
+
     def update(self, x):
         x = np.asarray(x)
         self.rows_dtype(x.dtype)
+        self._check_float32_valued(x)
         x = np.ascontiguousarray(x, np.float32)
         if x.ndim == 1:
             x = x[None, :]

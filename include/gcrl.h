@@ -105,7 +105,8 @@ typedef struct gcrl_her_config {
   int32_t goal_dim;    /* G */
   int64_t capacity;    /* max_mem_len (deque maxlen, src/buffer.py:101) */
   int32_t nenvs;       /* per-env staging areas (src/buffer.py:102) */
-  int32_t k_future;    /* relabels per step (src/buffer.py:151) */
+  int32_t k_future;    /* relabels per step (src/buffer.py:151); 1..64 here (gcrl_her_create refuses more: the flush kernel gives a
+                        * 16-lane group per stored row and keeps a step's picks in one wave) — the reference has no such limit */
   int32_t flush_len;   /* 50: literal in src/buffer.py:117 (max_eps_len is ignored there) */
   int32_t reward_kind; /* GCRL_REWARD_*: stands in for the injected compute_reward
                           (src/env.py:105, src/buffer.py:166): sparse = -(||ag-g||2 > thr) */
@@ -436,7 +437,9 @@ int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_
  *                               library's collectives) — handles created afterwards use the launch forms without waits;
  *   gcrl_agent_set_meetings     switches an existing handle (0: off; 1: on where admissible); captured graphs are dropped;
  *                               returns a bit mask of the forms now active (1 slab row groups, 2 row-chain roles: merged phases,
- *                               DDPG's two-role critic phase; 4 the opt-in weight-slice DDPG launch, GCRL_ROWTILE=1);
+ *                               DDPG's two-role critic phase; 4 the opt-in weight-slice DDPG launch, GCRL_ROWTILE=1; 8 the
+ *                               fused dW | db + clip + optimiser launch of the row-chain agents, csrc/dw_adam.hip — the reference's
+ *                               backward -> clip_grad_norm_ -> optimizer.step(), src/agent.py:1326-1333, :1288-1300, :199-222);
  *   gcrl_agent_get_meetings     the same mask, changing nothing;
  *   a wait that times out (~1 s) poisons that launch's statistics / gradients with NaN AND is reported: the next call that
  *   synchronises the handle (gcrl_agent_metrics, _get, _save_state) returns GCRL_ERR_STATE once, after which the handle works

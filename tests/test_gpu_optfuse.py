@@ -9,6 +9,8 @@ What has to hold: the same BITS as the two-launch form — tuples, parameters, t
 K-only, merged and P-only launches, Polyak steps and graph replays; the reference's full-size fixtures; and a slot that never
 arrives is an error at the next synchronising call (src/agent.py:659-699: the reference raises on any failed step), after which
 the handle works again."""
+import os
+
 import numpy as np
 import pytest
 
@@ -156,3 +158,40 @@ def test_fused_optimiser_launch_for_twin_critics_is_bitwise_the_two_launch_form(
     for x, y in zip(ms._state(two), ms._state(one)):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     assert all(np.isfinite(v) for t in t_one for v in t)
+
+
+def test_a_second_process_on_the_device_switches_the_waiting_forms_off(gcrl, monkeypatch, tmp_path):
+    """launch forms whose workgroups wait for each other assume the process has the GPU to itself; that used to
+    be detected under DataParallelUpdater only.  Now every process holds a shared lock on a per-device presence file
+    (csrc/abi_misc.hip meet_probe_device): a second process that creates a handle on the same device gets the forms without waits by
+    itself, and the process that was there first notices at its next probe (get_meetings, every 32nd update call)."""
+    import subprocess
+    import sys
+    import textwrap
+    first = _agent(gcrl, monkeypatch, True, 64, 3, 64)
+    if not first.meetings():
+        pytest.skip("no launch form with an in-kernel wait is admissible on this device")
+    child = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import gcrl_amd
+        from oracle.agent_oracle import make_config
+        cfg = make_config("DDPG", hidden_dim=64, layer_count=3, batch_size=64, max_len=3000)
+        ag = gcrl_amd.DDPG(10, 3, cfg, None, nenvs=1, gradient_step=4, rng="engine", seed=1)
+        print("child meetings", ag.meetings(), flush=True)
+        sys.stdin.readline()
+    """) % (str(__import__("pathlib").Path(__file__).resolve().parents[1]),)
+    env = dict(os.environ)      # (same TMPDIR: the presence file is found there)
+    p = subprocess.Popen([sys.executable, "-c", child], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
+    try:
+        line = p.stdout.readline()
+        assert line.strip() == "child meetings 0", line          # the newcomer saw the presence lock of this process
+        assert first.meetings() == 0                              # ... and this process sees the newcomer's
+        out = [tuple(float(x) for x in t) for t in first.update_many(1, 8)]
+        assert np.all(np.isfinite(np.array(out)))
+    finally:
+        p.stdin.write("\n"); p.stdin.flush()
+        p.wait(timeout=60)
+    gcrl._ffi.lib.gcrl_set_shared_device(0)                       # (process-wide switch: back for the tests that follow)
+    assert first.set_meetings(True) != 0
