@@ -33,6 +33,7 @@
 #include "meet.h"
 #include "ops.h"
 #include "rowchain.h"
+#include "sac_heads.h"
 #include "xchg_ipc.h"
 
 using namespace gcrl;
@@ -153,6 +154,7 @@ struct gcrl_agent {
   float *bn_xchg = nullptr, *bn_bar = nullptr;   // row-group exchange of the slab launches (bn_slab.hip): partials, barrier words
   int bn_rsplit = 1;          // > 1: K >= 128 slab launches split their rows over ceil(B/128) workgroups (GCRL_NO_BN_RSPLIT=1: off)
   int bn_slots = 0;           // sum-of-squares slots of one BatchNorm layer's dgamma | dbeta (16-column slabs)
+  bool heads_fused_off = false;   // GCRL_NO_HEADS_FUSED=1: the BatchNorm actor's heads and its sampling as two launches (rounds 1-4)
   bool red_off = false;       // GCRL_NO_MB_REDUCE=1: single-workgroup td_loss / actor_select_alpha at every batch size
   bool layer_adv_off = false; // GCRL_NO_LAYER_ADV=1: begin_step launches on the layer-per-launch path as in rounds 1-3
   bool bn_fused_tiled = true; // GCRL_NO_BN_TILED_STATS=1 turns it off: the LDS-tiled GEMM's epilogue leaves the 64-row BatchNorm partials (no bn_stats launch)
@@ -455,14 +457,18 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
     TRY(launch_bn_relu_fwd_multi(st, pb, nf, B, H, P + net.bn_g[l], P + net.bn_b[l], a->bn_rmean + (long long)l * H,
                                  a->bn_rvar + (long long)l * H, fused_stats ? kBnFusedRows : 64, a->bn_sync.world > 1 ? &a->bn_sync : nullptr, fused_tiled));
   }
-  {
-    const int ldh = 2 * a->Apad;
-    std::vector<GemmDesc> v;
-    for (int i = 0; i < nf; ++i) {
-      v.push_back(fwd(hbuf(f[i], net.L - 1), H, P, net.lin[net.L], f[i].head, ldh, B, EPI_NONE));                // mean
-      v.push_back(fwd(hbuf(f[i], net.L - 1), H, P, net.lin[net.L + 1], f[i].head + a->Apad, ldh, B, EPI_NONE));  // log_std
-    }
-    if (extra && (size_t)net.L < extra->steps.size()) v.insert(v.end(), extra->steps[net.L].begin(), extra->steps[net.L].end());
+  const int ldh = 2 * a->Apad;
+  std::vector<GemmDesc> v;
+  for (int i = 0; i < nf; ++i) {
+    v.push_back(fwd(hbuf(f[i], net.L - 1), H, P, net.lin[net.L], f[i].head, ldh, B, EPI_NONE));                // mean
+    v.push_back(fwd(hbuf(f[i], net.L - 1), H, P, net.lin[net.L + 1], f[i].head + a->Apad, ldh, B, EPI_NONE));  // log_std
+  }
+  const bool co_scheduled = extra && (size_t)net.L < extra->steps.size() && !extra->steps[net.L].empty();
+  // round 5: the heads and the sampling as ONE launch (sac_heads.h) unless other problems ride in the heads' launch (the layer-per-
+  // launch path's co-scheduled critic chains) or the head problems are not on the k-split 16x16 form (GCRL_NO_HEADS_FUSED=1: A/B knob)
+  const bool heads_fused = !a->heads_fused_off && !co_scheduled && gemm_shape_of(v[0]) == 1;
+  if (!heads_fused) {
+    if (co_scheduled) v.insert(v.end(), extra->steps[net.L].begin(), extra->steps[net.L].end());
     for (size_t o = 0; o < v.size(); o += kMaxProb) TRY(launch_gemm_batch(st, v.data() + o, (int)std::min<size_t>(kMaxProb, v.size() - o)));
   }
   TanhGaussArgs tg[2];
@@ -480,6 +486,13 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
   }
   if (slab)   // the running statistics of every layer, from the batch statistics the slab launches left: input 0's, then input 1's
     tg[0].run = BnRunning{{a->bn_bstat, nf == 2 ? a->bn_bstat + (long long)net.L * 2 * H : nullptr}, nf, a->bn_rmean, a->bn_rvar, net.L, H, B};
+  if (heads_fused) {
+    HeadsSampleArgs hs;
+    std::memset(&hs, 0, sizeof(hs));
+    hs.n = nf;
+    for (int i = 0; i < nf; ++i) { hs.mean[i] = v[2 * i]; hs.lstd[i] = v[2 * i + 1]; hs.tg[i] = tg[i]; }
+    return launch_heads_sample(st, hs);
+  }
   if (nf == 2) TRY(launch_tanh_gauss_fwd2(st, tg[0], tg[1]));
   else TRY(launch_tanh_gauss_fwd(st, tg[0]));
   return GCRL_OK;
@@ -1392,6 +1405,7 @@ int build(gcrl_agent* a) {
     a->bn_fused_tiled = std::getenv("GCRL_NO_BN_TILED_STATS") == nullptr;
     a->layer_adv_off = std::getenv("GCRL_NO_LAYER_ADV") != nullptr;
     a->red_off = std::getenv("GCRL_NO_MB_REDUCE") != nullptr;
+    a->heads_fused_off = std::getenv("GCRL_NO_HEADS_FUSED") != nullptr;
     a->bn_fused = std::getenv("GCRL_BN_FUSED") != nullptr;   // measured equal at cfg 5 (204.6 vs 203.6 us/step): off by default
     if (const char* e = std::getenv("GCRL_SPLIT_RG"))   // experiment knob: four digits, rows/4 per workgroup of the four launches
       for (int i = 0; i < 4 && e[i]; ++i) a->split_rg[i] = e[i] - '0';

@@ -487,5 +487,8 @@ int gemm_shape_of(const GemmDesc& d);
 
 // Launch `n` problems in one grid.  shape: 0 = auto.
 int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape = 0);
+// What launch_gemm_batch fills in for a problem of the k-split 16x16 form (vector-load flags, tile bookkeeping with tile0 = 0), for
+// kernels that call gemm_batch_tile<1, 1, 4> themselves (dw_adam.hip, ops_sac.hip heads_sample_kernel).  Returns the tile count.
+int gemm_prepare_ksplit(GemmDesc& d);
 
 }  // namespace gcrl

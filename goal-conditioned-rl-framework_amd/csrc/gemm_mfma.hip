@@ -162,6 +162,17 @@ int launch_tiled(hipStream_t st, GemmBatch& gb) {
 
 int gemm_shape_of(const GemmDesc& d) { return shape_of(d); }
 
+int gemm_prepare_ksplit(GemmDesc& d) {
+  d.a_vec = (d.a_cs == 1 && d.a_rs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
+  d.b_vec = (d.b_rs == 1 && d.b_cs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
+  d.a_rvec = (d.a_rs == 1 && d.a_cs % 4 == 0 && ((uintptr_t)d.A & 15) == 0);
+  d.b_rvec = (d.b_cs == 1 && d.b_rs % 4 == 0 && ((uintptr_t)d.B & 15) == 0);
+  d.tiles_n = (d.N + 15) / 16;
+  d.ntiles = ((d.M + 15) / 16) * d.tiles_n;
+  d.tile0 = 0;
+  return d.ntiles;
+}
+
 int launch_gemm_batch(hipStream_t st, GemmDesc* descs, int n, int shape) {
   GCRL_CHECK_ARG(n >= 1 && n <= kMaxProb, "launch_gemm_batch: %d problems (max %d)", n, kMaxProb);
   int shapes[kMaxProb];

@@ -312,6 +312,7 @@ struct TanhGaussArgs {
   BnRunning run;           // layers > 0: one extra workgroup of the launch updates the running statistics
 };
 int launch_tanh_gauss_fwd(hipStream_t st, const TanhGaussArgs& a);
+// (the two heads' GEMMs AND the sampling of one or two inputs as one launch: sac_heads.h)
 int launch_tanh_gauss_fwd2(hipStream_t st, const TanhGaussArgs& a0, const TanhGaussArgs& a1);   // two heads, one launch
 
 // actor loss of SAC/TQC: L = mean(alpha*logp - sel(q_c)) with sel = min (C=2) or mean of the

@@ -7,6 +7,7 @@
 #include "ops.h"
 #include "meet.h"
 #include "gemm_mfma.h"   // v4f
+#include "sac_heads.h"
 
 #include <algorithm>
 #include <cmath>
@@ -365,6 +366,27 @@ __device__ inline void tanh_gauss_fwd_body(const TanhGaussArgs& a) {
   if (b >= a.B) return;
   tanh_gauss_fwd_row(a, b);
 }
+// one (row, action) element of SACActorModel.sample: action t, std sd, the log-prob term, the eps used
+struct TgElem { float t, sd, term, e; };
+__device__ inline TgElem tanh_gauss_elem(const TanhGaussArgs& a, const StepCtrl& c, float mu, float ls_raw, long long i) {
+  const float ls = fminf(fmaxf(ls_raw, -20.0f), 2.0f);
+  // exp / tanh / log go through fp64 and round once: log(1 - tanh^2 + 1e-8) amplifies a 1-ulp
+  // tanh difference by 2|t|/(1-t^2), so the closer to correctly rounded, the closer to torch
+  const float sd = (float)exp((double)ls);
+  const float e = a.eps ? a.eps[i]
+                        : hash_normal(a.seed + (unsigned long long)a.rng_stream,
+                                      (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
+  const float x = __fadd_rn(mu, __fmul_rn(e, sd));  // rsample: loc + eps*scale
+  const float t = (float)tanh((double)x);
+  // Normal(mu, sd).log_prob(x) - log(1 - tanh(x)^2 + 1e-8), every op rounded to fp32 as torch does
+  const float df = __fsub_rn(x, mu);
+  const float var = __fmul_rn(sd, sd);
+  float term = __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(df, df), __fmul_rn(2.0f, var)), (float)log((double)sd)),
+                         0.91893853320467274f);
+  const float om = __fadd_rn(__fsub_rn(1.0f, __fmul_rn(t, t)), 1e-8f);
+  term = __fsub_rn(term, (float)log((double)om));
+  return {t, sd, term, e};
+}
 __device__ inline void tanh_gauss_fwd_row(const TanhGaussArgs& a, int b) {
   const StepCtrl c = *a.cur;
   float* act = a.act + (long long)c.batch_slot * a.act_slot_stride + (long long)b * a.ld_act;
@@ -372,26 +394,11 @@ __device__ inline void tanh_gauss_fwd_row(const TanhGaussArgs& a, int b) {
   for (int j = 0; j < a.A; ++j) {
     const float mu = a.mu[(long long)b * a.ld_head + j];
     if (a.deterministic) { act[j] = (float)tanh((double)mu); continue; }
-    const float ls = fminf(fmaxf(a.ls_raw[(long long)b * a.ld_head + j], -20.0f), 2.0f);
-    // exp / tanh / log go through fp64 and round once: log(1 - tanh^2 + 1e-8) amplifies a 1-ulp
-    // tanh difference by 2|t|/(1-t^2), so the closer to correctly rounded, the closer to torch
-    const float sd = (float)exp((double)ls);
     const long long i = (long long)b * a.A + j;
-    const float e = a.eps ? a.eps[i]
-                          : hash_normal(a.seed + (unsigned long long)a.rng_stream,
-                                        (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
-    const float x = __fadd_rn(mu, __fmul_rn(e, sd));  // rsample: loc + eps*scale
-    const float t = (float)tanh((double)x);
-    act[j] = t;
-    // Normal(mu, sd).log_prob(x) - log(1 - tanh(x)^2 + 1e-8), every op rounded to fp32 as torch does
-    const float df = __fsub_rn(x, mu);
-    const float var = __fmul_rn(sd, sd);
-    float term = __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(df, df), __fmul_rn(2.0f, var)), (float)log((double)sd)),
-                           0.91893853320467274f);
-    const float om = __fadd_rn(__fsub_rn(1.0f, __fmul_rn(t, t)), 1e-8f);
-    term = __fsub_rn(term, (float)log((double)om));
-    lp = __fadd_rn(lp, term);
-    if (a.save_eps) { a.save_eps[i] = e; a.save_std[i] = sd; }
+    const TgElem r = tanh_gauss_elem(a, c, mu, a.ls_raw[(long long)b * a.ld_head + j], i);
+    act[j] = r.t;
+    lp = __fadd_rn(lp, r.term);
+    if (a.save_eps) { a.save_eps[i] = r.e; a.save_std[i] = r.sd; }
   }
   if (!a.deterministic && a.logp) a.logp[b] = lp;
 }
@@ -418,6 +425,48 @@ __global__ void tanh_gauss_fwd2_kernel(TanhGaussArgs a0, TanhGaussArgs a1) {
   if (a0.run.layers && blockIdx.x == gridDim.x - 1) { if (blockIdx.y == 0) bn_running_update(a0.run); return; }
   if (blockIdx.y == 0) tanh_gauss_fwd_body(a0);
   else tanh_gauss_fwd_body(a1);
+}
+
+// The two heads and the sampling of one or two inputs as one launch (sac_heads.h): workgroup (x, y) owns rows [16 x, 16 x + 16) of
+// input y.  (The last workgroup of row y = 0 is the running-statistics rider when tg[0].run.layers.)
+__global__ __launch_bounds__(256) void heads_sample_kernel(HeadsSampleArgs h) {
+  __shared__ float s_mu[16][17], s_ls[16][17], s_term[16][17];
+  const int y = (int)blockIdx.y;
+  const TanhGaussArgs& a = h.tg[y];
+  if (h.tg[0].run.layers && blockIdx.x == gridDim.x - 1) { if (y == 0) bn_running_update(h.tg[0].run); return; }
+  const int t = (int)blockIdx.x;
+  if (t * 16 >= a.B) return;   // (uniform per workgroup)
+  gemm_pin(h.mean[y]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  float x_m, x_l, ss;
+  gemm_batch_tile<1, 1, 4>(h.mean[y], t, x_m, ss);
+  __syncthreads();   // (the tile body's partial-sum exchange buffer is about to be written again)
+  gemm_batch_tile<1, 1, 4>(h.lstd[y], t, x_l, ss);
+  s_mu[4 * lg + wave][li] = x_m;
+  s_ls[4 * lg + wave][li] = x_l;
+  __syncthreads();
+  const StepCtrl c = *a.cur;
+  const int A = a.A;
+  if ((int)threadIdx.x < 16 * A) {
+    const int r = (int)threadIdx.x / A, j = (int)threadIdx.x - r * A;
+    const int b = t * 16 + r;
+    if (b < a.B) {
+      const long long i = (long long)b * A + j;
+      const TgElem e = tanh_gauss_elem(a, c, s_mu[r][j], s_ls[r][j], i);
+      a.act[(long long)c.batch_slot * a.act_slot_stride + (long long)b * a.ld_act + j] = e.t;
+      s_term[r][j] = e.term;
+      if (a.save_eps) { a.save_eps[i] = e.e; a.save_std[i] = e.sd; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && a.logp) {
+    const int b = t * 16 + (int)threadIdx.x;
+    if (b < a.B) {
+      float lp = 0.f;
+      for (int j = 0; j < A; ++j) lp = __fadd_rn(lp, s_term[threadIdx.x][j]);   // in action order, as the row loop adds
+      a.logp[b] = lp;
+    }
+  }
 }
 
 // (round 4: every operand of a thread's (up to) two rows is requested before any store — the compiler must assume dq aliases
@@ -843,6 +892,24 @@ int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const 
   const int slabs = bn_slabs(B);
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots * slabs - 1) / (kBnSlots * slabs)), dim3(256), 0, st, dh,
                      dh2, xhat, invstd, gamma, beta, part_dy, part_dyx, B, H, dz, dgamma, dbeta, sumsq_out, slabs, world, rank);
+  GCRL_HIP(hipGetLastError());
+  return GCRL_OK;
+}
+
+int launch_heads_sample(hipStream_t st, HeadsSampleArgs& h) {
+  GCRL_CHECK_ARG(h.n == 1 || h.n == 2, "heads_sample: %d inputs", h.n);
+  int blocks = 0;
+  for (int i = 0; i < h.n; ++i) {
+    const TanhGaussArgs& a = h.tg[i];
+    GCRL_CHECK_ARG(!a.deterministic && a.A >= 1 && a.A <= 16 && h.mean[i].M == a.B && h.lstd[i].M == a.B && h.mean[i].N == a.A && h.lstd[i].N == a.A &&
+                       a.mu == h.mean[i].C && a.ls_raw == h.lstd[i].C && (long long)a.ld_head == h.mean[i].c_rs && (long long)a.ld_head == h.lstd[i].c_rs &&
+                       !h.mean[i].slot == !h.mean[i].a_slot && h.mean[i].c_slot == 0 && h.lstd[i].c_slot == 0,
+                   "heads_sample: input %d: the sampling must read what the two head problems write", i);
+    GCRL_CHECK_ARG(gemm_shape_of(h.mean[i]) == 1 && gemm_shape_of(h.lstd[i]) == 1, "heads_sample: input %d: not the k-split 16x16 form", i);
+    blocks = std::max(blocks, gemm_prepare_ksplit(h.mean[i]));
+    (void)gemm_prepare_ksplit(h.lstd[i]);
+  }
+  hipLaunchKernelGGL(heads_sample_kernel, dim3((unsigned)blocks + (h.tg[0].run.layers ? 1 : 0), (unsigned)h.n), dim3(256), 0, st, h);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }

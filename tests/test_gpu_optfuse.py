@@ -195,3 +195,35 @@ def test_a_second_process_on_the_device_switches_the_waiting_forms_off(gcrl, mon
         p.wait(timeout=60)
     gcrl._ffi.lib.gcrl_set_shared_device(0)                       # (process-wide switch: back for the tests that follow)
     assert first.set_meetings(True) != 0
+
+
+@pytest.mark.parametrize("kind,H,L,B", [("SAC", 256, 3, 512), ("SAC", 64, 3, 130), ("TQC", 32, 2, 40)])
+def test_heads_and_sampling_as_one_launch_are_bitwise_the_two_launches(gcrl, monkeypatch, kind, H, L, B):
+    """SACActorModel's mean / log_std heads (src/model.py:114-115) and sample() (:125-141) as one launch (csrc/sac_heads.h: the
+    heads' tiles by the batched GEMM's own tile body, one thread per (row, action) for the sampling arithmetic, the log-prob summed
+    in action order) against the GEMM launch + sampling launch of rounds 1-4 (GCRL_NO_HEADS_FUSED=1): 24 steps with device noise,
+    every tuple, parameter, BatchNorm statistic and alpha bitwise."""
+    import test_gpu_multistep as ms
+    cfg = ms._cfg(kind, H, L, B, max_len=20000 if B > 200 else 4000)
+
+    def build():
+        ag = ms._cls(gcrl, kind)(ms.S, ms.A, cfg, None, nenvs=2, gradient_step=5, rng="engine", seed=21)
+        gen = np.random.default_rng(3)
+        ep = 0
+        while len(ag.buffer) < B + 300:
+            for st in ms.her_oracle.synthetic_episode(gen, 50, ms.S, ms.A):
+                ag.push_her(ep % 2, *st)
+            ep += 1
+        return ag
+
+    monkeypatch.setenv("GCRL_NO_HEADS_FUSED", "1")
+    two = build()
+    monkeypatch.delenv("GCRL_NO_HEADS_FUSED")
+    one = build()
+    t_two = [tuple(float(x) for x in t) for t in two.update_many(1, 24)]
+    t_one = [tuple(float(x) for x in t) for t in one.update_many(1, 24)]
+    for step, (x, y) in enumerate(zip(t_two, t_one), start=1):
+        assert x == y, (kind, step, x, y)
+    for x, y in zip(ms._state(two), ms._state(one)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert all(np.isfinite(v) for t in t_one for v in t)
