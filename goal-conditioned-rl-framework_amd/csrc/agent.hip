@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <random>
 #include <string>
 #include <vector>
@@ -1094,10 +1095,12 @@ int finish_deferred_draw(gcrl_agent* a, hipStream_t st) {
                            a->rbuf + first * a->slot_rd, a->dbuf + first * a->slot_rd, st);
 }
 
+int order_after_other_handles(gcrl_agent* a, hipStream_t st);
 int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_update_inputs* in, float grad_scale,
                hipStream_t st, std::vector<StepPlan>& plans, int64_t* tickets, int32_t* lens, bool defer_rest = false,
                bool pre_advanced = false) {
   TRY(finish_deferred_draw(a, st));   // (never pending here; cheap safety)
+  TRY(order_after_other_handles(a, st));
   GCRL_CHECK_ARG(n >= 1 && n <= kMaxStepsPerCall && n <= a->Mmax, "update: n=%d steps per call (max %d)", n, std::min(kMaxStepsPerCall, a->Mmax));
   const bool injected = in && in->s_dev;
   GCRL_CHECK_ARG(injected || her, "update: neither a replay ring nor an injected batch was given");
@@ -1164,11 +1167,30 @@ int begin_call(gcrl_agent* a, gcrl_her* her, int64_t step0, int n, const gcrl_up
   return GCRL_OK;
 }
 
+// Launch forms whose workgroups wait for each other need every workgroup of the launch resident at once — also against the OTHER
+// handles of this process: two agents' update calls queued on their own streams could otherwise run such launches side by side
+// (the admission was a promise by the caller).  Per device, the handle that queued update work last and the event that
+// closes it; another handle's next call waits for that event on the device (no host wait; nothing happens while one handle is used).
+struct WaitOwner { gcrl_agent* a = nullptr; hipEvent_t ev = nullptr; };
+std::mutex g_wait_mu;
+WaitOwner g_wait_owner[16];
+
+int order_after_other_handles(gcrl_agent* a, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_wait_mu);
+  WaitOwner& w = g_wait_owner[a->cfg.device & 15];
+  if (w.a && w.a != a && w.ev) GCRL_HIP(hipStreamWaitEvent(st, w.ev, 0));
+  return GCRL_OK;
+}
+
 int end_call(gcrl_agent* a, hipStream_t st) {
   const int e = (int)(a->calls % kEventRing);
   GCRL_HIP(hipEventRecord(a->call_ev[e], st));
   a->call_last_ticket[e] = a->next_ticket - 1;
   a->calls++;
+  {
+    std::lock_guard<std::mutex> lk(g_wait_mu);
+    g_wait_owner[a->cfg.device & 15] = WaitOwner{a, a->call_ev[e]};
+  }
   return GCRL_OK;
 }
 
@@ -1586,6 +1608,10 @@ gcrl_agent* gcrl_agent_create(const gcrl_agent_config* cfg) {
 
 void gcrl_agent_destroy(gcrl_agent* a) {
   if (!a) return;
+  {
+    std::lock_guard<std::mutex> lk(g_wait_mu);
+    for (WaitOwner& w : g_wait_owner) if (w.a == a) w = WaitOwner{};
+  }
   if (a->stream) (void)hipStreamSynchronize(a->stream);
   (void)hipDeviceSynchronize();
   for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);

@@ -227,3 +227,25 @@ def test_heads_and_sampling_as_one_launch_are_bitwise_the_two_launches(gcrl, mon
     for x, y in zip(ms._state(two), ms._state(one)):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     assert all(np.isfinite(v) for t in t_one for v in t)
+
+
+def test_two_agents_queued_back_to_back_do_not_wait_on_each_other(gcrl, monkeypatch):
+    """Two handles of one process, their update calls queued WITHOUT a synchronisation in between (each agent has its own stream):
+    launches whose workgroups wait for each other must not end up side by side on the device.  The library orders a handle's call
+    after the other handle's last one (an event wait on the device, csrc/agent.hip order_after_other_handles): 12 interleaved
+    40-step calls finish without a timed-out wait and give the trajectories the agents produce when run one after the other."""
+    a1, a2 = _agent(gcrl, monkeypatch, True, 256, 3, 256, S=23, A=4), _agent(gcrl, monkeypatch, True, 256, 3, 256, S=23, A=4)
+    b1, b2 = _agent(gcrl, monkeypatch, True, 256, 3, 256, S=23, A=4), _agent(gcrl, monkeypatch, True, 256, 3, 256, S=23, A=4)
+    pend = []
+    for c in range(6):                       # interleaved, nothing fetched until the end
+        pend.append((0, a1.update_many(1 + 40 * c, 40)))
+        pend.append((1, a2.update_many(1 + 40 * c, 40)))
+    got = [[], []]
+    for who, tickets in pend:
+        got[who] += [tuple(float(x) for x in t) for t in tickets]
+    ref = [[], []]
+    for who, ag in ((0, b1), (1, b2)):       # one after the other, fetched call by call
+        for c in range(6):
+            ref[who] += [tuple(float(x) for x in t) for t in ag.update_many(1 + 40 * c, 40)]
+    assert got == ref
+    assert np.all(np.isfinite(np.array(got)))
