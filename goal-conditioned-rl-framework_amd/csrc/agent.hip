@@ -161,7 +161,6 @@ struct gcrl_agent {
   bool bn_fused_tiled = true; // GCRL_NO_BN_TILED_STATS=1 turns it off: the LDS-tiled GEMM's epilogue leaves the 64-row BatchNorm partials (no bn_stats launch)
   bool bn_fused = false;      // GCRL_BN_FUSED=1: BatchNorm statistics out of the producing GEMM's epilogue instead of bn_stats launches
   bool split_k = false;       // TD3: critic phase as role-parallel launches (agent_rowchain.inc)
-  int split_k_rg = 1;         // ... rows / 4 per workgroup of those launches: row_rg, or 8 (32 rows on the 32x32x2 MFMA, round 5; GCRL_NO_TD3_RG8=1: off)
   bool split_roles = false;   // twin-critic phases as role-parallel launches (rowchain.h launch_rowchain_split)
   int n_cus = 0;              // compute units of the device (residency checks of the launches whose workgroups meet)
   bool rc_merge = false;      // ... forward and backward part in ONE launch each (part 3; GCRL_NO_RC_MERGE=1: two launches)
@@ -1369,13 +1368,6 @@ int build(gcrl_agent* a) {
     // TD3 once the batch fills the chip (cfg 3: 183.5 -> 178.4 us/step; below that the fused launch is the shorter chain)
     a->split_k = a->rowchain && c.kind == GCRL_AGENT_TD3 && C == 2 && (B + 4 * a->row_rg - 1) / (4 * a->row_rg) >= 256 &&
                  !std::getenv("GCRL_NO_SPLIT_TD3");
-    // 32 rows per workgroup (v_mfma_f32_32x32x2_f32, weights as 16-byte loads along k: rowchain.h rows_linear32) once the 2C roles x
-    // ceil(B / 32) row blocks give every CU a workgroup: TD3 cfg 3 (B = 2048: 256 workgroups) — at 8 rows per workgroup the phase ran
-    // at 53 TFLOP/s on the 4x4x1 instruction, every workgroup streaming every weight matrix for itself
-    a->split_k_rg = a->row_rg;
-    if (a->split_k && H % 64 == 0 && 2 * C * ((B + 31) / 32) >= std::max(a->n_cus, 1) && !std::getenv("GCRL_NO_TD3_RG8") &&
-        rowchain_lds_bytes(8, a->row_ldl, A, H, C) <= 160 * 1024)
-      a->split_k_rg = 8;
     // ... and its two launches (forward | backward) as ONE: the online-critic workgroups go on to their backward chains once the
     // target roles of their rows have reported in (producers / consumers: no residency requirement, meet.h)
     a->rc_merge_k = a->split_k && !meet_device_shared() && !std::getenv("GCRL_NO_RC_MERGE");

@@ -89,111 +89,6 @@ __device__ inline void rows_matmul_wave(const float* xs, int ldx, __amdgpu_buffe
   }
 }
 
-// ---- 32 rows per workgroup (RG = 8; round 5) on v_mfma_f32_32x32x2_f32: the throughput form of a pass for batches that fill the
-// chip with 32-row blocks (TD3's critic phase at B = 2048: 4 roles x 64 row blocks = 256 workgroups).  At 8 rows per workgroup the
-// phase ran at 53 TFLOP/s — bound by the 4x4x1 instruction's issue rate and by every 8-row workgroup streaming every 256 KB
-// weight matrix for itself (1.44 GB through the L1s per launch).  Here a wave owns 64 output columns (two 32 x 32 accumulators)
-// over the WHOLE contraction — no partial sums to exchange, one barrier per pass.  The instruction wants a COLUMN of M per lane
-// (lane (r32 = lane & 31, hk = lane >> 5): M[k0 + 4 hk + q][c], q = 0..3), memory holds ROWS: measured first with M stored
-// k-contiguous and one 16-byte load per lane (every load instruction touches 32 cache lines: 112 us for the phase against 74), then
-// with four dword loads per lane and 8 k (256 load instructions per wave and pass, far more in flight than a CU keeps: 138 us).
-// So the wave fetches its 64 columns of a 32-k slab the way the other forms stream M — 16 bytes per lane ALONG a row, 4 k-rows x
-// 256 bytes per instruction, 8 loads in flight per wave — transposes it into a private LDS image (rows of 33 floats: the
-// dword writes and the fragment reads both spread over the banks) while the previous slab's MFMAs run, and reads the fragments back.
-// k-permutation and transposed accumulators as in gemm_tiled.h: the lane holds out[row r32][cols 8g + 4hk .. + 3] in acc[4g .. 4g + 3].
-//   J: contraction length (rows of M; x columns beyond the real input width are zero-padded up to J)
-//   wst: LDS, kRows32Stage floats per wave (wave-private)
-constexpr int kRows32Ld = 33, kRows32Stage = 64 * kRows32Ld;
-__device__ inline void rows_linear32(const float* xs, int ldx, int J, const float* M, int ldm, int N, const float* bias, int epi,
-                                     float* ys, int ldy, float* save, long long ld_save, int rows_valid, const float* mulH,
-                                     long long ld_mul, int mul, float* wst) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r32 = lane & 31, hk = lane >> 5;
-  constexpr int kPast = 0x7ffffff0;
-  const __amdgpu_buffer_rsrc_t rs = bounded_rsrc(M, (long long)J * ldm);   // (rows >= J: beyond the extent, zeros)
-  float* sw = wst + wave * kRows32Stage;   // [64 columns][33]: column c of the wave's 64, k of the slab
-  const float* xr = xs + r32 * ldx + 4 * hk;
-  const int kq = lane >> 4, cq = lane & 15;   // staging: this lane fetches k-rows 4 i + kq (i = 0..7) of a slab, columns 4 cq .. 4 cq + 3
-  const int ns = (J + 31) >> 5;
-  for (int c0 = 0; c0 < N; c0 += kRowChunk) {
-    const int cb = c0 + 64 * wave;   // this wave's columns [cb, cb + 64): two tiles
-    if (cb < N) {                    // (wave-uniform)
-      v16f acc[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-      const int fo = cb + 4 * cq < N ? (kq * ldm + cb + 4 * cq) * 4 : kPast;   // byte offset of this lane's first fetch of slab 0
-      const int rstep = 4 * ldm * 4;                                              // ... + i * rstep + slab * 8 * rstep
-      v4u st[8];
-      auto fetch = [&](int slab) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, fo + i * rstep, slab * 8 * rstep, 0);
-      };
-      fetch(0);
-      for (int sl = 0; sl < ns; ++sl) {
-        // the slab's image (the previous slab's fragment reads were issued before: LDS operations of a wave execute in order)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) sw[(4 * cq + j) * kRows32Ld + 4 * i + kq] = __uint_as_float(st[i][j]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        fetch(sl + 1);   // (past J: beyond the extent, zeros, no traffic) — in flight during this slab's MFMAs
-        __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler sank these loads BEHIND the slab's MFMAs — their registers were free for fragments until then — and the next slab began by waiting a full round trip for them)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int k0 = 32 * sl + 8 * g;
-          v4f a = *(const v4f*)(xr + k0);
-          float w[2][4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            a[q] = (k0 + 4 * hk + q < J) ? a[q] : 0.f;   // (stale LDS beyond the padded width of a first layer)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) w[t][q] = sw[(32 * t + r32) * kRows32Ld + 8 * g + 4 * hk + q];
-          }
-#ifdef GCRL_RG8_NO_MFMA
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc[t][q] += w[t][q] * a[q];
-#else
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][q], a[q], acc[t], 0, 0, 0);
-#endif
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cq4 = cb + 32 * t + 8 * g + 4 * hk;
-          if (cq4 < N) {   // (N % 4 == 0: whole quads)
-            v4f v = (v4f){acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-            if (bias) v += *(const v4f*)(bias + cq4);
-            v4f hm = (v4f){0.f, 0.f, 0.f, 0.f};
-            if (mul != MUL_NONE && r32 < rows_valid) hm = *(const v4f*)(mulH + (long long)r32 * ld_mul + cq4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              v[q] = act_apply(v[q], epi);
-              if (mul != MUL_NONE) v[q] *= act_deriv(hm[q], mul);
-            }
-            *(v4f*)(ys + r32 * ldy + cq4) = v;
-            if (save && r32 < rows_valid) *(v4f*)(save + (long long)r32 * ld_save + cq4) = v;
-          }
-        }
-    }
-  }
-  __syncthreads();   // the next pass (or the caller) reads ys across waves
-}
-
 // y = act(x . M + bias) [* act'(hprev)] for the block's rows; all kRowThreads threads call it.
 //   part   LDS scratch 2 x [4 waves][4*RG][kRowChunk] (two buffers, `pbuf` picks one)
 //   ys     LDS output [4*RG][ldy]   (must not alias xs)
@@ -209,10 +104,6 @@ __device__ inline void rows_linear(const float* xs, int ldx, int J, const float*
                                    int epi, float* part, float* ys, int ldy, float* save, long long ld_save,
                                    int rows_valid, const float* mulH = nullptr, long long ld_mul = 0, int mul = MUL_NONE,
                                    bool chained = false, int pbuf = 0) {
-  if constexpr (RG == 8) {   // (`part`: the waves' staging images, 4 * kRows32Stage floats)
-    rows_linear32(xs, ldx, J, M, ldm, N, bias, epi, ys, ldy, save, ld_save, rows_valid, mulH, ld_mul, mul, part);
-    return;
-  }
   constexpr int R = 4 * RG;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -461,7 +352,7 @@ long long rowtile_xb_floats(int B, int H, int L);
 long long rowtile_part_floats(int B, int H);
 int launch_rowtile_ddpg(hipStream_t st, RowTileArgs t);
 
-// rows per workgroup = 4*rg, rg in {1, 2, 4} (split launches: also 8 — 32 rows on the 32x32x2 MFMA)
+// rows per workgroup = 4*rg, rg in {1, 2, 4}
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg);
 size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C);
 

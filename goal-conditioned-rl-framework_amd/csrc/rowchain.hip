@@ -445,10 +445,9 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
   float* X0 = lds;
   float* X1 = X0 + R * ldl;
   float* X2 = X1 + R * ldl;
-  // (a workgroup is ONE role: the target roles use X0, the critic roles XS — at 32 rows per workgroup they share the space)
-  float* XS = RG == 8 ? X0 : X2 + R * ldl;
-  float* part_ = XS + (RG == 8 ? 3 : 1) * R * ldl;
-  float* sm = part_ + R * 16 + (RG == 8 ? 4 * kRows32Stage : (RG == 1 ? 2 : 1) * 4 * R * kRowChunk);   // (32 rows: the waves' weight images instead of partial sums)
+  float* XS = X2 + R * ldl;
+  float* part_ = XS + R * ldl;
+  float* sm = part_ + R * 16 + (RG == 1 ? 2 : 1) * 4 * R * kRowChunk;
   float* sm2 = sm + R * 16;
   float* sm3 = sm2 + R * 16;
   float* hw = sm3 + R * 16;
@@ -760,14 +759,14 @@ __global__ void wt_rebuild_kernel(RowNet net, float* Wt) {
 
 size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C) {
   const int R = 4 * rg;
-  return (size_t)((rg == 8 ? 3 : 4) * R * ldl + (rg == 8 ? 4 * kRows32Stage : (rg == 1 ? 2 : 1) * 4 * R * kRowChunk) + 4 * R * 16 + std::max(std::max(2 * A + 1, A + 2 * C), C * (A + 1)) * H + 32) * sizeof(float);
+  return (size_t)(4 * R * ldl + (rg == 1 ? 2 : 1) * 4 * R * kRowChunk + 4 * R * 16 + std::max(std::max(2 * A + 1, A + 2 * C), C * (A + 1)) * H + 32) * sizeof(float);
 }
 
 // the merged (part 3) launches wait inside the kernel: all 2C x nblk workgroups of the larger one must be resident at once
 bool rowchain_merge_ok(int rg, int ldl, int A, int H, int C, int B) {
   const size_t lds = rowchain_lds_bytes(rg, ldl, A, H, C);
   if (lds > 160 * 1024) return false;
-  const void* k = rg == 1 ? (const void*)rowchain_split_kernel<1> : (rg == 2 ? (const void*)rowchain_split_kernel<2> : (rg == 4 ? (const void*)rowchain_split_kernel<4> : (const void*)rowchain_split_kernel<8>));
+  const void* k = rg == 1 ? (const void*)rowchain_split_kernel<1> : (rg == 2 ? (const void*)rowchain_split_kernel<2> : (const void*)rowchain_split_kernel<4>);
   if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
   const long long nblk = (B + 4 * rg - 1) / (4 * rg);
   return 2LL * C * nblk <= meet_capacity(k, kRowThreads, lds);
@@ -798,7 +797,7 @@ int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
 }
 
 int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part) {
-  GCRL_CHECK_ARG(rg == 1 || rg == 2 || rg == 4 || rg == 8, "rowchain: rows per block must be 4, 8, 16 or 32");
+  GCRL_CHECK_ARG(rg == 1 || rg == 2 || rg == 4, "rowchain: rows per block must be 4, 8 or 16");
   GCRL_CHECK_ARG(a.critic[0].H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16 && a.C >= 1 && a.C <= 2 && (phase == 0 || phase == 1) &&
                      (part >= 1 && part <= 3) && (part != 3 || a.bar) && (phase == 0 || a.p_critic_only) && a.qt,
                  "rowchain split: unsupported shape (H=%d, A=%d, C=%d, phase %d part %d)", a.critic[0].H, a.A, a.C, phase, part);
@@ -822,8 +821,7 @@ int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int pha
   };
   if (rg == 1) return go(rowchain_split_kernel<1>);
   if (rg == 2) return go(rowchain_split_kernel<2>);
-  if (rg == 4) return go(rowchain_split_kernel<4>);
-  return go(rowchain_split_kernel<8>);
+  return go(rowchain_split_kernel<4>);
 }
 
 int launch_rowchain_act(hipStream_t st, const RowActArgs& a) {
