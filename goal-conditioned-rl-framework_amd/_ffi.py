@@ -160,6 +160,8 @@ PROTOTYPES = {
     "gcrl_bn_linear_slab_bwd_f32": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "gcrl_her_set_reward_callback": (C.c_int, [_vp, _vp, _vp]),
     "gcrl_agent_dp_sync_bn": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "gcrl_agent_bn_xchg_create": (_vp, [_vp, C.c_int, C.c_int]),
+    "gcrl_agent_dp_sync_bn_xchg": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "gcrl_xchg_create": (_vp, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gcrl_xchg_destroy": (None, [_vp]),
     "gcrl_xchg_handles": (C.c_int, [_vp, _vp, _i64]),

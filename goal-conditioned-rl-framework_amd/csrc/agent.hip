@@ -140,6 +140,7 @@ struct gcrl_agent {
   void* bn_sync_user = nullptr;
   float* bn_sync_buf = nullptr;
   long long bn_sync_cap = 0;   // floats allocated
+  gcrl_xchg* bn_xchg_h = nullptr;   // SyncBN partials through the in-engine peer-to-peer exchange (round 5; not owned): graphs stay on
   // dW problems at batch >= 1024 on the LDS-tiled form with the reduction split over dw_split_[c|a] workgroups per tile
   // (gemm_tiled.h; 1: off): partial tiles and tickets per net and layer
   int dw_split_c = 1, dw_split_a = 1;
@@ -550,7 +551,7 @@ int sac_actor_forwards(gcrl_agent* a, hipStream_t st, int variant, bool with_cur
 // (SAC keeps ~35 BatchNorm / head launches per step around its two row-block launches: graphs stay on)
 // (SyncBN: the statistics exchanges sit between a step's launches — plain launches only)
 bool graph_on(const gcrl_agent* a) {
-  if (a->bn_sync.world > 1) return false;
+  if (a->bn_sync.world > 1 && !a->bn_xchg_h) return false;   // (an exchange that is a kernel of the sequence replays like any other)
   return a->cfg.use_graph >= 2 || (a->cfg.use_graph == 1 && (!a->rowchain || a->sac));
 }
 
@@ -1953,31 +1954,69 @@ int gcrl_agent_dp_run_all(gcrl_agent* a, gcrl_dp* d, void* stream) {
   }
 }
 
-// BnSync exchange: the library-owned communicator when one was given, else the caller's function
+// BnSync exchange: the in-engine peer-to-peer exchange over the partials' own arena (segments: problem 0's array, problem 1's),
+// the library-owned communicator when one was given, else the caller's function
+static const float* bn_sync_result(const float* dev, void* user) {
+  gcrl_agent* a = (gcrl_agent*)user;
+  return a->bn_xchg_h ? gcrl_xchg_result(a->bn_xchg_h) + (dev - a->bn_sync_buf) : dev;
+}
 static int bn_sync_exchange(float* dev, long long n, hipStream_t st, void* user) {
   gcrl_agent* a = (gcrl_agent*)user;
+  if (a->bn_xchg_h) {
+    const long long n1 = a->bn_sync_cap / 2, off = dev - a->bn_sync_buf;
+    if (off % n1 != 0 || n % n1 != 0 || off + n > a->bn_sync_cap) return gcrl::fail(GCRL_ERR_STATE, "SyncBN: exchange of %lld floats at %lld is not a whole segment", n, off);
+    return gcrl_xchg_allreduce(a->bn_xchg_h, (int)(off / n1), (int)(n / n1), (void*)st);
+  }
   if (a->bn_sync_dp) return gcrl_dp_allreduce_sum(a->bn_sync_dp, dev, (int64_t)n, (void*)st);
   if (!a->bn_sync_fn) return gcrl::fail(GCRL_ERR_STATE, "SyncBN: no exchange function");
   if (a->bn_sync_fn(dev, (int64_t)n, (void*)st, a->bn_sync_user) != 0) return gcrl::fail(GCRL_ERR_STATE, "SyncBN: the exchange function reported a failure");
   return GCRL_OK;
 }
 
+static int dp_sync_bn_setup(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_exchange_fn fn, void* user, gcrl_xchg* bx);
+
 int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_exchange_fn fn, void* user) {
   GCRL_CHECK_ARG(a, "gcrl_agent_dp_sync_bn: null handle");
+  GCRL_CHECK_ARG(world == 1 || dp || fn, "gcrl_agent_dp_sync_bn: a communicator or an exchange function is required");
+  return dp_sync_bn_setup(a, world, rank, dp, fn, user, nullptr);
+}
+
+// The partials' arena and an exchange handle over it (two segments: the two co-scheduled forwards' arrays; the backward's partials
+// reuse the second).  The caller connects it like the gradient exchange (gcrl_xchg_handles / _connect / _selftest) and then hands
+// it to gcrl_agent_dp_sync_bn_xchg.  Not owned by the agent.
+gcrl_xchg* gcrl_agent_bn_xchg_create(gcrl_agent* a, int rank, int world) {
+  if (!a || !a->sac || world < 2 || world > 8 || rank < 0 || rank >= world) { fail(GCRL_ERR_ARG, "gcrl_agent_bn_xchg_create: a BatchNorm actor and 2 <= world <= 8 required"); return nullptr; }
+  if (hipDeviceSynchronize() != hipSuccess) { fail(GCRL_ERR_HIP, "gcrl_agent_bn_xchg_create: device error"); return nullptr; }
+  const long long n1 = 2LL * world * ((a->B + 63) / 64) * a->H;
+  if (2 * n1 != a->bn_sync_cap) {   // (the arena's size is part of the exchange's layout: exactly two segments)
+    if (a->bn_sync_buf) { (void)hipFree(a->bn_sync_buf); a->bn_sync_buf = nullptr; a->bn_sync_cap = 0; }
+    if (bytes_alloc(&a->bn_sync_buf, 2 * n1) != GCRL_OK) return nullptr;
+    a->bn_sync_cap = 2 * n1;
+  }
+  const int64_t off[2] = {0, n1}, n[2] = {n1, n1};
+  return gcrl_xchg_create(a->bn_sync_buf, 2 * n1, off, n, 2, rank, world, a->cfg.device);
+}
+
+int gcrl_agent_dp_sync_bn_xchg(gcrl_agent* a, int world, int rank, gcrl_xchg* bx) {
+  GCRL_CHECK_ARG(a && bx && world >= 2 && gcrl_xchg_world(bx) == world, "gcrl_agent_dp_sync_bn_xchg: a connected exchange handle of this world is required");
+  return dp_sync_bn_setup(a, world, rank, nullptr, nullptr, nullptr, bx);
+}
+
+static int dp_sync_bn_setup(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_exchange_fn fn, void* user, gcrl_xchg* bx) {
   GCRL_CHECK_ARG(world >= 1 && world <= 15 && rank >= 0 && rank < world, "gcrl_agent_dp_sync_bn: world must be 1..15 and 0 <= rank < world");
   GCRL_CHECK_ARG(world == 1 || a->sac, "gcrl_agent_dp_sync_bn: only the BatchNorm actors (SAC / TQC) have statistics to synchronise");
-  GCRL_CHECK_ARG(world == 1 || dp || fn, "gcrl_agent_dp_sync_bn: a communicator or an exchange function is required");
   GCRL_HIP(hipDeviceSynchronize());
   for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);   // captured steps hold the old buffers and have no exchanges
   a->graphs.clear();
   a->bn_sync = BnSync{};
-  a->bn_sync_dp = nullptr; a->bn_sync_fn = nullptr; a->bn_sync_user = nullptr;
+  a->bn_sync_dp = nullptr; a->bn_sync_fn = nullptr; a->bn_sync_user = nullptr; a->bn_xchg_h = nullptr;
   if (a->sac && a->parts_a)   // (the slab launches and the BatchNorm launches fill different subsets of a layer's sum-of-squares slots)
     GCRL_HIP(hipMemset(a->parts_a + a->part_off_bn, 0, (size_t)a->L * a->bn_slots * sizeof(float)));
   GCRL_HIP(hipDeviceSynchronize());
   if (world == 1) return GCRL_OK;
   // partial statistics of both co-scheduled forwards, every rank's slots, adjacent: ONE exchange per BatchNorm layer and pass
   const long long n1 = 2LL * world * ((a->B + 63) / 64) * a->H;
+  GCRL_CHECK_ARG(!bx || a->bn_sync_cap == 2 * n1, "gcrl_agent_dp_sync_bn_xchg: the handle was created for another world / batch");
   if (2 * n1 > a->bn_sync_cap) {   // a later call may name a larger world (2 -> 4): the buffer grows with it
     if (a->bn_sync_buf) { (void)hipFree(a->bn_sync_buf); a->bn_sync_buf = nullptr; a->bn_sync_cap = 0; }
     TRY(bytes_alloc(&a->bn_sync_buf, 2 * n1));
@@ -1990,6 +2029,8 @@ int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_
   a->bn_sync.world = world; a->bn_sync.rank = rank;
   a->bn_sync.exchange = bn_sync_exchange; a->bn_sync.user = a;
   a->bn_sync_dp = dp; a->bn_sync_fn = fn; a->bn_sync_user = user;
+  a->bn_xchg_h = bx;
+  if (bx) { a->bn_sync.result = bn_sync_result; gcrl_xchg_set_status(bx, a->status_dev); }
   GCRL_HIP(hipDeviceSynchronize());
   return GCRL_OK;
 }

@@ -243,6 +243,9 @@ struct BnSync {
   int world = 1, rank = 0;
   int (*exchange)(float* dev, long long n, hipStream_t st, void* user) = nullptr;
   void* user = nullptr;
+  // where the summed array is after `exchange` (null: in place).  The in-engine peer-to-peer exchange (xchg_ipc.hip) leaves its
+  // result in the receive buffer its peers write, never in the array the ranks read from each other
+  const float* (*result)(const float* dev, void* user) = nullptr;
 };
 // rows_per_part: 64 = this launch computes the row-block partials itself (bn_stats launch) — unless `stats_done`: the LDS-tiled
 // GEMM that produced z left them in `scratch` (GemmDesc::bn_part, 64-row tiles); 16 = the k-split GEMM that produced z left them

@@ -856,6 +856,8 @@ int launch_bn_relu_fwd_multi(hipStream_t st, const BnFwdProb* probs, int nprob, 
     else if (nprob == 2 && probs[0].scratch == probs[1].scratch + n1) rc = sync->exchange(probs[1].scratch, 2 * n1, st, sync->user);
     else for (int i = 0; i < nprob && !rc; ++i) rc = sync->exchange(probs[i].scratch, n1, st, sync->user);
     if (rc) return rc;
+    if (sync->result)   // (the apply launch only READS the partials)
+      for (int i = 0; i < 2; ++i) pr.p[i].scratch = const_cast<float*>(sync->result(pr.p[i].scratch, sync->user));
   }
   pr.slabs = bn_slabs(B);
   hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots * pr.slabs - 1) / (kBnSlots * pr.slabs), nprob), dim3(256), 0,
@@ -887,8 +889,13 @@ int launch_bn_relu_bwd(hipStream_t st, const float* dh, const float* dh2, const 
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((H + 63) / 64, nrb), dim3(256), 0, st, dh, dh2, xhat, gamma, beta, B, H, part_dy,
                      part_dyx, world, rank);
   GCRL_HIP(hipGetLastError());
-  if (world > 1)
+  if (world > 1) {
     if (int rc = sync->exchange(scratch, 2LL * world * nrb * H, st, sync->user)) return rc;
+    if (sync->result) {
+      part_dy = const_cast<float*>(sync->result(scratch, sync->user));
+      part_dyx = part_dy + (long long)world * nrb * H;
+    }
+  }
   const int slabs = bn_slabs(B);
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((H + 63) / 64, (B + kBnSlots * slabs - 1) / (kBnSlots * slabs)), dim3(256), 0, st, dh,
                      dh2, xhat, invstd, gamma, beta, part_dy, part_dyx, B, H, dz, dgamma, dbeta, sumsq_out, slabs, world, rank);

@@ -215,7 +215,33 @@ class DataParallelUpdater:
             _ffi.check(lib.gcrl_agent_set_meetings(agent._h, 0))
         self.sync_bn = bool(sync_bn) and agent._sac and self.world > 1
         self._bn_cb = None
-        if self.sync_bn:
+        self._bn_xchg = None
+        self.sync_bn_exchange = None
+        if self.sync_bn and self._xchg:
+            # round 5: the BatchNorm partials through the same peer-to-peer kernel as the gradients (an exchange handle over the
+            # partials' own arena: connect, self-test, collective fallback to the paths below) — hipGraphs and multi-step graphs stay on
+            bx = lib.gcrl_agent_bn_xchg_create(agent._h, self.rank, self.world)
+            rec = (C.c_uint8 * _ffi.XCHG_HANDLE_BYTES)()
+            ok = bool(bx) and lib.gcrl_xchg_handles(bx, rec, _ffi.XCHG_HANDLE_BYTES) == 0
+            recs = [None] * self.world
+            dist.all_gather_object(recs, bytes(rec) if ok else b"", group=group)
+            ok = ok and all(len(r) == _ffi.XCHG_HANDLE_BYTES for r in recs)
+            if ok:
+                ok = lib.gcrl_xchg_connect(bx, b"".join(recs), _ffi.XCHG_HANDLE_BYTES * self.world) == 0
+            if all_ok(ok):
+                dist.barrier(group=group)
+                ok = lib.gcrl_xchg_selftest(bx, _ffi.stream_handle()) == 0
+                ok = all_ok(ok)
+            else:
+                ok = False
+            if ok:
+                self._bn_xchg = bx
+                _ffi.check(lib.gcrl_agent_dp_sync_bn_xchg(agent._h, self.world, self.rank, bx))
+                self.sync_bn_exchange = "engine-ipc"
+            elif bx:
+                lib.gcrl_xchg_destroy(bx)
+        if self.sync_bn and not self._bn_xchg:
+            self.sync_bn_exchange = "engine-rccl" if self._native else "python"
             if self._native:
                 _ffi.check(lib.gcrl_agent_dp_sync_bn(agent._h, self.world, dist.get_rank(group), self._native, None, None))
             else:
@@ -239,6 +265,9 @@ class DataParallelUpdater:
     def __del__(self):
         if getattr(self, "sync_bn", False) and getattr(self.agent, "_h", None):
             self._ffi.lib.gcrl_agent_dp_sync_bn(self.agent._h, 1, 0, None, None, None)   # the agent outlives the callback / communicator
+        bx, self._bn_xchg = getattr(self, "_bn_xchg", None), None
+        if bx:
+            self._ffi.lib.gcrl_xchg_destroy(bx)
         x, self._xchg = getattr(self, "_xchg", None), None
         if x:
             if getattr(self.agent, "_h", None):
@@ -256,6 +285,8 @@ class DataParallelUpdater:
         dist.barrier(group=self.group)
         if self._xchg:
             self._ffi.check(self._ffi.lib.gcrl_xchg_reset(self._xchg))
+        if self._bn_xchg:
+            self._ffi.check(self._ffi.lib.gcrl_xchg_reset(self._bn_xchg))
         dist.barrier(group=self.group)
 
     def _allreduce_block(self, i: int, st):

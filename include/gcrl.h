@@ -429,6 +429,13 @@ int gcrl_agent_dp_run_all(gcrl_agent* a, gcrl_dp* d, void* stream);
  * them).  Steps then run as plain launches (no hipGraph replay).  Call it before the first update; world = 1 switches it off. */
 typedef int (*gcrl_exchange_fn)(float* buf_dev, int64_t n, void* stream, void* user);
 int gcrl_agent_dp_sync_bn(gcrl_agent* a, int world, int rank, gcrl_dp* dp, gcrl_exchange_fn fn, void* user);
+/* The same with the partials exchanged by the in-engine peer-to-peer kernel (round 5): gcrl_agent_bn_xchg_create allocates the
+ * partials' arena and returns an exchange handle over it (connect it like the gradient exchange: gcrl_xchg_handles / _connect /
+ * _selftest; the caller owns it and destroys it after switching SyncBN off); gcrl_agent_dp_sync_bn_xchg switches SyncBN on
+ * through it.  The exchange is then a kernel of the step's launch sequence: hipGraph replay and multi-step graphs stay on.
+ * New design (the reference is single-process, src/model.py:107 BatchNorm1d on one batch). */
+gcrl_xchg* gcrl_agent_bn_xchg_create(gcrl_agent* a, int rank, int world);
+int gcrl_agent_dp_sync_bn_xchg(gcrl_agent* a, int world, int rank, gcrl_xchg* bx);
 /* Launches whose workgroups WAIT for each other inside the kernel (csrc/meet.h: the row groups of a BatchNorm slab, the role
  * workgroups of a twin-critic row block) are admitted only when every workgroup of the launch is resident at once — judged by
  * the kernel's occupancy on a device this process has to itself.  New design (the reference is eager PyTorch: no such forms).

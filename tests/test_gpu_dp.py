@@ -82,6 +82,8 @@ def _worker(rank, world, port, kind, out_dir, sync_bn=False, exchange="auto", ta
     dp = DataParallelUpdater(ag, sync_bn=sync_bn, exchange=exchange)    # broadcasts rank 0's parameters
     assert dp.exchange == {"auto": "engine-ipc", "ipc": "engine-ipc", "python": "python"}[exchange], dp.exchange
     assert dp.sync_bn == (sync_bn and kind in ("SAC", "TQC"))
+    if dp.sync_bn:
+        assert dp.sync_bn_exchange == ("engine-ipc" if dp.exchange == "engine-ipc" else "python"), dp.sync_bn_exchange
     tuples = []
     for step, (full, eps) in enumerate(zip(_global_batches(world, 3), _global_eps(world, 3)), start=1):
         mine = tuple(torch.from_numpy(x[rank * B:(rank + 1) * B]).cuda() for x in full)
@@ -150,7 +152,7 @@ def test_three_ranks_through_the_ipc_exchange_equal_one_big_batch(gcrl, tmp_path
         assert float(np.mean(err > 2e-5)) < 0.02 and float(err.max()) < 3 * 2.2e-3, (k, float(err.max()))
 
 
-def _worker_cycle(rank, world, port, out_dir, kind="DDPG", exchange="auto", tag="cycle", sep_norm=False):
+def _worker_cycle(rank, world, port, out_dir, kind="DDPG", exchange="auto", tag="cycle", sep_norm=False, sync_bn=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if sep_norm:
         os.environ["GCRL_XCHG_SEPARATE_NORM"] = "1"
@@ -167,7 +169,9 @@ def _worker_cycle(rank, world, port, out_dir, kind="DDPG", exchange="auto", tag=
             ag.push_her(0, *st)
     if rank == 0:
         _init_params(ag)
-    dp = DataParallelUpdater(ag, exchange=exchange)
+    dp = DataParallelUpdater(ag, exchange=exchange, sync_bn=sync_bn)
+    if sync_bn:      # the partials travel with the gradients' exchange: in the engine (graphs stay on) or through the callback
+        assert dp.sync_bn and dp.sync_bn_exchange == ("engine-ipc" if exchange == "ipc" else "python"), dp.sync_bn_exchange
     out = [[float(x) for x in t] for t in dp.update_many(1, 45)]      # crosses the Polyak step 40
     out += [[float(x) for x in t] for t in dp.update_many(46, 5)]
     torch.cuda.synchronize()
@@ -196,6 +200,24 @@ def test_ipc_exchange_is_bitwise_the_gloo_exchange(gcrl, tmp_path, kind):
             i, p = np.load(tmp_path / f"i_{base}{r}.npz"), np.load(tmp_path / f"p_{base}{r}.npz")
             for k in keys:
                 assert np.array_equal(i[k], p[k]), (kind, base, r, k, float(np.abs(i[k].astype(np.float64) - p[k]).max()))
+
+
+def test_sync_batchnorm_through_the_engine_exchange_is_bitwise_the_callback_path(gcrl, tmp_path):
+    """with `sync_bn=True` the BatchNorm row-block partials ([world x nrb x 2H] floats per layer and pass:
+    reference semantics src/model.py:107 on the concatenated batch) used to travel through a host callback between the launches,
+    with hipGraphs off.  Now they go through the same peer-to-peer kernel as the gradients (an exchange handle over the partials'
+    own arena, gcrl_agent_bn_xchg_create / gcrl_agent_dp_sync_bn_xchg): an exchange of zero-padded slots in rank order is an
+    all-gather, so the merged statistics — and with them a 50-step SAC trainer cycle replayed from multi-step graphs and three
+    injected-batch steps — must be BITWISE what the callback path (torch.distributed all-reduce, plain launches) gives."""
+    world, kind = 2, "SAC"
+    for exchange, tag, sep in (("ipc", "i_", True), ("python", "p_", False)):
+        mp.spawn(_worker_cycle, args=(world, _free_port(), str(tmp_path), kind, exchange, tag + "cycle", sep, True), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), True, exchange, tag + "rank", sep), nprocs=world, join=True)
+    for base, keys in (("cycle", ("actor", "critic", "tactor", "tuples")), ("rank", ("actor", "critic", "critic_last", "target", "tuples", "bn_mean", "bn_var"))):
+        for r in range(world):
+            i, p = np.load(tmp_path / f"i_{base}{r}.npz"), np.load(tmp_path / f"p_{base}{r}.npz")
+            for k in keys:
+                assert np.array_equal(i[k], p[k]), (base, r, k, float(np.abs(i[k].astype(np.float64) - p[k]).max()))
 
 
 @pytest.mark.parametrize("exchange", ["ipc", "python"])
