@@ -154,6 +154,9 @@ struct gcrl_agent {
   bool slab_on() const { return bn_slab && bn_sync.world <= 1; }
   float* bn_bstat = nullptr;
   float *bn_xchg = nullptr, *bn_bar = nullptr;   // row-group exchange of the slab launches (bn_slab.hip): partials, barrier words
+  // round 5: with 64-row workgroups (bn_slab.hip) the narrow launches — the first layer's forward (K = state_dim), the top layer's backward (K = 2 x
+  // action_dim) — gain from the row split as well: SAC cfg 5 157.9 -> 155.6 us/step (profiles/r05_ab_slab_waves.txt); GCRL_NO_SLAB_SPLIT_ALL=1: round 3's rule (K >= 128 only)
+  bool bn_split_all = std::getenv("GCRL_NO_SLAB_SPLIT_ALL") == nullptr;
   int bn_rsplit = 1;          // > 1: K >= 128 slab launches split their rows over ceil(B/128) workgroups (GCRL_NO_BN_RSPLIT=1: off)
   int bn_slots = 0;           // sum-of-squares slots of one BatchNorm layer's dgamma | dbeta (16-column slabs)
   bool heads_fused_off = false;   // GCRL_NO_HEADS_FUSED=1: the BatchNorm actor's heads and its sampling as two launches (rounds 1-4)
@@ -429,7 +432,7 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
     sf.W = P + net.lin[l].w; sf.bias = P + net.lin[l].b; sf.gamma = P + net.bn_g[l]; sf.beta = P + net.bn_b[l];
     sf.ldx = l == 0 ? a->ldx : H;
     sf.B = B; sf.H = H; sf.K = net.lin[l].in;
-    sf.rsplit = sf.K >= 128 ? a->bn_rsplit : 1; sf.xchg = a->bn_xchg; sf.bar = reinterpret_cast<unsigned int*>(a->bn_bar); sf.status = a->status_dev;
+    sf.rsplit = (sf.K >= 128 || a->bn_split_all) ? a->bn_rsplit : 1; sf.xchg = a->bn_xchg; sf.bar = reinterpret_cast<unsigned int*>(a->bn_bar); sf.status = a->status_dev;
     TRY(launch_bn_linear_fwd_slab(st, sf));
     if (extra && (size_t)l < extra->steps.size()) {   // (co-scheduled critic chains of the launch-per-layer schedule: their own launch here)
       std::vector<GemmDesc> v = extra->steps[l];
@@ -860,7 +863,7 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
         sb.dgamma = Ga + a->actor.bn_g[l]; sb.dbeta = Ga + a->actor.bn_b[l];
         sb.sumsq_out = (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * a->bn_slots : nullptr;
         sb.B = B; sb.H = H;
-        sb.rsplit = l == L - 1 ? 1 : a->bn_rsplit; sb.xchg = a->bn_xchg; sb.bar = reinterpret_cast<unsigned int*>(a->bn_bar); sb.status = a->status_dev;
+        sb.rsplit = (l == L - 1 && !a->bn_split_all) ? 1 : a->bn_rsplit; sb.xchg = a->bn_xchg; sb.bar = reinterpret_cast<unsigned int*>(a->bn_bar); sb.status = a->status_dev;
         TRY(launch_bn_linear_bwd_slab(st, sb));
       }
       std::vector<GemmDesc> v;
@@ -1423,6 +1426,10 @@ int build(gcrl_agent* a) {
       }
     }
     a->head_batches = 3;   // (TD3 at batch 2048: the host draws 38 x 2048 indices in ~390 us, more than two 170 us steps)
+    // round 5, DDPG's overlapped step at 50 us: three steps of queued work no longer cover the host's six launches + the draw (a 20-step call showed
+    // 23 us of idle GPU before the main gather); four do: 57.0 -> 55.9 us/step on the 20-step line, the steady state unchanged
+    // (profiles/r05_ab_head_batches.txt; reading the indices straight from the pinned block instead of the staged copy: no gain)
+    if (c.kind == GCRL_AGENT_DDPG && c.pipeline_steps != 0) a->head_batches = 4;
     if (const char* e = std::getenv("GCRL_HEAD_BATCHES")) a->head_batches = std::max(1, std::min(8, std::atoi(e)));   // experiment knob
     a->dw_batch_off = std::getenv("GCRL_NO_DW_BATCH") != nullptr;
     a->bn_fused_tiled = std::getenv("GCRL_NO_BN_TILED_STATS") == nullptr;

@@ -21,19 +21,27 @@
 
 #include "gemm_mfma.h"
 #include "meet.h"
+#include <cstdlib>
+#ifdef GCRL_SLAB_STAMPS
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace gcrl {
 
 namespace {
 
 constexpr float kEps = 1e-5f;          // nn.BatchNorm1d defaults (as in ops_sac.hip)
-constexpr int kWaves = 8;              // 512 threads
+constexpr int kWaves = 8;              // waves of a workgroup that holds ALL rows of its slab (512 threads); the row-split forms: 8 or 4 (template parameter WV)
 // 16-row tiles per wave (template parameter NT): 4 = a workgroup holds all 512 rows of its 16 columns; 1 = a workgroup holds 128
 // rows and the row groups of a slab exchange their column partials through memory (see slab_exchange)
 #ifndef GCRL_SLAB_NS
 #define GCRL_SLAB_NS 4
 #endif
-constexpr int kNS = GCRL_SLAB_NS;      // chunks of global loads in flight per wave
+constexpr int kNSDefault = GCRL_SLAB_NS;   // chunks of global loads in flight per wave
+// A CU keeps ~64 vector-memory instructions in flight (rowchain.h measured the same ceiling): 8 waves x 4 stages x (A + W) = 64.  With more stages
+// the issue itself stalls (round 5, 8 waves: 8 stages +1.7 us per launch, 16 stages +16 us); the 4-wave row-split form has room for 8.
+template <int NT, int WV> struct SlabStages { static constexpr int value = (NT == 1 && WV == 4) ? 2 * kNSDefault : kNSDefault; };
 constexpr int kCK = 16;                // k per chunk (the k-permutation of gemm_mfma.h: a lane's 4 consecutive k feed 4 MFMAs)
 
 // 4 consecutive floats at byte offset `off` (one 16-byte load, or element loads when the operand is not 16-byte
@@ -54,6 +62,7 @@ __device__ inline v4f ld4b(__amdgpu_buffer_rsrc_t rs, int off, int soff) {
 }
 
 // sum over the rows of the batch for this lane's column: lanes (i, g) hold partial sums of column i; result in every lane
+template <int WV>
 __device__ inline float col_sum(float v, float (*red)[16], int wave, int li, int lg) {
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
@@ -62,7 +71,7 @@ __device__ inline float col_sum(float v, float (*red)[16], int wave, int li, int
   __syncthreads();
   float s = red[0][li];
 #pragma unroll
-  for (int w = 1; w < kWaves; ++w) s += red[w][li];
+  for (int w = 1; w < WV; ++w) s += red[w][li];
   return s;
 }
 
@@ -78,7 +87,7 @@ struct Operand { const float* p; long long ld; int K; };
 // slot quad ^ ((row >> 1) & 3) of their 64-byte row (conflict-free for these stores and for the fragment reads: 8 lanes on 8
 // consecutive rows at one k-quad), and lane (i, g) reads row 16 t + i, quad g back.  Wave-private: LDS instructions of one
 // wave execute in order, no barrier.  Two chunks of global loads stay in flight in registers.
-template <bool VEC, bool BROW, int kNT>
+template <bool VEC, bool BROW, int kNT, int kNS>
 __device__ inline void slab_gemm(v4f (&acc)[kNT], float* lds, const float* A, long long lda, const float* W, long long ldb, int K, int B,
                                  int ncols, int row0, int col0, int lane) {
   constexpr int kPast = 0x7ffffff0;
@@ -181,8 +190,8 @@ constexpr int kSc1 = 16;                 // agent-scope cache policy of the raw 
 struct Xchg { float* buf; unsigned int* bar; unsigned int* status; };     // buf [slot][RS][32] floats; bar [slot][32] words: a 64-bit counter per 128-byte line
 
 // a, b: this group's two values for column li (valid in wave 0, lanes lg == 0).  Returns false on a timed-out wait.
-__device__ inline bool slab_exchange(const Xchg& x, int slot, int RS, int r, float a, float b, int wave, int li, int lg, float (&oa)[4],
-                                     float (&ob)[4], unsigned int* s_flag) {
+__device__ inline bool slab_exchange(const Xchg& x, int slot, int RS, int r, float a, float b, int wave, int li, int lg, float (&oa)[8],
+                                     float (&ob)[8], unsigned int* s_flag) {
   const __amdgpu_buffer_rsrc_t rs = wave_uniform_rsrc(x.buf + (long long)slot * RS * 32);
   if (wave == 0 && lg == 0) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), rs, (r * 32 + li) * 4, 0, kSc1);
@@ -190,7 +199,7 @@ __device__ inline bool slab_exchange(const Xchg& x, int slot, int RS, int r, flo
   }
   const bool ok = meet(reinterpret_cast<unsigned long long*>(x.bar + (long long)slot * 32), (unsigned)RS, true, s_flag, x.status, MEET_ERR_BN_SLAB);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 8; ++j) {
     oa[j] = j < RS ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (j * 32 + li) * 4, 0, kSc1)) : 0.f;
     ob[j] = j < RS ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (j * 32 + 16 + li) * 4, 0, kSc1)) : 0.f;
   }
@@ -205,18 +214,26 @@ struct FwdArgs {
   long long ldx;
   int B, H, K, RS;
   Xchg x;
+#ifdef GCRL_SLAB_STAMPS
+  unsigned long long* stamps;   // development build (tools/slab_stamps.sh): [workgroup][8] constant-rate clock (100 MHz) stamps
+#endif
 };
+#ifdef GCRL_SLAB_STAMPS
+#define SLAB_STAMP(k) do { if (threadIdx.x == 0) g.stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define SLAB_STAMP(k) do { } while (0)
+#endif
 
-template <bool VEC, int NT>
-__global__ __launch_bounds__(64 * kWaves) void bn_linear_fwd_slab_kernel(FwdArgs g) {
-  __shared__ float red[kWaves][16];
+template <bool VEC, int NT, int WV>
+__global__ __launch_bounds__(64 * WV) void bn_linear_fwd_slab_kernel(FwdArgs g) {
+  __shared__ float red[WV][16];
   __shared__ unsigned int s_flag;
-  __shared__ __attribute__((aligned(16))) float stage[kWaves][16 * NT * kCK];   // wave-private images of the A operand
+  __shared__ __attribute__((aligned(16))) float stage[WV][16 * NT * kCK];   // wave-private images of the A operand
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   const int prob = NT == 1 ? (int)blockIdx.z : (int)blockIdx.y, rgrp = NT == 1 ? (int)blockIdx.y : 0;
   const FwdProb me = g.p[prob];
   const int B = g.B, H = g.H;
-  constexpr int kRowsWg = 16 * NT * kWaves;
+  constexpr int kRowsWg = 16 * NT * WV;
   const int col0 = blockIdx.x * 16, col = col0 + li, row0 = rgrp * kRowsWg + wave * 16 * NT;
   const int nl = min(kRowsWg, B - rgrp * kRowsWg);              // rows of this workgroup (>= 1: launcher)
   const long long sl = (g.slot && me.x_slot) ? (long long)*g.slot : 0;
@@ -225,7 +242,9 @@ __global__ __launch_bounds__(64 * kWaves) void bn_linear_fwd_slab_kernel(FwdArgs
   for (int t = 0; t < NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
   // epilogue operands first: their latency hides behind the GEMM
   const float bias = col < H ? g.bias[col] : 0.f, gm = col < H ? g.gamma[col] : 0.f, bt = col < H ? g.beta[col] : 0.f;
-  slab_gemm<VEC, true, NT>(acc, stage[wave], me.X + sl * me.x_slot, g.ldx, g.W, g.K, g.K, B, H, row0, col0, lane);
+  SLAB_STAMP(0);
+  slab_gemm<VEC, true, NT, SlabStages<NT, WV>::value>(acc, stage[wave], me.X + sl * me.x_slot, g.ldx, g.W, g.K, g.K, B, H, row0, col0, lane);
+  SLAB_STAMP(1);
   // acc[t][r] = z[row0 + 16 t + 4 lg + r][col] - bias
   float s = 0.f;
 #pragma unroll
@@ -235,28 +254,30 @@ __global__ __launch_bounds__(64 * kWaves) void bn_linear_fwd_slab_kernel(FwdArgs
       acc[t][r] += bias;
       if (row0 + 16 * t + 4 * lg + r < B) s += acc[t][r];
     }
-  float mean = col_sum(s, red, wave, li, lg) / (float)nl;      // of this workgroup's rows
+  float mean = col_sum<WV>(s, red, wave, li, lg) / (float)nl;      // of this workgroup's rows
   float q = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (row0 + 16 * t + 4 * lg + r < B) { const float d = acc[t][r] - mean; q += d * d; }
-  float m2 = col_sum(q, red, wave, li, lg);
+  float m2 = col_sum<WV>(q, red, wave, li, lg);
+  SLAB_STAMP(2);
   if (NT == 1 && g.RS > 1) {
     // merge of the row groups' (n_j, mean_j, M2_j) in index order: mean = sum n_j mean_j / B, M2 = sum (M2_j + n_j (mean_j - mean)^2)
-    float pm[4], pq[4];
+    float pm[8], pq[8];
     const bool ok = slab_exchange(g.x, prob * (H / 16) + (int)blockIdx.x, g.RS, rgrp, mean, m2, wave, li, lg, pm, pq, &s_flag);
     float sm = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (j < g.RS) sm += pm[j] * (float)min(kRowsWg, B - j * kRowsWg);
+    for (int j = 0; j < 8; ++j) if (j < g.RS) sm += pm[j] * (float)min(kRowsWg, B - j * kRowsWg);
     mean = sm / (float)B;
     m2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 8; ++j)
       if (j < g.RS) { const float dm = pm[j] - mean; m2 += pq[j] + dm * dm * (float)min(kRowsWg, B - j * kRowsWg); }
     if (!ok) mean = __builtin_nanf("");                        // a timed-out exchange must not pass for a result
   }
+  SLAB_STAMP(3);
   const float var = m2 / (float)B;                              // biased: what normalises the batch
   const float invstd = 1.0f / sqrtf(var + kEps);
   if (col < H) {
@@ -278,6 +299,10 @@ __global__ __launch_bounds__(64 * kWaves) void bn_linear_fwd_slab_kernel(FwdArgs
       me.bstat[H + col] = var;
     }
   }
+#ifdef GCRL_SLAB_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SLAB_STAMP(4);
+#endif
 }
 
 struct BwdArgs {
@@ -289,14 +314,14 @@ struct BwdArgs {
   Xchg x;
 };
 
-template <int NT>
-__global__ __launch_bounds__(64 * kWaves) void bn_linear_bwd_slab_kernel(BwdArgs g) {
-  __shared__ float red[kWaves][16];
+template <int NT, int WV>
+__global__ __launch_bounds__(64 * WV) void bn_linear_bwd_slab_kernel(BwdArgs g) {
+  __shared__ float red[WV][16];
   __shared__ unsigned int s_flag;
-  __shared__ __attribute__((aligned(16))) float stage[kWaves][16 * NT * kCK];
+  __shared__ __attribute__((aligned(16))) float stage[WV][16 * NT * kCK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   const int B = g.B, H = g.H;
-  constexpr int kRowsWg = 16 * NT * kWaves;
+  constexpr int kRowsWg = 16 * NT * WV;
   const int rgrp = NT == 1 ? (int)blockIdx.y : 0;
   const int col0 = blockIdx.x * 16, col = col0 + li, row0 = rgrp * kRowsWg + wave * 16 * NT;
   const bool okc = col < H;
@@ -312,7 +337,7 @@ __global__ __launch_bounds__(64 * kWaves) void bn_linear_bwd_slab_kernel(BwdArgs
   }
   const float gm = okc ? g.gamma[col] : 0.f, bt = okc ? g.beta[col] : 0.f, is = okc ? g.invstd[col] : 0.f;
   for (int u = 0; u < g.nup; ++u)
-    slab_gemm<true, false, NT>(acc, stage[wave], g.up[u].p, g.up[u].ld, g.Wup[u], g.ldw[u], g.up[u].K, B, H, row0, col0, lane);
+    slab_gemm<true, false, NT, SlabStages<NT, WV>::value>(acc, stage[wave], g.up[u].p, g.up[u].ld, g.Wup[u], g.ldw[u], g.up[u].K, B, H, row0, col0, lane);
   // dy = dh where the forward's output was positive (mask recomputed from xhat exactly as the forward computed y)
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -326,14 +351,14 @@ __global__ __launch_bounds__(64 * kWaves) void bn_linear_bwd_slab_kernel(BwdArgs
       s1 += dy;
       s2 += dy * xh[t][r];
     }
-  float sum_dy = col_sum(s1, red, wave, li, lg);
-  float sum_dyx = col_sum(s2, red, wave, li, lg);
+  float sum_dy = col_sum<WV>(s1, red, wave, li, lg);
+  float sum_dyx = col_sum<WV>(s2, red, wave, li, lg);
   if (NT == 1 && g.RS > 1) {
-    float pa[4], pb[4];
+    float pa[8], pb[8];
     const bool ok = slab_exchange(g.x, (int)blockIdx.x, g.RS, rgrp, sum_dy, sum_dyx, wave, li, lg, pa, pb, &s_flag);
     sum_dy = 0.f; sum_dyx = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (j < g.RS) { sum_dy += pa[j]; sum_dyx += pb[j]; }
+    for (int j = 0; j < 8; ++j) if (j < g.RS) { sum_dy += pa[j]; sum_dyx += pb[j]; }
     if (!ok) sum_dy = __builtin_nanf("");
   }
   const float m1 = sum_dy / (float)B, m2 = sum_dyx / (float)B, k = gm * is;
@@ -360,22 +385,36 @@ bool aligned16(const void* p) { return ((unsigned long long)p & 15ull) == 0; }
 }  // namespace
 
 bool bn_slab_ok(int B, int H) { return B >= 1 && B <= 16 * 4 * kWaves && H >= 16 && H % 16 == 0; }
-long long bn_slab_xchg_floats(int H) { return 2LL * (H / 16) * 4 * 32; }
+long long bn_slab_xchg_floats(int H) { return 2LL * (H / 16) * 8 * 32; }   // [input][slab][<= 8 row groups][32]
 long long bn_slab_bar_words(int H) { return 2LL * (H / 16) * 32; }
 
 // rows split: 1 (a workgroup holds all rows) or ceil(B / 128) row groups that exchange their partials (scratch required).  The
 // split form waits inside the launch: admitted only when all `slabs_x_inputs` x groups workgroups are resident at once by the
 // kernel's own occupancy, on a device this process has to itself (meet.h).  A function of the shapes, the device and the
 // process-wide sharing switch only: a launch's summation order never changes from step to step.
+// waves per workgroup of the row-split forms: 4 (64 rows per workgroup, up to 8 row groups; the default since round 5) or 8 (128 rows,
+// up to 4 groups: round 3's form, GCRL_SLAB_WAVES=8).  A function of the environment only: a launch's summation order never changes.
+static int split_waves() {
+  static const int wv = (std::getenv("GCRL_SLAB_WAVES") && std::atoi(std::getenv("GCRL_SLAB_WAVES")) == 8) ? 8 : 4;
+  return wv;
+}
+static const void* fwd_split_kernel(bool vec) {
+  if (split_waves() == 4) return vec ? (const void*)bn_linear_fwd_slab_kernel<true, 1, 4> : (const void*)bn_linear_fwd_slab_kernel<false, 1, 4>;
+  return vec ? (const void*)bn_linear_fwd_slab_kernel<true, 1, 8> : (const void*)bn_linear_fwd_slab_kernel<false, 1, 8>;
+}
+static const void* bwd_split_kernel() {
+  return split_waves() == 4 ? (const void*)bn_linear_bwd_slab_kernel<1, 4> : (const void*)bn_linear_bwd_slab_kernel<1, 8>;
+}
 static int row_split(int want, int B, const float* xchg, const unsigned int* bar, const void* kernel, long long slabs_x_inputs) {
-  if (want <= 1 || B <= 128 || !xchg || !bar) return 1;
-  const int rs = (B + 127) / 128;
-  return slabs_x_inputs * rs <= meet_capacity(kernel, 64 * kWaves, 0) ? rs : 1;
+  const int rows = 16 * split_waves();
+  if (want <= 1 || B <= rows || !xchg || !bar) return 1;
+  const int rs = (B + rows - 1) / rows;          // <= 8 (bn_slab_ok: B <= 512)
+  return slabs_x_inputs * rs <= meet_capacity(kernel, 64 * split_waves(), 0) ? rs : 1;
 }
 int bn_slab_row_split(int B, int H, int n_inputs) {   // what the launchers will choose for a layer that asks for the split (agent.hip: build)
   static float dummy_x; static unsigned int dummy_b;
-  const int f = row_split(4, B, &dummy_x, &dummy_b, (const void*)bn_linear_fwd_slab_kernel<true, 1>, (long long)(H / 16) * n_inputs);
-  const int b = row_split(4, B, &dummy_x, &dummy_b, (const void*)bn_linear_bwd_slab_kernel<1>, (long long)(H / 16));
+  const int f = row_split(4, B, &dummy_x, &dummy_b, fwd_split_kernel(true), (long long)(H / 16) * n_inputs);
+  const int b = row_split(4, B, &dummy_x, &dummy_b, bwd_split_kernel(), (long long)(H / 16));
   return (f > 1 && b > 1) ? f : 1;
 }
 
@@ -390,19 +429,43 @@ int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f) {
   g.B = f.B; g.H = f.H; g.K = f.K;
   bool vec = f.ldx % 4 == 0 && f.K % 4 == 0 && aligned16(f.W);
   for (int i = 0; i < f.n; ++i) vec = vec && aligned16(f.p[i].X) && f.p[i].x_slot % 4 == 0;
-  g.RS = row_split(f.rsplit, f.B, f.xchg, f.bar, vec ? (const void*)bn_linear_fwd_slab_kernel<true, 1> : (const void*)bn_linear_fwd_slab_kernel<false, 1>,
-                   (long long)(f.H / 16) * f.n);
+  g.RS = row_split(f.rsplit, f.B, f.xchg, f.bar, fwd_split_kernel(vec), (long long)(f.H / 16) * f.n);
   g.x = Xchg{f.xchg, f.bar, f.status};
+#ifdef GCRL_SLAB_STAMPS
+  static unsigned long long* stamps_dev = nullptr;
+  static long long launches = 0;
+  if (!stamps_dev) { GCRL_HIP(hipMalloc((void**)&stamps_dev, 1024 * 8 * 8)); }
+  GCRL_HIP(hipMemsetAsync(stamps_dev, 0, 1024 * 8 * 8, st));
+  g.stamps = stamps_dev;
+#endif
   if (g.RS > 1) {
     const dim3 grid(f.H / 16, g.RS, f.n);
-    if (vec) hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<true, 1>), grid, dim3(64 * kWaves), 0, st, g);
-    else hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<false, 1>), grid, dim3(64 * kWaves), 0, st, g);
+    if (split_waves() == 4) {
+      if (vec) hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<true, 1, 4>), grid, dim3(64 * 4), 0, st, g);
+      else hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<false, 1, 4>), grid, dim3(64 * 4), 0, st, g);
+    } else {
+      if (vec) hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<true, 1, 8>), grid, dim3(64 * 8), 0, st, g);
+      else hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<false, 1, 8>), grid, dim3(64 * 8), 0, st, g);
+    }
   } else {
     const dim3 grid(f.H / 16, f.n);
-    if (vec) hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<true, 4>), grid, dim3(64 * kWaves), 0, st, g);
-    else hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<false, 4>), grid, dim3(64 * kWaves), 0, st, g);
+    if (vec) hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<true, 4, kWaves>), grid, dim3(64 * kWaves), 0, st, g);
+    else hipLaunchKernelGGL((bn_linear_fwd_slab_kernel<false, 4, kWaves>), grid, dim3(64 * kWaves), 0, st, g);
   }
   GCRL_HIP(hipGetLastError());
+#ifdef GCRL_SLAB_STAMPS
+  {   // launches number GCRL_SLAB_STAMPS_AT .. +8 leave their per-workgroup stamps in the file GCRL_SLAB_STAMPS (never under a graph capture)
+    static const long long at = std::getenv("GCRL_SLAB_STAMPS_AT") ? std::atoll(std::getenv("GCRL_SLAB_STAMPS_AT")) : 3000;
+    const char* path = std::getenv("GCRL_SLAB_STAMPS");
+    if (path && launches >= at && launches < at + 9) {
+      std::vector<unsigned long long> h(1024 * 8);
+      GCRL_HIP(hipStreamSynchronize(st));
+      GCRL_HIP(hipMemcpy(h.data(), stamps_dev, h.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE* fp = std::fopen(path, launches == at ? "wb" : "ab")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
+    }
+    ++launches;
+  }
+#endif
   return GCRL_OK;
 }
 
@@ -420,10 +483,11 @@ int launch_bn_linear_bwd_slab(hipStream_t st, const BnSlabBwd& b) {
   g.xhat_dz = b.xhat_dz; g.invstd = b.invstd; g.gamma = b.gamma; g.beta = b.beta;
   g.dgamma = b.dgamma; g.dbeta = b.dbeta; g.sumsq_out = b.sumsq_out;
   g.B = b.B; g.H = b.H;
-  g.RS = row_split(b.rsplit, b.B, b.xchg, b.bar, (const void*)bn_linear_bwd_slab_kernel<1>, (long long)(b.H / 16));
+  g.RS = row_split(b.rsplit, b.B, b.xchg, b.bar, bwd_split_kernel(), (long long)(b.H / 16));
   g.x = Xchg{b.xchg, b.bar, b.status};
-  if (g.RS > 1) hipLaunchKernelGGL(bn_linear_bwd_slab_kernel<1>, dim3(b.H / 16, g.RS), dim3(64 * kWaves), 0, st, g);
-  else hipLaunchKernelGGL(bn_linear_bwd_slab_kernel<4>, dim3(b.H / 16), dim3(64 * kWaves), 0, st, g);
+  if (g.RS > 1 && split_waves() == 4) hipLaunchKernelGGL((bn_linear_bwd_slab_kernel<1, 4>), dim3(b.H / 16, g.RS), dim3(64 * 4), 0, st, g);
+  else if (g.RS > 1) hipLaunchKernelGGL((bn_linear_bwd_slab_kernel<1, 8>), dim3(b.H / 16, g.RS), dim3(64 * 8), 0, st, g);
+  else hipLaunchKernelGGL((bn_linear_bwd_slab_kernel<4, kWaves>), dim3(b.H / 16), dim3(64 * kWaves), 0, st, g);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
