@@ -191,10 +191,7 @@ static int slab_scratch(int H, float** xchg, unsigned int** bar) {
 // The meeting counters are monotonic and must be a multiple of a launch's row-group count when it starts (meet.h): an agent's
 // own counters always are (its row-group count never changes); this process-wide scratch serves launches of ANY shape, so
 // every launch starts from zeroed counters (stream-ordered)
-static int slab_scratch_reset(int H, unsigned int* bar, hipStream_t st) {
-  GCRL_HIP(hipMemsetAsync(bar, 0, (size_t)gcrl::bn_slab_bar_words(H) * sizeof(unsigned int), st));
-  return GCRL_OK;
-}
+static int slab_scratch_reset(int H, float* xchg, unsigned int* bar, hipStream_t st) { return gcrl::bn_slab_scratch_reset(xchg, bar, H, st); }
 
 int gcrl_bn_linear_slab_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, const float* gamma, const float* beta,
                                 int B, int H, int K, float* h, float* xhat, float* invstd, float* bstat, int row_split, void* stream) {
@@ -208,7 +205,7 @@ int gcrl_bn_linear_slab_fwd_f32(const float* x, int64_t ldx, const float* w, con
   if (row_split > 1) {
     f.rsplit = row_split;
     if (int rc = slab_scratch(H, &f.xchg, &f.bar)) return rc;
-    if (int rc = slab_scratch_reset(H, f.bar, as_stream(stream))) return rc;
+    if (int rc = slab_scratch_reset(H, f.xchg, f.bar, as_stream(stream))) return rc;
   }
   return gcrl::launch_bn_linear_fwd_slab(as_stream(stream), f);
 }
@@ -226,7 +223,7 @@ int gcrl_bn_linear_slab_bwd_f32(const float* g_up, int64_t ldg, int K_up, const 
   if (row_split > 1) {
     b.rsplit = row_split;
     if (int rc = slab_scratch(H, &b.xchg, &b.bar)) return rc;
-    if (int rc = slab_scratch_reset(H, b.bar, as_stream(stream))) return rc;
+    if (int rc = slab_scratch_reset(H, b.xchg, b.bar, as_stream(stream))) return rc;
   }
   return gcrl::launch_bn_linear_bwd_slab(as_stream(stream), b);
 }

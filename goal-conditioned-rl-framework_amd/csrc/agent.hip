@@ -157,6 +157,7 @@ struct gcrl_agent {
   // round 5: with 64-row workgroups (bn_slab.hip) the narrow launches — the first layer's forward (K = state_dim), the top layer's backward (K = 2 x
   // action_dim) — gain from the row split as well: SAC cfg 5 157.9 -> 155.6 us/step (profiles/r05_ab_slab_waves.txt); GCRL_NO_SLAB_SPLIT_ALL=1: round 3's rule (K >= 128 only)
   bool bn_split_all = std::getenv("GCRL_NO_SLAB_SPLIT_ALL") == nullptr;
+  bool tg_fold_off = std::getenv("GCRL_NO_TG_FOLD") != nullptr;   // A/B knob: the sampling backward as its own launch (round 4's form)
   int bn_rsplit = 1;          // > 1: K >= 128 slab launches split their rows over ceil(B/128) workgroups (GCRL_NO_BN_RSPLIT=1: off)
   int bn_slots = 0;           // sum-of-squares slots of one BatchNorm layer's dgamma | dbeta (16-column slabs)
   bool heads_fused_off = false;   // GCRL_NO_HEADS_FUSED=1: the BatchNorm actor's heads and its sampling as two launches (rounds 1-4)
@@ -839,7 +840,10 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
     if (kind == GCRL_AGENT_SAC) tb.alpha_const = 0.2f; else tb.alpha_dev = a->alpha_dev;
     tb.gmu = a->ghead; tb.gls = a->ghead + a->Apad; tb.ld_g = 2 * a->Apad;
     tb.B = B; tb.A = A;
-    if (sel_deferred) TRY(launch_tanh_gauss_bwd_select(st, tb, as_d, al_d));
+    // round 5: the top layer's backward slab forms the heads' gradients itself and carries the selection block (bn_slab.hip FOLD) — one launch less
+    const bool tg_fold = a->slab_on() && a->bn_rsplit > 1 && a->bn_split_all && !a->tg_fold_off && bn_slab_bwd_can_fold(B, H, A);
+    if (tg_fold) { /* inside the slab launch below */ }
+    else if (sel_deferred) TRY(launch_tanh_gauss_bwd_select(st, tb, as_d, al_d));
     else TRY(launch_tanh_gauss_bwd(st, tb));
     if (a->slab_on()) {
       // one launch per BatchNorm layer: the dX GEMM(s) of the consumer(s), the ReLU mask, BatchNorm's backward; dz_l takes
@@ -863,6 +867,7 @@ int enqueue_phase1_body(gcrl_agent* a, hipStream_t st, int variant) {
         sb.dgamma = Ga + a->actor.bn_g[l]; sb.dbeta = Ga + a->actor.bn_b[l];
         sb.sumsq_out = (variant & V_FUSED_NORM) ? a->parts_a + a->part_off_bn + l * a->bn_slots : nullptr;
         sb.B = B; sb.H = H;
+        if (l == L - 1 && tg_fold) { sb.fold_tg = &tb; if (sel_deferred) { sb.fold_sel = &as_d; sb.fold_al = &al_d; } }
         sb.rsplit = (l == L - 1 && !a->bn_split_all) ? 1 : a->bn_rsplit; sb.xchg = a->bn_xchg; sb.bar = reinterpret_cast<unsigned int*>(a->bn_bar); sb.status = a->status_dev;
         TRY(launch_bn_linear_bwd_slab(st, sb));
       }
@@ -1209,7 +1214,7 @@ int meet_check(gcrl_agent* a) {
   const unsigned int bits = __atomic_load_n(a->status_host, __ATOMIC_ACQUIRE);
   if (!bits) return GCRL_OK;
   (void)hipDeviceSynchronize();
-  if (a->bn_bar) (void)hipMemset(a->bn_bar, 0, (size_t)bn_slab_bar_words(a->H) * sizeof(unsigned int));
+  if (a->bn_bar && a->bn_xchg) (void)bn_slab_scratch_reset(a->bn_xchg, reinterpret_cast<unsigned int*>(a->bn_bar), a->H, nullptr);
   if (a->rc_bar && a->rc_bar_words) (void)hipMemset(a->rc_bar, 0, (size_t)a->rc_bar_words * sizeof(unsigned int));
   (void)rowtile_reset(a);
   (void)optfuse_reset(a);
@@ -1498,6 +1503,7 @@ int build(gcrl_agent* a) {
   for (auto& w : wants) { *w.first = a->work + used; used += align_up(w.second, 64); }
   TRY(rowtile_reset(a));
   TRY(optfuse_reset(a));
+  if (a->bn_xchg && a->bn_bar) { TRY(bn_slab_scratch_reset(a->bn_xchg, reinterpret_cast<unsigned int*>(a->bn_bar), H, nullptr)); GCRL_HIP(hipDeviceSynchronize()); }
 
   // upload block + pinned mirrors, metrics, events
   a->upload_bytes = sizeof(UploadBlock) + (size_t)kMaxStepsPerCall * B * sizeof(uint32_t);
@@ -2124,6 +2130,11 @@ int gcrl_agent_debug_meet_fault(gcrl_agent* a) {
     return GCRL_OK;
   }
   GCRL_CHECK_ARG(words, "gcrl_agent_debug_meet_fault: this agent's launches contain no waits (meetings off or not applicable)");
+  if (words == a->bn_bar && bn_slab_data_flag()) {   // the slab exchange whose words are their own flags: row group 1 of slab 0 withholds its words (once)
+    const unsigned int on = 1;
+    GCRL_HIP(hipMemcpy(reinterpret_cast<unsigned int*>(a->bn_bar) + 1, &on, sizeof(on), hipMemcpyHostToDevice));
+    return GCRL_OK;
+  }
   GCRL_HIP(hipMemcpy(words, &one, sizeof(one), hipMemcpyHostToDevice));
   return GCRL_OK;
 }

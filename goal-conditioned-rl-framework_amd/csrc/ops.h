@@ -277,7 +277,7 @@ struct BnSlabFwd {
   long long ldx;
   int B, H, K;
   // rsplit > 1 (and B > 128): the rows split over ceil(B/128) workgroups per slab that exchange their column partials through
-  // `xchg` (bn_slab_xchg_floats(H) floats) and wait on `bar` (bn_slab_bar_words(H) words, zero-initialised) — bn_slab.hip
+  // `xchg` (bn_slab_xchg_floats(H) floats) and wait on `bar` (bn_slab_bar_words(H) words); both initialised by bn_slab_scratch_reset — bn_slab.hip
   // `status`: host-visible word that takes MEET_ERR_BN_SLAB when a wait inside the launch times out (meet.h; may be null)
   int rsplit; float* xchg; unsigned int* bar; unsigned int* status;
 };
@@ -290,10 +290,17 @@ struct BnSlabBwd {
   float *dgamma, *dbeta, *sumsq_out;
   int B, H;
   int rsplit; float* xchg; unsigned int* bar; unsigned int* status;   // as in BnSlabFwd
+  // the top layer of the SAC / TQC actor (nup == 2: G[0] / G[1] are the two heads' output gradients): the launch FORMS them itself from the critics'
+  // action gradients (fold_tg: the arguments of launch_tanh_gauss_bwd, whose gmu / gls must be G[0] / G[1]) and, with fold_sel / fold_al, carries
+  // the selection + log-alpha block of launch_tanh_gauss_bwd_select as one more workgroup.  Row-split form only (bn_slab_bwd_can_fold).
+  const struct TanhGaussBwdArgs* fold_tg; const struct ActorSelArgs* fold_sel; const struct AlphaArgs* fold_al;
 };
+bool bn_slab_bwd_can_fold(int B, int H, int A);
 bool bn_slab_ok(int B, int H);
 long long bn_slab_xchg_floats(int H);
 long long bn_slab_bar_words(int H);
+bool bn_slab_data_flag();   // the row groups exchange through words that are their own flags (default) / through a counter meeting (GCRL_SLAB_MEET=1)
+int bn_slab_scratch_reset(float* xchg, unsigned int* bar, int H, hipStream_t st);   // all words "not written yet", counters zero
 int bn_slab_row_split(int B, int H, int n_inputs);   // row groups the launchers use when a layer asks for the split (1: none) on this device
 int launch_bn_linear_fwd_slab(hipStream_t st, const BnSlabFwd& f);
 int launch_bn_linear_bwd_slab(hipStream_t st, const BnSlabBwd& b);

@@ -8,6 +8,7 @@
 #include "meet.h"
 #include "gemm_mfma.h"   // v4f
 #include "sac_heads.h"
+#include "sac_select.h"
 
 #include <algorithm>
 #include <cmath>
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(HeadsSampleArgs h) {
   const int t = (int)blockIdx.x;
   if (t * 16 >= a.B) return;   // (uniform per workgroup)
   gemm_pin(h.mean[y]);
+  const StepCtrl c = *a.cur;   // (requested here: its round trip — the record was rewritten by the previous step's last launch — hides behind the two tiles)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   float x_m, x_l, ss;
   gemm_batch_tile<1, 1, 4>(h.mean[y], t, x_m, ss);
@@ -445,7 +447,6 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(HeadsSampleArgs h) {
   s_mu[4 * lg + wave][li] = x_m;
   s_ls[4 * lg + wave][li] = x_l;
   __syncthreads();
-  const StepCtrl c = *a.cur;
   const int A = a.A;
   if ((int)threadIdx.x < 16 * A) {
     const int r = (int)threadIdx.x / A, j = (int)threadIdx.x - r * A;
@@ -469,80 +470,6 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(HeadsSampleArgs h) {
   }
 }
 
-// (round 4: every operand of a thread's (up to) two rows is requested before any store — the compiler must assume dq aliases
-// q / logp, and each row's later loads used to wait behind its first stores; ops.hip td_loss_kernel has the numbers)
-struct SelRow { float q[kMaxCritics], lp; };
-// the thread's share of sum_b (alpha * logp_b - sel_b); mb: row blockIdx.x * 256 + threadIdx.x only (multi-workgroup form)
-__device__ inline float actor_select_acc(const ActorSelArgs& a, bool mb) {
-  const float alpha = a.alpha_dev ? *a.alpha_dev : a.alpha_const;
-  const int B = a.B, C = a.C, keep = a.C - a.drop;
-  const float gb = -1.0f / (float)B;
-  float acc = 0.f;
-  auto fetch = [&](SelRow& w, int b) {
-    const bool in = b < B;
-#pragma unroll
-    for (int k = 0; k < kMaxCritics; ++k) w.q[k] = (in && k < C) ? a.q[(long long)k * B + b] : INFINITY;
-    w.lp = in ? a.logp[b] : 0.f;
-  };
-  auto finish = [&](SelRow& w, int b) {
-    float* q = w.q;
-    float sel;
-    if (C == 2 && a.drop == 0) {
-      // torch.min(q1, q2): gradient to the smaller, split on ties
-      sel = fminf(q[0], q[1]);
-      const float w0 = q[0] < q[1] ? 1.f : (q[0] == q[1] ? 0.5f : 0.f);
-      a.dq[b] = gb * w0;
-      a.dq[(long long)B + b] = gb * (1.f - w0);
-    } else {
-      // rank of each critic in the ascending (stable) order; the lowest `keep` carry gradient
-      const float gk = gb / (float)keep;
-#pragma unroll
-      for (int k = 0; k < kMaxCritics; ++k) {
-        if (k < C) {
-          int rank = 0;
-#pragma unroll
-          for (int j = 0; j < kMaxCritics; ++j)
-            if (j < C && (q[j] < q[k] || (q[j] == q[k] && j < k))) ++rank;
-          a.dq[(long long)k * B + b] = rank < keep ? gk : 0.f;
-        }
-      }
-#pragma unroll
-      for (int pass = 0; pass < kMaxCritics - 1; ++pass)
-#pragma unroll
-        for (int k = 0; k < kMaxCritics - 1 - pass; ++k) {
-          const float lo = fminf(q[k], q[k + 1]), hi = fmaxf(q[k], q[k + 1]);
-          q[k] = lo; q[k + 1] = hi;
-        }
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < kMaxCritics; ++k) if (k < keep) s = __fadd_rn(s, q[k]);
-      sel = s / (float)keep;
-    }
-    acc += __fsub_rn(__fmul_rn(alpha, w.lp), sel);
-  };
-  if (mb) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    SelRow w;
-    fetch(w, b);
-    if (b < B) finish(w, b);
-    return acc;
-  }
-  for (int b0 = threadIdx.x; b0 < B; b0 += 2 * blockDim.x) {
-    const int b1 = b0 + blockDim.x;
-    SelRow w0, w1;
-    fetch(w0, b0);
-    fetch(w1, b1);
-    finish(w0, b0);
-    if (b1 < B) finish(w1, b1);
-  }
-  return acc;
-}
-__device__ inline void actor_select_body(const ActorSelArgs& a, float* scratch) {
-  const StepCtrl c = *a.cur;
-  const float acc = block_sum(actor_select_acc(a, false), scratch);
-  if (threadIdx.x == 0) a.metrics[(long long)c.metrics_slot * kMetricFloats + MET_ACTOR_LOSS] = acc / (float)a.B;
-}
-
 __global__ __launch_bounds__(1024) void actor_select_kernel(ActorSelArgs a) {
   __shared__ float scratch[16];
   actor_select_body(a, scratch);
@@ -552,46 +479,14 @@ __device__ inline void tanh_gauss_bwd_body(const TanhGaussBwdArgs& a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.B * a.A) return;
   const int b = i / a.A, j = i - b * a.A;
-  const StepCtrl c = *a.cur;
+  const long long slot_off = a.act_slot_stride ? (long long)a.cur->batch_slot * a.act_slot_stride : 0;
   const float alpha = a.alpha_dev ? *a.alpha_dev : a.alpha_const;
-  float da = 0.f;
-  for (int k = 0; k < a.C; ++k) da += a.dact[(long long)k * a.dact_stride + (long long)b * a.ld_dact + j];
-  const float t = a.act[(long long)c.batch_slot * a.act_slot_stride + (long long)b * a.ld_act + j];
-  const float om = 1.0f - t * t;
-  const float wlp = alpha / (float)a.B;  // d loss / d logp_b
-  // d/dx [ -log(1 - tanh(x)^2 + 1e-8) ] = 2 t (1-t^2) / (1 - t^2 + 1e-8); the Normal terms of
-  // the log-prob cancel through the reparameterisation (x - mu = eps*sd)
-  const float dx = da * om + wlp * (2.0f * t * om / (om + 1e-8f));
-  const float lsr = a.ls_raw[(long long)b * a.ld_head + j];
-  const bool in_range = lsr >= -20.0f && lsr <= 2.0f;  // clamp backward
-  a.gmu[(long long)b * a.ld_g + j] = dx;
-  a.gls[(long long)b * a.ld_g + j] = in_range ? (dx * a.eps[i] * a.std[i] - wlp) : 0.f;
+  float gmu, gls;
+  tanh_gauss_bwd_elem(a, slot_off, alpha, b, j, gmu, gls);
+  a.gmu[(long long)b * a.ld_g + j] = gmu;
+  a.gls[(long long)b * a.ld_g + j] = gls;
 }
-
 __global__ __launch_bounds__(256) void tanh_gauss_bwd_kernel(TanhGaussBwdArgs a) { tanh_gauss_bwd_body(a); }
-
-__device__ inline void alpha_body(const AlphaArgs& a, float* scratch) {
-  const StepCtrl c = *a.cur;
-  float* met = a.metrics + (long long)c.metrics_slot * kMetricFloats;
-  if (!c.do_alpha) {  // `gradient_step <= alpha_min_steps: return 0.0`
-    if (threadIdx.x == 0 && a.phase != 1) { met[MET_ALPHA_LOSS] = 0.f; met[MET_ALPHA] = *a.alpha; }
-    return;
-  }
-  if (a.phase != 1) {
-    float s = 0.f;
-    for (int b = threadIdx.x; b < a.B; b += blockDim.x) s += a.logp[b] + a.target_entropy;
-    s = block_sum(s, scratch);
-    if (threadIdx.x == 0) {
-      const float mean_x = s / (float)a.B;
-      met[MET_ALPHA_LOSS] = -(*a.log_alpha * mean_x);
-      *a.grad_out = -mean_x;
-    }
-  }
-  if (a.phase != 0 && threadIdx.x == 0) {
-    const AlphaStep st{a.log_alpha, a.m, a.v, a.alpha, a.grad_out, a.beta2, a.w1, a.w2, a.eps, a.metrics};
-    alpha_step(st, c);
-  }
-}
 
 __global__ __launch_bounds__(1024) void alpha_update_kernel(AlphaArgs a) {
   __shared__ float scratch[16];

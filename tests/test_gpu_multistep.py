@@ -256,9 +256,11 @@ def test_sampled_noisy_updates_track_oracle(gcrl, kind):
     print(f"sampled noisy updates [{kind}]: worst relative tuple error {worst:.2e}")
 
 
-@pytest.mark.parametrize("kind,H,L,B", [("SAC", 256, 3, 512), ("TD3", 256, 3, 2048), ("DDPG", 256, 3, 256)])
+@pytest.mark.parametrize("kind,H,L,B", [("SAC", 256, 3, 512), ("TD3", 256, 3, 2048), ("DDPG", 256, 3, 256), ("TQC", 64, 2, 200)])
 def test_failed_meeting_inside_a_launch_is_reported_and_the_handle_recovers(gcrl, tmp_path, kind, H, L, B):
-    """SAC at batch 512: the BatchNorm slab launches split their rows over four workgroups that wait for each other inside the
+    """TQC at batch 200 (layer-per-launch critics, round 5): the only waits are those of the BatchNorm slab launches, whose row groups
+    exchange their column partials as words that are their own flags (csrc/bn_slab.hip slab_exchange_df) — the hook makes row group 1 of
+    slab 0 withhold its words once.  SAC at batch 512: the BatchNorm slab launches split their rows over four workgroups that wait for each other inside the
     launch, and so do the role workgroups of the twin-critic row chains (csrc/meet.h).  TD3 at batch 2048: the critic phase's
     online-critic workgroups wait for the target roles of their rows (producers / consumers: 1 024 workgroups, not all resident);
     DDPG at batch 256 (round 4): the same two roles inside the fused launch (k_split).  A wait that times out used to leave NaN

@@ -25,7 +25,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--c
 
 # translation unit -> substrings of the (mangled) kernel names that must pass, and must be present
 UNITS = {
-    "bn_slab.hip": ["bn_linear_fwd_slab_kernel", "bn_linear_bwd_slab_kernel"],
+    "bn_slab.hip": ["bn_linear_fwd_slab_kernel", "bn_linear_bwd_slab_kernel", "bn_linear_bwd_slab_fold_kernel"],
     "rowchain.hip": ["rowchain_split_kernel", "rowchain_ddpg_kernel"],
     "rowtile.hip": ["rowtile_ddpg_kernel"],
     "gemm_mfma.hip": ["gemm_tiled_kernel"],
@@ -114,18 +114,20 @@ def scratch_report(asm_text, unit):
 # Third lint (round 5): the fused dW + optimiser launch (dw_adam.hip) hands a workgroup's sum of squares to every other workgroup as
 # ONE 8-byte word that is its own flag — no arrival follows it, so there is nothing to release — but the word must leave as a
 # write-through store and every poll of it must bypass the L1: a plain store or load here would be a silent stale read.
-def slot_report(asm_text):
+# The row groups of a BatchNorm slab (bn_slab.hip slab_exchange_df, round 5) exchange their column partials the same way: the row-split
+# instantiations (template argument NT = 1) must contain such stores and loads.
+def slot_report(asm_text, unit="dw_adam.hip", patterns=("dw_adam_kernel",)):
     bad, lines = 0, []
     for name, body in kernels(asm_text):
-        if "dw_adam_kernel" not in name:
+        if not any(p in name for p in patterns):
             continue
         st = [l for l in body if re.match(r"^\s*global_store_dwordx2\s.*\bsc1\b", l)]
         ld = [l for l in body if re.match(r"^\s*global_load_dwordx2\s.*\bsc1\b", l)]
         ok = len(st) >= 1 and len(ld) >= 1
-        lines.append(f"dw_adam.hip: {name}: {len(st)} write-through slot store(s), {len(ld)} L1-bypassing slot loads: {'ok' if ok else 'FAIL'}")
+        lines.append(f"{unit}: {name}: {len(st)} write-through slot store(s), {len(ld)} L1-bypassing slot loads: {'ok' if ok else 'FAIL'}")
         bad += 0 if ok else 1
     if not lines:
-        lines.append("dw_adam.hip: dw_adam_kernel not found (pattern changed?)")
+        lines.append(f"{unit}: none of {patterns} found (pattern changed?)")
         bad += 1
     return bad, lines
 
@@ -177,6 +179,11 @@ def main():
         b3, lines = slot_report(open(os.path.join(out_dir, "dw_adam.hip.s")).read())
         report += lines
         sbad += b3
+        # (mangled names: bn_linear_fwd_slab_kernelILb<VEC>ELi<NT>ELi<WV>EE / bn_linear_bwd_slab_kernelILi<NT>ELi<WV>EE)
+        b4, lines = slot_report(open(os.path.join(out_dir, "bn_slab.hip.s")).read(), "bn_slab.hip",
+                                ("bn_linear_fwd_slab_kernelILb1ELi1E", "bn_linear_fwd_slab_kernelILb0ELi1E", "bn_linear_bwd_slab_kernelILi1E", "bn_linear_bwd_slab_fold_kernel"))
+        report += lines
+        sbad += b4
     print("\n".join(report))
     print("release check:", "PASS" if bad == 0 else f"FAIL ({bad})")
     print("scratch check:", "PASS" if sbad == 0 else f"FAIL ({sbad})")
