@@ -158,6 +158,11 @@ struct gcrl_agent {
   // action_dim) — gain from the row split as well: SAC cfg 5 157.9 -> 155.6 us/step (profiles/r05_ab_slab_waves.txt); GCRL_NO_SLAB_SPLIT_ALL=1: round 3's rule (K >= 128 only)
   bool bn_split_all = std::getenv("GCRL_NO_SLAB_SPLIT_ALL") == nullptr;
   bool tg_fold_off = std::getenv("GCRL_NO_TG_FOLD") != nullptr;   // A/B knob: the sampling backward as its own launch (round 4's form)
+  // round 5: the actor's heads + sampling inside the row-chain launches that consume the actions (rowchain.h HeadsFold); GCRL_NO_HEADS_FOLD=1: the
+  // heads + sampling launch of sac_heads.h.  hf_*: what sac_actor_forwards leaves for the chain launches of the same step
+  bool heads_fold_off = std::getenv("GCRL_NO_HEADS_FOLD") != nullptr;
+  const float *hf_eps_next = nullptr, *hf_eps_cur = nullptr;
+  int hf_nf = 0;
   int bn_rsplit = 1;          // > 1: K >= 128 slab launches split their rows over ceil(B/128) workgroups (GCRL_NO_BN_RSPLIT=1: off)
   int bn_slots = 0;           // sum-of-squares slots of one BatchNorm layer's dgamma | dbeta (16-column slabs)
   bool heads_fused_off = false;   // GCRL_NO_HEADS_FUSED=1: the BatchNorm actor's heads and its sampling as two launches (rounds 1-4)
@@ -414,6 +419,7 @@ struct ActorFwd {
   float *z, *h, *head, *bn_part;       // z [B,H] scratch, h [L][B][H] (save) or [2][B][H] ping-pong, head [B][2*Apad]
 };
 
+bool heads_fold_on(const gcrl_agent* a);
 int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, int nf, Launches* extra) {
   const NetSpec& net = a->actor;
   const float* P = a->P_actor();
@@ -473,6 +479,10 @@ int sac_actor_forward_multi(gcrl_agent* a, hipStream_t st, const ActorFwd* f, in
   // round 5: the heads and the sampling as ONE launch (sac_heads.h) unless other problems ride in the heads' launch (the layer-per-
   // launch path's co-scheduled critic chains) or the head problems are not on the k-split 16x16 form (GCRL_NO_HEADS_FUSED=1: A/B knob)
   const bool heads_fused = !a->heads_fused_off && !co_scheduled && gemm_shape_of(v[0]) == 1;
+  if (heads_fold_on(a) && slab && !co_scheduled) {   // the chain launches form the heads' outputs and sample themselves (rowchain.h HeadsFold)
+    a->hf_eps_next = f[0].eps; a->hf_eps_cur = nf == 2 ? f[1].eps : nullptr; a->hf_nf = nf;
+    return GCRL_OK;
+  }
   if (!heads_fused) {
     if (co_scheduled) v.insert(v.end(), extra->steps[net.L].begin(), extra->steps[net.L].end());
     for (size_t o = 0; o < v.size(); o += kMaxProb) TRY(launch_gemm_batch(st, v.data() + o, (int)std::min<size_t>(kMaxProb, v.size() - o)));

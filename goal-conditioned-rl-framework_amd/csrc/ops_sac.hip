@@ -18,7 +18,7 @@ namespace gcrl {
 namespace {
 
 constexpr float kBnEps = 1e-5f;       // nn.BatchNorm1d default eps
-constexpr float kBnMomentum = 0.1f;   // default momentum
+// (kBnMomentum, bn_running_update, tanh_gauss_elem: sac_select.h)
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll
@@ -367,27 +367,6 @@ __device__ inline void tanh_gauss_fwd_body(const TanhGaussArgs& a) {
   if (b >= a.B) return;
   tanh_gauss_fwd_row(a, b);
 }
-// one (row, action) element of SACActorModel.sample: action t, std sd, the log-prob term, the eps used
-struct TgElem { float t, sd, term, e; };
-__device__ inline TgElem tanh_gauss_elem(const TanhGaussArgs& a, const StepCtrl& c, float mu, float ls_raw, long long i) {
-  const float ls = fminf(fmaxf(ls_raw, -20.0f), 2.0f);
-  // exp / tanh / log go through fp64 and round once: log(1 - tanh^2 + 1e-8) amplifies a 1-ulp
-  // tanh difference by 2|t|/(1-t^2), so the closer to correctly rounded, the closer to torch
-  const float sd = (float)exp((double)ls);
-  const float e = a.eps ? a.eps[i]
-                        : hash_normal(a.seed + (unsigned long long)a.rng_stream,
-                                      (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
-  const float x = __fadd_rn(mu, __fmul_rn(e, sd));  // rsample: loc + eps*scale
-  const float t = (float)tanh((double)x);
-  // Normal(mu, sd).log_prob(x) - log(1 - tanh(x)^2 + 1e-8), every op rounded to fp32 as torch does
-  const float df = __fsub_rn(x, mu);
-  const float var = __fmul_rn(sd, sd);
-  float term = __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(df, df), __fmul_rn(2.0f, var)), (float)log((double)sd)),
-                         0.91893853320467274f);
-  const float om = __fadd_rn(__fsub_rn(1.0f, __fmul_rn(t, t)), 1e-8f);
-  term = __fsub_rn(term, (float)log((double)om));
-  return {t, sd, term, e};
-}
 __device__ inline void tanh_gauss_fwd_row(const TanhGaussArgs& a, int b) {
   const StepCtrl c = *a.cur;
   float* act = a.act + (long long)c.batch_slot * a.act_slot_stride + (long long)b * a.ld_act;
@@ -402,20 +381,6 @@ __device__ inline void tanh_gauss_fwd_row(const TanhGaussArgs& a, int b) {
     if (a.save_eps) { a.save_eps[i] = r.e; a.save_std[i] = r.sd; }
   }
   if (!a.deterministic && a.logp) a.logp[b] = lp;
-}
-
-// running statistics from the batch statistics of the slab launches (bn_slab.hip), momentum 0.1, unbiased variance
-__device__ inline void bn_running_update(const BnRunning& r) {
-  const float ub = r.B > 1 ? (float)r.B / (float)(r.B - 1) : 1.0f;
-  for (int e = threadIdx.x; e < r.layers * r.H; e += blockDim.x) {
-    const int l = e / r.H, c = e - l * r.H;
-    float rm = r.rmean[e], rv = r.rvar[e];
-    for (int i = 0; i < r.n; ++i) {
-      rm = (1.0f - kBnMomentum) * rm + kBnMomentum * r.bstat[i][(2 * l) * r.H + c];
-      rv = (1.0f - kBnMomentum) * rv + kBnMomentum * (r.bstat[i][(2 * l + 1) * r.H + c] * ub);
-    }
-    r.rmean[e] = rm; r.rvar[e] = rv;
-  }
 }
 
 __global__ void tanh_gauss_fwd_kernel(TanhGaussArgs a) {

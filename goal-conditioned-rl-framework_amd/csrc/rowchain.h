@@ -296,7 +296,23 @@ struct RowChainArgs {
 // their backward chains.  All role x block workgroups of a launch are resident at once (<= 2 per CU at SAC's 512 rows: the
 // launcher checks), so a waiting workgroup never keeps an awaited one off the chip; a wait that times out poisons the gradient
 // with NaN instead of hanging.  Same per-row arithmetic: bitwise the results of the two-launch form.
-int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part);
+// SAC (round 5): the BatchNorm actor's two heads (src/model.py:114-115) and its sampling (:125-141) INSIDE the chain launches — before, one launch
+// of 11 us between the actor's last slab launch and the critic phase (sac_heads.h).  A role workgroup that needs actions takes the last hidden
+// activation of ITS rows, forms both heads' outputs (rows_head) and samples: the target-critic roles of phase 0 the next action a' (no_grad pass
+// on next_state; role 0 also publishes logp_next for the online roles' TD target), the critic roles of phase 1 pi(s) (role 0 also writes what the
+// actor's backward and the actor loss read: pi, logp, eps, std, the heads' outputs).  One more workgroup of the phase-0 launch applies the
+// BatchNorm running-statistics update the sampling launch used to carry.
+struct HeadsFold {
+  int on;
+  const float* P;                          // the actor's parameter block
+  long long w_mean, b_mean, w_ls, b_ls;    // offsets of the two heads ([A][H] weights, [A] biases)
+  const float* h_next; const float* h_cur; // [B][H] last hidden activation of actor(next_state) / actor(state)
+  const float* eps_next; const float* eps_cur;   // injected N(0,1) [B][A] or null (counter hash: streams 1 / 2 of the seed, as the sampling launch)
+  float* logp_next;                        // [B]
+  float* pi; float* logp; float* save_eps; float* save_std; float* head;   // phase 1: [B][Apad], [B], [B][A], [B][A], [B][2*Apad] (mu | ls_raw)
+  BnRunning run;                           // layers > 0: the running-statistics rider (phase 0)
+};
+int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part, const HeadsFold* hf = nullptr);
 bool rowchain_merge_ok(int rg, int ldl, int A, int H, int C, int B);   // part 3 admissible: all its workgroups resident at once on an unshared device
 
 // Batched actor inference (select_action, src/agent.py:1345-1366) as one row-block launch: 4 observation

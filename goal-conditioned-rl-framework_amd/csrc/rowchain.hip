@@ -11,6 +11,7 @@
 #include "rowchain.h"
 #include "norm_math.h"
 #include "meet.h"
+#include "sac_select.h"
 
 #include <algorithm>
 
@@ -145,7 +146,7 @@ __device__ inline void stage(float* dst, const float* src, int n) {
 }
 
 template <int RG>
-__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid);
+__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid, const HeadsFold* hf = nullptr);
 
 template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs a) {
@@ -437,8 +438,64 @@ __device__ inline bool rc_meet(unsigned int* words, int arrivals, bool wait, uns
 __device__ inline void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// the two heads of the BatchNorm actor on the rows in `hrows` (global [.][H], this block's rows: contiguous) and the sampling (rowchain.h HeadsFold):
+// action -> X0's action columns, log-prob terms -> sm3; mu / ls_raw stay in sm / sm2; eps / std -> es[r * 16 + o] / es[R * 16 + r * 16 + o].
+// hw_m: LDS room for 2 * A * H floats; es: 2 * R * 16 floats.  Two steps, like the kernels' other prologue staging: heads_request puts every
+// global load in flight (into registers) BEFORE the caller's own staging waits for anything — requested after it, the three regions were three more
+// dependent round trips in front of the first layer pass (measured: the fold gained 2 us of the launch's 11).
+struct HeadsStaged { Staged<4> wm, wl, h; float bm, bl; };
 template <int RG>
-__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid) {
+__device__ inline void heads_request(HeadsStaged& g, const HeadsFold& f, const float* hrows, int H, int A, int rv) {
+  seg_load(g.wm, f.P + f.w_mean, A * H);
+  seg_load(g.wl, f.P + f.w_ls, A * H);
+  seg_load(g.h, hrows, rv * H);
+  const int tid = threadIdx.x;
+  g.bm = tid < A ? f.P[f.b_mean + tid] : 0.f;
+  g.bl = tid < A ? f.P[f.b_ls + tid] : 0.f;
+}
+template <int RG>
+__device__ inline void heads_sample_rows(const HeadsStaged& g, const HeadsFold& f, const float* hrows, const float* eps, int rng_stream, unsigned long long seed,
+                                         const StepCtrl& c, float* X0, float* X1, int ldl, int H, int S, int A, long long row0, int rv,
+                                         float* hw_m, float* hb, float* sm, float* sm2, float* sm3, float* es) {
+  constexpr int R = 4 * RG;
+  const int tid = threadIdx.x;
+  seg_store(g.wm, hw_m, f.P + f.w_mean, A * H);
+  seg_store(g.wl, hw_m + A * H, f.P + f.w_ls, A * H);
+  if (tid < A) { hb[32 + tid] = g.bm; hb[48 + tid] = g.bl; }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = tid + u * kRowThreads, r = i / H, kk = i - r * H;
+    if (i < R * H) X1[r * ldl + kk] = g.h.v[u];             // (rows >= rv: zeros, seg_load's bound)
+  }
+  for (int i = tid + 4 * kRowThreads; i < R * H; i += kRowThreads) {
+    const int r = i / H, kk = i - r * H;
+    X1[r * ldl + kk] = r < rv ? hrows[(long long)r * H + kk] : 0.f;
+  }
+  __syncthreads();
+  rows_head<RG>(X1, ldl, H, hw_m, H, hb + 32, A, EPI_NONE, sm);
+  rows_head<RG>(X1, ldl, H, hw_m + A * H, H, hb + 48, A, EPI_NONE, sm2);
+  __syncthreads();
+  if (tid < R * A) {
+    const int r = tid / A, o = tid - r * A;
+    float t = 0.f;
+    if (r < rv) {
+      const TgElem e = tanh_gauss_elem_raw(eps, seed, rng_stream, c, sm[r * 16 + o], sm2[r * 16 + o], (row0 + r) * A + o);
+      t = e.t;
+      sm3[r * 16 + o] = e.term;
+      es[r * 16 + o] = e.e; es[R * 16 + r * 16 + o] = e.sd;
+    }
+    X0[r * ldl + S + o] = t;
+  }
+  __syncthreads();
+}
+__device__ inline float logp_row(const float* sm3, int r, int A) {
+  float lp = 0.f;
+  for (int j = 0; j < A; ++j) lp = __fadd_rn(lp, sm3[r * 16 + j]);   // in action order, as the sampling launch adds
+  return lp;
+}
+
+template <int RG>
+__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid, const HeadsFold* hf) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int R = 4 * RG;
   const int ldl = a.ldl, H = a.critic[0].H, S = a.S, A = a.A, B = a.B, C = a.C;
@@ -455,6 +512,11 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
   const int nblk = (B + R - 1) / R;
   const int role = bid / nblk;
   const int blk = bid - role * nblk;
+  const bool fold = hf != nullptr && hf->on != 0;
+  if (fold && phase == 0 && part != 2 && role == 2 * C) {   // the launch's extra workgroup: BatchNorm's running statistics (input 0's batch, then input 1's)
+    if (blk == 0 && hf->run.layers) bn_running_update(hf->run);
+    return;
+  }
   const long long row0 = (long long)blk * R;
   const int rv = min(R, B - (int)row0);
   const long long BH = (long long)B * H;
@@ -470,8 +532,10 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
     // ---- target critic `role` on [ns | a'] (a' given: SAC; else the target actor runs first: TD3)
     const int k = role;
     const float* ns_rows = a.nsa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
-    const int jp_ns = max(a.tactor.jpad0, a.tcritic[0].jpad0), nc_ns = a.given_next ? S + A : S;
-    float* hw_ta = hw; float* hw_tc = hw + A * H;
+    const int jp_ns = max(a.tactor.jpad0, a.tcritic[0].jpad0), nc_ns = (a.given_next && !fold) ? S + A : S;
+    float* hw_ta = hw; float* hw_tc = hw + (fold ? 2 * A : A) * H;
+    HeadsStaged hst;
+    if (fold) heads_request<RG>(hst, *hf, hf->h_next + row0 * H, H, A, rv);
     load_rows<RG>(X0, ldl, ns_rows, a.ldx, nc_ns, jp_ns, rv);
     stage(hw_tc, a.tcritic[k].P + a.tcritic[k].w[a.tcritic[k].L], H);
     if (tid == 0) hb[16] = a.tcritic[k].P[a.tcritic[k].b[a.tcritic[k].L]];
@@ -485,6 +549,10 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
         if (r < rv) e = a.noise ? a.noise[i] : hash_normal(a.seed, (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
         part_[tid] = fminf(fmaxf(__fmul_rn(e, a.policy_noise), -a.noise_clamp), a.noise_clamp);
       }
+    }
+    if (fold) {   // a' = actor.sample(next_state) for these rows; role 0 publishes logp_next (the online roles read it after the meeting)
+      heads_sample_rows<RG>(hst, *hf, hf->h_next + row0 * H, hf->eps_next, 1, a.seed, c, X0, X1, ldl, H, S, A, row0, rv, hw, hb, sm, sm2, sm3, part_);
+      if (k == 0 && tid < rv) st_agent(hf->logp_next + row0 + tid, logp_row(sm3, tid, A));
     }
     __syncthreads();
     float* h;
@@ -548,7 +616,7 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
         const float rew = a.rbuf[(long long)c.batch_slot * a.slot_rd + row0 + r], dn = a.dbuf[(long long)c.batch_slot * a.slot_rd + row0 + r];
         const float t0 = ld_agent(a.qt + row0 + r), t1 = C > 1 ? ld_agent(a.qt + (long long)B + row0 + r) : t0;
         float tq = a.target_kind == TGT_DDPG ? t0 : fminf(t0, t1);
-        if (a.target_kind == TGT_MIN_ENT) tq = __fsub_rn(tq, __fmul_rn(a.alpha, a.logp_next[row0 + r]));
+        if (a.target_kind == TGT_MIN_ENT) tq = __fsub_rn(tq, __fmul_rn(a.alpha, fold ? ld_agent(a.logp_next + row0 + r) : a.logp_next[row0 + r]));
         float y = __fadd_rn(rew, __fmul_rn(__fmul_rn(a.gamma, __fsub_rn(1.0f, dn)), tq));
         if (a.target_kind == TGT_DDPG) y = fminf(fmaxf(y, a.clamp_lo), 0.0f);
         const float q = a.q[(long long)k * B + row0 + r];
@@ -573,17 +641,36 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
     const int k = role;
     const float* s_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
     const int jpad = a.critic[0].jpad0;
+    HeadsStaged hst;
+    if (fold) heads_request<RG>(hst, *hf, hf->h_cur + row0 * H, H, A, rv);
     for (int i = tid; i < R * jpad; i += kRowThreads) {
       const int r = i / jpad, cc = i - r * jpad;
       float v = 0.f;
       if (r < rv) {
         if (cc < S) v = s_rows[(long long)r * a.ldx + cc];
-        else if (cc < S + A) v = a.pi[(row0 + r) * a.Apad + (cc - S)];
+        else if (cc < S + A && !fold) v = a.pi[(row0 + r) * a.Apad + (cc - S)];
       }
-      X0[r * ldl + cc] = v;
+      if (!fold || cc < S || cc >= S + A) X0[r * ldl + cc] = v;
     }
     stage(hw, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
     if (tid == 0) hb[0] = a.critic[k].P[a.critic[k].b[a.critic[k].L]];
+    if (fold) {   // pi(s) = actor.sample(states) for these rows; role 0 writes what the actor's backward and the actor loss read
+      float* hw_m = hw + H;
+      heads_sample_rows<RG>(hst, *hf, hf->h_cur + row0 * H, hf->eps_cur, 2, a.seed, c, X0, X1, ldl, H, S, A, row0, rv, hw_m, hb, sm, sm2, sm3, part_);
+      if (k == 0) {
+        if (tid < R * A) {
+          const int r = tid / A, o = tid - r * A;
+          if (r < rv) {
+            const long long i = (row0 + r) * A + o;
+            hf->pi[(row0 + r) * a.Apad + o] = X0[r * ldl + S + o];
+            hf->save_eps[i] = part_[r * 16 + o]; hf->save_std[i] = part_[R * 16 + r * 16 + o];
+            hf->head[(row0 + r) * 2 * a.Apad + o] = sm[r * 16 + o];
+            hf->head[(row0 + r) * 2 * a.Apad + a.Apad + o] = sm2[r * 16 + o];
+          }
+        }
+        if (tid < rv) hf->logp[row0 + tid] = logp_row(sm3, tid, A);
+      }
+    }
     __syncthreads();
     float* h = mlp_hidden<RG>(a.critic[k], X0, X1, X2, ldl, part_ + R * 16, a.hC2 + (long long)k * a.critic[k].L * BH, BH, row0, rv);
     rows_head<RG>(h, ldl, H, hw, H, hb, 1, EPI_NONE, sm);
@@ -634,6 +721,11 @@ template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArgs a, int phase, int part) {
   kernarg_warm<sizeof(RowChainArgs) + 8>();
   rowchain_split_body<RG>(a, phase, part, (int)blockIdx.x);
+}
+template <int RG>
+__global__ __launch_bounds__(kRowThreads) void rowchain_split_heads_kernel(RowChainArgs a, int phase, int part, HeadsFold hf) {
+  kernarg_warm<sizeof(RowChainArgs) + 8 + sizeof(HeadsFold)>();
+  rowchain_split_body<RG>(a, phase, part, (int)blockIdx.x, &hf);
 }
 
 // `row_at(i)`: element i of the launch's input rows ([n][ld_obs] flattened); `noise_at(t)`: exploration noise of action element t —
@@ -759,7 +851,7 @@ __global__ void wt_rebuild_kernel(RowNet net, float* Wt) {
 
 size_t rowchain_lds_bytes(int rg, int ldl, int A, int H, int C) {
   const int R = 4 * rg;
-  return (size_t)(4 * R * ldl + (rg == 1 ? 2 : 1) * 4 * R * kRowChunk + 4 * R * 16 + std::max(std::max(2 * A + 1, A + 2 * C), C * (A + 1)) * H + 32) * sizeof(float);
+  return (size_t)(4 * R * ldl + (rg == 1 ? 2 : 1) * 4 * R * kRowChunk + 4 * R * 16 + std::max(std::max(2 * A + 1, A + 2 * C), C * (A + 1)) * H + 96) * sizeof(float);   // (the trailing floats: head biases — hb[0 .. 64))
 }
 
 // the merged (part 3) launches wait inside the kernel: all 2C x nblk workgroups of the larger one must be resident at once
@@ -769,7 +861,11 @@ bool rowchain_merge_ok(int rg, int ldl, int A, int H, int C, int B) {
   const void* k = rg == 1 ? (const void*)rowchain_split_kernel<1> : (rg == 2 ? (const void*)rowchain_split_kernel<2> : (const void*)rowchain_split_kernel<4>);
   if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
   const long long nblk = (B + 4 * rg - 1) / (4 * rg);
-  return 2LL * C * nblk <= meet_capacity(k, kRowThreads, lds);
+  // (the form with the actor's heads inside — SAC, rowchain.h HeadsFold — is another kernel with its own register count: both must fit)
+  const void* kh = rg == 1 ? (const void*)rowchain_split_heads_kernel<1> : (rg == 2 ? (const void*)rowchain_split_heads_kernel<2> : (const void*)rowchain_split_heads_kernel<4>);
+  if (lds > 64 * 1024 && hipFuncSetAttribute(kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+  // (its extra workgroup has the launch's LAST index and waits for nobody: it may start once a role workgroup has finished)
+  return 2LL * C * nblk <= meet_capacity(k, kRowThreads, lds) && 2LL * C * nblk <= meet_capacity(kh, kRowThreads, lds);
 }
 
 int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
@@ -796,7 +892,7 @@ int launch_rowchain_ddpg(hipStream_t st, const RowChainArgs& a, int rg) {
   return go(rowchain_ddpg_kernel<4>);
 }
 
-int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part) {
+int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int phase, int part, const HeadsFold* hf) {
   GCRL_CHECK_ARG(rg == 1 || rg == 2 || rg == 4, "rowchain: rows per block must be 4, 8 or 16");
   GCRL_CHECK_ARG(a.critic[0].H % 4 == 0 && a.ldl % 4 == 0 && a.A <= 16 && a.C >= 1 && a.C <= 2 && (phase == 0 || phase == 1) &&
                      (part >= 1 && part <= 3) && (part != 3 || a.bar) && (phase == 0 || a.p_critic_only) && a.qt,
@@ -819,6 +915,23 @@ int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int pha
     GCRL_HIP(hipGetLastError());
     return GCRL_OK;
   };
+  if (hf && hf->on) {   // the BatchNorm actor's heads and sampling inside the launch (rowchain.h HeadsFold); phase 0 carries the running-statistics workgroup
+    GCRL_CHECK_ARG(a.given_next && a.p_critic_only && part != 2 && a.A <= 16, "rowchain split: the folded heads need the SAC form (given_next, critic-only actor phase)");
+    const int grid = roles * nblk + ((phase == 0 && hf->run.layers) ? 1 : 0);
+    auto goh = [&](auto kern) -> int {
+      static thread_local size_t raised = 0;
+      if (lds > 64 * 1024 && lds > raised) {
+        GCRL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = lds;
+      }
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, st, a, phase, part, *hf);
+      GCRL_HIP(hipGetLastError());
+      return GCRL_OK;
+    };
+    if (rg == 1) return goh(rowchain_split_heads_kernel<1>);
+    if (rg == 2) return goh(rowchain_split_heads_kernel<2>);
+    return goh(rowchain_split_heads_kernel<4>);
+  }
   if (rg == 1) return go(rowchain_split_kernel<1>);
   if (rg == 2) return go(rowchain_split_kernel<2>);
   return go(rowchain_split_kernel<4>);

@@ -27,6 +27,48 @@ __device__ inline float sel_block_sum(float v, float* scratch) {
   return s;
 }
 
+// one (row, action) element of SACActorModel.sample: action t, std sd, the log-prob term, the eps used
+struct TgElem { float t, sd, term, e; };
+// (eps: injected N(0,1) [B][A] or null: the counter hash, stream `rng_stream` of `seed`, at the step's counter + i)
+__device__ inline TgElem tanh_gauss_elem_raw(const float* eps, unsigned long long seed, int rng_stream, const StepCtrl& c, float mu, float ls_raw, long long i) {
+  const float ls = fminf(fmaxf(ls_raw, -20.0f), 2.0f);
+  // exp / tanh / log go through fp64 and round once: log(1 - tanh^2 + 1e-8) amplifies a 1-ulp
+  // tanh difference by 2|t|/(1-t^2), so the closer to correctly rounded, the closer to torch
+  const float sd = (float)exp((double)ls);
+  const float e = eps ? eps[i]
+                        : hash_normal(seed + (unsigned long long)rng_stream,
+                                      (((unsigned long long)c.rng_hi << 32) | c.rng_lo) + (unsigned long long)i);
+  const float x = __fadd_rn(mu, __fmul_rn(e, sd));  // rsample: loc + eps*scale
+  const float t = (float)tanh((double)x);
+  // Normal(mu, sd).log_prob(x) - log(1 - tanh(x)^2 + 1e-8), every op rounded to fp32 as torch does
+  const float df = __fsub_rn(x, mu);
+  const float var = __fmul_rn(sd, sd);
+  float term = __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(df, df), __fmul_rn(2.0f, var)), (float)log((double)sd)),
+                         0.91893853320467274f);
+  const float om = __fadd_rn(__fsub_rn(1.0f, __fmul_rn(t, t)), 1e-8f);
+  term = __fsub_rn(term, (float)log((double)om));
+  return {t, sd, term, e};
+}
+__device__ inline TgElem tanh_gauss_elem(const TanhGaussArgs& a, const StepCtrl& c, float mu, float ls_raw, long long i) {
+  return tanh_gauss_elem_raw(a.eps, a.seed, a.rng_stream, c, mu, ls_raw, i);
+}
+
+constexpr float kBnMomentum = 0.1f;   // nn.BatchNorm1d's default momentum
+// running statistics from the batch statistics of the slab launches (bn_slab.hip), momentum 0.1, unbiased variance
+__device__ inline void bn_running_update(const BnRunning& r) {
+  const float ub = r.B > 1 ? (float)r.B / (float)(r.B - 1) : 1.0f;
+  for (int e = threadIdx.x; e < r.layers * r.H; e += blockDim.x) {
+    const int l = e / r.H, c = e - l * r.H;
+    float rm = r.rmean[e], rv = r.rvar[e];
+    for (int i = 0; i < r.n; ++i) {
+      rm = (1.0f - kBnMomentum) * rm + kBnMomentum * r.bstat[i][(2 * l) * r.H + c];
+      rv = (1.0f - kBnMomentum) * rv + kBnMomentum * (r.bstat[i][(2 * l + 1) * r.H + c] * ub);
+    }
+    r.rmean[e] = rm; r.rvar[e] = rv;
+  }
+}
+
+
 // backward of SACActorModel.sample for element (b, j): gradients of the two heads' outputs
 // (slot_off = cur->batch_slot * act_slot_stride; the callers skip the control-block load — a dependent memory round trip — when the stride is 0)
 __device__ inline void tanh_gauss_bwd_elem(const TanhGaussBwdArgs& a, long long slot_off, float alpha, int b, int j, float& gmu, float& gls) {

@@ -26,7 +26,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--c
 # translation unit -> substrings of the (mangled) kernel names that must pass, and must be present
 UNITS = {
     "bn_slab.hip": ["bn_linear_fwd_slab_kernel", "bn_linear_bwd_slab_kernel", "bn_linear_bwd_slab_fold_kernel"],
-    "rowchain.hip": ["rowchain_split_kernel", "rowchain_ddpg_kernel"],
+    "rowchain.hip": ["rowchain_split_kernel", "rowchain_ddpg_kernel", "rowchain_split_heads_kernel"],
     "rowtile.hip": ["rowtile_ddpg_kernel"],
     "gemm_mfma.hip": ["gemm_tiled_kernel"],
     "xchg_ipc.hip": ["xchg_two_shot_kernel"],
@@ -89,7 +89,7 @@ def check_kernel(body):
 SCRATCH_UNITS = ["her_ring.hip", "ops.hip", "ops_sac.hip", "bn_slab.hip", "rowchain.hip", "agent.hip", "normalizer.hip", "abi_misc.hip",
                  "gemm_mfma.hip", "xchg_ipc.hip", "dw_adam.hip"]
 SCRATCH_ALLOWED = {   # kernel-name substring -> bytes tolerated
-    "rowchain_split_kernelILi4E": 1024, "rowchain_ddpg_kernelILi4E": 1024,   # 16 rows per workgroup: register spills; never selected by default (GCRL_ROW_RG=4)
+    "rowchain_split_kernelILi4E": 1024, "rowchain_ddpg_kernelILi4E": 1024, "rowchain_split_heads_kernelILi4E": 1024,   # 16 rows per workgroup: register spills; never selected by default (GCRL_ROW_RG=4)
     "gemm_tiled_kernel": 16,                                                   # three spilled dwords outside the k-loop
 }
 
