@@ -4,7 +4,8 @@
 direction.  Round 5 changed HOW, not what: 64-row workgroups (8 row groups per slab) with 8 load stages, the narrow layers split
 as well, the row groups' column partials exchanged as words that are their own flags, W's tile of the backward pass through an LDS
 image, and the sampling backward (src/model.py:125-141 differentiated; src/agent.py:516-521) folded into the top layer's backward
-launch with the selection + log-alpha block riding along.  The knobs that select round 4's forms are read once per process, so each
+launch with the selection + log-alpha block riding along; and (SAC on the role-parallel row-chain launches) the two heads and the
+sampling itself (src/model.py:114-115, :125-141) formed by the chain launches that consume the actions.  The knobs that select round 4's forms are read once per process, so each
 form runs in a child process on the same seeds; the summation orders differ (merge of 8 partials instead of 4, multiply-adds
 instead of MFMAs for the heads' K = 2 x action_dim contraction), so the first step is compared at 1e-5 and the trajectory with
 a bound, as the oracle comparisons do."""
@@ -41,7 +42,8 @@ state = [np.asarray(v, np.float32).ravel().tolist() for v in ms._state(ag)]
 print("RESULT " + json.dumps({"tuples": tuples, "state": state, "meetings": int(ag.meetings())}))
 """
 
-ROUND4 = {"GCRL_SLAB_WAVES": "8", "GCRL_SLAB_MEET": "1", "GCRL_NO_SLAB_WTILE": "1", "GCRL_NO_TG_FOLD": "1", "GCRL_NO_SLAB_SPLIT_ALL": "1"}
+ROUND4 = {"GCRL_SLAB_WAVES": "8", "GCRL_SLAB_MEET": "1", "GCRL_NO_SLAB_WTILE": "1", "GCRL_NO_TG_FOLD": "1", "GCRL_NO_SLAB_SPLIT_ALL": "1",
+          "GCRL_NO_HEADS_FOLD": "1"}
 
 
 def _child(kind, H, L, B, steps, extra):
@@ -61,7 +63,7 @@ def test_round5_slab_forms_track_round4s(kind, H, L, B):
     steps = 12
     new = _child(kind, H, L, B, steps, {})
     old = _child(kind, H, L, B, steps, ROUND4)
-    single = [_child(kind, H, L, B, steps, {k: v}) for k, v in (("GCRL_SLAB_MEET", "1"), ("GCRL_NO_TG_FOLD", "1"))]
+    single = [_child(kind, H, L, B, steps, {k: v}) for k, v in (("GCRL_SLAB_MEET", "1"), ("GCRL_NO_TG_FOLD", "1"), ("GCRL_NO_HEADS_FOLD", "1"))]
     a, b = np.array(new["tuples"]), np.array(old["tuples"])
     assert a.shape == b.shape and a.shape[0] == steps and np.all(np.isfinite(a))
     np.testing.assert_allclose(a[0], b[0], rtol=1e-5, atol=1e-6)                      # one step: summation-order noise only
@@ -82,3 +84,7 @@ def test_round5_slab_forms_track_round4s(kind, H, L, B):
     nofold = np.array(single[1]["tuples"])
     np.testing.assert_allclose(a[0], nofold[0], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(a, nofold, rtol=1e-2, atol=1e-3)
+    # ... and so do the heads formed inside the chain launches (a row's 256-term dot products in another order)
+    noheads = np.array(single[2]["tuples"])
+    np.testing.assert_allclose(a[0], noheads[0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a, noheads, rtol=1e-2, atol=1e-3)
