@@ -116,6 +116,9 @@ constexpr int kMaxAdamSeg = 2 * kMaxTransposed + 2;
 // written, through an LDS transpose, to an [cols][rows] copy (rowchain.h streams those): 64-byte runs
 // instead of 4-byte scattered stores (the scattered form cost 3.2 us of a 10.8 us launch).
 struct AdamSeg { long long beg, dst; int rows, cols; int blk0, nblk; int tiled, pad; };
+// a block of the segmented launch: kAdamPerThread elements per thread — 1 024 consecutive elements of a flat segment, or a
+// kAdamTile x kAdamTile tile of a hidden layer's weight as four 16 x 16 sub-tiles (the launchers count `nblk` accordingly)
+constexpr int kAdamPerThread = 4, kAdamTile = 32;
 // partial[net][kNormBlocks] = sum of squares of block-strided chunks of g[net][n]
 int launch_sumsq(hipStream_t st, const float* g, long long n, long long net_stride, int nets,
                  float* partial);
