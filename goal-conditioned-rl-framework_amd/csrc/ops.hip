@@ -259,7 +259,13 @@ __global__ __launch_bounds__(256) void sumsq2_kernel(const float* g0, long long 
 }
 
 // ------------------------------------------------------------------ Adam / AdamW
-__device__ inline void adam_body(const AdamArgs& a, const int net) {
+// riders_here: this launch's metric riders run in workgroup 0 of net 0 (the paired launch); else in a workgroup of their own (adam_kernel).
+// nblocks: workgroups stepping elements (the flat form's stride)
+__device__ inline void adam_riders(const AdamArgs& a, const StepCtrl& c) {
+  if (a.mean_x) rider_mean_metric(a.mean_x, a.mean_n, a.mean_scale, a.metrics + (long long)c.metrics_slot * kMetricFloats + a.mean_index);
+  if (a.td_q) rider_td_metrics(a.td_q, a.td_y, a.td_n, a.td_C, a.td_loss_kind, a.metrics + (long long)c.metrics_slot * kMetricFloats);
+}
+__device__ inline void adam_body(const AdamArgs& a, const int net, const bool riders_here = true, const unsigned nblocks = gridDim.x) {
   __shared__ float s_coef;
   const StepCtrl c = *a.cur;
   const AdamStepScalars sc = adam_scalars(c, a.which);
@@ -339,10 +345,7 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
     }
   }
   __syncthreads();
-  if (a.mean_x && blockIdx.x == 0 && net == 0)
-    rider_mean_metric(a.mean_x, a.mean_n, a.mean_scale, a.metrics + (long long)c.metrics_slot * kMetricFloats + a.mean_index);
-  if (a.td_q && blockIdx.x == 0 && net == 0)
-    rider_td_metrics(a.td_q, a.td_y, a.td_n, a.td_C, a.td_loss_kind, a.metrics + (long long)c.metrics_slot * kMetricFloats);
+  if (riders_here && blockIdx.x == 0 && net == 0) adam_riders(a, c);
   const float gmul = gscale * s_coef;
   const float w1 = a.w1, w2 = a.w2, one_m_tau = a.one_m_tau;
   const bool pk = tp && a.polyak;
@@ -355,7 +358,7 @@ __device__ inline void adam_body(const AdamArgs& a, const int net) {
   };
   if (a.n_seg == 0) {
     float ti;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)nblocks * 256)
       step_vals(i, g[i], p[i], m[i], v[i], pk ? tp[i] : 0.f, &ti);
     return;
   }
@@ -392,7 +395,14 @@ __device__ inline void advance_ctrl(const AdamArgs& a) {
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
-  adam_body(a, blockIdx.y);
+  // round 5: the metric riders (TD metrics of 2 048 rows x 2 critics at TD3's cfg 3: one memory round trip and four block reductions) have a
+  // workgroup of their own — the launch's last — instead of extending workgroup 0's norm -> step chain
+  const bool extra = a.mean_x || a.td_q;
+  if (extra && blockIdx.x == gridDim.x - 1) {
+    if (blockIdx.y == 0) adam_riders(a, *a.cur);
+    return;
+  }
+  adam_body(a, blockIdx.y, false, gridDim.x - (extra ? 1u : 0u));
   if (a.alpha.log_alpha && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) alpha_step(a.alpha, *a.cur);
   advance_ctrl(a);
 }
@@ -482,7 +492,8 @@ int launch_sumsq2(hipStream_t st, const float* g0, long long n0, float* partial0
 
 int launch_adam(hipStream_t st, const AdamArgs& a) {
   GCRL_CHECK_ARG(a.nets >= 1 && a.nets <= kMaxCritics, "adam: bad net count %d", a.nets);
-  hipLaunchKernelGGL(adam_kernel, dim3(a.n_seg ? (unsigned)a.seg_blocks : adam_blocks(a.n), a.nets), dim3(256), 0, st, a);
+  const unsigned rider = (a.mean_x || a.td_q) ? 1u : 0u;   // (the riders' own workgroup: adam_kernel)
+  hipLaunchKernelGGL(adam_kernel, dim3((a.n_seg ? (unsigned)a.seg_blocks : adam_blocks(a.n)) + rider, a.nets), dim3(256), 0, st, a);
   GCRL_HIP(hipGetLastError());
   return GCRL_OK;
 }
