@@ -117,9 +117,9 @@ def flops_per_step(w, actor_step=None):
     return 2 * B * (4 * Pa + 7 * 5 * Pc)
 
 
-def head_batches(gstep):
-    """batches of a call's head gather launch (csrc/agent.hip build(): 3 by default, GCRL_HEAD_BATCHES overrides)"""
-    return min(int(gstep), max(1, min(8, int(os.environ.get("GCRL_HEAD_BATCHES", "3")))))
+def head_batches(gstep, kind="DDPG"):
+    """batches of a call's head gather launch (csrc/agent.hip build(): 4 for the pipelined DDPG step, 3 otherwise; GCRL_HEAD_BATCHES overrides)"""
+    return min(int(gstep), max(1, min(8, int(os.environ.get("GCRL_HEAD_BATCHES", "4" if kind == "DDPG" else "3")))))
 
 
 def chain_flops_per_launch(w):
@@ -560,11 +560,11 @@ def main():
                                 "algorithmic_bytes_per_row": alg_bytes_per_row, "timing": clock,
                                 "hip_event_us": ev_us, "hip_event_launches": launches.value,
                                 "achieved_hip_event": (alg_bytes_per_row * rows_per_launch) / (ev_us * 1e-6) / 1e9 if ev_us > 0 else None,
-                                "head_launch": ({"kernel": "her_gather_update_kernel<true>", "rows": head_batches(gstep) * w["B"], **ks["gather_head"]} if "gather_head" in ks else None),
+                                "head_launch": ({"kernel": "her_gather_update_kernel<true>", "rows": head_batches(gstep, w["kind"]) * w["B"], **ks["gather_head"]} if "gather_head" in ks else None),
                                 "profiler": ks.get("gather_main"),
                                 "note": "a call's first launch gathers its first %d batches (indices read from the pinned upload block, carries the control "
                                         "block) so that the first steps start while the host draws the rest; the main launch gathers the other "
-                                        "gradient_step - %d batches." % (head_batches(gstep), head_batches(gstep)) + "  Below ~1e5 rows a launch is bounded by the ~1.3 us dispatch + two dependent "
+                                        "gradient_step - %d batches." % (head_batches(gstep, w["kind"]), head_batches(gstep, w["kind"])) + "  Below ~1e5 rows a launch is bounded by the ~1.3 us dispatch + two dependent "
                                         "memory latencies, not by bandwidth (profiles/r03_gather_rows_curve.txt)"},
             "update_flops": {"gflop_per_step": flops_per_step(w) / 1e9,
                              "achieved_tflops": flops_per_step(w) * args.steps / elapsed / 1e12,
