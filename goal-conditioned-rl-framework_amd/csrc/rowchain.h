@@ -46,7 +46,7 @@ __device__ inline __amdgpu_buffer_rsrc_t bounded_rsrc(const float* p, long long 
 //   rs   buffer resource over M (reads past the end return 0)
 //   jb, je   this wave's j range (multiples of 4)
 template <int RG>
-__device__ inline void rows_matmul_wave(const float* xs, int ldx, __amdgpu_buffer_rsrc_t rs, int ldm, int c0,
+__device__ __forceinline__ void rows_matmul_wave(const float* xs, int ldx, __amdgpu_buffer_rsrc_t rs, int ldm, int c0,
                                         int jb, int je, v4f (&acc)[RG][4]) {
   const int lane = threadIdx.x & 63;
   // k per stage; two stages in flight.  A sharp optimum: 16 loads per wave = 64 per CU in flight.  Measured end
@@ -100,7 +100,7 @@ __device__ inline void rows_matmul_wave(const float* xs, int ldx, __amdgpu_buffe
 //          wave's next exchange must not overwrite what a slow wave is still summing); whoever reads
 //          ys across waves afterwards (heads, element-wise steps) must __syncthreads() first.
 template <int RG>
-__device__ inline void rows_linear(const float* xs, int ldx, int J, const float* M, int ldm, int N, const float* bias,
+__device__ __forceinline__ void rows_linear(const float* xs, int ldx, int J, const float* M, int ldm, int N, const float* bias,
                                    int epi, float* part, float* ys, int ldy, float* save, long long ld_save,
                                    int rows_valid, const float* mulH = nullptr, long long ld_mul = 0, int mul = MUL_NONE,
                                    bool chained = false, int pbuf = 0) {
