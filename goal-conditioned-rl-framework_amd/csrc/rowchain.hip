@@ -145,8 +145,8 @@ __device__ inline void stage(float* dst, const float* src, int n) {
   }
 }
 
-template <int RG>
-__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid, const HeadsFold* hf = nullptr);
+template <int RG, bool HF = false>
+__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid, const HeadsFold& hfr = HeadsFold{});
 
 template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_ddpg_kernel(RowChainArgs a) {
@@ -445,7 +445,7 @@ __device__ inline float ld_agent(const float* p) { return __hip_atomic_load(p, _
 // dependent round trips in front of the first layer pass (measured: the fold gained 2 us of the launch's 11).
 struct HeadsStaged { Staged<4> wm, wl, h; float bm, bl; };
 template <int RG>
-__device__ inline void heads_request(HeadsStaged& g, const HeadsFold& f, const float* hrows, int H, int A, int rv) {
+__device__ __forceinline__ void heads_request(HeadsStaged& g, const HeadsFold& f, const float* hrows, int H, int A, int rv) {
   seg_load(g.wm, f.P + f.w_mean, A * H);
   seg_load(g.wl, f.P + f.w_ls, A * H);
   seg_load(g.h, hrows, rv * H);
@@ -454,7 +454,7 @@ __device__ inline void heads_request(HeadsStaged& g, const HeadsFold& f, const f
   g.bl = tid < A ? f.P[f.b_ls + tid] : 0.f;
 }
 template <int RG>
-__device__ inline void heads_sample_rows(const HeadsStaged& g, const HeadsFold& f, const float* hrows, const float* eps, int rng_stream, unsigned long long seed,
+__device__ __forceinline__ void heads_sample_rows(const HeadsStaged& g, const HeadsFold& f, const float* hrows, const float* eps, int rng_stream, unsigned long long seed,
                                          const StepCtrl& c, float* X0, float* X1, int ldl, int H, int S, int A, long long row0, int rv,
                                          float* hw_m, float* hb, float* sm, float* sm2, float* sm3, float* es) {
   constexpr int R = 4 * RG;
@@ -488,6 +488,10 @@ __device__ inline void heads_sample_rows(const HeadsStaged& g, const HeadsFold& 
   }
   __syncthreads();
 }
+// what the actor's backward and the actor loss read of actor.sample(states), from heads_sample_rows' LDS results (one role per row block calls it)
+template <int RG>
+__device__ __forceinline__ void heads_write_cur(const HeadsFold& f, const float* X0, int ldl, int S, int A, int Apad, long long row0, int rv,
+                                       const float* sm, const float* sm2, const float* sm3, const float* es);
 __device__ inline float logp_row(const float* sm3, int r, int A) {
   float lp = 0.f;
   for (int j = 0; j < A; ++j) lp = __fadd_rn(lp, sm3[r * 16 + j]);   // in action order, as the sampling launch adds
@@ -495,7 +499,28 @@ __device__ inline float logp_row(const float* sm3, int r, int A) {
 }
 
 template <int RG>
-__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid, const HeadsFold* hf) {
+__device__ __forceinline__ void heads_write_cur(const HeadsFold& f, const float* X0, int ldl, int S, int A, int Apad, long long row0, int rv,
+                                       const float* sm, const float* sm2, const float* sm3, const float* es) {
+  constexpr int R = 4 * RG;
+  const int tid = threadIdx.x;
+  if (tid < R * A) {
+    const int r = tid / A, o = tid - r * A;
+    if (r < rv) {
+      const long long i = (row0 + r) * A + o;
+      f.pi[(row0 + r) * Apad + o] = X0[r * ldl + S + o];
+      f.save_eps[i] = es[r * 16 + o]; f.save_std[i] = es[R * 16 + r * 16 + o];
+      f.head[(row0 + r) * 2 * Apad + o] = sm[r * 16 + o];
+      f.head[(row0 + r) * 2 * Apad + Apad + o] = sm2[r * 16 + o];
+    }
+  }
+  if (tid < rv) f.logp[row0 + tid] = logp_row(sm3, tid, A);
+}
+
+// HF: the instantiation of rowchain_split_heads_kernel (the record is a kernel argument: read in place, never through a pointer that could be null —
+// with `const HeadsFold*` and run-time null checks hipcc copied the 192-byte record to per-thread scratch once a third use site appeared)
+template <int RG, bool HF>
+__device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int phase, int part, int bid, const HeadsFold& hfr) {
+  const HeadsFold* const hf = &hfr;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int R = 4 * RG;
   const int ldl = a.ldl, H = a.critic[0].H, S = a.S, A = a.A, B = a.B, C = a.C;
@@ -512,7 +537,7 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
   const int nblk = (B + R - 1) / R;
   const int role = bid / nblk;
   const int blk = bid - role * nblk;
-  const bool fold = hf != nullptr && hf->on != 0;
+  const bool fold = HF && hfr.on != 0;
   if (fold && phase == 0 && part != 2 && role == 2 * C) {   // the launch's extra workgroup: BatchNorm's running statistics (input 0's batch, then input 1's)
     if (blk == 0 && hf->run.layers) bn_running_update(hf->run);
     return;
@@ -583,6 +608,11 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
     // ---- online critic `role - C` on [s | a]: forward, activations saved
     const int k = role - C;
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
+    const bool cur_here = fold && hf->cur_in_k && k == 0;   // (uniform) this workgroup also forms pi(s) of its rows: HeadsFold::cur_in_k
+    // (requested unconditionally, with empty extents when this workgroup does not sample: a conditionally initialised record that lives across
+    // the layer passes went to scratch memory — 192 bytes per thread)
+    HeadsStaged hst;
+    if (HF) heads_request<RG>(hst, *hf, hf->h_cur + row0 * H, H, cur_here ? A : 0, cur_here ? rv : 0);
     load_rows<RG>(XS, ldl, sa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
     stage(hw, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
     if (tid == 0) hb[18] = a.critic[k].P[a.critic[k].b[a.critic[k].L]];
@@ -591,6 +621,10 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
     rows_head<RG>(h, ldl, H, hw, H, hb + 18, 1, EPI_NONE, sm);
     __syncthreads();
     if (tid < rv) a.q[(long long)k * B + row0 + tid] = sm[tid * 16];
+    if (cur_here) {   // the target roles are a sampling prologue behind: this fits in front of the wait for them
+      heads_sample_rows<RG>(hst, *hf, hf->h_cur + row0 * H, hf->eps_cur, 2, a.seed, c, X0, X1, ldl, H, S, A, row0, rv, hw + H, hb, sm, sm2, sm3, part_);
+      heads_write_cur<RG>(*hf, X0, ldl, S, A, a.Apad, row0, rv, sm, sm2, sm3, part_);
+    }
     if (!merged) return;
     // both target critics' outputs of these rows are out
     if (a.producers_first)
@@ -657,19 +691,7 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
     if (fold) {   // pi(s) = actor.sample(states) for these rows; role 0 writes what the actor's backward and the actor loss read
       float* hw_m = hw + H;
       heads_sample_rows<RG>(hst, *hf, hf->h_cur + row0 * H, hf->eps_cur, 2, a.seed, c, X0, X1, ldl, H, S, A, row0, rv, hw_m, hb, sm, sm2, sm3, part_);
-      if (k == 0) {
-        if (tid < R * A) {
-          const int r = tid / A, o = tid - r * A;
-          if (r < rv) {
-            const long long i = (row0 + r) * A + o;
-            hf->pi[(row0 + r) * a.Apad + o] = X0[r * ldl + S + o];
-            hf->save_eps[i] = part_[r * 16 + o]; hf->save_std[i] = part_[R * 16 + r * 16 + o];
-            hf->head[(row0 + r) * 2 * a.Apad + o] = sm[r * 16 + o];
-            hf->head[(row0 + r) * 2 * a.Apad + a.Apad + o] = sm2[r * 16 + o];
-          }
-        }
-        if (tid < rv) hf->logp[row0 + tid] = logp_row(sm3, tid, A);
-      }
+      if (k == 0) heads_write_cur<RG>(*hf, X0, ldl, S, A, a.Apad, row0, rv, sm, sm2, sm3, part_);
     }
     __syncthreads();
     float* h = mlp_hidden<RG>(a.critic[k], X0, X1, X2, ldl, part_ + R * 16, a.hC2 + (long long)k * a.critic[k].L * BH, BH, row0, rv);
@@ -725,7 +747,7 @@ __global__ __launch_bounds__(kRowThreads) void rowchain_split_kernel(RowChainArg
 template <int RG>
 __global__ __launch_bounds__(kRowThreads) void rowchain_split_heads_kernel(RowChainArgs a, int phase, int part, HeadsFold hf) {
   kernarg_warm<sizeof(RowChainArgs) + 8 + sizeof(HeadsFold)>();
-  rowchain_split_body<RG>(a, phase, part, (int)blockIdx.x, &hf);
+  rowchain_split_body<RG, true>(a, phase, part, (int)blockIdx.x, hf);
 }
 
 // `row_at(i)`: element i of the launch's input rows ([n][ld_obs] flattened); `noise_at(t)`: exploration noise of action element t —

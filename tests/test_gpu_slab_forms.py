@@ -63,7 +63,8 @@ def test_round5_slab_forms_track_round4s(kind, H, L, B):
     steps = 12
     new = _child(kind, H, L, B, steps, {})
     old = _child(kind, H, L, B, steps, ROUND4)
-    single = [_child(kind, H, L, B, steps, {k: v}) for k, v in (("GCRL_SLAB_MEET", "1"), ("GCRL_NO_TG_FOLD", "1"), ("GCRL_NO_HEADS_FOLD", "1"))]
+    single = [_child(kind, H, L, B, steps, {k: v}) for k, v in (("GCRL_SLAB_MEET", "1"), ("GCRL_NO_TG_FOLD", "1"), ("GCRL_NO_HEADS_FOLD", "1"),
+                                                                 ("GCRL_HEADS_CUR_IN_P", "1"))]
     a, b = np.array(new["tuples"]), np.array(old["tuples"])
     assert a.shape == b.shape and a.shape[0] == steps and np.all(np.isfinite(a))
     np.testing.assert_allclose(a[0], b[0], rtol=1e-5, atol=1e-6)                      # one step: summation-order noise only
@@ -85,6 +86,10 @@ def test_round5_slab_forms_track_round4s(kind, H, L, B):
     np.testing.assert_allclose(a[0], nofold[0], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(a, nofold, rtol=1e-2, atol=1e-3)
     # ... and so do the heads formed inside the chain launches (a row's 256-term dot products in another order)
+    # pi(s) formed by the critic phase's online roles (default) or by the actor phase's critic roles: the same arithmetic on the same rows
+    assert single[3]["tuples"] == new["tuples"]
+    for x, y in zip(single[3]["state"], new["state"]):
+        assert x == y
     noheads = np.array(single[2]["tuples"])
     np.testing.assert_allclose(a[0], noheads[0], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(a, noheads, rtol=1e-2, atol=1e-3)
