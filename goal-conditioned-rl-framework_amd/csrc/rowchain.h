@@ -304,8 +304,8 @@ struct RowChainArgs {
 // BatchNorm running-statistics update the sampling launch used to carry.
 struct HeadsFold {
   int on;
-  // 1: pi(s) and everything phase 1 reads are formed by phase 0's ONLINE-critic role 0 while it would otherwise wait for the target roles (whose
-  // prologue carries the a' sampling: the online roles are that much ahead) — phase 1 then runs without this record, on the stored pi
+  // 1: pi(s) and everything phase 1 reads are formed by one more role of phase 0's launch (a workgroup per row block, dispatched as the critic roles
+  // finish: beside the online roles' backward passes) — phase 1 then runs without this record, on the stored pi
   int cur_in_k;
   const float* P;                          // the actor's parameter block
   long long w_mean, b_mean, w_ls, b_ls;    // offsets of the two heads ([A][H] weights, [A] biases)

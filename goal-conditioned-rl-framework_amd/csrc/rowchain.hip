@@ -538,15 +538,26 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
   const int role = bid / nblk;
   const int blk = bid - role * nblk;
   const bool fold = HF && hfr.on != 0;
-  if (fold && phase == 0 && part != 2 && role == 2 * C) {   // the launch's extra workgroup: BatchNorm's running statistics (input 0's batch, then input 1's)
-    if (blk == 0 && hf->run.layers) bn_running_update(hf->run);
-    return;
-  }
+
   const long long row0 = (long long)blk * R;
   const int rv = min(R, B - (int)row0);
   const long long BH = (long long)B * H;
   const int tid = threadIdx.x;
   const StepCtrl c = phase == 0 ? *a.cur_k : *a.cur_p;
+  if (fold && phase == 0 && part != 2 && role == 2 * C) {
+    // the launch's extra workgroups (highest indices, waiting for nobody: they start as role workgroups finish and run beside the online roles'
+    // backward passes): with cur_in_k one per row block forms pi(s) and what phase 1 and the actor's backward read of it — in the online role's
+    // own workgroup the same work sat on the launch's critical path (34.4 us against 32.2) —; block 0 also applies BatchNorm's running statistics
+    // (input 0's batch, then input 1's)
+    if (hf->cur_in_k) {
+      HeadsStaged hst;
+      heads_request<RG>(hst, *hf, hf->h_cur + row0 * H, H, A, rv);
+      heads_sample_rows<RG>(hst, *hf, hf->h_cur + row0 * H, hf->eps_cur, 2, a.seed, c, X0, X1, ldl, H, S, A, row0, rv, hw, hb, sm, sm2, sm3, part_);
+      heads_write_cur<RG>(*hf, X0, ldl, S, A, a.Apad, row0, rv, sm, sm2, sm3, part_);
+    }
+    if (blk == 0 && hf->run.layers) bn_running_update(hf->run);
+    return;
+  }
   const bool merged = part == 3;                 // parts 1 and 2 in this launch (rowchain.h)
   __shared__ unsigned int s_flag;
   unsigned int* meet = merged ? a.bar + ((long long)phase * nblk + blk) * 32 : nullptr;
@@ -608,11 +619,6 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
     // ---- online critic `role - C` on [s | a]: forward, activations saved
     const int k = role - C;
     const float* sa_rows = a.sa + (long long)c.batch_slot * a.slot_x + row0 * a.ldx;
-    const bool cur_here = fold && hf->cur_in_k && k == 0;   // (uniform) this workgroup also forms pi(s) of its rows: HeadsFold::cur_in_k
-    // (requested unconditionally, with empty extents when this workgroup does not sample: a conditionally initialised record that lives across
-    // the layer passes went to scratch memory — 192 bytes per thread)
-    HeadsStaged hst;
-    if (HF) heads_request<RG>(hst, *hf, hf->h_cur + row0 * H, H, cur_here ? A : 0, cur_here ? rv : 0);
     load_rows<RG>(XS, ldl, sa_rows, a.ldx, S + A, a.critic[0].jpad0, rv);
     stage(hw, a.critic[k].P + a.critic[k].w[a.critic[k].L], H);
     if (tid == 0) hb[18] = a.critic[k].P[a.critic[k].b[a.critic[k].L]];
@@ -621,10 +627,6 @@ __device__ __forceinline__ void rowchain_split_body(const RowChainArgs& a, int p
     rows_head<RG>(h, ldl, H, hw, H, hb + 18, 1, EPI_NONE, sm);
     __syncthreads();
     if (tid < rv) a.q[(long long)k * B + row0 + tid] = sm[tid * 16];
-    if (cur_here) {   // the target roles are a sampling prologue behind: this fits in front of the wait for them
-      heads_sample_rows<RG>(hst, *hf, hf->h_cur + row0 * H, hf->eps_cur, 2, a.seed, c, X0, X1, ldl, H, S, A, row0, rv, hw + H, hb, sm, sm2, sm3, part_);
-      heads_write_cur<RG>(*hf, X0, ldl, S, A, a.Apad, row0, rv, sm, sm2, sm3, part_);
-    }
     if (!merged) return;
     // both target critics' outputs of these rows are out
     if (a.producers_first)
@@ -939,7 +941,7 @@ int launch_rowchain_split(hipStream_t st, const RowChainArgs& a, int rg, int pha
   };
   if (hf && hf->on) {   // the BatchNorm actor's heads and sampling inside the launch (rowchain.h HeadsFold); phase 0 carries the running-statistics workgroup
     GCRL_CHECK_ARG(a.given_next && a.p_critic_only && part != 2 && a.A <= 16, "rowchain split: the folded heads need the SAC form (given_next, critic-only actor phase)");
-    const int grid = roles * nblk + ((phase == 0 && hf->run.layers) ? 1 : 0);
+    const int grid = roles * nblk + (phase == 0 ? (hf->cur_in_k ? nblk : (hf->run.layers ? 1 : 0)) : 0);
     auto goh = [&](auto kern) -> int {
       static thread_local size_t raised = 0;
       if (lds > 64 * 1024 && lds > raised) {
