@@ -461,7 +461,8 @@ __device__ __forceinline__ void heads_sample_rows(const HeadsStaged& g, const He
   const int tid = threadIdx.x;
   seg_store(g.wm, hw_m, f.P + f.w_mean, A * H);
   seg_store(g.wl, hw_m + A * H, f.P + f.w_ls, A * H);
-  if (tid < A) { hb[32 + tid] = g.bm; hb[48 + tid] = g.bl; }
+  const bool one_pass = 2 * A <= 16;   // both heads as ONE 2A-output pass (weights and biases are contiguous in LDS: mean rows, then log_std rows)
+  if (tid < A) { hb[32 + tid] = g.bm; hb[(one_pass ? 32 + A : 48) + tid] = g.bl; }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int i = tid + u * kRowThreads, r = i / H, kk = i - r * H;
@@ -472,8 +473,14 @@ __device__ __forceinline__ void heads_sample_rows(const HeadsStaged& g, const He
     X1[r * ldl + kk] = r < rv ? hrows[(long long)r * H + kk] : 0.f;
   }
   __syncthreads();
-  rows_head<RG>(X1, ldl, H, hw_m, H, hb + 32, A, EPI_NONE, sm);
-  rows_head<RG>(X1, ldl, H, hw_m + A * H, H, hb + 48, A, EPI_NONE, sm2);
+  if (one_pass) {
+    rows_head<RG>(X1, ldl, H, hw_m, H, hb + 32, 2 * A, EPI_NONE, sm);
+    __syncthreads();
+    if (tid < R * A) { const int r = tid / A, o = tid - r * A; sm2[r * 16 + o] = sm[r * 16 + A + o]; }   // (the callers read log_std's outputs from sm2)
+  } else {
+    rows_head<RG>(X1, ldl, H, hw_m, H, hb + 32, A, EPI_NONE, sm);
+    rows_head<RG>(X1, ldl, H, hw_m + A * H, H, hb + 48, A, EPI_NONE, sm2);
+  }
   __syncthreads();
   if (tid < R * A) {
     const int r = tid / A, o = tid - r * A;
